@@ -1,0 +1,201 @@
+/*
+ * rass_engine.h — C ABI of the MI355X-native embedding + vector-search engine
+ * that drops in behind RASSEngine's embed_*() functions and OpenSearchIndexer
+ * k-NN lookup.
+ *
+ * The reference has no FFI for this path: its boundary is HTTP/JSON to Ollama
+ * (app/main.py:225-237) and to the OpenSearch k-NN plugin (app/main.py:1552).
+ * Every entry point below names the reference call site whose arithmetic it
+ * replaces.  The Python shim (rassengine_amd/) binds these with ctypes and is
+ * the only caller; see INTEGRATION.md for the reference-side rebinding.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch / C++ types cross this boundary
+ *   - every function returns RASS_OK (0) or a negative rass_status; the text of
+ *     the last failure on the calling thread is rass_last_error()
+ *   - nothing throws across the ABI
+ *   - "d_" parameters are device (HBM) pointers, everything else is host memory
+ *   - `stream` parameters are a hipStream_t passed as void* (NULL = the
+ *     engine's own stream / the null stream for the stateless kernels)
+ *   - one engine drives ONE GPU; multi-GPU is one process per GPU (RCCL via
+ *     torch.distributed in the Python layer), never several devices per engine
+ */
+#ifndef RASS_ENGINE_H
+#define RASS_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RASS_ABI_VERSION 1
+
+typedef enum rass_status {
+    RASS_OK = 0,
+    RASS_ERR_INVALID = -1,     /* bad argument (shape, k, dtype, NULL) */
+    RASS_ERR_HIP = -2,         /* a HIP runtime call failed */
+    RASS_ERR_OOM = -3,         /* device or host allocation failed */
+    RASS_ERR_NOT_FOUND = -4,   /* unknown index name / row */
+    RASS_ERR_UNSUPPORTED = -5, /* valid request this build cannot serve */
+    RASS_ERR_IO = -6           /* save/load failure */
+} rass_status;
+
+/* Corpus storage dtype (fp32 is the parity path). */
+typedef enum rass_dtype {
+    RASS_F32 = 0,
+    RASS_BF16 = 1
+} rass_dtype;
+
+/* Limits of the fused scan kernel. */
+#define RASS_MAX_K 32        /* top-k kept in one half-wave sorted list */
+#define RASS_MAX_QBATCH 32   /* queries per scan launch (two 16-wide MFMA N tiles) */
+#define RASS_ROW_TAG_DELETED (-1)
+#define RASS_QFILTER_NONE (-1)
+
+typedef struct rass_engine rass_engine_t;
+typedef struct rass_index rass_index_t;
+
+/* ------------------------------------------------------------------ misc */
+
+int rass_abi_version(void);
+/* Thread-local text of the last error on this thread ("" if none). */
+const char* rass_last_error(void);
+/* Number of visible HIP devices, or a negative rass_status. */
+int rass_device_count(void);
+
+/* ---------------------------------------------------------------- engine */
+
+/* One engine per process per GPU.  `dim` = EMBED_DIM (app/main.py:80). */
+int rass_engine_create(int device, int dim, rass_engine_t** out);
+void rass_engine_destroy(rass_engine_t* eng);
+int rass_engine_dim(const rass_engine_t* eng);
+int rass_engine_device(const rass_engine_t* eng);
+/* Run all engine work on a caller-owned hipStream_t (e.g. torch's current
+ * stream) instead of the engine's own.  NULL restores the engine stream. */
+int rass_engine_set_stream(rass_engine_t* eng, void* stream);
+int rass_engine_synchronize(rass_engine_t* eng);
+
+/* ----------------------------------------------------------------- index */
+
+/* Replaces ensure_index_exists()'s knn_vector field (app/main.py:350-579,
+ * vector field 563-572; name from get_index_name 346-347): look up the named
+ * cosine index, creating it when absent.  O(1) when it exists, because the
+ * reference constructs OpenSearchIndexer per request (app/main.py:2802). */
+int rass_index_open(rass_engine_t* eng, const char* name, rass_dtype dtype,
+                    int64_t initial_capacity_rows, rass_index_t** out);
+/* Drop an index and free its HBM. */
+int rass_index_drop(rass_engine_t* eng, const char* name);
+/* Replaces OpenSearchIndexer.has_any_data's count (app/main.py:1470-1478):
+ * live (non-deleted) rows. */
+int64_t rass_index_count(const rass_index_t* idx);
+/* Rows ever appended (live + tombstoned) = next row id. */
+int64_t rass_index_rows(const rass_index_t* idx);
+int rass_index_dim(const rass_index_t* idx);
+int rass_index_row_stride(const rass_index_t* idx); /* elements, dim padded to 128 */
+
+/* Replaces the vector half of store_fhir_docs_in_opensearch (app/main.py:
+ * 1245-1282: normalise 1249-1251 + bulk index).  Appends n rows of `dim`
+ * floats (host memory).  When `normalize` != 0 rows are L2-normalised on the
+ * GPU with the reference's formula e / (||e|| + 1e-9).  `tags` (may be NULL =
+ * all 0) is one int32 per row: the dictionary code of the row's patientId
+ * (the reference's `_routing` / term-filter key, app/main.py:1263, 1549);
+ * must be >= 0.  Row ids are insertion ordinals; *first_row receives the id of
+ * the first appended row.  Append-only: overwrite = rass_index_delete + add. */
+int rass_index_add(rass_index_t* idx, const float* vecs, const int32_t* tags,
+                   int64_t n, int normalize, int64_t* first_row);
+/* Same, from device memory (the encoder's pooled output), async on the
+ * engine stream. */
+int rass_index_add_device(rass_index_t* idx, const float* d_vecs,
+                          const int32_t* d_tags, int64_t n, int normalize,
+                          int64_t* first_row);
+/* Tombstone a row (the overwrite semantics of `_id=doc_id`, app/main.py:1260). */
+int rass_index_delete(rass_index_t* idx, int64_t row);
+/* Copy one stored (normalised) row back to the host as fp32 (dim floats): the
+ * reference returns the embedding inside `_source` (app/main.py:1555-1557). */
+int rass_index_get_row(rass_index_t* idx, int64_t row, float* out);
+
+/* Replaces the knn query of OpenSearchIndexer.semantic_search (app/main.py:
+ * 1527-1560) and the knn sub-clauses of hybrid_search (1595),
+ * hybrid_structured_search (1754), multi_intent_search (2003): exact cosine
+ * top-k.  `queries` is nq x dim fp32 (host); they are re-normalised on the
+ * GPU exactly as the reference does (1536-1537).  `q_filter` (may be NULL) is
+ * one int32 per query: RASS_QFILTER_NONE or the patientId code to restrict to
+ * (the `term: patientId` filter, 1549), applied as a pre-filter.
+ * Outputs: out_scores[nq*k] raw cosine, best first; out_ids[nq*k] global row
+ * ids (id_base + local row), -1 (score -inf) where fewer than k rows match.
+ * Order: score descending, ties by id ascending.  1 <= k <= RASS_MAX_K; any nq
+ * (scanned in batches of RASS_MAX_QBATCH). */
+int rass_index_search(rass_index_t* idx, const float* queries, int nq, int k,
+                      const int32_t* q_filter, float* out_scores,
+                      int64_t* out_ids);
+/* Device-resident variant for the multi-GPU path and the benchmark: queries
+ * and outputs live in HBM, nothing is synchronised; nq <= RASS_MAX_QBATCH.
+ * `id_base` is added to local row ids (row-sharded corpus). */
+int rass_index_search_device(rass_index_t* idx, const float* d_queries, int nq,
+                             int k, const int32_t* d_q_filter, int64_t id_base,
+                             float* d_out_scores, int64_t* d_out_ids);
+
+/* Shard persistence: raw rows + tags + manifest header. */
+int rass_index_save(rass_index_t* idx, const char* path);
+int rass_index_load(rass_engine_t* eng, const char* name, const char* path,
+                    rass_index_t** out);
+
+/* Fill rows [first, first+n) of the index with synthetic unit vectors
+ * generated ON DEVICE (counter-based RNG keyed by (seed, global row id), so
+ * any shard regenerates identically; SURVEY §8d cfg 2/4).  Appends when
+ * first == rass_index_rows().  `row_id_base` offsets the RNG key for sharding. */
+int rass_index_fill_synthetic(rass_index_t* idx, int64_t n, uint64_t seed,
+                              int64_t row_id_base);
+
+/* --------------------------------------------- stateless kernel launchers */
+
+/* Bytes of scratch the scan needs for (nq, k). */
+size_t rass_scan_workspace_bytes(int nq, int k);
+
+/* K1+K2: fused flat cosine scan + per-workgroup top-k + merge over a
+ * row-major fp32 corpus slab in HBM.  d_corpus rows must already be
+ * normalised; d_queries (nq x dim) are normalised by the launcher.
+ * row_stride is in elements and must be a multiple of 128 with zero padding
+ * beyond dim.  d_row_tag / d_q_filter may be NULL. */
+int rass_scan_topk_f32(const float* d_corpus, int64_t n_rows, int dim,
+                       int64_t row_stride, const int32_t* d_row_tag,
+                       const float* d_queries, int nq,
+                       const int32_t* d_q_filter, int k, int64_t id_base,
+                       float* d_out_scores, int64_t* d_out_ids,
+                       void* d_workspace, size_t workspace_bytes,
+                       void* stream);
+
+/* K2/K3 merge: n_lists sorted candidate lists per query, laid out
+ * [n_lists][nq][k] (score f32, id i64; id < 0 = empty), -> [nq][k] with the
+ * same total order.  Used after the RCCL all-gather of per-shard top-k. */
+int rass_topk_merge(const float* d_scores, const int64_t* d_ids, int n_lists,
+                    int nq, int k, float* d_out_scores, int64_t* d_out_ids,
+                    void* stream);
+
+/* a4 (app/main.py:1249-1251, 1536-1537): out = in / (||in||_2 + 1e-9), rows
+ * of `dim` floats read at in_stride, written at out_stride (elements); the
+ * out_stride - dim tail of each output row is zero-filled. */
+int rass_normalize_rows_f32(const float* d_in, int64_t in_stride, float* d_out,
+                            int64_t out_stride, int64_t n, int dim,
+                            void* stream);
+
+/* HIP-event timing on an explicit stream (bench.py measures kernels on the
+ * stream they run on; torch.cuda.Event only sees torch's current stream). */
+typedef struct rass_timer rass_timer_t;
+int rass_timer_create(rass_timer_t** out);
+void rass_timer_destroy(rass_timer_t* t);
+int rass_timer_start(rass_timer_t* t, void* stream);
+int rass_timer_stop(rass_timer_t* t, void* stream);
+/* Blocks until the stop event has completed; milliseconds between the two. */
+int rass_timer_elapsed_ms(rass_timer_t* t, float* ms);
+
+/* Name of the scan kernel variant a (dim, nq) request dispatches to, for
+ * matching rocprofv3 kernel-trace rows ("" if unsupported). */
+const char* rass_scan_kernel_name(int dim, int nq);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RASS_ENGINE_H */

@@ -1,0 +1,262 @@
+/*
+ * rass_oracle.c — CPU restatement of the reference's embedding-normalise + cosine k-NN
+ * arithmetic.  TEST INFRASTRUCTURE ONLY: nothing under rassengine_amd/ may link, import
+ * or call this; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do,
+ * and only as the checker / the timed CPU stand-in.
+ *
+ * PARITY PINNING.  The reference delegates this arithmetic to OpenSearch 2.11.1's k-NN
+ * plugin (nmslib HNSW, cosinesimil; docker-compose.yml:5, app/main.py:563-572) and holds
+ * no golden vector for it (tests/test_main.py:26 accepts HTTP 200/400/403), so for the
+ * k-NN scores this oracle is "parity unpinned": it restates the published definition the
+ * reference relies on (exact cosine similarity, which HNSW approximates) and is anchored
+ * on the reference's call sites:
+ *   - normalise:  app/main.py:1249-1251 (ingest) and 1536-1537 (query)
+ *                 norms = np.linalg.norm(e, axis=1, keepdims=True); e / (norms + 1e-9)
+ *   - ranking:    app/main.py:1538-1557  size=k, best first, len <= k
+ *   - filter:     app/main.py:1543-1550  {"term": {"patientId": ...}}
+ *   - overwrite:  app/main.py:1260       _id = doc_id (tombstone + append here)
+ * The normalise restatement IS pinned: tests/test_oracle.py checks it bit-for-bit against
+ * the verbatim numpy expression.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define RASS_ORACLE_MAX_K 1024
+
+/* numpy's float32 pairwise summation (numpy/_core/src/umath/loops_utils.h.src,
+ * @TYPE@_pairwise_sum): what add.reduce runs along a contiguous axis, hence what
+ * np.linalg.norm(e, axis=1) computes for each row after squaring. */
+static float np_pairwise_sum_f32(const float* a, size_t n) {
+    if (n < 8) {
+        float res = 0.f;
+        for (size_t i = 0; i < n; ++i) res += a[i];
+        return res;
+    } else if (n <= 128) {
+        float r[8];
+        size_t i;
+        for (int k = 0; k < 8; ++k) r[k] = a[k];
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int k = 0; k < 8; ++k) r[k] += a[i + k];
+        float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += a[i];
+        return res;
+    } else {
+        size_t n2 = n / 2;
+        n2 -= n2 % 8;
+        return np_pairwise_sum_f32(a, n2) + np_pairwise_sum_f32(a + n2, n - n2);
+    }
+}
+
+/* a4: out = in / (||in|| + 1e-9), fp32, numpy's operation order.  Returns 0. */
+int rass_oracle_normalize_f32(const float* in, int64_t in_stride, float* out, int64_t out_stride, int64_t n,
+                              int dim) {
+    float* sq = (float*)malloc((size_t)dim * sizeof(float));
+    if (!sq) return -1;
+    for (int64_t r = 0; r < n; ++r) {
+        const float* x = in + r * in_stride;
+        for (int c = 0; c < dim; ++c) sq[c] = x[c] * x[c];
+        const float norm = sqrtf(np_pairwise_sum_f32(sq, (size_t)dim));
+        const float denom = norm + 1e-9f; /* float32 + python float -> float32 (NEP 50) */
+        float* y = out + r * out_stride;
+        for (int c = 0; c < dim; ++c) y[c] = x[c] / denom;
+        for (int64_t c = dim; c < out_stride; ++c) y[c] = 0.f;
+    }
+    free(sq);
+    return 0;
+}
+
+/* ---- top-k under the total order (score desc, id asc) ---- */
+typedef struct {
+    double s;
+    int64_t id;
+} cand_t;
+
+static int cand_better(double sa, int64_t ia, double sb, int64_t ib) {
+    return (sa > sb) || (sa == sb && ia < ib);
+}
+
+/* sorted insert into list[0..*len) (best first), capacity k */
+static void topk_insert(cand_t* list, int* len, int k, double s, int64_t id) {
+    if (!(s > -INFINITY)) return; /* -inf and NaN never rank */
+    if (*len == k && !cand_better(s, id, list[k - 1].s, list[k - 1].id)) return;
+    int pos = *len < k ? *len : k - 1;
+    while (pos > 0 && cand_better(s, id, list[pos - 1].s, list[pos - 1].id)) {
+        list[pos] = list[pos - 1];
+        --pos;
+    }
+    list[pos].s = s;
+    list[pos].id = id;
+    if (*len < k) ++*len;
+}
+
+static int row_passes(const int32_t* tags, int64_t row, int32_t qf) {
+    if (!tags) return 1;
+    const int32_t t = tags[row];
+    if (t == -1) return 0;
+    return qf < 0 || qf == t;
+}
+
+/* score kinds */
+#define KIND_F64 0       /* double accumulate: the truth the GPU result is ranked against   */
+#define KIND_F32_MFMA 1  /* bit-exact emulation of scan_topk.hip's fmaf order (see below)   */
+#define KIND_F32_FAST 2  /* plain float accumulate, vectorisable: the timed CPU baseline    */
+
+static double score_f64(const float* x, const float* q, int dim) {
+    double acc = 0.0;
+    for (int c = 0; c < dim; ++c) acc += (double)x[c] * (double)q[c];
+    return acc;
+}
+
+/* scan_topk.hip order: the K axis (row_stride = 128*CH, zero padded) is cut into 8 wave
+ * slices of 16*CH columns; inside a slice chunk j (16 columns), component i (0..3) and
+ * lane group g (0..3) address column 16j + 4g + i, and one v_mfma_f32_16x16x4_f32 is the
+ * fmaf chain over g = 0..3; the 8 slice partials are added in slice order. */
+static float score_f32_mfma(const float* x, const float* q, int dim, int stride) {
+    const int ch = stride / 128;
+    float part[8];
+    for (int w = 0; w < 8; ++w) {
+        float acc = 0.f;
+        for (int j = 0; j < ch; ++j)
+            for (int i = 0; i < 4; ++i)
+                for (int g = 0; g < 4; ++g) {
+                    const int c = w * 16 * ch + 16 * j + 4 * g + i;
+                    const float xv = c < dim ? x[c] : 0.f, qv = c < dim ? q[c] : 0.f;
+                    acc = fmaf(xv, qv, acc);
+                }
+        part[w] = acc;
+    }
+    float s = part[0];
+    for (int w = 1; w < 8; ++w) s += part[w];
+    return s;
+}
+
+static float score_f32_fast(const float* x, const float* q, int dim) {
+    float acc = 0.f;
+#pragma omp simd reduction(+ : acc)
+    for (int c = 0; c < dim; ++c) acc += x[c] * q[c];
+    return acc;
+}
+
+/*
+ * Exact cosine top-k.  X: n rows (already normalised) at x_stride floats; Q: nq rows
+ * (already normalised) at q_stride; tags / qfilter may be NULL.  Outputs [nq][k]:
+ * scores (double), ids (id_base + row, or -1 with score -inf where fewer than k match).
+ * kind selects the accumulation (see above).  threads <= 0 -> all cores.
+ */
+int rass_oracle_search(const float* X, int64_t n, int dim, int64_t x_stride, const int32_t* tags,
+                       const float* Q, int nq, int64_t q_stride, const int32_t* qfilter, int k, int64_t id_base,
+                       int kind, int threads, double* out_scores, int64_t* out_ids) {
+    if (k < 1 || k > RASS_ORACLE_MAX_K || nq < 0 || n < 0 || dim < 1) return -1;
+    int nthreads = 1;
+#ifdef _OPENMP
+    nthreads = threads > 0 ? threads : omp_get_max_threads();
+#endif
+    (void)threads;
+    const int stride_pad = (int)((dim + 127) / 128 * 128);
+    cand_t* lists = (cand_t*)malloc((size_t)nthreads * nq * k * sizeof(cand_t));
+    int* lens = (int*)calloc((size_t)nthreads * nq, sizeof(int));
+    if (!lists || !lens) {
+        free(lists);
+        free(lens);
+        return -1;
+    }
+#pragma omp parallel num_threads(nthreads)
+    {
+        int tid = 0;
+#ifdef _OPENMP
+        tid = omp_get_thread_num();
+#endif
+        cand_t* my = lists + (size_t)tid * nq * k;
+        int* mylen = lens + (size_t)tid * nq;
+#pragma omp for schedule(static)
+        for (int64_t r = 0; r < n; ++r) {
+            const float* x = X + r * x_stride;
+            for (int q = 0; q < nq; ++q) {
+                if (!row_passes(tags, r, qfilter ? qfilter[q] : -1)) continue;
+                const float* qv = Q + (int64_t)q * q_stride;
+                double s;
+                if (kind == KIND_F64)
+                    s = score_f64(x, qv, dim);
+                else if (kind == KIND_F32_MFMA)
+                    s = (double)score_f32_mfma(x, qv, dim, stride_pad);
+                else
+                    s = (double)score_f32_fast(x, qv, dim);
+                topk_insert(my + (size_t)q * k, mylen + q, k, s, id_base + r);
+            }
+        }
+    }
+    for (int q = 0; q < nq; ++q) {
+        cand_t* dst = lists + (size_t)q * k; /* thread 0's list is the merge target */
+        int* dlen = lens + q;
+        for (int t = 1; t < nthreads; ++t) {
+            const cand_t* src = lists + ((size_t)t * nq + q) * k;
+            const int sl = lens[(size_t)t * nq + q];
+            for (int e = 0; e < sl; ++e) topk_insert(dst, dlen, k, src[e].s, src[e].id);
+        }
+        for (int e = 0; e < k; ++e) {
+            out_scores[(size_t)q * k + e] = e < *dlen ? dst[e].s : -INFINITY;
+            out_ids[(size_t)q * k + e] = e < *dlen ? dst[e].id : -1;
+        }
+    }
+    free(lists);
+    free(lens);
+    return 0;
+}
+
+/* All nq x n scores of one kind (small cases: tie / near-tie analysis in the tests). */
+int rass_oracle_scores(const float* X, int64_t n, int dim, int64_t x_stride, const float* Q, int nq,
+                       int64_t q_stride, int kind, double* out /* [nq][n] */) {
+    const int stride_pad = (int)((dim + 127) / 128 * 128);
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < n; ++r) {
+        const float* x = X + r * x_stride;
+        for (int q = 0; q < nq; ++q) {
+            const float* qv = Q + (int64_t)q * q_stride;
+            double s;
+            if (kind == KIND_F64)
+                s = score_f64(x, qv, dim);
+            else if (kind == KIND_F32_MFMA)
+                s = (double)score_f32_mfma(x, qv, dim, stride_pad);
+            else
+                s = (double)score_f32_fast(x, qv, dim);
+            out[(size_t)q * n + r] = s;
+        }
+    }
+    return 0;
+}
+
+/* Merge n_lists sorted lists [n_lists][nq][k] -> [nq][k] (restates the shard ->
+ * coordinator merge; checker for merge_topk.hip and the multi-GPU path). */
+int rass_oracle_merge(const double* scores, const int64_t* ids, int n_lists, int nq, int k, double* out_scores,
+                      int64_t* out_ids) {
+    if (k < 1 || k > RASS_ORACLE_MAX_K) return -1;
+    cand_t* list = (cand_t*)malloc((size_t)k * sizeof(cand_t));
+    if (!list) return -1;
+    for (int q = 0; q < nq; ++q) {
+        int len = 0;
+        for (int l = 0; l < n_lists; ++l)
+            for (int e = 0; e < k; ++e) {
+                const size_t o = ((size_t)l * nq + q) * k + e;
+                if (ids[o] >= 0) topk_insert(list, &len, k, scores[o], ids[o]);
+            }
+        for (int e = 0; e < k; ++e) {
+            out_scores[(size_t)q * k + e] = e < len ? list[e].s : -INFINITY;
+            out_ids[(size_t)q * k + e] = e < len ? list[e].id : -1;
+        }
+    }
+    free(list);
+    return 0;
+}
+
+int rass_oracle_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

@@ -1,0 +1,120 @@
+"""ctypes binding of ``librass_hip.so`` (the C ABI declared in ``include/rass_engine.h``).
+
+There is NO fallback: if the HIP library is missing or fails to load, importing the
+product path raises.  A CPU stand-in exists only under ``oracle/`` for the tests.
+
+H1 of SURVEY §7 (two HIP runtimes): ``torch 2.10+rocm7.0`` ships its own
+``libamdhip64.so`` with the same soname (``libamdhip64.so.7``) as ROCm 7.2's.  We import
+torch first so the HIP runtime torch uses is the one already mapped when
+``librass_hip.so`` resolves its ``DT_NEEDED``; device pointers from torch tensors and from
+the engine then belong to one runtime.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "librass_hip.so")
+
+RASS_OK = 0
+RASS_MAX_K = 32
+RASS_MAX_QBATCH = 32
+RASS_F32 = 0
+RASS_BF16 = 1
+RASS_QFILTER_NONE = -1
+
+c_float_p = ctypes.POINTER(ctypes.c_float)
+c_i32_p = ctypes.POINTER(ctypes.c_int32)
+c_i64_p = ctypes.POINTER(ctypes.c_int64)
+c_void_pp = ctypes.POINTER(ctypes.c_void_p)
+
+# name -> (restype, argtypes); the export test walks this table against the header.
+SIGNATURES = {
+    "rass_abi_version": (ctypes.c_int, []),
+    "rass_last_error": (ctypes.c_char_p, []),
+    "rass_device_count": (ctypes.c_int, []),
+    "rass_engine_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_void_pp]),
+    "rass_engine_destroy": (None, [ctypes.c_void_p]),
+    "rass_engine_dim": (ctypes.c_int, [ctypes.c_void_p]),
+    "rass_engine_device": (ctypes.c_int, [ctypes.c_void_p]),
+    "rass_engine_set_stream": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "rass_engine_synchronize": (ctypes.c_int, [ctypes.c_void_p]),
+    "rass_index_open": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int64, c_void_pp]),
+    "rass_index_drop": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p]),
+    "rass_index_count": (ctypes.c_int64, [ctypes.c_void_p]),
+    "rass_index_rows": (ctypes.c_int64, [ctypes.c_void_p]),
+    "rass_index_dim": (ctypes.c_int, [ctypes.c_void_p]),
+    "rass_index_row_stride": (ctypes.c_int, [ctypes.c_void_p]),
+    "rass_index_add": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                      ctypes.c_int, c_i64_p]),
+    "rass_index_add_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                             ctypes.c_int, c_i64_p]),
+    "rass_index_delete": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64]),
+    "rass_index_get_row": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
+    "rass_index_search": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "rass_index_search_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                                ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                                ctypes.c_void_p]),
+    "rass_index_save": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p]),
+    "rass_index_load": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, c_void_pp]),
+    "rass_index_fill_synthetic": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64,
+                                                 ctypes.c_int64]),
+    "rass_scan_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
+    "rass_scan_topk_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int64,
+                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                          ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                                          ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "rass_topk_merge": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "rass_normalize_rows_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
+                                               ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
+    "rass_timer_create": (ctypes.c_int, [c_void_pp]),
+    "rass_timer_destroy": (None, [ctypes.c_void_p]),
+    "rass_timer_start": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "rass_timer_stop": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "rass_timer_elapsed_ms": (ctypes.c_int, [ctypes.c_void_p, c_float_p]),
+    "rass_scan_kernel_name": (ctypes.c_char_p, [ctypes.c_int, ctypes.c_int]),
+}
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+class RassError(RuntimeError):
+    """A C-ABI call returned a negative rass_status."""
+
+    def __init__(self, fn: str, code: int, text: str):
+        super().__init__(f"{fn} failed ({code}): {text}")
+        self.code = code
+
+
+def lib() -> ctypes.CDLL:
+    """Load librass_hip.so once.  Raises (never falls back) when it is unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C rassengine_amd/csrc`. rassengine_amd has no CPU fallback.")
+    try:
+        import torch  # noqa: F401  -- map torch's HIP runtime first (see module docstring)
+    except Exception:  # torch-free C/ctypes users link against the system ROCm instead
+        pass
+    L = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(L, name)  # AttributeError = header/library mismatch: fail loudly
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if L.rass_abi_version() != 1:
+        raise ImportError(f"librass_hip.so ABI {L.rass_abi_version()} != 1")
+    _lib = L
+    return L
+
+
+def check(fn: str, code: int) -> int:
+    if code < 0:
+        raise RassError(fn, code, lib().rass_last_error().decode("utf-8", "replace"))
+    return code

@@ -1,0 +1,729 @@
+// api.hip — the C ABI of include/rass_engine.h: engine / index objects that own HBM, and
+// the stateless launchers.  Host-side C++ only; the kernels live in the other .hip files.
+//
+// Ownership model: the engine singleton of a process owns the corpus slabs
+// for process lifetime; callers own every host buffer they pass in or get filled.
+// Threading: add/delete/grow take the index mutex; searches take the engine mutex only
+// while enqueuing (all GPU work of an engine is ordered on one stream, so the shared
+// scratch is safe by stream order).
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/rass_engine.h"
+#include "kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess) {                                                                         \
+            char _b[512];                                                                               \
+            snprintf(_b, sizeof(_b), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,   \
+                     __LINE__);                                                                         \
+            return fail(_e == hipErrorOutOfMemory ? RASS_ERR_OOM : RASS_ERR_HIP, _b);                   \
+        }                                                                                               \
+    } while (0)
+
+constexpr int kMaxGrid = 1024;        // upper bound on scan workgroups (sizing of scratch)
+constexpr int kMaxStride = 1024;      // dim_padded limit of the fused scan (CH <= 8)
+constexpr int64_t kStageRows = 8192;  // host -> device staging granule for add()
+
+int64_t pad128(int64_t d) { return (d + 127) / 128 * 128; }
+
+int device_cus(int device) {
+    static std::mutex mu;
+    static std::map<int, int> cache;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find(device);
+    if (it != cache.end()) return it->second;
+    hipDeviceProp_t prop;
+    int cus = 256;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+        cus = prop.multiProcessorCount;
+    cache[device] = cus;
+    return cus;
+}
+
+struct ScratchLayout {
+    size_t q_padded, part_scores, part_ids, total;
+};
+
+ScratchLayout scratch_layout(int nq, int k) {
+    ScratchLayout L;
+    size_t off = 0;
+    L.q_padded = off;
+    off += (size_t)RASS_MAX_QBATCH * kMaxStride * sizeof(float);
+    L.part_scores = off;
+    off += (size_t)kMaxGrid * nq * k * sizeof(float);
+    off = (off + 255) / 256 * 256;
+    L.part_ids = off;
+    off += (size_t)kMaxGrid * nq * k * sizeof(int64_t);
+    off = (off + 255) / 256 * 256;
+    L.total = off;
+    return L;
+}
+
+}  // namespace
+
+struct rass_engine {
+    int device = 0;
+    int dim = 0;
+    int n_cus = 256;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    std::map<std::string, rass_index*> indices;
+    // scratch for searches (sized for nq = RASS_MAX_QBATCH, k = RASS_MAX_K)
+    unsigned char* d_scratch = nullptr;
+    size_t scratch_bytes = 0;
+    // host-API staging
+    float* d_qraw = nullptr;        // [32][dim]
+    int32_t* d_qfilter = nullptr;   // [32]
+    float* d_out_scores = nullptr;  // [32][32]
+    int64_t* d_out_ids = nullptr;   // [32][32]
+    float* d_stage = nullptr;       // [kStageRows][dim]
+    int32_t* d_stage_tags = nullptr;
+};
+
+struct rass_index {
+    rass_engine* eng = nullptr;
+    std::string name;
+    rass_dtype dtype = RASS_F32;
+    int dim = 0;
+    int64_t stride = 0;
+    int64_t rows = 0;
+    int64_t capacity = 0;
+    int64_t deleted = 0;
+    bool has_tags = false;  // any non-zero tag ever stored
+    float* d_rows = nullptr;
+    int32_t* d_tags = nullptr;
+    std::vector<uint8_t> host_deleted;  // tombstone bitmap mirror (host)
+    std::mutex mu;
+};
+
+namespace {
+
+int set_device(const rass_engine* eng) {
+    HIP_TRY(hipSetDevice(eng->device));
+    return RASS_OK;
+}
+
+int index_reserve(rass_index* idx, int64_t need_rows) {
+    if (need_rows <= idx->capacity) return RASS_OK;
+    int64_t cap = std::max<int64_t>(idx->capacity * 2, std::max<int64_t>(need_rows, 1024));
+    float* nrows = nullptr;
+    int32_t* ntags = nullptr;
+    hipStream_t st = idx->eng->stream;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&nrows), (size_t)cap * idx->stride * sizeof(float));
+    if (e != hipSuccess) {
+        // retry with the exact size before giving up
+        cap = need_rows;
+        e = hipMalloc(reinterpret_cast<void**>(&nrows), (size_t)cap * idx->stride * sizeof(float));
+        if (e != hipSuccess) return fail(RASS_ERR_OOM, "index grow: hipMalloc of corpus slab failed");
+    }
+    e = hipMalloc(reinterpret_cast<void**>(&ntags), (size_t)cap * sizeof(int32_t));
+    if (e != hipSuccess) {
+        (void)hipFree(nrows);
+        return fail(RASS_ERR_OOM, "index grow: hipMalloc of tag array failed");
+    }
+    if (idx->rows > 0) {
+        HIP_TRY(hipMemcpyAsync(nrows, idx->d_rows, (size_t)idx->rows * idx->stride * sizeof(float),
+                               hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(ntags, idx->d_tags, (size_t)idx->rows * sizeof(int32_t), hipMemcpyDeviceToDevice,
+                               st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    if (idx->d_rows) (void)hipFree(idx->d_rows);
+    if (idx->d_tags) (void)hipFree(idx->d_tags);
+    idx->d_rows = nrows;
+    idx->d_tags = ntags;
+    idx->capacity = cap;
+    return RASS_OK;
+}
+
+int scan_launch(const float* d_corpus, int64_t n_rows, int64_t stride, const int32_t* d_row_tag,
+                const float* d_queries, int q_dim, int64_t q_stride, int nq, const int32_t* d_q_filter, int k,
+                int64_t id_base, float* d_out_scores, int64_t* d_out_ids, unsigned char* ws, size_t ws_bytes,
+                int n_cus, hipStream_t st) {
+    if (nq < 1 || nq > RASS_MAX_QBATCH) return fail(RASS_ERR_INVALID, "nq must be in [1, RASS_MAX_QBATCH]");
+    if (k < 1 || k > RASS_MAX_K) return fail(RASS_ERR_INVALID, "k must be in [1, RASS_MAX_K]");
+    if (n_rows < 0 || n_rows > 0x7fffffc0LL) return fail(RASS_ERR_INVALID, "n_rows out of range for one scan");
+    if (!rass::scan_supported_stride(stride) || stride > kMaxStride)
+        return fail(RASS_ERR_UNSUPPORTED, "row_stride must be 128*{1,2,3,4,6,8} elements");
+    if (q_dim > stride) return fail(RASS_ERR_INVALID, "dim exceeds row_stride");
+    const ScratchLayout L = scratch_layout(nq, k);
+    if (ws == nullptr || ws_bytes < L.total) return fail(RASS_ERR_INVALID, "scan workspace too small");
+    if ((reinterpret_cast<uintptr_t>(d_corpus) & 15) != 0) return fail(RASS_ERR_INVALID, "corpus not 16-B aligned");
+
+    float* q_padded = reinterpret_cast<float*>(ws + L.q_padded);
+    float* part_scores = reinterpret_cast<float*>(ws + L.part_scores);
+    int64_t* part_ids = reinterpret_cast<int64_t*>(ws + L.part_ids);
+    const int nq_pad = nq <= 16 ? 16 : 32;
+
+    // a4 on the query side (reference app/main.py:1536-1537), written zero-padded.
+    HIP_TRY(rass::launch_normalize_rows_f32(d_queries, q_stride, q_padded, stride, nq, q_dim, st));
+    if (nq_pad > nq) HIP_TRY(rass::launch_zero_rows(q_padded + (int64_t)nq * stride, stride, nq_pad - nq, st));
+
+    const int64_t n_tiles = (n_rows + 31) / 32;
+    int grid = (int)std::min<int64_t>(std::max<int64_t>(n_tiles, 1), std::min(n_cus, kMaxGrid));
+    if ((int64_t)grid * k > rass::kMergeMaxCandidates) grid = rass::kMergeMaxCandidates / k;
+
+    rass::ScanArgs a;
+    a.corpus = d_corpus;
+    a.row_tag = d_row_tag;
+    a.q_padded = q_padded;
+    a.q_filter = d_q_filter;
+    a.part_scores = part_scores;
+    a.part_ids = part_ids;
+    a.row_stride = stride;
+    a.id_base = id_base;
+    a.n_rows = (int)n_rows;
+    a.nq = nq;
+    a.k = k;
+    HIP_TRY(rass::launch_scan_topk_f32(a, grid, st));
+    HIP_TRY(rass::launch_merge_topk(part_scores, part_ids, grid, nq, k, d_out_scores, d_out_ids, st));
+    return RASS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rass_abi_version(void) { return RASS_ABI_VERSION; }
+
+const char* rass_last_error(void) { return g_err.c_str(); }
+
+int rass_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return fail(RASS_ERR_HIP, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+    return n;
+}
+
+int rass_engine_create(int device, int dim, rass_engine_t** out) {
+    if (out == nullptr) return fail(RASS_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (dim < 1 || pad128(dim) > kMaxStride)
+        return fail(RASS_ERR_UNSUPPORTED, "dim must be in [1, 1024] for the fused scan");
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return fail(RASS_ERR_INVALID, "no such HIP device");
+    rass_engine* eng = new (std::nothrow) rass_engine();
+    if (!eng) return fail(RASS_ERR_OOM, "host allocation failed");
+    eng->device = device;
+    eng->dim = dim;
+    HIP_TRY(hipSetDevice(device));
+    eng->n_cus = device_cus(device);
+    HIP_TRY(hipStreamCreateWithFlags(&eng->own_stream, hipStreamNonBlocking));
+    eng->stream = eng->own_stream;
+    eng->scratch_bytes = scratch_layout(RASS_MAX_QBATCH, RASS_MAX_K).total;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&eng->d_scratch), eng->scratch_bytes));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&eng->d_qraw), (size_t)RASS_MAX_QBATCH * dim * sizeof(float)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&eng->d_qfilter), RASS_MAX_QBATCH * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&eng->d_out_scores), RASS_MAX_QBATCH * RASS_MAX_K * sizeof(float)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&eng->d_out_ids), RASS_MAX_QBATCH * RASS_MAX_K * sizeof(int64_t)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&eng->d_stage), (size_t)kStageRows * dim * sizeof(float)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&eng->d_stage_tags), (size_t)kStageRows * sizeof(int32_t)));
+    *out = eng;
+    return RASS_OK;
+}
+
+void rass_engine_destroy(rass_engine_t* eng) {
+    if (!eng) return;
+    (void)hipSetDevice(eng->device);
+    (void)hipDeviceSynchronize();
+    for (auto& kv : eng->indices) {
+        rass_index* idx = kv.second;
+        if (idx->d_rows) (void)hipFree(idx->d_rows);
+        if (idx->d_tags) (void)hipFree(idx->d_tags);
+        delete idx;
+    }
+    eng->indices.clear();
+    (void)hipFree(eng->d_scratch);
+    (void)hipFree(eng->d_qraw);
+    (void)hipFree(eng->d_qfilter);
+    (void)hipFree(eng->d_out_scores);
+    (void)hipFree(eng->d_out_ids);
+    (void)hipFree(eng->d_stage);
+    (void)hipFree(eng->d_stage_tags);
+    if (eng->own_stream) (void)hipStreamDestroy(eng->own_stream);
+    delete eng;
+}
+
+int rass_engine_dim(const rass_engine_t* eng) { return eng ? eng->dim : fail(RASS_ERR_INVALID, "engine is NULL"); }
+int rass_engine_device(const rass_engine_t* eng) {
+    return eng ? eng->device : fail(RASS_ERR_INVALID, "engine is NULL");
+}
+
+int rass_engine_set_stream(rass_engine_t* eng, void* stream) {
+    if (!eng) return fail(RASS_ERR_INVALID, "engine is NULL");
+    std::lock_guard<std::mutex> lk(eng->mu);
+    HIP_TRY(hipSetDevice(eng->device));
+    HIP_TRY(hipStreamSynchronize(eng->stream));
+    eng->stream = stream ? reinterpret_cast<hipStream_t>(stream) : eng->own_stream;
+    return RASS_OK;
+}
+
+int rass_engine_synchronize(rass_engine_t* eng) {
+    if (!eng) return fail(RASS_ERR_INVALID, "engine is NULL");
+    HIP_TRY(hipSetDevice(eng->device));
+    HIP_TRY(hipStreamSynchronize(eng->stream));
+    return RASS_OK;
+}
+
+int rass_index_open(rass_engine_t* eng, const char* name, rass_dtype dtype, int64_t initial_capacity_rows,
+                    rass_index_t** out) {
+    if (!eng || !name || !out) return fail(RASS_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    if (dtype != RASS_F32) return fail(RASS_ERR_UNSUPPORTED, "only the fp32 corpus is implemented");
+    std::lock_guard<std::mutex> lk(eng->mu);
+    auto it = eng->indices.find(name);
+    if (it != eng->indices.end()) {
+        if (it->second->dtype != dtype) return fail(RASS_ERR_INVALID, "index exists with another dtype");
+        *out = it->second;
+        return RASS_OK;
+    }
+    int rc = set_device(eng);
+    if (rc != RASS_OK) return rc;
+    rass_index* idx = new (std::nothrow) rass_index();
+    if (!idx) return fail(RASS_ERR_OOM, "host allocation failed");
+    idx->eng = eng;
+    idx->name = name;
+    idx->dtype = dtype;
+    idx->dim = eng->dim;
+    idx->stride = pad128(eng->dim);
+    if (initial_capacity_rows > 0) {
+        rc = index_reserve(idx, initial_capacity_rows);
+        if (rc != RASS_OK) {
+            delete idx;
+            return rc;
+        }
+    }
+    eng->indices[name] = idx;
+    *out = idx;
+    return RASS_OK;
+}
+
+int rass_index_drop(rass_engine_t* eng, const char* name) {
+    if (!eng || !name) return fail(RASS_ERR_INVALID, "NULL argument");
+    std::lock_guard<std::mutex> lk(eng->mu);
+    auto it = eng->indices.find(name);
+    if (it == eng->indices.end()) return fail(RASS_ERR_NOT_FOUND, "no such index");
+    HIP_TRY(hipSetDevice(eng->device));
+    HIP_TRY(hipStreamSynchronize(eng->stream));
+    rass_index* idx = it->second;
+    if (idx->d_rows) (void)hipFree(idx->d_rows);
+    if (idx->d_tags) (void)hipFree(idx->d_tags);
+    delete idx;
+    eng->indices.erase(it);
+    return RASS_OK;
+}
+
+int64_t rass_index_count(const rass_index_t* idx) { return idx ? idx->rows - idx->deleted : 0; }
+int64_t rass_index_rows(const rass_index_t* idx) { return idx ? idx->rows : 0; }
+int rass_index_dim(const rass_index_t* idx) { return idx ? idx->dim : fail(RASS_ERR_INVALID, "index is NULL"); }
+int rass_index_row_stride(const rass_index_t* idx) {
+    return idx ? (int)idx->stride : fail(RASS_ERR_INVALID, "index is NULL");
+}
+
+static int add_common(rass_index_t* idx, const float* vecs, const int32_t* tags, int64_t n, int normalize,
+                      int64_t* first_row, bool device_src) {
+    if (!idx) return fail(RASS_ERR_INVALID, "index is NULL");
+    if (n < 0 || (n > 0 && !vecs)) return fail(RASS_ERR_INVALID, "bad vecs / n");
+    rass_engine* eng = idx->eng;
+    std::lock_guard<std::mutex> lk(idx->mu);
+    int rc = set_device(eng);
+    if (rc != RASS_OK) return rc;
+    if (!device_src && tags) {
+        for (int64_t i = 0; i < n; ++i)
+            if (tags[i] < 0) return fail(RASS_ERR_INVALID, "row tags must be >= 0");
+    }
+    if (first_row) *first_row = idx->rows;
+    if (n == 0) return RASS_OK;
+    {
+        std::lock_guard<std::mutex> elk(eng->mu);  // grow swaps pointers searches read
+        rc = index_reserve(idx, idx->rows + n);
+        if (rc != RASS_OK) return rc;
+    }
+    hipStream_t st = eng->stream;
+    const int dim = idx->dim;
+    for (int64_t done = 0; done < n;) {
+        const int64_t m = std::min<int64_t>(kStageRows, n - done);
+        float* dst = idx->d_rows + (idx->rows + done) * idx->stride;
+        int32_t* tdst = idx->d_tags + idx->rows + done;
+        const float* src = vecs + done * dim;
+        const float* dsrc = src;
+        if (!device_src) {
+            HIP_TRY(hipMemcpyAsync(eng->d_stage, src, (size_t)m * dim * sizeof(float), hipMemcpyHostToDevice, st));
+            dsrc = eng->d_stage;
+        }
+        if (normalize) {
+            HIP_TRY(rass::launch_normalize_rows_f32(dsrc, dim, dst, idx->stride, m, dim, st));
+        } else {
+            if (idx->stride != dim) HIP_TRY(rass::launch_zero_rows(dst, idx->stride, (int)m, st));
+            HIP_TRY(hipMemcpy2DAsync(dst, (size_t)idx->stride * sizeof(float), dsrc, (size_t)dim * sizeof(float),
+                                     (size_t)dim * sizeof(float), (size_t)m, hipMemcpyDeviceToDevice, st));
+        }
+        if (tags) {
+            HIP_TRY(hipMemcpyAsync(tdst, tags + done, (size_t)m * sizeof(int32_t),
+                                   device_src ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+        } else {
+            HIP_TRY(rass::launch_fill_i32(tdst, m, 0, st));
+        }
+        // the staging buffer is reused by the next chunk
+        if (!device_src) HIP_TRY(hipStreamSynchronize(st));
+        done += m;
+    }
+    if (tags) idx->has_tags = true;
+    idx->rows += n;
+    idx->host_deleted.resize((size_t)((idx->rows + 7) / 8), 0);
+    return RASS_OK;
+}
+
+int rass_index_add(rass_index_t* idx, const float* vecs, const int32_t* tags, int64_t n, int normalize,
+                   int64_t* first_row) {
+    return add_common(idx, vecs, tags, n, normalize, first_row, false);
+}
+
+int rass_index_add_device(rass_index_t* idx, const float* d_vecs, const int32_t* d_tags, int64_t n, int normalize,
+                          int64_t* first_row) {
+    return add_common(idx, d_vecs, d_tags, n, normalize, first_row, true);
+}
+
+int rass_index_delete(rass_index_t* idx, int64_t row) {
+    if (!idx) return fail(RASS_ERR_INVALID, "index is NULL");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    if (row < 0 || row >= idx->rows) return fail(RASS_ERR_NOT_FOUND, "row out of range");
+    uint8_t& byte = idx->host_deleted[(size_t)(row >> 3)];
+    const uint8_t bit = (uint8_t)(1u << (row & 7));
+    if (byte & bit) return RASS_OK;  // idempotent
+    int rc = set_device(idx->eng);
+    if (rc != RASS_OK) return rc;
+    HIP_TRY(rass::launch_fill_i32(idx->d_tags + row, 1, RASS_ROW_TAG_DELETED, idx->eng->stream));
+    byte |= bit;
+    idx->deleted += 1;
+    return RASS_OK;
+}
+
+int rass_index_get_row(rass_index_t* idx, int64_t row, float* out) {
+    if (!idx || !out) return fail(RASS_ERR_INVALID, "NULL argument");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    if (row < 0 || row >= idx->rows) return fail(RASS_ERR_NOT_FOUND, "row out of range");
+    int rc = set_device(idx->eng);
+    if (rc != RASS_OK) return rc;
+    hipStream_t st = idx->eng->stream;
+    HIP_TRY(hipMemcpyAsync(out, idx->d_rows + row * idx->stride, (size_t)idx->dim * sizeof(float),
+                           hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return RASS_OK;
+}
+
+int rass_index_search_device(rass_index_t* idx, const float* d_queries, int nq, int k, const int32_t* d_q_filter,
+                             int64_t id_base, float* d_out_scores, int64_t* d_out_ids) {
+    if (!idx || !d_queries || !d_out_scores || !d_out_ids) return fail(RASS_ERR_INVALID, "NULL argument");
+    rass_engine* eng = idx->eng;
+    std::lock_guard<std::mutex> lk(eng->mu);
+    int rc = set_device(eng);
+    if (rc != RASS_OK) return rc;
+    const bool need_tags = (idx->deleted > 0) || (d_q_filter != nullptr);
+    return scan_launch(idx->d_rows ? idx->d_rows : reinterpret_cast<const float*>(eng->d_scratch), idx->rows,
+                       idx->stride, need_tags ? idx->d_tags : nullptr, d_queries, idx->dim, idx->dim, nq,
+                       d_q_filter, k, id_base, d_out_scores, d_out_ids, eng->d_scratch, eng->scratch_bytes,
+                       eng->n_cus, eng->stream);
+}
+
+int rass_index_search(rass_index_t* idx, const float* queries, int nq, int k, const int32_t* q_filter,
+                      float* out_scores, int64_t* out_ids) {
+    if (!idx || !out_scores || !out_ids) return fail(RASS_ERR_INVALID, "NULL argument");
+    if (nq < 0 || (nq > 0 && !queries)) return fail(RASS_ERR_INVALID, "bad queries / nq");
+    if (k < 1 || k > RASS_MAX_K) return fail(RASS_ERR_INVALID, "k must be in [1, RASS_MAX_K]");
+    rass_engine* eng = idx->eng;
+    int rc = set_device(eng);
+    if (rc != RASS_OK) return rc;
+    const int dim = idx->dim;
+    for (int done = 0; done < nq;) {
+        const int b = std::min(RASS_MAX_QBATCH, nq - done);
+        hipStream_t st;
+        {
+            // staging buffers are per engine: hold the lock across the whole batch round trip
+            std::lock_guard<std::mutex> lk(eng->mu);
+            st = eng->stream;
+            HIP_TRY(hipMemcpyAsync(eng->d_qraw, queries + (int64_t)done * dim, (size_t)b * dim * sizeof(float),
+                                   hipMemcpyHostToDevice, st));
+            const int32_t* d_filter = nullptr;
+            if (q_filter) {
+                HIP_TRY(hipMemcpyAsync(eng->d_qfilter, q_filter + done, (size_t)b * sizeof(int32_t),
+                                       hipMemcpyHostToDevice, st));
+                d_filter = eng->d_qfilter;
+            }
+            const bool need_tags = (idx->deleted > 0) || (d_filter != nullptr);
+            rc = scan_launch(idx->d_rows ? idx->d_rows : reinterpret_cast<const float*>(eng->d_scratch), idx->rows,
+                             idx->stride, need_tags ? idx->d_tags : nullptr, eng->d_qraw, dim, dim, b, d_filter, k,
+                             0, eng->d_out_scores, eng->d_out_ids, eng->d_scratch, eng->scratch_bytes, eng->n_cus,
+                             st);
+            if (rc != RASS_OK) return rc;
+            HIP_TRY(hipMemcpyAsync(out_scores + (int64_t)done * k, eng->d_out_scores, (size_t)b * k * sizeof(float),
+                                   hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(out_ids + (int64_t)done * k, eng->d_out_ids, (size_t)b * k * sizeof(int64_t),
+                                   hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+        }
+        done += b;
+    }
+    return RASS_OK;
+}
+
+// ---- persistence: header + unpadded fp32 rows + tags
+struct SaveHeader {
+    char magic[8];
+    int32_t version;
+    int32_t dim;
+    int32_t dtype;
+    int32_t reserved;
+    int64_t rows;
+    int64_t deleted;
+};
+
+int rass_index_save(rass_index_t* idx, const char* path) {
+    if (!idx || !path) return fail(RASS_ERR_INVALID, "NULL argument");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    int rc = set_device(idx->eng);
+    if (rc != RASS_OK) return rc;
+    FILE* f = fopen(path, "wb");
+    if (!f) return fail(RASS_ERR_IO, std::string("cannot open for write: ") + path);
+    SaveHeader h;
+    memset(&h, 0, sizeof(h));
+    memcpy(h.magic, "RASSIDX1", 8);
+    h.version = 1;
+    h.dim = idx->dim;
+    h.dtype = (int32_t)idx->dtype;
+    h.rows = idx->rows;
+    h.deleted = idx->deleted;
+    bool ok = fwrite(&h, sizeof(h), 1, f) == 1;
+    hipStream_t st = idx->eng->stream;
+    std::vector<float> buf((size_t)kStageRows * idx->dim);
+    for (int64_t r = 0; ok && r < idx->rows; r += kStageRows) {
+        const int64_t m = std::min<int64_t>(kStageRows, idx->rows - r);
+        hipError_t e = hipMemcpy2DAsync(buf.data(), (size_t)idx->dim * 4, idx->d_rows + r * idx->stride,
+                                        (size_t)idx->stride * 4, (size_t)idx->dim * 4, (size_t)m,
+                                        hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) {
+            fclose(f);
+            return fail(RASS_ERR_HIP, std::string("save: device read failed: ") + hipGetErrorString(e));
+        }
+        ok = fwrite(buf.data(), sizeof(float), (size_t)m * idx->dim, f) == (size_t)m * idx->dim;
+    }
+    if (ok && idx->rows > 0) {
+        std::vector<int32_t> tags((size_t)idx->rows);
+        hipError_t e = hipMemcpyAsync(tags.data(), idx->d_tags, (size_t)idx->rows * 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) {
+            fclose(f);
+            return fail(RASS_ERR_HIP, std::string("save: tag read failed: ") + hipGetErrorString(e));
+        }
+        ok = fwrite(tags.data(), 4, (size_t)idx->rows, f) == (size_t)idx->rows;
+    }
+    ok = (fclose(f) == 0) && ok;
+    return ok ? RASS_OK : fail(RASS_ERR_IO, std::string("short write: ") + path);
+}
+
+int rass_index_load(rass_engine_t* eng, const char* name, const char* path, rass_index_t** out) {
+    if (!eng || !name || !path || !out) return fail(RASS_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    FILE* f = fopen(path, "rb");
+    if (!f) return fail(RASS_ERR_IO, std::string("cannot open for read: ") + path);
+    SaveHeader h;
+    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "RASSIDX1", 8) != 0 || h.version != 1) {
+        fclose(f);
+        return fail(RASS_ERR_IO, "not a rass index file");
+    }
+    if (h.dim != eng->dim || h.dtype != RASS_F32 || h.rows < 0) {
+        fclose(f);
+        return fail(RASS_ERR_INVALID, "index file does not match the engine (dim / dtype)");
+    }
+    {
+        std::lock_guard<std::mutex> lk(eng->mu);
+        if (eng->indices.count(name)) {
+            fclose(f);
+            return fail(RASS_ERR_INVALID, "an index of that name is already open");
+        }
+    }
+    rass_index_t* idx = nullptr;
+    int rc = rass_index_open(eng, name, RASS_F32, h.rows, &idx);
+    if (rc != RASS_OK) {
+        fclose(f);
+        return rc;
+    }
+    std::vector<float> buf((size_t)kStageRows * h.dim);
+    for (int64_t r = 0; r < h.rows; r += kStageRows) {
+        const int64_t m = std::min<int64_t>(kStageRows, h.rows - r);
+        if (fread(buf.data(), sizeof(float), (size_t)m * h.dim, f) != (size_t)m * h.dim) {
+            fclose(f);
+            (void)rass_index_drop(eng, name);
+            return fail(RASS_ERR_IO, "truncated index file (rows)");
+        }
+        rc = rass_index_add(idx, buf.data(), nullptr, m, /*normalize*/ 0, nullptr);
+        if (rc != RASS_OK) {
+            fclose(f);
+            (void)rass_index_drop(eng, name);
+            return rc;
+        }
+    }
+    if (h.rows > 0) {
+        std::vector<int32_t> tags((size_t)h.rows);
+        if (fread(tags.data(), 4, (size_t)h.rows, f) != (size_t)h.rows) {
+            fclose(f);
+            (void)rass_index_drop(eng, name);
+            return fail(RASS_ERR_IO, "truncated index file (tags)");
+        }
+        std::lock_guard<std::mutex> lk(idx->mu);
+        hipError_t e = hipMemcpyAsync(idx->d_tags, tags.data(), (size_t)h.rows * 4, hipMemcpyHostToDevice, eng->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(eng->stream);
+        if (e != hipSuccess) {
+            fclose(f);
+            return fail(RASS_ERR_HIP, std::string("load: tag upload failed: ") + hipGetErrorString(e));
+        }
+        for (int64_t r = 0; r < h.rows; ++r) {
+            if (tags[(size_t)r] == RASS_ROW_TAG_DELETED) {
+                idx->host_deleted[(size_t)(r >> 3)] |= (uint8_t)(1u << (r & 7));
+                idx->deleted += 1;
+            } else if (tags[(size_t)r] != 0) {
+                idx->has_tags = true;
+            }
+        }
+    }
+    fclose(f);
+    *out = idx;
+    return RASS_OK;
+}
+
+int rass_index_fill_synthetic(rass_index_t* idx, int64_t n, uint64_t seed, int64_t row_id_base) {
+    if (!idx) return fail(RASS_ERR_INVALID, "index is NULL");
+    if (n < 0) return fail(RASS_ERR_INVALID, "n < 0");
+    rass_engine* eng = idx->eng;
+    std::lock_guard<std::mutex> lk(idx->mu);
+    int rc = set_device(eng);
+    if (rc != RASS_OK) return rc;
+    if (n == 0) return RASS_OK;
+    {
+        std::lock_guard<std::mutex> elk(eng->mu);
+        rc = index_reserve(idx, idx->rows + n);
+        if (rc != RASS_OK) return rc;
+    }
+    hipStream_t st = eng->stream;
+    HIP_TRY(rass::launch_fill_synthetic_f32(idx->d_rows + idx->rows * idx->stride, idx->stride, n, idx->dim, seed,
+                                            row_id_base + idx->rows, st));
+    HIP_TRY(rass::launch_fill_i32(idx->d_tags + idx->rows, n, 0, st));
+    idx->rows += n;
+    idx->host_deleted.resize((size_t)((idx->rows + 7) / 8), 0);
+    return RASS_OK;
+}
+
+size_t rass_scan_workspace_bytes(int nq, int k) {
+    if (nq < 1 || nq > RASS_MAX_QBATCH || k < 1 || k > RASS_MAX_K) return 0;
+    return scratch_layout(nq, k).total;
+}
+
+int rass_scan_topk_f32(const float* d_corpus, int64_t n_rows, int dim, int64_t row_stride,
+                       const int32_t* d_row_tag, const float* d_queries, int nq, const int32_t* d_q_filter, int k,
+                       int64_t id_base, float* d_out_scores, int64_t* d_out_ids, void* d_workspace,
+                       size_t workspace_bytes, void* stream) {
+    if (!d_queries || !d_out_scores || !d_out_ids) return fail(RASS_ERR_INVALID, "NULL argument");
+    if (n_rows > 0 && !d_corpus) return fail(RASS_ERR_INVALID, "corpus is NULL");
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    const float* corpus = d_corpus ? d_corpus : reinterpret_cast<const float*>(d_workspace);
+    return scan_launch(corpus, n_rows, row_stride, d_row_tag, d_queries, dim, dim, nq, d_q_filter, k, id_base,
+                       d_out_scores, d_out_ids, reinterpret_cast<unsigned char*>(d_workspace), workspace_bytes,
+                       device_cus(dev), reinterpret_cast<hipStream_t>(stream));
+}
+
+int rass_topk_merge(const float* d_scores, const int64_t* d_ids, int n_lists, int nq, int k, float* d_out_scores,
+                    int64_t* d_out_ids, void* stream) {
+    if (!d_scores || !d_ids || !d_out_scores || !d_out_ids) return fail(RASS_ERR_INVALID, "NULL argument");
+    if (n_lists < 1 || nq < 1 || k < 1 || k > RASS_MAX_K) return fail(RASS_ERR_INVALID, "bad n_lists / nq / k");
+    if ((int64_t)n_lists * k > rass::kMergeMaxCandidates)
+        return fail(RASS_ERR_UNSUPPORTED, "n_lists * k exceeds 8192 candidates");
+    HIP_TRY(rass::launch_merge_topk(d_scores, d_ids, n_lists, nq, k, d_out_scores, d_out_ids,
+                                    reinterpret_cast<hipStream_t>(stream)));
+    return RASS_OK;
+}
+
+int rass_normalize_rows_f32(const float* d_in, int64_t in_stride, float* d_out, int64_t out_stride, int64_t n,
+                            int dim, void* stream) {
+    if (n < 0 || dim < 1 || in_stride < dim || out_stride < dim) return fail(RASS_ERR_INVALID, "bad shape");
+    if (n > 0 && (!d_in || !d_out)) return fail(RASS_ERR_INVALID, "NULL argument");
+    HIP_TRY(rass::launch_normalize_rows_f32(d_in, in_stride, d_out, out_stride, n, dim,
+                                            reinterpret_cast<hipStream_t>(stream)));
+    return RASS_OK;
+}
+
+struct rass_timer {
+    hipEvent_t start = nullptr, stop = nullptr;
+};
+
+int rass_timer_create(rass_timer_t** out) {
+    if (!out) return fail(RASS_ERR_INVALID, "out is NULL");
+    rass_timer* t = new (std::nothrow) rass_timer();
+    if (!t) return fail(RASS_ERR_OOM, "host allocation failed");
+    HIP_TRY(hipEventCreate(&t->start));
+    HIP_TRY(hipEventCreate(&t->stop));
+    *out = t;
+    return RASS_OK;
+}
+
+void rass_timer_destroy(rass_timer_t* t) {
+    if (!t) return;
+    if (t->start) (void)hipEventDestroy(t->start);
+    if (t->stop) (void)hipEventDestroy(t->stop);
+    delete t;
+}
+
+int rass_timer_start(rass_timer_t* t, void* stream) {
+    if (!t) return fail(RASS_ERR_INVALID, "timer is NULL");
+    HIP_TRY(hipEventRecord(t->start, reinterpret_cast<hipStream_t>(stream)));
+    return RASS_OK;
+}
+
+int rass_timer_stop(rass_timer_t* t, void* stream) {
+    if (!t) return fail(RASS_ERR_INVALID, "timer is NULL");
+    HIP_TRY(hipEventRecord(t->stop, reinterpret_cast<hipStream_t>(stream)));
+    return RASS_OK;
+}
+
+int rass_timer_elapsed_ms(rass_timer_t* t, float* ms) {
+    if (!t || !ms) return fail(RASS_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipEventSynchronize(t->stop));
+    HIP_TRY(hipEventElapsedTime(ms, t->start, t->stop));
+    return RASS_OK;
+}
+
+const char* rass_scan_kernel_name(int dim, int nq) {
+    static thread_local char buf[64];
+    const int64_t stride = pad128(dim);
+    if (dim < 1 || !rass::scan_supported_stride(stride) || stride > kMaxStride || nq < 1 || nq > RASS_MAX_QBATCH)
+        return "";
+    snprintf(buf, sizeof(buf), "scan_topk_f32_kernel<%d, %d>", (int)(stride / 128), nq <= 16 ? 1 : 2);
+    return buf;
+}
+
+}  // extern "C"

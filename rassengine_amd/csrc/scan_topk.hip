@@ -1,0 +1,299 @@
+// scan_topk.hip — K1+K2 of SURVEY §8a: fused flat cosine scan + top-k for gfx950.
+//
+// Replaces the arithmetic behind OpenSearchIndexer.semantic_search's knn query
+// (reference app/main.py:1527-1560; HNSW walk in the k-NN plugin) with an exact
+// scan: S[q][row] = <Qn[q], Xn[row]> over a row-major fp32 corpus resident in HBM,
+// top-k per query under the total order (score desc, id asc).
+//
+// Shape of the kernel (one 512-thread workgroup per CU, persistent over row tiles):
+//   * a tile is 32 corpus rows; the 8 waves split the K (=dim) axis, wave w owns the
+//     contiguous column slice [w*16*CH, (w+1)*16*CH) of every row (dim_padded = 128*CH)
+//   * corpus bytes go HBM -> VGPR directly (read-once stream, GEMV-shaped: no LDS
+//     round trip), 16 B per lane, as the A operand of v_mfma_f32_16x16x4_f32:
+//     lane (m = lane&15, g = lane>>4) holds X[row0+m][slice + 16j + 4g .. +3]
+//   * the query fragments (B operand) stay in registers for the whole launch
+//   * loads are buffer loads through a per-tile descriptor, so rows past n_rows and
+//     the run-ahead prefetch of a tile past the end cost no HBM traffic (range check)
+//   * register double buffering keeps the next tile's 16 KiB per wave in flight while
+//     the current tile is multiplied: 128 KiB in flight per CU
+//   * per tile, each wave dumps its 32x(16*NT) partial scores to LDS (one barrier per
+//     tile, two LDS buffers), then wave w sums the 8 K-partials of "its" queries in a
+//     fixed order and runs the half-wave sorted-list insert (threshold filter by ballot)
+//   * at the end each workgroup writes a sorted top-k list per query; merge_topk.hip
+//     reduces [n_workgroups][nq][k] -> [nq][k]
+//
+// Numerics: v_mfma_f32_16x16x4_f32 is an exact f32 fmaf chain in k order, so a score is
+// a fixed sequence of fmaf's per K-slice followed by 7 f32 adds: independent of the grid,
+// of the shard split and of the query batch (oracle/rass_oracle.c restates that order
+// on the CPU and the GPU tests require bit-equality with it).
+//
+// Algorithmic bytes per launch (roofline.achieved in bench.py): n_rows * row_stride * 4.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.h"
+
+namespace rass {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kWaves = 8;
+constexpr int kThreads = kWaves * 64;
+constexpr int kTileRows = 32;
+constexpr int kPitch = 36;  // floats per query row of the LDS partial image (32 rows + pad)
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// One tile's A fragments for one wave: 2 M-tiles x CH chunks of 16 B per lane.
+template <int CH>
+struct TileRegs {
+    f32x4 a[2][CH];
+    int tag;
+};
+
+template <int CH>
+__device__ __forceinline__ void issue_tile_loads(TileRegs<CH>& r, const float* __restrict__ X,
+                                                 int64_t row_stride, const int32_t* __restrict__ row_tag,
+                                                 int tile, int n_tiles, int n_rows, int voff_lane) {
+    // Wave-uniform tile base and byte count: the descriptor's range check drops every
+    // lane past the end (zeros, no memory request).
+    const int row0 = tile * kTileRows;
+    int rows_here = n_rows - row0;
+    rows_here = rows_here < 0 ? 0 : (rows_here > kTileRows ? kTileRows : rows_here);
+    if (tile >= n_tiles) rows_here = 0;
+    const int64_t base_row = (tile < n_tiles) ? (int64_t)row0 : 0;
+    // The descriptor must be PROVABLY wave-uniform or hipcc wraps every buffer op in a
+    // waterfall loop: pin its inputs with readfirstlane (guide T20).
+    const uint64_t base_u = reinterpret_cast<uint64_t>(X + base_row * row_stride);
+    const uint32_t base_lo = __builtin_amdgcn_readfirstlane((uint32_t)base_u);
+    const uint32_t base_hi = __builtin_amdgcn_readfirstlane((uint32_t)(base_u >> 32));
+    float* base = reinterpret_cast<float*>(((uint64_t)base_hi << 32) | base_lo);
+    const unsigned bytes =
+        __builtin_amdgcn_readfirstlane((unsigned)rows_here * (unsigned)row_stride * 4u);
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(base, /*stride*/ 0, (int)bytes, 0x00020000);
+    // Row tags: always issued (straight-line code keeps hipcc's vmcnt counts exact); with no
+    // tag array the descriptor has zero records, so the load returns 0 and costs no traffic.
+    {
+        const bool has_tags = row_tag != nullptr;
+        const uint64_t tbase_u = has_tags ? reinterpret_cast<uint64_t>(row_tag + base_row) : base_u;
+        const uint32_t tlo = __builtin_amdgcn_readfirstlane((uint32_t)tbase_u);
+        const uint32_t thi = __builtin_amdgcn_readfirstlane((uint32_t)(tbase_u >> 32));
+        const unsigned tbytes = __builtin_amdgcn_readfirstlane(has_tags ? (unsigned)(rows_here * 4) : 0u);
+        __amdgpu_buffer_rsrc_t trsrc = __builtin_amdgcn_make_buffer_rsrc(
+            reinterpret_cast<int32_t*>(((uint64_t)thi << 32) | tlo), 0, (int)tbytes, 0x00020000);
+        r.tag = (int)__builtin_amdgcn_raw_buffer_load_b32(trsrc, (lane_id() & 31) * 4, 0, 0);
+    }
+    const int mt_step = 16 * (int)row_stride * 4;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff_lane + mt * mt_step + j * 64, 0,
+                                                            /*aux: nt*/ 2);
+            r.a[mt][j] = __builtin_bit_cast(f32x4, v);
+        }
+    }
+}
+
+template <int CH, int NT>
+__device__ __forceinline__ void multiply_tile(const TileRegs<CH>& r, const f32x4 (&qf)[NT][CH],
+                                              f32x4 (&acc)[2][NT]) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                f32x4 c = acc[mt][nt];
+                c = __builtin_amdgcn_mfma_f32_16x16x4f32(r.a[mt][j].x, qf[nt][j].x, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x4f32(r.a[mt][j].y, qf[nt][j].y, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x4f32(r.a[mt][j].z, qf[nt][j].z, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x4f32(r.a[mt][j].w, qf[nt][j].w, c, 0, 0, 0);
+                acc[mt][nt] = c;
+            }
+        }
+    }
+}
+
+// Half-wave sorted list: lanes 0..31 hold query A's best-first top-32, lanes 32..63 query B's.
+struct TopList {
+    float s;
+    int i;
+};
+
+__device__ __forceinline__ float bcast_kth(float v, int k) {
+    return __shfl(v, (lane_id() & 32) + k - 1, 64);
+}
+
+// Insert every lane's candidate (cs valid where cs > tau of its half) into the half-wave lists.
+__device__ __forceinline__ void insert_candidates(TopList& L, float& tau, float s, int row, int k) {
+    unsigned long long mask = __ballot(s > tau);
+    const int lane = lane_id();
+    const int lpos = lane & 31;
+    while (mask) {
+        const int c = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        const float cs = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), c));
+        const int ci = __builtin_amdgcn_readlane(row, c);
+        const bool mine = ((lane ^ c) & 32) == 0;
+        const bool better = (L.s > cs) || (L.s == cs && L.i < ci);
+        const unsigned long long bm = __ballot(better && mine);
+        const int pos = __builtin_popcountll(bm);
+        if (pos < k) {
+            const float us = __shfl_up(L.s, 1, 64);
+            const int ui = __shfl_up(L.i, 1, 64);
+            if (mine) {
+                if (lpos == pos) {
+                    L.s = cs;
+                    L.i = ci;
+                } else if (lpos > pos) {
+                    L.s = us;
+                    L.i = ui;
+                }
+            }
+            tau = bcast_kth(L.s, k);
+        }
+    }
+}
+
+template <int CH, int NT>
+__global__ __launch_bounds__(kThreads, 2) void scan_topk_f32_kernel(ScanArgs p) {
+    constexpr int NQ = NT * 16;
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // [2][kWaves][NQ][kPitch]
+
+    const int lane = lane_id();
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m = lane & 15, g = lane >> 4;
+    const int n_tiles = (p.n_rows + kTileRows - 1) / kTileRows;
+    const int G = gridDim.x;
+
+    // Query fragments: lane (n = m, g) holds Qn[nt*16 + n][slice + 16j + 4g .. +3].
+    f32x4 qf[NT][CH];
+    {
+        const float* qbase = p.q_padded + (int64_t)m * p.row_stride + wid * 16 * CH + 4 * g;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int j = 0; j < CH; ++j)
+                qf[nt][j] = *reinterpret_cast<const f32x4*>(qbase + (int64_t)nt * 16 * p.row_stride + 16 * j);
+    }
+    // Byte offset of this lane inside a tile: row m of M-tile 0, its 16 B of chunk 0.
+    const int voff_lane = (m * (int)p.row_stride + wid * 16 * CH + 4 * g) * 4;
+
+    // Top-k state: pass pq handles query pq*16 + (lane>>5)*8 + wid for row lane&31.
+    TopList L[NT];
+    float tau[NT];
+    int qfilt[NT];
+#pragma unroll
+    for (int pq = 0; pq < NT; ++pq) {
+        L[pq].s = -INFINITY;
+        L[pq].i = 0x7fffffff;
+        tau[pq] = -INFINITY;
+        const int q = pq * 16 + (lane >> 5) * 8 + wid;
+        qfilt[pq] = (p.q_filter != nullptr && q < p.nq) ? p.q_filter[q] : -1;
+    }
+
+    TileRegs<CH> R0, R1;
+    int t = blockIdx.x;
+    issue_tile_loads<CH>(R0, p.corpus, p.row_stride, p.row_tag, t, n_tiles, p.n_rows, voff_lane);
+
+    auto finish_tile = [&](const f32x4 (&acc)[2][NT], int tile, int tag, int buf) {
+        float* P = lds + buf * (kWaves * NQ * kPitch);
+        // dump: lane (n=m, g) holds rows 4g..4g+3 of M-tile mt for query nt*16+n
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                *reinterpret_cast<f32x4*>(P + (wid * NQ + nt * 16 + m) * kPitch + mt * 16 + 4 * g) = acc[mt][nt];
+        __syncthreads();
+        const int r = lane & 31;
+        const int row = tile * kTileRows + r;
+        bool row_ok = (tile < n_tiles) && (row < p.n_rows) && (tag != -1);
+#pragma unroll
+        for (int pq = 0; pq < NT; ++pq) {
+            const int q = pq * 16 + (lane >> 5) * 8 + wid;
+            const float* src = P + q * kPitch + r;
+            float s = src[0];
+#pragma unroll
+            for (int w = 1; w < kWaves; ++w) s += src[w * NQ * kPitch];
+            const bool ok = row_ok && (qfilt[pq] < 0 || qfilt[pq] == tag);
+            s = ok ? s : -INFINITY;
+            insert_candidates(L[pq], tau[pq], s, row, p.k);
+        }
+    };
+
+    // sched_barrier(0) after each load group: without it hipcc sinks the next tile's loads
+    // behind the MFMA block to save registers, and the prefetch is gone.
+    for (; t < n_tiles; t += 2 * G) {
+        f32x4 acc[2][NT];
+        issue_tile_loads<CH>(R1, p.corpus, p.row_stride, p.row_tag, t + G, n_tiles, p.n_rows, voff_lane);
+        __builtin_amdgcn_sched_barrier(0);
+        multiply_tile<CH, NT>(R0, qf, acc);
+        finish_tile(acc, t, R0.tag, 0);
+        issue_tile_loads<CH>(R0, p.corpus, p.row_stride, p.row_tag, t + 2 * G, n_tiles, p.n_rows, voff_lane);
+        __builtin_amdgcn_sched_barrier(0);
+        multiply_tile<CH, NT>(R1, qf, acc);
+        finish_tile(acc, t + G, R1.tag, 1);
+    }
+
+    // Per-workgroup sorted lists -> [gridDim.x][nq][k]
+    const int lpos = lane & 31;
+#pragma unroll
+    for (int pq = 0; pq < NT; ++pq) {
+        const int q = pq * 16 + (lane >> 5) * 8 + wid;
+        if (q < p.nq && lpos < p.k) {
+            const int64_t o = ((int64_t)blockIdx.x * p.nq + q) * p.k + lpos;
+            const bool filled = L[pq].i != 0x7fffffff;
+            p.part_scores[o] = filled ? L[pq].s : -INFINITY;
+            p.part_ids[o] = filled ? (p.id_base + (int64_t)L[pq].i) : (int64_t)-1;
+        }
+    }
+}
+
+template <int CH, int NT>
+static hipError_t launch_variant(const ScanArgs& a, int grid, hipStream_t stream) {
+    constexpr size_t lds_bytes = (size_t)2 * kWaves * NT * 16 * kPitch * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_topk_f32_kernel<CH, NT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((scan_topk_f32_kernel<CH, NT>), dim3(grid), dim3(kThreads), lds_bytes, stream, a);
+    return hipGetLastError();
+}
+
+template <int NT>
+static hipError_t launch_ch(int ch, const ScanArgs& a, int grid, hipStream_t stream) {
+    switch (ch) {
+        case 1: return launch_variant<1, NT>(a, grid, stream);
+        case 2: return launch_variant<2, NT>(a, grid, stream);
+        case 3: return launch_variant<3, NT>(a, grid, stream);
+        case 4: return launch_variant<4, NT>(a, grid, stream);
+        case 6: return launch_variant<6, NT>(a, grid, stream);
+        case 8: return launch_variant<8, NT>(a, grid, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+bool scan_supported_stride(int64_t row_stride) {
+    if (row_stride % 128 != 0) return false;
+    const int64_t ch = row_stride / 128;
+    return ch == 1 || ch == 2 || ch == 3 || ch == 4 || ch == 6 || ch == 8;
+}
+
+hipError_t launch_scan_topk_f32(const ScanArgs& a, int grid, hipStream_t stream) {
+    if (!scan_supported_stride(a.row_stride)) return hipErrorInvalidValue;
+    const int ch = (int)(a.row_stride / 128);
+    if (a.nq <= 16) return launch_ch<1>(ch, a, grid, stream);
+    return launch_ch<2>(ch, a, grid, stream);
+}
+
+}  // namespace rass

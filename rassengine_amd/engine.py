@@ -1,0 +1,215 @@
+"""Thin object layer over the C ABI: one ``Engine`` per process per GPU, named ``FlatIndex``
+objects that live in HBM.  Host arrays are numpy; device-resident entry points take torch
+tensors only as (pointer, shape) carriers — torch is plumbing for memory and streams here.
+"""
+from __future__ import annotations
+
+import ctypes
+import threading
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+
+from . import _native as N
+
+
+def _np_ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+class Engine:
+    """Owns one GPU's corpus slabs for the life of the process (SURVEY §8b ownership)."""
+
+    _lock = threading.Lock()
+    _singletons: Dict[Tuple[int, int], "Engine"] = {}
+
+    def __init__(self, device: int = 0, dim: int = 1024):
+        self._L = N.lib()
+        h = ctypes.c_void_p()
+        N.check("rass_engine_create", self._L.rass_engine_create(device, dim, ctypes.byref(h)))
+        self._h = h
+        self.device = device
+        self.dim = dim
+        self._indices: Dict[str, "FlatIndex"] = {}
+
+    @classmethod
+    def get(cls, device: int = 0, dim: int = 1024) -> "Engine":
+        """Process-global engine for (device, dim): OpenSearchIndexer is built per request
+        (reference app/main.py:2802), so lookups must be O(1)."""
+        with cls._lock:
+            eng = cls._singletons.get((device, dim))
+            if eng is None:
+                eng = cls._singletons[(device, dim)] = Engine(device, dim)
+            return eng
+
+    def close(self) -> None:
+        if self._h:
+            with Engine._lock:
+                for key, eng in list(Engine._singletons.items()):
+                    if eng is self:
+                        del Engine._singletons[key]
+            self._L.rass_engine_destroy(self._h)
+            self._h = None
+            self._indices.clear()
+
+    def __del__(self):  # pragma: no cover - interpreter shutdown ordering
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_ptr: Optional[int]) -> None:
+        """Run engine work on a caller-owned hipStream_t (e.g. torch's current stream)."""
+        N.check("rass_engine_set_stream", self._L.rass_engine_set_stream(self._h, ctypes.c_void_p(stream_ptr or 0)))
+
+    def synchronize(self) -> None:
+        N.check("rass_engine_synchronize", self._L.rass_engine_synchronize(self._h))
+
+    def open_index(self, name: str, capacity_rows: int = 0) -> "FlatIndex":
+        """Look up or create the named cosine index (ensure_index_exists, app/main.py:350)."""
+        idx = self._indices.get(name)
+        if idx is not None:
+            return idx
+        h = ctypes.c_void_p()
+        N.check("rass_index_open",
+                self._L.rass_index_open(self._h, name.encode(), N.RASS_F32, int(capacity_rows), ctypes.byref(h)))
+        idx = FlatIndex(self, name, h)
+        self._indices[name] = idx
+        return idx
+
+    def drop_index(self, name: str) -> None:
+        N.check("rass_index_drop", self._L.rass_index_drop(self._h, name.encode()))
+        self._indices.pop(name, None)
+
+    def load_index(self, name: str, path: str) -> "FlatIndex":
+        h = ctypes.c_void_p()
+        N.check("rass_index_load", self._L.rass_index_load(self._h, name.encode(), path.encode(), ctypes.byref(h)))
+        idx = FlatIndex(self, name, h)
+        self._indices[name] = idx
+        return idx
+
+
+class FlatIndex:
+    """Row-major fp32 cosine index resident in HBM; row ids are insertion ordinals."""
+
+    def __init__(self, engine: Engine, name: str, handle: ctypes.c_void_p):
+        self.engine = engine
+        self.name = name
+        self._h = handle
+        self._L = engine._L
+
+    # ---- bookkeeping
+    @property
+    def count(self) -> int:
+        """Live rows (OpenSearchIndexer.has_any_data's count, app/main.py:1475)."""
+        return int(self._L.rass_index_count(self._h))
+
+    @property
+    def rows(self) -> int:
+        return int(self._L.rass_index_rows(self._h))
+
+    @property
+    def dim(self) -> int:
+        return int(self._L.rass_index_dim(self._h))
+
+    @property
+    def row_stride(self) -> int:
+        return int(self._L.rass_index_row_stride(self._h))
+
+    # ---- write path
+    def add(self, vecs: np.ndarray, tags: Optional[np.ndarray] = None, normalize: bool = True) -> int:
+        """Append rows (host fp32 [n, dim]); returns the id of the first appended row."""
+        v = np.ascontiguousarray(vecs, dtype=np.float32)
+        if v.ndim != 2 or v.shape[1] != self.dim:
+            raise ValueError(f"expected [n, {self.dim}] vectors, got {v.shape}")
+        t = None
+        if tags is not None:
+            t = np.ascontiguousarray(tags, dtype=np.int32)
+            if t.shape != (v.shape[0],):
+                raise ValueError("tags must be one int32 per row")
+        first = ctypes.c_int64(-1)
+        N.check("rass_index_add", self._L.rass_index_add(self._h, _np_ptr(v), _np_ptr(t), v.shape[0],
+                                                        1 if normalize else 0, ctypes.byref(first)))
+        return int(first.value)
+
+    def add_device(self, d_vecs_ptr: int, n: int, d_tags_ptr: int = 0, normalize: bool = True) -> int:
+        first = ctypes.c_int64(-1)
+        N.check("rass_index_add_device",
+                self._L.rass_index_add_device(self._h, ctypes.c_void_p(d_vecs_ptr), ctypes.c_void_p(d_tags_ptr or 0),
+                                              int(n), 1 if normalize else 0, ctypes.byref(first)))
+        return int(first.value)
+
+    def fill_synthetic(self, n: int, seed: int, row_id_base: int = 0) -> None:
+        N.check("rass_index_fill_synthetic",
+                self._L.rass_index_fill_synthetic(self._h, int(n), ctypes.c_uint64(seed), int(row_id_base)))
+
+    def delete(self, row: int) -> None:
+        N.check("rass_index_delete", self._L.rass_index_delete(self._h, int(row)))
+
+    def get_row(self, row: int) -> np.ndarray:
+        out = np.empty(self.dim, dtype=np.float32)
+        N.check("rass_index_get_row", self._L.rass_index_get_row(self._h, int(row), _np_ptr(out)))
+        return out
+
+    def save(self, path: str) -> None:
+        N.check("rass_index_save", self._L.rass_index_save(self._h, path.encode()))
+
+    # ---- read path
+    def search(self, queries: np.ndarray, k: int, q_filter: Optional[np.ndarray] = None
+               ) -> Tuple[np.ndarray, np.ndarray]:
+        """Exact cosine top-k.  Returns (scores f32 [nq,k], ids i64 [nq,k]); raw cosine, best
+        first, ties by id ascending, (-inf, -1) padding."""
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        if q.ndim != 2 or q.shape[1] != self.dim:
+            raise ValueError(f"expected [nq, {self.dim}] queries, got {q.shape}")
+        f = None
+        if q_filter is not None:
+            f = np.ascontiguousarray(q_filter, dtype=np.int32)
+            if f.shape != (q.shape[0],):
+                raise ValueError("q_filter must be one int32 per query")
+        out_s = np.empty((q.shape[0], k), dtype=np.float32)
+        out_i = np.empty((q.shape[0], k), dtype=np.int64)
+        N.check("rass_index_search", self._L.rass_index_search(self._h, _np_ptr(q), q.shape[0], int(k), _np_ptr(f),
+                                                              _np_ptr(out_s), _np_ptr(out_i)))
+        return out_s, out_i
+
+    def search_device(self, d_queries_ptr: int, nq: int, k: int, d_out_scores_ptr: int, d_out_ids_ptr: int,
+                      id_base: int = 0, d_q_filter_ptr: int = 0) -> None:
+        """Async, device-resident variant (multi-GPU path, benchmark); nq <= 32."""
+        N.check("rass_index_search_device",
+                self._L.rass_index_search_device(self._h, ctypes.c_void_p(d_queries_ptr), int(nq), int(k),
+                                                 ctypes.c_void_p(d_q_filter_ptr or 0), int(id_base),
+                                                 ctypes.c_void_p(d_out_scores_ptr), ctypes.c_void_p(d_out_ids_ptr)))
+
+
+class HipTimer:
+    """hipEvent pair on an explicit stream (rass_timer_*)."""
+
+    def __init__(self):
+        self._L = N.lib()
+        h = ctypes.c_void_p()
+        N.check("rass_timer_create", self._L.rass_timer_create(ctypes.byref(h)))
+        self._h = h
+
+    def start(self, stream_ptr: int = 0) -> None:
+        N.check("rass_timer_start", self._L.rass_timer_start(self._h, ctypes.c_void_p(stream_ptr or 0)))
+
+    def stop(self, stream_ptr: int = 0) -> None:
+        N.check("rass_timer_stop", self._L.rass_timer_stop(self._h, ctypes.c_void_p(stream_ptr or 0)))
+
+    def elapsed_ms(self) -> float:
+        ms = ctypes.c_float(0)
+        N.check("rass_timer_elapsed_ms", self._L.rass_timer_elapsed_ms(self._h, ctypes.byref(ms)))
+        return float(ms.value)
+
+    def __del__(self):  # pragma: no cover
+        try:
+            if self._h:
+                self._L.rass_timer_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+def scan_kernel_name(dim: int, nq: int) -> str:
+    return N.lib().rass_scan_kernel_name(int(dim), int(nq)).decode()

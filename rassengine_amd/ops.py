@@ -1,0 +1,101 @@
+"""Stateless launchers on torch device tensors (pointer carriers): the fused scan+top-k,
+the top-k merge and the reference normalise.  Everything runs on torch's current stream so
+that ``torch.cuda.Event`` / ``torch.distributed`` ordering just works.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Tuple
+
+import torch
+
+from . import _native as N
+
+_workspaces = {}
+
+
+def _stream_ptr() -> int:
+    return int(torch.cuda.current_stream().cuda_stream)
+
+
+def _ws(device: torch.device, nbytes: int) -> torch.Tensor:
+    key = (device.index, _stream_ptr())
+    w = _workspaces.get(key)
+    if w is None or w.numel() < nbytes:
+        w = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _workspaces[key] = w
+    return w
+
+
+def _req(t: torch.Tensor, dtype: torch.dtype, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise ValueError(f"{name} must live in HBM (a cuda tensor); rassengine_amd has no CPU path")
+    if t.dtype != dtype:
+        raise ValueError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    return t
+
+
+def normalize_rows(x: torch.Tensor, out_stride: Optional[int] = None) -> torch.Tensor:
+    """out = x / (||x|| + 1e-9) row-wise (reference app/main.py:1249-1251), zero padded to
+    ``out_stride`` columns."""
+    _req(x, torch.float32, "x")
+    n, d = x.shape
+    stride = d if out_stride is None else int(out_stride)
+    out = torch.empty((n, stride), dtype=torch.float32, device=x.device)
+    N.check("rass_normalize_rows_f32",
+            N.lib().rass_normalize_rows_f32(ctypes.c_void_p(x.data_ptr()), d, ctypes.c_void_p(out.data_ptr()),
+                                            stride, n, d, ctypes.c_void_p(_stream_ptr())))
+    return out
+
+
+def scan_topk(corpus: torch.Tensor, queries: torch.Tensor, k: int, *, dim: Optional[int] = None,
+              row_tag: Optional[torch.Tensor] = None, q_filter: Optional[torch.Tensor] = None,
+              id_base: int = 0, n_rows: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Exact cosine top-k of ``queries`` [nq<=32, dim] over a normalised fp32 ``corpus``
+    [n, row_stride] (row_stride a multiple of 128, zero padded past ``dim``).
+
+    Returns (scores f32 [nq,k], ids i64 [nq,k]) on the device, async on the current stream.
+    """
+    _req(corpus, torch.float32, "corpus")
+    _req(queries, torch.float32, "queries")
+    stride = corpus.shape[1]
+    d = int(dim) if dim is not None else queries.shape[1]
+    if queries.shape[1] != d:
+        raise ValueError("queries must be [nq, dim]")
+    nq = queries.shape[0]
+    n = corpus.shape[0] if n_rows is None else int(n_rows)
+    if row_tag is not None:
+        _req(row_tag, torch.int32, "row_tag")
+    if q_filter is not None:
+        _req(q_filter, torch.int32, "q_filter")
+    L = N.lib()
+    ws_bytes = int(L.rass_scan_workspace_bytes(nq, k))
+    if ws_bytes == 0:
+        raise ValueError(f"unsupported (nq={nq}, k={k}); nq<=32, k<=32")
+    ws = _ws(corpus.device, ws_bytes)
+    out_s = torch.empty((nq, k), dtype=torch.float32, device=corpus.device)
+    out_i = torch.empty((nq, k), dtype=torch.int64, device=corpus.device)
+    N.check("rass_scan_topk_f32",
+            L.rass_scan_topk_f32(ctypes.c_void_p(corpus.data_ptr()), n, d, stride,
+                                 ctypes.c_void_p(row_tag.data_ptr() if row_tag is not None else 0),
+                                 ctypes.c_void_p(queries.data_ptr()), nq,
+                                 ctypes.c_void_p(q_filter.data_ptr() if q_filter is not None else 0), k,
+                                 int(id_base), ctypes.c_void_p(out_s.data_ptr()), ctypes.c_void_p(out_i.data_ptr()),
+                                 ctypes.c_void_p(ws.data_ptr()), ws.numel(), ctypes.c_void_p(_stream_ptr())))
+    return out_s, out_i
+
+
+def topk_merge(list_scores: torch.Tensor, list_ids: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Merge [n_lists, nq, k] candidate lists -> [nq, k] under (score desc, id asc)."""
+    _req(list_scores, torch.float32, "list_scores")
+    _req(list_ids, torch.int64, "list_ids")
+    n_lists, nq, k = list_scores.shape
+    out_s = torch.empty((nq, k), dtype=torch.float32, device=list_scores.device)
+    out_i = torch.empty((nq, k), dtype=torch.int64, device=list_scores.device)
+    N.check("rass_topk_merge",
+            N.lib().rass_topk_merge(ctypes.c_void_p(list_scores.data_ptr()), ctypes.c_void_p(list_ids.data_ptr()),
+                                    n_lists, nq, k, ctypes.c_void_p(out_s.data_ptr()),
+                                    ctypes.c_void_p(out_i.data_ptr()), ctypes.c_void_p(_stream_ptr())))
+    return out_s, out_i

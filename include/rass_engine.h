@@ -73,8 +73,12 @@ void rass_engine_destroy(rass_engine_t* eng);
 int rass_engine_dim(const rass_engine_t* eng);
 int rass_engine_device(const rass_engine_t* eng);
 /* Run all engine work on a caller-owned hipStream_t (e.g. torch's current
- * stream) instead of the engine's own.  NULL restores the engine stream. */
+ * stream).  The value is taken literally: NULL is HIP's legacy null stream. */
 int rass_engine_set_stream(rass_engine_t* eng, void* stream);
+/* Go back to the engine's own (non-blocking) stream. */
+int rass_engine_reset_stream(rass_engine_t* eng);
+/* The hipStream_t engine work is currently enqueued on. */
+void* rass_engine_get_stream(rass_engine_t* eng);
 int rass_engine_synchronize(rass_engine_t* eng);
 
 /* ----------------------------------------------------------------- index */
@@ -154,11 +158,27 @@ int rass_index_fill_synthetic(rass_index_t* idx, int64_t n, uint64_t seed,
 /* Bytes of scratch the scan needs for (nq, k). */
 size_t rass_scan_workspace_bytes(int nq, int k);
 
-/* K1+K2: fused flat cosine scan + per-workgroup top-k + merge over a
- * row-major fp32 corpus slab in HBM.  d_corpus rows must already be
- * normalised; d_queries (nq x dim) are normalised by the launcher.
- * row_stride is in elements and must be a multiple of 128 with zero padding
- * beyond dim.  d_row_tag / d_q_filter may be NULL. */
+/* Corpus layout in HBM ("tile16"): rows live in 16-row blocks of 16*row_stride
+ * floats; inside a block, chunk j (columns 16j..16j+15) of the 16 rows is one
+ * contiguous 1 KiB in MFMA lane order, i.e. element (row r, col c) sits at
+ *   (r>>4)*16*row_stride + (c>>4)*256 + ((((c>>2)&3)*16 + (r&15))*4) + (c&3)
+ * floats from the slab base.  Every wave-level load of the scan is then a fully
+ * coalesced 1 KiB burst that already is the MFMA A operand.  row_stride = dim
+ * rounded up to 128, zero padded; a slab holds whole blocks (rows rounded up
+ * to 16).  The two converters below move between row-major and tile16. */
+int rass_pack_rows_f32(const float* d_in, int64_t in_stride, float* d_packed,
+                       int64_t row_stride, int64_t first_row, int64_t n, int dim,
+                       int normalize, void* stream);
+int rass_unpack_rows_f32(const float* d_packed, int64_t row_stride,
+                         int64_t first_row, int64_t n, int dim, float* d_out,
+                         int64_t out_stride, void* stream);
+
+/* K1+K2: fused flat cosine scan + per-workgroup top-k + merge over a tile16
+ * fp32 corpus slab in HBM.  Rows must already be normalised (rass_pack_rows_f32
+ * with normalize=1 does both); d_queries (nq x dim, row-major) are normalised
+ * by the launcher.  row_stride is in elements, a multiple of 128 with zero
+ * padding beyond dim; the slab must hold ceil(n_rows/16) whole blocks.
+ * d_row_tag / d_q_filter may be NULL. */
 int rass_scan_topk_f32(const float* d_corpus, int64_t n_rows, int dim,
                        int64_t row_stride, const int32_t* d_row_tag,
                        const float* d_queries, int nq,

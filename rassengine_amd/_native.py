@@ -40,6 +40,8 @@ SIGNATURES = {
     "rass_engine_dim": (ctypes.c_int, [ctypes.c_void_p]),
     "rass_engine_device": (ctypes.c_int, [ctypes.c_void_p]),
     "rass_engine_set_stream": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "rass_engine_reset_stream": (ctypes.c_int, [ctypes.c_void_p]),
+    "rass_engine_get_stream": (ctypes.c_void_p, [ctypes.c_void_p]),
     "rass_engine_synchronize": (ctypes.c_int, [ctypes.c_void_p]),
     "rass_index_open": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int64, c_void_pp]),
     "rass_index_drop": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p]),
@@ -67,6 +69,11 @@ SIGNATURES = {
                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                           ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
                                           ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "rass_pack_rows_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
+                                          ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_void_p]),
+    "rass_unpack_rows_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                            ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
     "rass_topk_merge": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "rass_normalize_rows_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,

@@ -129,13 +129,14 @@ int set_device(const rass_engine* eng) {
 int index_reserve(rass_index* idx, int64_t need_rows) {
     if (need_rows <= idx->capacity) return RASS_OK;
     int64_t cap = std::max<int64_t>(idx->capacity * 2, std::max<int64_t>(need_rows, 1024));
+    cap = (cap + 15) / 16 * 16;  // tile16: whole 16-row blocks
     float* nrows = nullptr;
     int32_t* ntags = nullptr;
     hipStream_t st = idx->eng->stream;
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&nrows), (size_t)cap * idx->stride * sizeof(float));
     if (e != hipSuccess) {
         // retry with the exact size before giving up
-        cap = need_rows;
+        cap = (need_rows + 15) / 16 * 16;
         e = hipMalloc(reinterpret_cast<void**>(&nrows), (size_t)cap * idx->stride * sizeof(float));
         if (e != hipSuccess) return fail(RASS_ERR_OOM, "index grow: hipMalloc of corpus slab failed");
     }
@@ -144,8 +145,13 @@ int index_reserve(rass_index* idx, int64_t need_rows) {
         (void)hipFree(nrows);
         return fail(RASS_ERR_OOM, "index grow: hipMalloc of tag array failed");
     }
+    // rows of a block past the last appended one must read as finite zeros (they are masked,
+    // never ranked): zero the part of the slab the copy below does not overwrite
+    const int64_t used_rows = (idx->rows + 15) / 16 * 16;
+    HIP_TRY(hipMemsetAsync(nrows + used_rows * idx->stride, 0, (size_t)(cap - used_rows) * idx->stride * sizeof(float),
+                           st));
     if (idx->rows > 0) {
-        HIP_TRY(hipMemcpyAsync(nrows, idx->d_rows, (size_t)idx->rows * idx->stride * sizeof(float),
+        HIP_TRY(hipMemcpyAsync(nrows, idx->d_rows, (size_t)used_rows * idx->stride * sizeof(float),
                                hipMemcpyDeviceToDevice, st));
         HIP_TRY(hipMemcpyAsync(ntags, idx->d_tags, (size_t)idx->rows * sizeof(int32_t), hipMemcpyDeviceToDevice,
                                st));
@@ -179,8 +185,7 @@ int scan_launch(const float* d_corpus, int64_t n_rows, int64_t stride, const int
     const int nq_pad = nq <= 16 ? 16 : 32;
 
     // a4 on the query side (reference app/main.py:1536-1537), written zero-padded.
-    HIP_TRY(rass::launch_normalize_rows_f32(d_queries, q_stride, q_padded, stride, nq, q_dim, st));
-    if (nq_pad > nq) HIP_TRY(rass::launch_zero_rows(q_padded + (int64_t)nq * stride, stride, nq_pad - nq, st));
+    HIP_TRY(rass::launch_normalize_rows_f32(d_queries, q_stride, q_padded, stride, nq, q_dim, st, nq_pad));
 
     const int64_t n_tiles = (n_rows + 31) / 32;
     int grid = (int)std::min<int64_t>(std::max<int64_t>(n_tiles, 1), std::min(n_cus, kMaxGrid));
@@ -278,9 +283,20 @@ int rass_engine_set_stream(rass_engine_t* eng, void* stream) {
     std::lock_guard<std::mutex> lk(eng->mu);
     HIP_TRY(hipSetDevice(eng->device));
     HIP_TRY(hipStreamSynchronize(eng->stream));
-    eng->stream = stream ? reinterpret_cast<hipStream_t>(stream) : eng->own_stream;
+    eng->stream = reinterpret_cast<hipStream_t>(stream);
     return RASS_OK;
 }
+
+int rass_engine_reset_stream(rass_engine_t* eng) {
+    if (!eng) return fail(RASS_ERR_INVALID, "engine is NULL");
+    std::lock_guard<std::mutex> lk(eng->mu);
+    HIP_TRY(hipSetDevice(eng->device));
+    HIP_TRY(hipStreamSynchronize(eng->stream));
+    eng->stream = eng->own_stream;
+    return RASS_OK;
+}
+
+void* rass_engine_get_stream(rass_engine_t* eng) { return eng ? reinterpret_cast<void*>(eng->stream) : nullptr; }
 
 int rass_engine_synchronize(rass_engine_t* eng) {
     if (!eng) return fail(RASS_ERR_INVALID, "engine is NULL");
@@ -367,7 +383,6 @@ static int add_common(rass_index_t* idx, const float* vecs, const int32_t* tags,
     const int dim = idx->dim;
     for (int64_t done = 0; done < n;) {
         const int64_t m = std::min<int64_t>(kStageRows, n - done);
-        float* dst = idx->d_rows + (idx->rows + done) * idx->stride;
         int32_t* tdst = idx->d_tags + idx->rows + done;
         const float* src = vecs + done * dim;
         const float* dsrc = src;
@@ -375,13 +390,8 @@ static int add_common(rass_index_t* idx, const float* vecs, const int32_t* tags,
             HIP_TRY(hipMemcpyAsync(eng->d_stage, src, (size_t)m * dim * sizeof(float), hipMemcpyHostToDevice, st));
             dsrc = eng->d_stage;
         }
-        if (normalize) {
-            HIP_TRY(rass::launch_normalize_rows_f32(dsrc, dim, dst, idx->stride, m, dim, st));
-        } else {
-            if (idx->stride != dim) HIP_TRY(rass::launch_zero_rows(dst, idx->stride, (int)m, st));
-            HIP_TRY(hipMemcpy2DAsync(dst, (size_t)idx->stride * sizeof(float), dsrc, (size_t)dim * sizeof(float),
-                                     (size_t)dim * sizeof(float), (size_t)m, hipMemcpyDeviceToDevice, st));
-        }
+        HIP_TRY(rass::launch_pack_rows_tile16(dsrc, dim, idx->d_rows, idx->stride, idx->rows + done, m, dim,
+                                              normalize ? 1 : 0, st));
         if (tags) {
             HIP_TRY(hipMemcpyAsync(tdst, tags + done, (size_t)m * sizeof(int32_t),
                                    device_src ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
@@ -430,9 +440,13 @@ int rass_index_get_row(rass_index_t* idx, int64_t row, float* out) {
     int rc = set_device(idx->eng);
     if (rc != RASS_OK) return rc;
     hipStream_t st = idx->eng->stream;
-    HIP_TRY(hipMemcpyAsync(out, idx->d_rows + row * idx->stride, (size_t)idx->dim * sizeof(float),
-                           hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    {
+        std::lock_guard<std::mutex> elk(idx->eng->mu);  // d_stage is shared engine scratch
+        HIP_TRY(rass::launch_unpack_rows_tile16(idx->d_rows, idx->stride, row, 1, idx->dim, idx->eng->d_stage,
+                                                idx->dim, st));
+        HIP_TRY(hipMemcpyAsync(out, idx->eng->d_stage, (size_t)idx->dim * sizeof(float), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
     return RASS_OK;
 }
 
@@ -522,9 +536,11 @@ int rass_index_save(rass_index_t* idx, const char* path) {
     std::vector<float> buf((size_t)kStageRows * idx->dim);
     for (int64_t r = 0; ok && r < idx->rows; r += kStageRows) {
         const int64_t m = std::min<int64_t>(kStageRows, idx->rows - r);
-        hipError_t e = hipMemcpy2DAsync(buf.data(), (size_t)idx->dim * 4, idx->d_rows + r * idx->stride,
-                                        (size_t)idx->stride * 4, (size_t)idx->dim * 4, (size_t)m,
-                                        hipMemcpyDeviceToHost, st);
+        std::lock_guard<std::mutex> elk(idx->eng->mu);  // d_stage is shared engine scratch
+        hipError_t e = rass::launch_unpack_rows_tile16(idx->d_rows, idx->stride, r, m, idx->dim, idx->eng->d_stage,
+                                                       idx->dim, st);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(buf.data(), idx->eng->d_stage, (size_t)m * idx->dim * 4, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) {
             fclose(f);
@@ -630,8 +646,7 @@ int rass_index_fill_synthetic(rass_index_t* idx, int64_t n, uint64_t seed, int64
         if (rc != RASS_OK) return rc;
     }
     hipStream_t st = eng->stream;
-    HIP_TRY(rass::launch_fill_synthetic_f32(idx->d_rows + idx->rows * idx->stride, idx->stride, n, idx->dim, seed,
-                                            row_id_base + idx->rows, st));
+    HIP_TRY(rass::launch_fill_synthetic_f32(idx->d_rows, idx->stride, idx->rows, n, idx->dim, seed, row_id_base, st));
     HIP_TRY(rass::launch_fill_i32(idx->d_tags + idx->rows, n, 0, st));
     idx->rows += n;
     idx->host_deleted.resize((size_t)((idx->rows + 7) / 8), 0);
@@ -655,6 +670,26 @@ int rass_scan_topk_f32(const float* d_corpus, int64_t n_rows, int dim, int64_t r
     return scan_launch(corpus, n_rows, row_stride, d_row_tag, d_queries, dim, dim, nq, d_q_filter, k, id_base,
                        d_out_scores, d_out_ids, reinterpret_cast<unsigned char*>(d_workspace), workspace_bytes,
                        device_cus(dev), reinterpret_cast<hipStream_t>(stream));
+}
+
+int rass_pack_rows_f32(const float* d_in, int64_t in_stride, float* d_packed, int64_t row_stride, int64_t first_row,
+                       int64_t n, int dim, int normalize, void* stream) {
+    if (n < 0 || dim < 1 || in_stride < dim || row_stride < dim || row_stride % 128 != 0 || first_row < 0)
+        return fail(RASS_ERR_INVALID, "bad shape");
+    if (n > 0 && (!d_in || !d_packed)) return fail(RASS_ERR_INVALID, "NULL argument");
+    HIP_TRY(rass::launch_pack_rows_tile16(d_in, in_stride, d_packed, row_stride, first_row, n, dim, normalize ? 1 : 0,
+                                          reinterpret_cast<hipStream_t>(stream)));
+    return RASS_OK;
+}
+
+int rass_unpack_rows_f32(const float* d_packed, int64_t row_stride, int64_t first_row, int64_t n, int dim,
+                         float* d_out, int64_t out_stride, void* stream) {
+    if (n < 0 || dim < 1 || out_stride < dim || row_stride < dim || row_stride % 128 != 0 || first_row < 0)
+        return fail(RASS_ERR_INVALID, "bad shape");
+    if (n > 0 && (!d_out || !d_packed)) return fail(RASS_ERR_INVALID, "NULL argument");
+    HIP_TRY(rass::launch_unpack_rows_tile16(d_packed, row_stride, first_row, n, dim, d_out, out_stride,
+                                            reinterpret_cast<hipStream_t>(stream)));
+    return RASS_OK;
 }
 
 int rass_topk_merge(const float* d_scores, const int64_t* d_ids, int n_lists, int nq, int k, float* d_out_scores,

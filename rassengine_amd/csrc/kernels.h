@@ -8,7 +8,7 @@
 namespace rass {
 
 struct ScanArgs {
-    const float* corpus;      // [n_rows][row_stride] fp32, rows L2-normalised, zero padded past dim
+    const float* corpus;      // tile16-packed fp32 slab (see below), rows L2-normalised, zero padded past dim
     const int32_t* row_tag;   // [n_rows] or nullptr; -1 = tombstone, >= 0 = patientId code
     const float* q_padded;    // [16*NT][row_stride] normalised queries, zero rows past nq
     const int32_t* q_filter;  // [nq] or nullptr; -1 = no filter
@@ -29,17 +29,35 @@ constexpr int kMergeMaxCandidates = 8192;
 hipError_t launch_merge_topk(const float* scores, const int64_t* ids, int n_lists, int nq, int k,
                              float* out_scores, int64_t* out_ids, hipStream_t stream);
 
-// out[r][0..dim) = in[r] / (||in[r]|| + 1e-9); out[r][dim..out_stride) = 0.
+// out[r][0..dim) = in[r] / (||in[r]|| + 1e-9); out[r][dim..out_stride) = 0 for r < n;
+// rows [n, n_total) of out are zero-filled (query padding), all in one launch.
 hipError_t launch_normalize_rows_f32(const float* in, int64_t in_stride, float* out, int64_t out_stride,
-                                     int64_t n, int dim, hipStream_t stream);
+                                     int64_t n, int dim, hipStream_t stream, int64_t n_total = 0);
 
 // Zero `n_pad_rows` rows of `stride` floats starting at `dst` (query padding).
 hipError_t launch_zero_rows(float* dst, int64_t stride, int n_rows, hipStream_t stream);
 
-// Synthetic corpus: rows [0,n) of out get iid N(0,1) from Philox4x32-10 keyed by
-// (seed, row_id_base + r, col), then L2-normalised in place; padding zeroed.
-hipError_t launch_fill_synthetic_f32(float* out, int64_t stride, int64_t n, int dim, uint64_t seed,
-                                     int64_t row_id_base, hipStream_t stream);
+// ---- "tile16" corpus layout (what the scan kernel streams) ---------------------------------
+// Rows live in 16-row blocks of 16*stride floats.  Inside block b, chunk j (columns
+// 16j..16j+15) of the 16 rows is ONE contiguous 1 KiB in MFMA lane order:
+//   element (row r, col c) -> (r>>4)*16*stride + (c>>4)*256 + ((((c>>2)&3)*16 + (r&15))*4) + (c&3)
+// so a wave's `base + lane*16 B` load is fully coalesced AND already is the A operand of
+// v_mfma_f32_16x16x4_f32 (lane = g*16 + m holds row m, k-group g).  A slab holds whole blocks.
+inline int64_t tile16_offset(int64_t row, int64_t col, int64_t stride) {
+    return (row >> 4) * 16 * stride + (col >> 4) * 256 + ((((col >> 2) & 3) * 16 + (row & 15)) * 4) + (col & 3);
+}
+
+// packed rows [first_row, first_row+n) <- in[0..n) row-major; optional reference normalise.
+hipError_t launch_pack_rows_tile16(const float* in, int64_t in_stride, float* packed, int64_t stride,
+                                   int64_t first_row, int64_t n, int dim, int normalize, hipStream_t stream);
+// out[0..n) row-major <- packed rows [first_row, first_row+n).
+hipError_t launch_unpack_rows_tile16(const float* packed, int64_t stride, int64_t first_row, int64_t n, int dim,
+                                     float* out, int64_t out_stride, hipStream_t stream);
+
+// Synthetic corpus: packed rows [first_row, first_row+n) get iid N(0,1) from Philox4x32-10
+// keyed by (seed, row_id_base + row, col/4), L2-normalised; padding columns zero.
+hipError_t launch_fill_synthetic_f32(float* packed, int64_t stride, int64_t first_row, int64_t n, int dim,
+                                     uint64_t seed, int64_t row_id_base, hipStream_t stream);
 
 hipError_t launch_fill_i32(int32_t* dst, int64_t n, int32_t value, hipStream_t stream);
 

@@ -6,8 +6,11 @@
 // RCCL all-gather, gives exactly the single-scan result.  This is the analogue of
 // OpenSearch's shard -> coordinator top-k merge (reference SHARD_COUNT, app/main.py:89).
 //
-// One 1024-thread workgroup per query; the candidates are bitonic-sorted in LDS
-// (<= 8192 candidates = 96 KiB).  A few microseconds next to a >= 600 us scan.
+// Wavefront bitonic top-k: one workgroup per query, 16 waves.  A wave pulls 64 candidates
+// at a time, sorts them in registers with a 21-stage shuffle network (no LDS, no barrier),
+// and folds them into its running best-32 with a 6-stage bitonic merge (running list in
+// lanes 0..31, the new group's best 32 reversed into lanes 32..63).  The 16 per-wave lists
+// meet once in LDS and wave 0 folds them the same way.  k <= 32.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -16,91 +19,139 @@
 
 namespace rass {
 
-constexpr int kMergeThreads = 1024;
+constexpr int kMergeWaves = 16;
+constexpr int kMergeThreads = kMergeWaves * 64;
+constexpr int64_t kWorstId = 0x7fffffffffffffffLL;
 
-__device__ __forceinline__ bool cand_better(float sa, int64_t ia, float sb, int64_t ib) {
-    return (sa > sb) || (sa == sb && ia < ib);
+struct Cand {
+    float s;
+    int64_t id;
+};
+
+__device__ __forceinline__ bool cand_better(const Cand& a, const Cand& b) {
+    return (a.s > b.s) || (a.s == b.s && a.id < b.id);
+}
+
+__device__ __forceinline__ Cand shfl_xor_cand(const Cand& c, int mask) {
+    Cand o;
+    o.s = __shfl_xor(c.s, mask, 64);
+    const int lo = __shfl_xor((int)(c.id & 0xffffffffLL), mask, 64);
+    const int hi = __shfl_xor((int)(c.id >> 32), mask, 64);
+    o.id = ((int64_t)hi << 32) | (uint32_t)lo;
+    return o;
+}
+
+__device__ __forceinline__ Cand shfl_cand(const Cand& c, int src) {
+    Cand o;
+    o.s = __shfl(c.s, src, 64);
+    const int lo = __shfl((int)(c.id & 0xffffffffLL), src, 64);
+    const int hi = __shfl((int)(c.id >> 32), src, 64);
+    o.id = ((int64_t)hi << 32) | (uint32_t)lo;
+    return o;
+}
+
+// compare-exchange with lane ^ stride; keep the better one when keep_better
+__device__ __forceinline__ void cmpx(Cand& c, int stride, bool keep_better) {
+    const Cand o = shfl_xor_cand(c, stride);
+    const bool mine_better = cand_better(c, o);
+    if (mine_better != keep_better) c = o;
+}
+
+// full bitonic sort of the wave's 64 candidates, best first
+__device__ __forceinline__ void wave_sort64(Cand& c, int lane) {
+#pragma unroll
+    for (int size = 2; size <= 64; size <<= 1) {
+#pragma unroll
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            const bool best_first = (lane & size) == 0;  // size == 64: always true
+            const bool lower = (lane & stride) == 0;
+            cmpx(c, stride, best_first == lower);
+        }
+    }
+}
+
+// lanes 0..31 sorted best-first, lanes 32..63 sorted worst-first (a bitonic sequence)
+// -> whole wave sorted best-first
+__device__ __forceinline__ void wave_bitonic_merge64(Cand& c, int lane) {
+#pragma unroll
+    for (int stride = 32; stride > 0; stride >>= 1) cmpx(c, stride, (lane & stride) == 0);
+}
+
+// fold a sorted-best-first 64 group (only its best 32 matter) into the running list
+__device__ __forceinline__ void fold_group(Cand& run, const Cand& grp_sorted, int lane) {
+    // lane 32+i takes the group's element 31-i (reversed), lanes 0..31 keep the running list
+    const Cand rev = shfl_cand(grp_sorted, 63 - lane);
+    Cand c = (lane < 32) ? run : rev;
+    wave_bitonic_merge64(c, lane);
+    run = c;
 }
 
 __global__ __launch_bounds__(kMergeThreads) void merge_topk_kernel(const float* __restrict__ scores,
                                                                    const int64_t* __restrict__ ids, int n_lists,
-                                                                   int nq, int k, int P,
-                                                                   float* __restrict__ out_scores,
+                                                                   int nq, int k, float* __restrict__ out_scores,
                                                                    int64_t* __restrict__ out_ids) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int64_t* sid = reinterpret_cast<int64_t*>(smem);       // [P]
-    float* ssc = reinterpret_cast<float*>(smem + (size_t)P * 8);  // [P]
+    __shared__ float sh_s[kMergeWaves * 32];
+    __shared__ int64_t sh_i[kMergeWaves * 32];
     const int q = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
     const int n = n_lists * k;
-    constexpr int64_t kWorstId = 0x7fffffffffffffffLL;
 
-    for (int e = threadIdx.x; e < P; e += kMergeThreads) {
-        float s = -INFINITY;
-        int64_t id = kWorstId;
+    Cand run;
+    run.s = -INFINITY;
+    run.id = kWorstId;
+    // groups of 64 consecutive candidates, dealt round-robin to the waves
+    for (int base = wave * 64; base < n; base += kMergeWaves * 64) {
+        const int e = base + lane;
+        Cand c;
+        c.s = -INFINITY;
+        c.id = kWorstId;
         if (e < n) {
             const int list = e / k, kk = e - list * k;
             const int64_t o = ((int64_t)list * nq + q) * k + kk;
             const int64_t gi = ids[o];
             const float gs = scores[o];
-            // NaN and -inf never rank (the scan never emits them; foreign lists might).
+            // NaN and -inf never rank (the scan never emits them; foreign lists might)
             if (gi >= 0 && gs > -INFINITY) {
-                s = gs;
-                id = gi;
+                c.s = gs;
+                c.id = gi;
             }
         }
-        ssc[e] = s;
-        sid[e] = id;
+        wave_sort64(c, lane);
+        fold_group(run, c, lane);
     }
-
-    for (int size = 2; size <= P; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            __syncthreads();
-            for (int t = threadIdx.x; t < (P >> 1); t += kMergeThreads) {
-                const int i = 2 * t - (t & (stride - 1));
-                const int j = i + stride;
-                const bool best_first = (i & size) == 0;
-                const float si = ssc[i], sj = ssc[j];
-                const int64_t ii = sid[i], ij = sid[j];
-                const bool j_better = cand_better(sj, ij, si, ii);
-                const bool i_better = cand_better(si, ii, sj, ij);
-                if (best_first ? j_better : i_better) {
-                    ssc[i] = sj;
-                    ssc[j] = si;
-                    sid[i] = ij;
-                    sid[j] = ii;
-                }
-            }
-        }
+    if (lane < 32) {
+        sh_s[wave * 32 + lane] = run.s;
+        sh_i[wave * 32 + lane] = run.id;
     }
     __syncthreads();
-    if ((int)threadIdx.x < k) {
-        const int e = threadIdx.x;
-        const bool filled = (e < P) && sid[e] != kWorstId;
-        out_scores[(int64_t)q * k + e] = filled ? ssc[e] : -INFINITY;
-        out_ids[(int64_t)q * k + e] = filled ? sid[e] : (int64_t)-1;
+    if (wave != 0) return;
+    // wave 0 folds the 16 per-wave lists, two at a time (each already sorted best-first)
+    Cand acc = run;  // wave 0's own list in lanes 0..31
+#pragma unroll 1
+    for (int w = 1; w < kMergeWaves; ++w) {
+        Cand other;
+        other.s = sh_s[w * 32 + (lane & 31)];
+        other.id = sh_i[w * 32 + (lane & 31)];
+        // lanes 32..63 take list w reversed
+        const Cand rev = shfl_cand(other, 31 - (lane & 31));
+        Cand c = (lane < 32) ? acc : rev;
+        wave_bitonic_merge64(c, lane);
+        acc = c;
+    }
+    if (lane < k) {
+        const bool filled = acc.id != kWorstId;
+        out_scores[(int64_t)q * k + lane] = filled ? acc.s : -INFINITY;
+        out_ids[(int64_t)q * k + lane] = filled ? acc.id : (int64_t)-1;
     }
 }
 
 hipError_t launch_merge_topk(const float* scores, const int64_t* ids, int n_lists, int nq, int k,
                              float* out_scores, int64_t* out_ids, hipStream_t stream) {
-    const int n = n_lists * k;
-    if (n_lists < 1 || nq < 1 || k < 1 || n > kMergeMaxCandidates) return hipErrorInvalidValue;
-    int P = 2;
-    while (P < n) P <<= 1;
-    if (P < k) {
-        while (P < k) P <<= 1;
-    }
-    const size_t lds_bytes = (size_t)P * 12;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&merge_topk_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           kMergeMaxCandidates * 12);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(merge_topk_kernel, dim3(nq), dim3(kMergeThreads), lds_bytes, stream, scores, ids,
-                       n_lists, nq, k, P, out_scores, out_ids);
+    const int64_t n = (int64_t)n_lists * k;
+    if (n_lists < 1 || nq < 1 || k < 1 || k > 32 || n > kMergeMaxCandidates) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(merge_topk_kernel, dim3(nq), dim3(kMergeThreads), 0, stream, scores, ids, n_lists, nq, k,
+                       out_scores, out_ids);
     return hipGetLastError();
 }
 

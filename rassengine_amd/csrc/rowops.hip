@@ -27,9 +27,15 @@ __device__ __forceinline__ float wave_sum(float v) {
 // order of the sum of squares differs from numpy's pairwise sum (<= a few ulp of the norm).
 __global__ __launch_bounds__(kRowThreads) void normalize_rows_kernel(const float* __restrict__ in,
                                                                      int64_t in_stride, float* __restrict__ out,
-                                                                     int64_t out_stride, int64_t n, int dim) {
+                                                                     int64_t out_stride, int64_t n, int dim,
+                                                                     int64_t n_total) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
+    // rows [n, n_total) are zero-filled (query padding up to a multiple of 16 rows)
+    for (int64_t r = n + (int64_t)blockIdx.x * 4 + wave; r < n_total; r += (int64_t)gridDim.x * 4) {
+        float* dst = out + r * out_stride;
+        for (int c = lane; c < (int)out_stride; c += 64) dst[c] = 0.f;
+    }
     const bool vec = ((dim & 3) == 0) && ((in_stride & 3) == 0) && ((out_stride & 3) == 0) &&
                      ((reinterpret_cast<uintptr_t>(in) & 15) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
     for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < n; r += (int64_t)gridDim.x * 4) {
@@ -68,12 +74,13 @@ __global__ __launch_bounds__(kRowThreads) void normalize_rows_kernel(const float
 }
 
 hipError_t launch_normalize_rows_f32(const float* in, int64_t in_stride, float* out, int64_t out_stride,
-                                     int64_t n, int dim, hipStream_t stream) {
-    if (n <= 0) return hipSuccess;
-    int64_t blocks = (n + 3) / 4;
+                                     int64_t n, int dim, hipStream_t stream, int64_t n_total) {
+    if (n_total < n) n_total = n;
+    if (n_total <= 0) return hipSuccess;
+    int64_t blocks = (n_total + 3) / 4;
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(normalize_rows_kernel, dim3((unsigned)blocks), dim3(kRowThreads), 0, stream, in, in_stride,
-                       out, out_stride, n, dim);
+                       out, out_stride, n, dim, n_total);
     return hipGetLastError();
 }
 
@@ -135,45 +142,176 @@ __device__ __forceinline__ f32x4 normals4(uint64_t seed, int64_t row, int chunk)
     return f32x4{ra * ca, ra * sa, rb * cb, rb * sb};
 }
 
-__global__ __launch_bounds__(kRowThreads) void fill_synthetic_kernel(float* __restrict__ out, int64_t stride,
-                                                                     int64_t n, int dim, uint64_t seed,
-                                                                     int64_t row_id_base) {
+// ---------------------------------------------------------------------------- tile16 layout
+// (kernels.h) One wave owns one 16-row block: lane (m = lane&15, g = lane>>4) handles row
+// 16b+m, columns 16j + 4g .. +3 of every chunk j, so each chunk is written / read as one
+// coalesced 1 KiB burst in exactly the order the scan kernel's MFMA A operand wants.
+
+__device__ __forceinline__ float block_row_sum(float v) {
+    // the 4 lanes that share a row are lane, lane^16, lane^32, lane^48
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+__device__ __forceinline__ f32x4 load_row_piece(const float* src, int c, int dim, bool vec) {
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (vec && c + 3 < dim) {
+        v = *reinterpret_cast<const f32x4*>(src + c);
+    } else {
+        if (c < dim) v.x = src[c];
+        if (c + 1 < dim) v.y = src[c + 1];
+        if (c + 2 < dim) v.z = src[c + 2];
+        if (c + 3 < dim) v.w = src[c + 3];
+    }
+    return v;
+}
+
+// rows [first_row, first_row + n) of the packed slab <- in[0..n) (row-major), optionally
+// L2-normalised with the reference formula (app/main.py:1249-1251).  Rows of a touched
+// block outside that range are left as they are.
+__global__ __launch_bounds__(kRowThreads) void pack_rows_tile16_kernel(const float* __restrict__ in,
+                                                                       int64_t in_stride,
+                                                                       float* __restrict__ packed, int64_t stride,
+                                                                       int64_t first_row, int64_t n, int dim,
+                                                                       int normalize) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < n; r += (int64_t)gridDim.x * 4) {
-        const int64_t gid = row_id_base + r;
-        float ss = 0.f;
-        for (int c = lane * 4; c < dim; c += 256) {
-            const f32x4 v = normals4(seed, gid, c >> 2);
-            ss = fmaf(v.x, v.x, ss);
-            if (c + 1 < dim) ss = fmaf(v.y, v.y, ss);
-            if (c + 2 < dim) ss = fmaf(v.z, v.z, ss);
-            if (c + 3 < dim) ss = fmaf(v.w, v.w, ss);
-        }
-        ss = wave_sum(ss);
-        const float denom = sqrtf(ss) + 1e-9f;
-        float* dst = out + r * stride;
-        for (int c = lane * 4; c < (int)stride; c += 256) {
-            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (c < dim) {
-                const f32x4 g = normals4(seed, gid, c >> 2);
-                v.x = g.x / denom;
-                if (c + 1 < dim) v.y = g.y / denom;
-                if (c + 2 < dim) v.z = g.z / denom;
-                if (c + 3 < dim) v.w = g.w / denom;
+    const int m = lane & 15, g = lane >> 4;
+    const int nchunks = (int)(stride >> 4);
+    const int64_t b0 = first_row >> 4, b1 = (first_row + n + 15) >> 4;
+    const bool vec = ((in_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(in) & 15) == 0);
+    for (int64_t b = b0 + (int64_t)blockIdx.x * 4 + wave; b < b1; b += (int64_t)gridDim.x * 4) {
+        const int64_t row = b * 16 + m;
+        const bool valid = row >= first_row && row < first_row + n;
+        const float* src = in + (valid ? (row - first_row) : 0) * in_stride;
+        float denom = 1.f;
+        if (normalize) {
+            float ss = 0.f;
+            for (int j = 0; j < nchunks; ++j) {
+                const f32x4 v = valid ? load_row_piece(src, 16 * j + 4 * g, dim, vec) : f32x4{0.f, 0.f, 0.f, 0.f};
+                ss = fmaf(v.x, v.x, ss);
+                ss = fmaf(v.y, v.y, ss);
+                ss = fmaf(v.z, v.z, ss);
+                ss = fmaf(v.w, v.w, ss);
             }
-            *reinterpret_cast<f32x4*>(dst + c) = v;
+            denom = sqrtf(block_row_sum(ss)) + 1e-9f;
+        }
+        float* dst = packed + b * 16 * stride + lane * 4;
+        for (int j = 0; j < nchunks; ++j) {
+            if (valid) {
+                f32x4 v = load_row_piece(src, 16 * j + 4 * g, dim, vec);
+                if (normalize) {
+                    v.x = v.x / denom;
+                    v.y = v.y / denom;
+                    v.z = v.z / denom;
+                    v.w = v.w / denom;
+                }
+                *reinterpret_cast<f32x4*>(dst + j * 256) = v;
+            }
         }
     }
 }
 
-hipError_t launch_fill_synthetic_f32(float* out, int64_t stride, int64_t n, int dim, uint64_t seed,
-                                     int64_t row_id_base, hipStream_t stream) {
+hipError_t launch_pack_rows_tile16(const float* in, int64_t in_stride, float* packed, int64_t stride,
+                                   int64_t first_row, int64_t n, int dim, int normalize, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
-    int64_t blocks = (n + 3) / 4;
+    const int64_t nblk = ((first_row + n + 15) >> 4) - (first_row >> 4);
+    int64_t blocks = (nblk + 3) / 4;
     if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(fill_synthetic_kernel, dim3((unsigned)blocks), dim3(kRowThreads), 0, stream, out, stride, n,
-                       dim, seed, row_id_base);
+    hipLaunchKernelGGL(pack_rows_tile16_kernel, dim3((unsigned)blocks), dim3(kRowThreads), 0, stream, in, in_stride,
+                       packed, stride, first_row, n, dim, normalize);
+    return hipGetLastError();
+}
+
+// out[0..n) (row-major, out_stride) <- rows [first_row, first_row + n) of the packed slab
+__global__ __launch_bounds__(kRowThreads) void unpack_rows_tile16_kernel(const float* __restrict__ packed,
+                                                                         int64_t stride, int64_t first_row,
+                                                                         int64_t n, int dim, float* __restrict__ out,
+                                                                         int64_t out_stride) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int m = lane & 15, g = lane >> 4;
+    const int nchunks = (int)(stride >> 4);
+    const int64_t b0 = first_row >> 4, b1 = (first_row + n + 15) >> 4;
+    for (int64_t b = b0 + (int64_t)blockIdx.x * 4 + wave; b < b1; b += (int64_t)gridDim.x * 4) {
+        const int64_t row = b * 16 + m;
+        const bool valid = row >= first_row && row < first_row + n;
+        const float* src = packed + b * 16 * stride + lane * 4;
+        float* dst = out + (valid ? (row - first_row) : 0) * out_stride;
+        for (int j = 0; j < nchunks; ++j) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src + j * 256);
+            const int c = 16 * j + 4 * g;
+            if (valid) {
+                if (c < dim) dst[c] = v.x;
+                if (c + 1 < dim) dst[c + 1] = v.y;
+                if (c + 2 < dim) dst[c + 2] = v.z;
+                if (c + 3 < dim) dst[c + 3] = v.w;
+            }
+        }
+    }
+}
+
+hipError_t launch_unpack_rows_tile16(const float* packed, int64_t stride, int64_t first_row, int64_t n, int dim,
+                                     float* out, int64_t out_stride, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    const int64_t nblk = ((first_row + n + 15) >> 4) - (first_row >> 4);
+    int64_t blocks = (nblk + 3) / 4;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(unpack_rows_tile16_kernel, dim3((unsigned)blocks), dim3(kRowThreads), 0, stream, packed,
+                       stride, first_row, n, dim, out, out_stride);
+    return hipGetLastError();
+}
+
+// Synthetic unit rows [first_row, first_row + n) written straight into the packed slab.
+__global__ __launch_bounds__(kRowThreads) void fill_synthetic_kernel(float* __restrict__ packed, int64_t stride,
+                                                                     int64_t first_row, int64_t n, int dim,
+                                                                     uint64_t seed, int64_t row_id_base) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int m = lane & 15, g = lane >> 4;
+    const int nchunks = (int)(stride >> 4);
+    const int64_t b0 = first_row >> 4, b1 = (first_row + n + 15) >> 4;
+    for (int64_t b = b0 + (int64_t)blockIdx.x * 4 + wave; b < b1; b += (int64_t)gridDim.x * 4) {
+        const int64_t row = b * 16 + m;
+        const bool valid = row >= first_row && row < first_row + n;
+        const int64_t gid = row_id_base + row;
+        float ss = 0.f;
+        for (int j = 0; j < nchunks; ++j) {
+            const int c = 16 * j + 4 * g;
+            if (c < dim) {
+                const f32x4 v = normals4(seed, gid, c >> 2);
+                ss = fmaf(v.x, v.x, ss);
+                if (c + 1 < dim) ss = fmaf(v.y, v.y, ss);
+                if (c + 2 < dim) ss = fmaf(v.z, v.z, ss);
+                if (c + 3 < dim) ss = fmaf(v.w, v.w, ss);
+            }
+        }
+        const float denom = sqrtf(block_row_sum(ss)) + 1e-9f;
+        float* dst = packed + b * 16 * stride + lane * 4;
+        for (int j = 0; j < nchunks; ++j) {
+            const int c = 16 * j + 4 * g;
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (c < dim) {
+                const f32x4 x = normals4(seed, gid, c >> 2);
+                v.x = x.x / denom;
+                if (c + 1 < dim) v.y = x.y / denom;
+                if (c + 2 < dim) v.z = x.z / denom;
+                if (c + 3 < dim) v.w = x.w / denom;
+            }
+            if (valid) *reinterpret_cast<f32x4*>(dst + j * 256) = v;
+        }
+    }
+}
+
+hipError_t launch_fill_synthetic_f32(float* packed, int64_t stride, int64_t first_row, int64_t n, int dim,
+                                     uint64_t seed, int64_t row_id_base, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    const int64_t nblk = ((first_row + n + 15) >> 4) - (first_row >> 4);
+    int64_t blocks = (nblk + 3) / 4;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(fill_synthetic_kernel, dim3((unsigned)blocks), dim3(kRowThreads), 0, stream, packed, stride,
+                       first_row, n, dim, seed, row_id_base);
     return hipGetLastError();
 }
 

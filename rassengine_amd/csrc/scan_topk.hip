@@ -6,16 +6,22 @@
 // top-k per query under the total order (score desc, id asc).
 //
 // Shape of the kernel (one 512-thread workgroup per CU, persistent over row tiles):
-//   * a tile is 32 corpus rows; the 8 waves split the K (=dim) axis, wave w owns the
-//     contiguous column slice [w*16*CH, (w+1)*16*CH) of every row (dim_padded = 128*CH)
+//   * HBM layout ("tile16", kernels.h): the corpus is stored in 16-row blocks; inside a block
+//     the 16 rows x 16 columns (64 B each) of chunk j are ONE contiguous 1 KiB in MFMA lane
+//     order, lane (m = lane&15, g = lane>>4) <-> X[16b+m][16j + 4g .. +3].  So every wave-level
+//     load is a fully coalesced 1 KiB burst that lands directly in A-operand layout (measured:
+//     6.6 TB/s for this pattern vs 5.6 TB/s for 16 rows x 64 B fragment-shaped loads from a
+//     plain row-major slab; scripts/microbench/stream_patterns.hip)
+//   * a tile is 32 corpus rows (two blocks); the 8 waves split the K (=dim) axis, wave w owns
+//     chunks [w*CH, (w+1)*CH) of every block (dim_padded = 128*CH)
 //   * corpus bytes go HBM -> VGPR directly (read-once stream, GEMV-shaped: no LDS
-//     round trip), 16 B per lane, as the A operand of v_mfma_f32_16x16x4_f32:
-//     lane (m = lane&15, g = lane>>4) holds X[row0+m][slice + 16j + 4g .. +3]
+//     round trip), 16 B per lane, as the A operand of v_mfma_f32_16x16x4_f32
 //   * the query fragments (B operand) stay in registers for the whole launch
 //   * loads are buffer loads through a per-tile descriptor, so rows past n_rows and
 //     the run-ahead prefetch of a tile past the end cost no HBM traffic (range check)
-//   * register double buffering keeps the next tile's 16 KiB per wave in flight while
-//     the current tile is multiplied: 128 KiB in flight per CU
+//   * two register tile buffers per wave; each 16 B register is re-loaded for the tile two
+//     steps ahead right after the MFMAs that consumed it, so ~32 KiB per wave (256 KiB per
+//     CU) stay in flight continuously
 //   * per tile, each wave dumps its 32x(16*NT) partial scores to LDS (one barrier per
 //     tile, two LDS buffers), then wave w sums the 8 K-partials of "its" queries in a
 //     fixed order and runs the half-wave sorted-list insert (threshold filter by ballot)
@@ -28,6 +34,7 @@
 // on the CPU and the GPU tests require bit-equality with it).
 //
 // Algorithmic bytes per launch (roofline.achieved in bench.py): n_rows * row_stride * 4.
+// The corpus must be allocated in whole 16-row blocks (rows past n_rows are masked).
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -53,12 +60,17 @@ struct TileRegs {
     int tag;
 };
 
-template <int CH>
-__device__ __forceinline__ void issue_tile_loads(TileRegs<CH>& r, const float* __restrict__ X,
-                                                 int64_t row_stride, const int32_t* __restrict__ row_tag,
-                                                 int tile, int n_tiles, int n_rows, int voff_lane) {
-    // Wave-uniform tile base and byte count: the descriptor's range check drops every
-    // lane past the end (zeros, no memory request).
+// Wave-uniform buffer descriptors of one tile: corpus rows and row tags.  The range check
+// drops every lane past the end (rows beyond n_rows, or a whole run-ahead tile past the last
+// one): zeros come back and no memory request is made.
+struct TileDesc {
+    __amdgpu_buffer_rsrc_t rows;
+    __amdgpu_buffer_rsrc_t tags;
+};
+
+__device__ __forceinline__ TileDesc make_tile_desc(const float* __restrict__ X, int64_t row_stride,
+                                                   const int32_t* __restrict__ row_tag, int tile, int n_tiles,
+                                                   int n_rows) {
     const int row0 = tile * kTileRows;
     int rows_here = n_rows - row0;
     rows_here = rows_here < 0 ? 0 : (rows_here > kTileRows ? kTileRows : rows_here);
@@ -69,55 +81,72 @@ __device__ __forceinline__ void issue_tile_loads(TileRegs<CH>& r, const float* _
     const uint64_t base_u = reinterpret_cast<uint64_t>(X + base_row * row_stride);
     const uint32_t base_lo = __builtin_amdgcn_readfirstlane((uint32_t)base_u);
     const uint32_t base_hi = __builtin_amdgcn_readfirstlane((uint32_t)(base_u >> 32));
-    float* base = reinterpret_cast<float*>(((uint64_t)base_hi << 32) | base_lo);
-    const unsigned bytes =
-        __builtin_amdgcn_readfirstlane((unsigned)rows_here * (unsigned)row_stride * 4u);
-    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(base, /*stride*/ 0, (int)bytes, 0x00020000);
-    // Row tags: always issued (straight-line code keeps hipcc's vmcnt counts exact); with no
-    // tag array the descriptor has zero records, so the load returns 0 and costs no traffic.
-    {
-        const bool has_tags = row_tag != nullptr;
-        const uint64_t tbase_u = has_tags ? reinterpret_cast<uint64_t>(row_tag + base_row) : base_u;
-        const uint32_t tlo = __builtin_amdgcn_readfirstlane((uint32_t)tbase_u);
-        const uint32_t thi = __builtin_amdgcn_readfirstlane((uint32_t)(tbase_u >> 32));
-        const unsigned tbytes = __builtin_amdgcn_readfirstlane(has_tags ? (unsigned)(rows_here * 4) : 0u);
-        __amdgpu_buffer_rsrc_t trsrc = __builtin_amdgcn_make_buffer_rsrc(
-            reinterpret_cast<int32_t*>(((uint64_t)thi << 32) | tlo), 0, (int)tbytes, 0x00020000);
-        r.tag = (int)__builtin_amdgcn_raw_buffer_load_b32(trsrc, (lane_id() & 31) * 4, 0, 0);
-    }
-    const int mt_step = 16 * (int)row_stride * 4;
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-#pragma unroll
-        for (int j = 0; j < CH; ++j) {
-            u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff_lane + mt * mt_step + j * 64, 0,
-                                                            /*aux: nt*/ 2);
-            r.a[mt][j] = __builtin_bit_cast(f32x4, v);
-        }
-    }
+    const unsigned blocks_here = (unsigned)(rows_here + 15) >> 4;  // tile16: whole 16-row blocks
+    const unsigned bytes = __builtin_amdgcn_readfirstlane(blocks_here * 16u * (unsigned)row_stride * 4u);
+    TileDesc d;
+    d.rows = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(((uint64_t)base_hi << 32) | base_lo),
+                                               /*stride*/ 0, (int)bytes, 0x00020000);
+    // Row tags: always loaded (straight-line code keeps hipcc's vmcnt counts exact); with no
+    // tag array the descriptor has zero records: the load returns 0 and costs no traffic.
+    const bool has_tags = row_tag != nullptr;
+    const uint64_t tbase_u = has_tags ? reinterpret_cast<uint64_t>(row_tag + base_row) : base_u;
+    const uint32_t tlo = __builtin_amdgcn_readfirstlane((uint32_t)tbase_u);
+    const uint32_t thi = __builtin_amdgcn_readfirstlane((uint32_t)(tbase_u >> 32));
+    const unsigned tbytes = __builtin_amdgcn_readfirstlane(has_tags ? (unsigned)(rows_here * 4) : 0u);
+    d.tags = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<int32_t*>(((uint64_t)thi << 32) | tlo), 0,
+                                               (int)tbytes, 0x00020000);
+    return d;
 }
 
+__device__ __forceinline__ f32x4 load_chunk(const TileDesc& d, int voff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(d.rows, voff, 0, /*aux: nt*/ 2));
+}
+
+__device__ __forceinline__ int load_tag(const TileDesc& d) {
+    return (int)__builtin_amdgcn_raw_buffer_load_b32(d.tags, (lane_id() & 31) * 4, 0, 0);
+}
+
+// Prologue: all of a tile's loads, in the order multiply_and_refill consumes them.
+template <int CH>
+__device__ __forceinline__ void issue_tile_loads(TileRegs<CH>& r, const TileDesc& d, int voff_lane, int mt_step) {
+    r.tag = load_tag(d);
+#pragma unroll
+    for (int j = 0; j < CH; ++j)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) r.a[mt][j] = load_chunk(d, voff_lane + mt * mt_step + j * 1024);
+}
+
+// Multiply the resident tile and, chunk by chunk, re-issue each consumed register's load
+// for the tile two steps ahead (`next`): about two tiles (32 KiB per wave, 256 KiB per CU)
+// stay in flight at all times instead of one tile requested in a burst after the previous
+// one has fully arrived.  sched_barrier(0) per chunk pins the load placement (hipcc would
+// otherwise sink the loads behind the whole MFMA block).
 template <int CH, int NT>
-__device__ __forceinline__ void multiply_tile(const TileRegs<CH>& r, const f32x4 (&qf)[NT][CH],
-                                              f32x4 (&acc)[2][NT]) {
+__device__ __forceinline__ void multiply_and_refill(TileRegs<CH>& r, const f32x4 (&qf)[NT][CH],
+                                                    f32x4 (&acc)[2][NT], const TileDesc& next, int voff_lane,
+                                                    int mt_step) {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    r.tag = load_tag(next);
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
+            const f32x4 a = r.a[mt][j];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 f32x4 c = acc[mt][nt];
-                c = __builtin_amdgcn_mfma_f32_16x16x4f32(r.a[mt][j].x, qf[nt][j].x, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x4f32(r.a[mt][j].y, qf[nt][j].y, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x4f32(r.a[mt][j].z, qf[nt][j].z, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x4f32(r.a[mt][j].w, qf[nt][j].w, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, qf[nt][j].x, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, qf[nt][j].y, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, qf[nt][j].z, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, qf[nt][j].w, c, 0, 0, 0);
                 acc[mt][nt] = c;
             }
+            r.a[mt][j] = load_chunk(next, voff_lane + mt * mt_step + j * 1024);
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -183,8 +212,8 @@ __global__ __launch_bounds__(kThreads, 2) void scan_topk_f32_kernel(ScanArgs p) 
             for (int j = 0; j < CH; ++j)
                 qf[nt][j] = *reinterpret_cast<const f32x4*>(qbase + (int64_t)nt * 16 * p.row_stride + 16 * j);
     }
-    // Byte offset of this lane inside a tile: row m of M-tile 0, its 16 B of chunk 0.
-    const int voff_lane = (m * (int)p.row_stride + wid * 16 * CH + 4 * g) * 4;
+    // Byte offset of this lane inside a tile: block 0, this wave's chunk 0, 16 B per lane.
+    const int voff_lane = wid * CH * 1024 + lane * 16;
 
     // Top-k state: pass pq handles query pq*16 + (lane>>5)*8 + wid for row lane&31.
     TopList L[NT];
@@ -199,9 +228,14 @@ __global__ __launch_bounds__(kThreads, 2) void scan_topk_f32_kernel(ScanArgs p) 
         qfilt[pq] = (p.q_filter != nullptr && q < p.nq) ? p.q_filter[q] : -1;
     }
 
+    const int mt_step = 16 * (int)p.row_stride * 4;
     TileRegs<CH> R0, R1;
     int t = blockIdx.x;
-    issue_tile_loads<CH>(R0, p.corpus, p.row_stride, p.row_tag, t, n_tiles, p.n_rows, voff_lane);
+    issue_tile_loads<CH>(R0, make_tile_desc(p.corpus, p.row_stride, p.row_tag, t, n_tiles, p.n_rows), voff_lane,
+                         mt_step);
+    issue_tile_loads<CH>(R1, make_tile_desc(p.corpus, p.row_stride, p.row_tag, t + G, n_tiles, p.n_rows),
+                         voff_lane, mt_step);
+    __builtin_amdgcn_sched_barrier(0);
 
     auto finish_tile = [&](const f32x4 (&acc)[2][NT], int tile, int tag, int buf) {
         float* P = lds + buf * (kWaves * NQ * kPitch);
@@ -228,18 +262,18 @@ __global__ __launch_bounds__(kThreads, 2) void scan_topk_f32_kernel(ScanArgs p) 
         }
     };
 
-    // sched_barrier(0) after each load group: without it hipcc sinks the next tile's loads
-    // behind the MFMA block to save registers, and the prefetch is gone.
     for (; t < n_tiles; t += 2 * G) {
         f32x4 acc[2][NT];
-        issue_tile_loads<CH>(R1, p.corpus, p.row_stride, p.row_tag, t + G, n_tiles, p.n_rows, voff_lane);
-        __builtin_amdgcn_sched_barrier(0);
-        multiply_tile<CH, NT>(R0, qf, acc);
-        finish_tile(acc, t, R0.tag, 0);
-        issue_tile_loads<CH>(R0, p.corpus, p.row_stride, p.row_tag, t + 2 * G, n_tiles, p.n_rows, voff_lane);
-        __builtin_amdgcn_sched_barrier(0);
-        multiply_tile<CH, NT>(R1, qf, acc);
-        finish_tile(acc, t + G, R1.tag, 1);
+        int tag = R0.tag;
+        multiply_and_refill<CH, NT>(R0, qf, acc,
+                                    make_tile_desc(p.corpus, p.row_stride, p.row_tag, t + 2 * G, n_tiles, p.n_rows),
+                                    voff_lane, mt_step);
+        finish_tile(acc, t, tag, 0);
+        tag = R1.tag;
+        multiply_and_refill<CH, NT>(R1, qf, acc,
+                                    make_tile_desc(p.corpus, p.row_stride, p.row_tag, t + 3 * G, n_tiles, p.n_rows),
+                                    voff_lane, mt_step);
+        finish_tile(acc, t + G, tag, 1);
     }
 
     // Per-workgroup sorted lists -> [gridDim.x][nq][k]

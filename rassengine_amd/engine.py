@@ -58,9 +58,18 @@ class Engine:
         except Exception:
             pass
 
-    def set_stream(self, stream_ptr: Optional[int]) -> None:
-        """Run engine work on a caller-owned hipStream_t (e.g. torch's current stream)."""
-        N.check("rass_engine_set_stream", self._L.rass_engine_set_stream(self._h, ctypes.c_void_p(stream_ptr or 0)))
+    def set_stream(self, stream_ptr: int) -> None:
+        """Run engine work on a caller-owned hipStream_t (0 = HIP's null stream, which is
+        what ``torch.cuda.current_stream().cuda_stream`` returns for torch's default stream)."""
+        N.check("rass_engine_set_stream", self._L.rass_engine_set_stream(self._h, ctypes.c_void_p(stream_ptr)))
+
+    def reset_stream(self) -> None:
+        N.check("rass_engine_reset_stream", self._L.rass_engine_reset_stream(self._h))
+
+    @property
+    def stream(self) -> int:
+        """The hipStream_t (as int) engine work is enqueued on."""
+        return int(self._L.rass_engine_get_stream(self._h) or 0)
 
     def synchronize(self) -> None:
         N.check("rass_engine_synchronize", self._L.rass_engine_synchronize(self._h))

@@ -50,22 +50,41 @@ def normalize_rows(x: torch.Tensor, out_stride: Optional[int] = None) -> torch.T
     return out
 
 
-def scan_topk(corpus: torch.Tensor, queries: torch.Tensor, k: int, *, dim: Optional[int] = None,
-              row_tag: Optional[torch.Tensor] = None, q_filter: Optional[torch.Tensor] = None,
-              id_base: int = 0, n_rows: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Exact cosine top-k of ``queries`` [nq<=32, dim] over a normalised fp32 ``corpus``
-    [n, row_stride] (row_stride a multiple of 128, zero padded past ``dim``).
+def pack_rows(x: torch.Tensor, normalize: bool = False, row_stride: Optional[int] = None) -> torch.Tensor:
+    """Row-major fp32 [n, dim] -> tile16 slab [ceil(n/16)*16, row_stride] (the HBM layout the
+    scan streams; see include/rass_engine.h).  ``normalize`` applies the reference formula."""
+    _req(x, torch.float32, "x")
+    n, d = x.shape
+    stride = (d + 127) // 128 * 128 if row_stride is None else int(row_stride)
+    packed = torch.zeros(((n + 15) // 16 * 16, stride), dtype=torch.float32, device=x.device)
+    N.check("rass_pack_rows_f32",
+            N.lib().rass_pack_rows_f32(ctypes.c_void_p(x.data_ptr()), d, ctypes.c_void_p(packed.data_ptr()), stride,
+                                       0, n, d, 1 if normalize else 0, ctypes.c_void_p(_stream_ptr())))
+    return packed
 
-    Returns (scores f32 [nq,k], ids i64 [nq,k]) on the device, async on the current stream.
-    """
-    _req(corpus, torch.float32, "corpus")
+
+def unpack_rows(packed: torch.Tensor, n: int, dim: int, first_row: int = 0) -> torch.Tensor:
+    """tile16 slab -> row-major fp32 [n, dim] (rows first_row .. first_row+n)."""
+    _req(packed, torch.float32, "packed")
+    out = torch.empty((n, dim), dtype=torch.float32, device=packed.device)
+    N.check("rass_unpack_rows_f32",
+            N.lib().rass_unpack_rows_f32(ctypes.c_void_p(packed.data_ptr()), packed.shape[1], int(first_row), n, dim,
+                                         ctypes.c_void_p(out.data_ptr()), dim, ctypes.c_void_p(_stream_ptr())))
+    return out
+
+
+def scan_topk_packed(packed: torch.Tensor, n_rows: int, queries: torch.Tensor, k: int, *,
+                     row_tag: Optional[torch.Tensor] = None, q_filter: Optional[torch.Tensor] = None,
+                     id_base: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Exact cosine top-k of ``queries`` [nq<=32, dim] over a normalised tile16 slab holding
+    ``n_rows`` rows.  Returns (scores f32 [nq,k], ids i64 [nq,k]) on the device, async on the
+    current stream."""
+    _req(packed, torch.float32, "packed")
     _req(queries, torch.float32, "queries")
-    stride = corpus.shape[1]
-    d = int(dim) if dim is not None else queries.shape[1]
-    if queries.shape[1] != d:
-        raise ValueError("queries must be [nq, dim]")
-    nq = queries.shape[0]
-    n = corpus.shape[0] if n_rows is None else int(n_rows)
+    stride = packed.shape[1]
+    nq, d = queries.shape
+    if packed.shape[0] % 16 != 0 or packed.shape[0] < n_rows:
+        raise ValueError("packed slab must hold whole 16-row blocks covering n_rows")
     if row_tag is not None:
         _req(row_tag, torch.int32, "row_tag")
     if q_filter is not None:
@@ -74,17 +93,26 @@ def scan_topk(corpus: torch.Tensor, queries: torch.Tensor, k: int, *, dim: Optio
     ws_bytes = int(L.rass_scan_workspace_bytes(nq, k))
     if ws_bytes == 0:
         raise ValueError(f"unsupported (nq={nq}, k={k}); nq<=32, k<=32")
-    ws = _ws(corpus.device, ws_bytes)
-    out_s = torch.empty((nq, k), dtype=torch.float32, device=corpus.device)
-    out_i = torch.empty((nq, k), dtype=torch.int64, device=corpus.device)
+    ws = _ws(packed.device, ws_bytes)
+    out_s = torch.empty((nq, k), dtype=torch.float32, device=packed.device)
+    out_i = torch.empty((nq, k), dtype=torch.int64, device=packed.device)
     N.check("rass_scan_topk_f32",
-            L.rass_scan_topk_f32(ctypes.c_void_p(corpus.data_ptr()), n, d, stride,
+            L.rass_scan_topk_f32(ctypes.c_void_p(packed.data_ptr()), int(n_rows), d, stride,
                                  ctypes.c_void_p(row_tag.data_ptr() if row_tag is not None else 0),
                                  ctypes.c_void_p(queries.data_ptr()), nq,
                                  ctypes.c_void_p(q_filter.data_ptr() if q_filter is not None else 0), k,
                                  int(id_base), ctypes.c_void_p(out_s.data_ptr()), ctypes.c_void_p(out_i.data_ptr()),
                                  ctypes.c_void_p(ws.data_ptr()), ws.numel(), ctypes.c_void_p(_stream_ptr())))
     return out_s, out_i
+
+
+def scan_topk(corpus: torch.Tensor, queries: torch.Tensor, k: int, *, row_tag: Optional[torch.Tensor] = None,
+              q_filter: Optional[torch.Tensor] = None, id_base: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Convenience for tests: ``corpus`` is ROW-MAJOR normalised fp32 [n, dim]; it is packed
+    to tile16 first (an index keeps its rows packed, so the product path never does this)."""
+    n = corpus.shape[0]
+    packed = pack_rows(corpus, normalize=False)
+    return scan_topk_packed(packed, n, queries, k, row_tag=row_tag, q_filter=q_filter, id_base=id_base)
 
 
 def topk_merge(list_scores: torch.Tensor, list_ids: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:

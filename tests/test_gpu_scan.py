@@ -38,11 +38,11 @@ def _ids_match_with_ties(ids_gpu, s_gpu, ids_ref, s_ref, all_scores64):
 
 def _run_scan(torch, xn, q_raw, k, dim, stride, tags=None, qfilter=None, id_base=0):
     from rassengine_amd import ops
-    corpus = torch.from_numpy(_pad(xn, stride)).cuda()
+    corpus = torch.from_numpy(np.ascontiguousarray(xn)).cuda()
     queries = torch.from_numpy(np.ascontiguousarray(q_raw, dtype=np.float32)).cuda()
     t = None if tags is None else torch.from_numpy(tags.astype(np.int32)).cuda()
     f = None if qfilter is None else torch.from_numpy(qfilter.astype(np.int32)).cuda()
-    s, i = ops.scan_topk(corpus, queries, k, dim=dim, row_tag=t, q_filter=f, id_base=id_base)
+    s, i = ops.scan_topk(corpus, queries, k, row_tag=t, q_filter=f, id_base=id_base)
     torch.cuda.synchronize()
     return s.cpu().numpy(), i.cpu().numpy()
 
@@ -164,9 +164,9 @@ def test_scan_filter_and_tombstones(gpu, oracle):
 
 def test_scan_empty_corpus(gpu):
     from rassengine_amd import ops
-    corpus = gpu.zeros((0, 1024), dtype=gpu.float32, device="cuda")
+    corpus = gpu.zeros((16, 1024), dtype=gpu.float32, device="cuda")
     q = gpu.randn((2, 1024), device="cuda")
-    s, i = ops.scan_topk(corpus, q, 5)
+    s, i = ops.scan_topk_packed(corpus, 0, q, 5)
     gpu.cuda.synchronize()
     assert np.all(i.cpu().numpy() == -1)
     assert np.all(np.isneginf(s.cpu().numpy()))
@@ -191,6 +191,33 @@ def test_scan_result_independent_of_sharding(gpu, oracle):
     gpu.cuda.synchronize()
     assert gpu.equal(i_m, i_all)
     assert gpu.equal(s_m, s_all)
+
+
+@pytest.mark.parametrize("n,dim,first", [(1, 1024, 0), (37, 1024, 5), (160, 384, 16), (50, 100, 3), (16, 7, 15)])
+def test_pack_unpack_roundtrip(gpu, n, dim, first):
+    """tile16 pack/unpack is a pure permutation: bit-exact round trip at any row offset, and
+    the documented address formula holds."""
+    import ctypes
+    from rassengine_amd import ops, _native as N
+    rng = np.random.default_rng(n + dim)
+    x = rng.standard_normal((n, dim), dtype=np.float32)
+    stride = (dim + 127) // 128 * 128
+    total = (first + n + 15) // 16 * 16
+    packed = gpu.full((total, stride), 7.0, dtype=gpu.float32, device="cuda")
+    xd = gpu.from_numpy(x).cuda()
+    N.check("pack", N.lib().rass_pack_rows_f32(ctypes.c_void_p(xd.data_ptr()), dim, ctypes.c_void_p(packed.data_ptr()),
+                                               stride, first, n, dim, 0, None))
+    back = ops.unpack_rows(packed, n, dim, first_row=first).cpu().numpy()
+    assert np.array_equal(back, x)
+    flat = packed.cpu().numpy().reshape(-1)
+    for (r, c) in [(0, 0), (n - 1, dim - 1), (n // 2, dim // 3)]:
+        rr = r + first
+        off = (rr >> 4) * 16 * stride + (c >> 4) * 256 + ((((c >> 2) & 3) * 16 + (rr & 15)) * 4) + (c & 3)
+        assert flat[off] == x[r, c]
+    # rows of touched blocks outside [first, first+n) keep their previous content
+    if first > 0:
+        before = ops.unpack_rows(packed, first, dim, first_row=0).cpu().numpy()
+        assert np.all(before == 7.0)
 
 
 def test_merge_matches_oracle(gpu, oracle):

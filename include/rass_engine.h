@@ -119,6 +119,9 @@ int rass_index_delete(rass_index_t* idx, int64_t row);
 /* Copy one stored (normalised) row back to the host as fp32 (dim floats): the
  * reference returns the embedding inside `_source` (app/main.py:1555-1557). */
 int rass_index_get_row(rass_index_t* idx, int64_t row, float* out);
+/* Same for rows [first_row, first_row + n): n x dim floats, row-major. */
+int rass_index_get_rows(rass_index_t* idx, int64_t first_row, int64_t n,
+                        float* out);
 
 /* Replaces the knn query of OpenSearchIndexer.semantic_search (app/main.py:
  * 1527-1560) and the knn sub-clauses of hybrid_search (1595),
@@ -210,6 +213,18 @@ int rass_timer_start(rass_timer_t* t, void* stream);
 int rass_timer_stop(rass_timer_t* t, void* stream);
 /* Blocks until the stop event has completed; milliseconds between the two. */
 int rass_timer_elapsed_ms(rass_timer_t* t, float* ms);
+
+/* Bracket every scan-kernel launch the engine makes with a hipEvent pair on
+ * the engine stream (up to max_launches launches), then read back the summed
+ * kernel time: bench.py's live per-kernel duration for the roofline figure. */
+int rass_engine_kernel_timing_begin(rass_engine_t* eng, int max_launches);
+int rass_engine_kernel_timing_end(rass_engine_t* eng, double* total_ms,
+                                  int* launches);
+
+/* Device pointers of an index's tile16 slab / tag array (zero-copy interop,
+ * e.g. rass_scan_topk_f32 over a row prefix).  Invalidated by growth. */
+void* rass_index_device_rows(rass_index_t* idx);
+void* rass_index_device_tags(rass_index_t* idx);
 
 /* Name of the scan kernel variant a (dim, nq) request dispatches to, for
  * matching rocprofv3 kernel-trace rows ("" if unsupported). */

@@ -55,6 +55,7 @@ SIGNATURES = {
                                              ctypes.c_int, c_i64_p]),
     "rass_index_delete": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64]),
     "rass_index_get_row": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
+    "rass_index_get_rows": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]),
     "rass_index_search": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "rass_index_search_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
@@ -83,6 +84,11 @@ SIGNATURES = {
     "rass_timer_start": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "rass_timer_stop": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "rass_timer_elapsed_ms": (ctypes.c_int, [ctypes.c_void_p, c_float_p]),
+    "rass_engine_kernel_timing_begin": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "rass_engine_kernel_timing_end": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double),
+                                                     ctypes.POINTER(ctypes.c_int)]),
+    "rass_index_device_rows": (ctypes.c_void_p, [ctypes.c_void_p]),
+    "rass_index_device_tags": (ctypes.c_void_p, [ctypes.c_void_p]),
     "rass_scan_kernel_name": (ctypes.c_char_p, [ctypes.c_int, ctypes.c_int]),
 }
 

@@ -1,0 +1,30 @@
+"""Configuration: the same environment names the reference reads at import
+(app/main.py:60-108, app/embedding_gen.py:39-70), plus ``RASS_*`` for the engine."""
+import os
+
+
+def _int(name: str, default: int) -> int:
+    try:
+        return int(os.getenv(name, default))
+    except (TypeError, ValueError):
+        return default
+
+
+EMBED_MODEL_NAME = os.getenv("OLLAMA_EMBED_MODEL", "mxbai-embed-large:latest")  # app/main.py:67
+BATCH_SIZE = _int("BATCH_SIZE", 64)            # app/main.py:78
+CHUNK_SIZE = _int("CHUNK_SIZE", 512)           # app/main.py:79
+EMBED_DIM = _int("EMBED_DIM", 1024)            # app/main.py:80
+OPENSEARCH_INDEX_NAME = os.getenv("OPENSEARCH_INDEX_NAME", "")  # app/main.py:87
+TOP_K = _int("TOP_K", 3)                       # app/main.py:88
+SHARD_COUNT = _int("SHARD_COUNT", 1)           # app/main.py:89 (here: informational; shards = GPUs)
+
+RASS_DEVICE = _int("RASS_DEVICE", _int("LOCAL_RANK", 0))   # the GPU this process drives
+RASS_MODEL_DIR = os.getenv("RASS_MODEL_DIR", "")           # local dir with encoder weights + vocab.txt
+RASS_SCORE_MODE = os.getenv("RASS_SCORE_MODE", "opensearch")  # "opensearch": 1/(2-cos); "cosine": raw
+RASS_RETURN_EMBEDDING = os.getenv("RASS_RETURN_EMBEDDING", "0") == "1"
+RASS_POOLING = os.getenv("RASS_POOLING", "")               # "cls" | "mean" | "" (from the model dir)
+
+
+def get_index_name(user_id: str) -> str:
+    """app/main.py:346-347."""
+    return f"{OPENSEARCH_INDEX_NAME}-{user_id}"

@@ -101,6 +101,10 @@ struct rass_engine {
     int64_t* d_out_ids = nullptr;   // [32][32]
     float* d_stage = nullptr;       // [kStageRows][dim]
     int32_t* d_stage_tags = nullptr;
+    // optional HIP-event bracket around every scan kernel launch (bench.py's roofline leg)
+    std::vector<hipEvent_t> ev_pool;  // pairs: [2i] before, [2i+1] after
+    int ev_used = 0;                  // pairs recorded since timing_begin
+    bool ev_on = false;
 };
 
 struct rass_index {
@@ -168,7 +172,7 @@ int index_reserve(rass_index* idx, int64_t need_rows) {
 int scan_launch(const float* d_corpus, int64_t n_rows, int64_t stride, const int32_t* d_row_tag,
                 const float* d_queries, int q_dim, int64_t q_stride, int nq, const int32_t* d_q_filter, int k,
                 int64_t id_base, float* d_out_scores, int64_t* d_out_ids, unsigned char* ws, size_t ws_bytes,
-                int n_cus, hipStream_t st) {
+                int n_cus, hipStream_t st, rass_engine* timing = nullptr) {
     if (nq < 1 || nq > RASS_MAX_QBATCH) return fail(RASS_ERR_INVALID, "nq must be in [1, RASS_MAX_QBATCH]");
     if (k < 1 || k > RASS_MAX_K) return fail(RASS_ERR_INVALID, "k must be in [1, RASS_MAX_K]");
     if (n_rows < 0 || n_rows > 0x7fffffc0LL) return fail(RASS_ERR_INVALID, "n_rows out of range for one scan");
@@ -203,7 +207,13 @@ int scan_launch(const float* d_corpus, int64_t n_rows, int64_t stride, const int
     a.n_rows = (int)n_rows;
     a.nq = nq;
     a.k = k;
+    const bool timed = timing && timing->ev_on && (size_t)(2 * timing->ev_used + 1) < timing->ev_pool.size();
+    if (timed) HIP_TRY(hipEventRecord(timing->ev_pool[2 * timing->ev_used], st));
     HIP_TRY(rass::launch_scan_topk_f32(a, grid, st));
+    if (timed) {
+        HIP_TRY(hipEventRecord(timing->ev_pool[2 * timing->ev_used + 1], st));
+        timing->ev_used += 1;
+    }
     HIP_TRY(rass::launch_merge_topk(part_scores, part_ids, grid, nq, k, d_out_scores, d_out_ids, st));
     return RASS_OK;
 }
@@ -269,6 +279,7 @@ void rass_engine_destroy(rass_engine_t* eng) {
     (void)hipFree(eng->d_out_ids);
     (void)hipFree(eng->d_stage);
     (void)hipFree(eng->d_stage_tags);
+    for (hipEvent_t e : eng->ev_pool) (void)hipEventDestroy(e);
     if (eng->own_stream) (void)hipStreamDestroy(eng->own_stream);
     delete eng;
 }
@@ -450,6 +461,25 @@ int rass_index_get_row(rass_index_t* idx, int64_t row, float* out) {
     return RASS_OK;
 }
 
+int rass_index_get_rows(rass_index_t* idx, int64_t first_row, int64_t n, float* out) {
+    if (!idx || (n > 0 && !out)) return fail(RASS_ERR_INVALID, "NULL argument");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    if (first_row < 0 || n < 0 || first_row + n > idx->rows) return fail(RASS_ERR_NOT_FOUND, "rows out of range");
+    int rc = set_device(idx->eng);
+    if (rc != RASS_OK) return rc;
+    hipStream_t st = idx->eng->stream;
+    std::lock_guard<std::mutex> elk(idx->eng->mu);  // d_stage is shared engine scratch
+    for (int64_t done = 0; done < n; done += kStageRows) {
+        const int64_t m = std::min<int64_t>(kStageRows, n - done);
+        HIP_TRY(rass::launch_unpack_rows_tile16(idx->d_rows, idx->stride, first_row + done, m, idx->dim,
+                                                idx->eng->d_stage, idx->dim, st));
+        HIP_TRY(hipMemcpyAsync(out + done * idx->dim, idx->eng->d_stage, (size_t)m * idx->dim * sizeof(float),
+                               hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    return RASS_OK;
+}
+
 int rass_index_search_device(rass_index_t* idx, const float* d_queries, int nq, int k, const int32_t* d_q_filter,
                              int64_t id_base, float* d_out_scores, int64_t* d_out_ids) {
     if (!idx || !d_queries || !d_out_scores || !d_out_ids) return fail(RASS_ERR_INVALID, "NULL argument");
@@ -461,7 +491,7 @@ int rass_index_search_device(rass_index_t* idx, const float* d_queries, int nq, 
     return scan_launch(idx->d_rows ? idx->d_rows : reinterpret_cast<const float*>(eng->d_scratch), idx->rows,
                        idx->stride, need_tags ? idx->d_tags : nullptr, d_queries, idx->dim, idx->dim, nq,
                        d_q_filter, k, id_base, d_out_scores, d_out_ids, eng->d_scratch, eng->scratch_bytes,
-                       eng->n_cus, eng->stream);
+                       eng->n_cus, eng->stream, eng);
 }
 
 int rass_index_search(rass_index_t* idx, const float* queries, int nq, int k, const int32_t* q_filter,
@@ -492,7 +522,7 @@ int rass_index_search(rass_index_t* idx, const float* queries, int nq, int k, co
             rc = scan_launch(idx->d_rows ? idx->d_rows : reinterpret_cast<const float*>(eng->d_scratch), idx->rows,
                              idx->stride, need_tags ? idx->d_tags : nullptr, eng->d_qraw, dim, dim, b, d_filter, k,
                              0, eng->d_out_scores, eng->d_out_ids, eng->d_scratch, eng->scratch_bytes, eng->n_cus,
-                             st);
+                             st, eng);
             if (rc != RASS_OK) return rc;
             HIP_TRY(hipMemcpyAsync(out_scores + (int64_t)done * k, eng->d_out_scores, (size_t)b * k * sizeof(float),
                                    hipMemcpyDeviceToHost, st));
@@ -751,6 +781,41 @@ int rass_timer_elapsed_ms(rass_timer_t* t, float* ms) {
     HIP_TRY(hipEventElapsedTime(ms, t->start, t->stop));
     return RASS_OK;
 }
+
+int rass_engine_kernel_timing_begin(rass_engine_t* eng, int max_launches) {
+    if (!eng || max_launches < 1) return fail(RASS_ERR_INVALID, "bad argument");
+    std::lock_guard<std::mutex> lk(eng->mu);
+    HIP_TRY(hipSetDevice(eng->device));
+    while (eng->ev_pool.size() < (size_t)max_launches * 2) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        eng->ev_pool.push_back(e);
+    }
+    eng->ev_used = 0;
+    eng->ev_on = true;
+    return RASS_OK;
+}
+
+int rass_engine_kernel_timing_end(rass_engine_t* eng, double* total_ms, int* launches) {
+    if (!eng || !total_ms || !launches) return fail(RASS_ERR_INVALID, "NULL argument");
+    std::lock_guard<std::mutex> lk(eng->mu);
+    HIP_TRY(hipSetDevice(eng->device));
+    eng->ev_on = false;
+    double sum = 0.0;
+    for (int i = 0; i < eng->ev_used; ++i) {
+        float ms = 0.f;
+        HIP_TRY(hipEventSynchronize(eng->ev_pool[2 * i + 1]));
+        HIP_TRY(hipEventElapsedTime(&ms, eng->ev_pool[2 * i], eng->ev_pool[2 * i + 1]));
+        sum += ms;
+    }
+    *total_ms = sum;
+    *launches = eng->ev_used;
+    eng->ev_used = 0;
+    return RASS_OK;
+}
+
+void* rass_index_device_rows(rass_index_t* idx) { return idx ? reinterpret_cast<void*>(idx->d_rows) : nullptr; }
+void* rass_index_device_tags(rass_index_t* idx) { return idx ? reinterpret_cast<void*>(idx->d_tags) : nullptr; }
 
 const char* rass_scan_kernel_name(int dim, int nq) {
     static thread_local char buf[64];

@@ -1,0 +1,99 @@
+"""Drop-in replacements for the reference's Ollama embedding client
+(app/main.py:225-274; variant in app/embedding_gen.py:152-192): same names, signatures,
+dtypes, shapes and blank-text behaviour, with the per-text HTTP POST replaced by batched
+calls into the in-process encoder.
+
+Contract reproduced:
+
+* ``ollama_embed_text(text)``: blank text -> ``[0.0] * EMBED_DIM`` (227-228), else a list of
+  EMBED_DIM floats; errors raise (``raise_for_status``, 235);
+* ``embed_texts_in_batches(texts, batch_size)``: order-preserving, C-contiguous fp32
+  ``[n, EMBED_DIM]``; empty input -> ``np.array([])`` (shape (0,), 246-247);
+* ``embed_query(query)``: blank -> ``np.array([])`` whose ``.size == 0`` is what
+  ``semantic_search`` tests (1534); else ``[1, EMBED_DIM]`` fp32; no query prompt prefix.
+
+The reference bounds concurrency with ``Semaphore(MAX_EMBED_CONCURRENCY)`` around one
+request per text; here a whole batch is one GPU call, run in a worker thread so the event
+loop is not blocked.
+"""
+from __future__ import annotations
+
+import asyncio
+import threading
+from typing import List, Optional, Protocol
+
+import numpy as np
+
+from . import config
+
+BATCH_SIZE = config.BATCH_SIZE
+EMBED_DIM = config.EMBED_DIM
+
+
+class Embedder(Protocol):
+    dim: int
+
+    def encode(self, texts: List[str]) -> np.ndarray:
+        """Pooled sentence embeddings, fp32 [len(texts), dim] (not necessarily normalised)."""
+
+
+_embedder: Optional[Embedder] = None
+_lock = threading.Lock()
+
+
+def set_embedder(embedder: Optional[Embedder]) -> None:
+    global _embedder
+    with _lock:
+        _embedder = embedder
+
+
+def get_embedder() -> Embedder:
+    """The process-global encoder; loaded from ``RASS_MODEL_DIR`` on first use."""
+    global _embedder
+    with _lock:
+        if _embedder is None:
+            if not config.RASS_MODEL_DIR:
+                raise RuntimeError(
+                    "no encoder loaded: set RASS_MODEL_DIR to a local directory with the "
+                    f"{config.EMBED_MODEL_NAME} weights and vocab.txt, or call set_embedder()")
+            from .encoder import HipSentenceEncoder
+            _embedder = HipSentenceEncoder.from_dir(config.RASS_MODEL_DIR, device=config.RASS_DEVICE)
+        return _embedder
+
+
+def _encode_nonblank(texts: List[str]) -> np.ndarray:
+    """Blank texts -> zero rows (app/main.py:227-228); the rest go through the encoder."""
+    enc = get_embedder()
+    out = np.zeros((len(texts), enc.dim), dtype=np.float32)
+    keep = [i for i, t in enumerate(texts) if t.strip()]
+    if keep:
+        vecs = np.asarray(enc.encode([texts[i] for i in keep]), dtype=np.float32)
+        out[keep] = vecs
+    return out
+
+
+async def ollama_embed_text(text: str) -> List[float]:
+    """Get an embedding for a single text (app/main.py:225-237)."""
+    if not text.strip():
+        return [0.0] * EMBED_DIM
+    vec = await asyncio.to_thread(_encode_nonblank, [text])
+    return vec[0].tolist()
+
+
+async def embed_texts_in_batches(texts: List[str], batch_size: int = BATCH_SIZE) -> np.ndarray:
+    """Embeds a list of texts in batches (app/main.py:240-263)."""
+    if not texts:
+        return np.array([])
+    all_embeddings = []
+    for i in range(0, len(texts), batch_size):
+        batch = texts[i:i + batch_size]
+        all_embeddings.append(await asyncio.to_thread(_encode_nonblank, batch))
+    return np.ascontiguousarray(np.concatenate(all_embeddings, axis=0), dtype=np.float32)
+
+
+async def embed_query(query: str) -> np.ndarray:
+    """Embedding of a single query, shape [1, EMBED_DIM] (app/main.py:266-274)."""
+    if not query.strip():
+        return np.array([])
+    emb_list = await ollama_embed_text(query)
+    return np.array([emb_list], dtype=np.float32)

@@ -74,6 +74,18 @@ class Engine:
     def synchronize(self) -> None:
         N.check("rass_engine_synchronize", self._L.rass_engine_synchronize(self._h))
 
+    def kernel_timing_begin(self, max_launches: int) -> None:
+        """Bracket every scan-kernel launch with a hipEvent pair on the engine stream."""
+        N.check("rass_engine_kernel_timing_begin", self._L.rass_engine_kernel_timing_begin(self._h, int(max_launches)))
+
+    def kernel_timing_end(self) -> Tuple[float, int]:
+        """(summed scan-kernel milliseconds, launches) since ``kernel_timing_begin``."""
+        ms = ctypes.c_double(0.0)
+        n = ctypes.c_int(0)
+        N.check("rass_engine_kernel_timing_end",
+                self._L.rass_engine_kernel_timing_end(self._h, ctypes.byref(ms), ctypes.byref(n)))
+        return float(ms.value), int(n.value)
+
     def open_index(self, name: str, capacity_rows: int = 0) -> "FlatIndex":
         """Look up or create the named cosine index (ensure_index_exists, app/main.py:350)."""
         idx = self._indices.get(name)
@@ -125,6 +137,15 @@ class FlatIndex:
     def row_stride(self) -> int:
         return int(self._L.rass_index_row_stride(self._h))
 
+    @property
+    def device_rows_ptr(self) -> int:
+        """Device pointer of the tile16 slab (invalidated by growth)."""
+        return int(self._L.rass_index_device_rows(self._h) or 0)
+
+    @property
+    def device_tags_ptr(self) -> int:
+        return int(self._L.rass_index_device_tags(self._h) or 0)
+
     # ---- write path
     def add(self, vecs: np.ndarray, tags: Optional[np.ndarray] = None, normalize: bool = True) -> int:
         """Append rows (host fp32 [n, dim]); returns the id of the first appended row."""
@@ -158,6 +179,12 @@ class FlatIndex:
     def get_row(self, row: int) -> np.ndarray:
         out = np.empty(self.dim, dtype=np.float32)
         N.check("rass_index_get_row", self._L.rass_index_get_row(self._h, int(row), _np_ptr(out)))
+        return out
+
+    def get_rows(self, first_row: int, n: int) -> np.ndarray:
+        """Stored (normalised) rows [first_row, first_row+n) as fp32 [n, dim]."""
+        out = np.empty((int(n), self.dim), dtype=np.float32)
+        N.check("rass_index_get_rows", self._L.rass_index_get_rows(self._h, int(first_row), int(n), _np_ptr(out)))
         return out
 
     def save(self, path: str) -> None:

@@ -1,0 +1,62 @@
+"""Test doubles: a CPU stand-in for FlatIndex (oracle-backed) so the host-side shim logic
+can be exercised without a GPU.  Lives under tests/ — never imported by the product."""
+import numpy as np
+
+from oracle import oracle as O
+
+
+class OracleIndex:
+    """Same surface as rassengine_amd.engine.FlatIndex; arithmetic = the CPU oracle."""
+
+    def __init__(self, dim=1024):
+        self.dim = dim
+        self._rows = np.zeros((0, dim), dtype=np.float32)
+        self._tags = np.zeros((0,), dtype=np.int32)
+
+    @property
+    def rows(self):
+        return self._rows.shape[0]
+
+    @property
+    def count(self):
+        return int((self._tags != -1).sum())
+
+    def add(self, vecs, tags=None, normalize=True):
+        v = np.ascontiguousarray(vecs, dtype=np.float32)
+        first = self.rows
+        if normalize:
+            v = O.normalize_ref(v).astype(np.float32)
+        t = np.zeros(v.shape[0], dtype=np.int32) if tags is None else np.asarray(tags, dtype=np.int32)
+        self._rows = np.concatenate([self._rows, v])
+        self._tags = np.concatenate([self._tags, t])
+        return first
+
+    def delete(self, row):
+        if not 0 <= row < self.rows:
+            raise IndexError(row)
+        self._tags[row] = -1
+
+    def get_row(self, row):
+        return self._rows[row].copy()
+
+    def search(self, queries, k, q_filter=None):
+        qn = O.normalize_ref(np.ascontiguousarray(queries, dtype=np.float32)).astype(np.float32)
+        s, i = O.search(self._rows, qn, k, tags=self._tags, qfilter=q_filter)
+        return s.astype(np.float32), i
+
+
+class HashEmbedder:
+    """Deterministic text -> vector stand-in for the encoder (host-logic tests only)."""
+
+    def __init__(self, dim=1024):
+        self.dim = dim
+        self.calls = []
+
+    def encode(self, texts):
+        self.calls.append(list(texts))
+        out = np.zeros((len(texts), self.dim), dtype=np.float32)
+        for r, t in enumerate(texts):
+            for w in t.lower().split():
+                rng = np.random.default_rng(abs(hash(w)) % (2 ** 32))
+                out[r] += rng.standard_normal(self.dim).astype(np.float32)
+        return out * 3.0  # deliberately un-normalised

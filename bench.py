@@ -134,6 +134,8 @@ def main():
         },
     }
 
+    result["roofline"]["traffic"] = pmc_traffic(result["roofline"]["kernel"], bytes_per_launch)
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result.update(cpu_baseline_and_recall(np, torch, eng, idx, pool, args, n_local, dim, B, k))
 
@@ -143,6 +145,25 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     eng.close()
+
+
+def pmc_traffic(kernel: str, bytes_per_launch: int):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC pass
+    (`--pmc FETCH_SIZE` in its own run, gfx950 x2 correction; scripts/pmc_traffic.py).
+    PMC counters cannot be read from inside this process, so the figure comes from the newest
+    profiles/*pmc_traffic*.json that holds THIS kernel at THIS byte count (+-10%); else null."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json"))):
+        try:
+            data = json.load(open(path))
+        except Exception:
+            continue
+        for name, e in data.items():
+            b = e.get("hbm_read_bytes_per_launch")
+            if kernel in name and b and abs(b - bytes_per_launch) <= 0.1 * bytes_per_launch:
+                best = round(b + e.get("hbm_write_bytes_per_launch", 0.0))
+    return best
 
 
 def cpu_baseline_and_recall(np, torch, eng, idx, pool, args, n_local, dim, B, k):

@@ -204,6 +204,55 @@ int rass_normalize_rows_f32(const float* d_in, int64_t in_stride, float* d_out,
                             int64_t out_stride, int64_t n, int dim,
                             void* stream);
 
+/* ---------------------------------------------------------------- encoder
+ * Replaces ollama_embed_text / embed_texts_in_batches / embed_query's HTTP hop
+ * to Ollama (app/main.py:225-274): a BERT-class post-LN sentence encoder
+ * (mxbai-embed-large class, OLLAMA_EMBED_MODEL app/main.py:67) run as one
+ * batched, varlen-packed forward of hand-written gfx950 kernels (bf16 MFMA
+ * GEMMs with fused bias/GELU/residual epilogues, LDS-resident attention,
+ * LayerNorm, pooling). */
+typedef struct rass_encoder rass_encoder_t;
+
+typedef struct rass_encoder_config {
+    int32_t vocab_size;     /* 30522 */
+    int32_t hidden;         /* 1024 = EMBED_DIM; must be heads * 64 */
+    int32_t layers;         /* 24 */
+    int32_t heads;          /* 16 */
+    int32_t intermediate;   /* 4096 */
+    int32_t max_positions;  /* <= 512 */
+    int32_t pooling;        /* 0 = cls, 1 = mean over tokens */
+    int32_t normalize;      /* != 0: L2-normalise the pooled vector, e/(||e||+1e-9) */
+    float layer_norm_eps;   /* 1e-12 */
+} rass_encoder_config;
+
+int rass_encoder_create(int device, const rass_encoder_config* cfg,
+                        rass_encoder_t** out);
+void rass_encoder_destroy(rass_encoder_t* enc);
+int rass_encoder_hidden(const rass_encoder_t* enc);
+/* One call per tensor, by its Hugging Face BERT name ("embeddings.word_
+ * embeddings.weight", "encoder.layer.7.attention.self.query.weight", ...),
+ * fp32 host data in the checkpoint's layout ([out][in] for Linear). */
+int rass_encoder_set_weight(rass_encoder_t* enc, const char* name,
+                            const float* data, int64_t numel);
+/* Checks that every tensor of the architecture was supplied. */
+int rass_encoder_finalize(rass_encoder_t* enc);
+/* token_ids: all sequences back to back (each already [CLS] ... [SEP],
+ * <= max_positions tokens); cu_seqlens[nseq+1] prefix sums starting at 0.
+ * out: nseq x hidden fp32, order = input order. */
+int rass_encode(rass_encoder_t* enc, const int32_t* token_ids,
+                const int32_t* cu_seqlens, int nseq, float* out);
+/* Device-resident, asynchronous on `stream` (NULL = the encoder's stream):
+ * the output can be handed straight to rass_index_add_device. */
+int rass_encode_device(rass_encoder_t* enc, const int32_t* d_token_ids,
+                       const int32_t* d_cu_seqlens, int nseq, int total_tokens,
+                       int max_seqlen, float* d_out, void* stream);
+/* The encoder's GEMM on its own: Y[m,n] = epi(X[m,k] W[n,k]^T + bias), bf16
+ * operands; epilogue 0 bias, 1 bias+residual, 2 bias+GELU(erf).  m_pad
+ * (multiple of 128) rows must be allocated; n % 128 == 0, k % 64 == 0. */
+int rass_gemm_bf16(const void* d_x, const void* d_w, const float* d_bias,
+                   const void* d_residual, void* d_y, int m, int m_pad, int n,
+                   int k, int epilogue, void* stream);
+
 /* HIP-event timing on an explicit stream (bench.py measures kernels on the
  * stream they run on; torch.cuda.Event only sees torch's current stream). */
 typedef struct rass_timer rass_timer_t;

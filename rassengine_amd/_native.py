@@ -79,6 +79,17 @@ SIGNATURES = {
                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "rass_normalize_rows_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
                                                ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
+    "rass_encoder_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, c_void_pp]),
+    "rass_encoder_destroy": (None, [ctypes.c_void_p]),
+    "rass_encoder_hidden": (ctypes.c_int, [ctypes.c_void_p]),
+    "rass_encoder_set_weight": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int64]),
+    "rass_encoder_finalize": (ctypes.c_int, [ctypes.c_void_p]),
+    "rass_encode": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    "rass_encode_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                          ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
+    "rass_gemm_bf16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                      ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                      ctypes.c_int, ctypes.c_void_p]),
     "rass_timer_create": (ctypes.c_int, [c_void_pp]),
     "rass_timer_destroy": (None, [ctypes.c_void_p]),
     "rass_timer_start": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),

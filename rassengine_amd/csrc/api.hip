@@ -220,6 +220,8 @@ int scan_launch(const float* d_corpus, int64_t n_rows, int64_t stride, const int
 
 }  // namespace
 
+extern "C" void rassint_set_last_error(const char* msg) { g_err = msg ? msg : ""; }
+
 extern "C" {
 
 int rass_abi_version(void) { return RASS_ABI_VERSION; }

@@ -1,0 +1,360 @@
+// encoder_api.hip — C ABI of the sentence encoder (include/rass_engine.h, "encoder" section):
+// a BERT-class post-LN transformer (mxbai-embed-large class: 24 x 1024 x 16 heads x 4096,
+// reference OLLAMA_EMBED_MODEL, app/main.py:67) whose forward pass is the K4-K8 kernels.
+// Replaces the arithmetic behind ollama_embed_text (app/main.py:225-237): one batched,
+// varlen-packed forward instead of one HTTP request per text.
+//
+// Weights arrive by their Hugging Face BERT names as fp32 host arrays (the Python loader
+// reads a local model.safetensors); matrices are stored bf16 in HBM ([out][in], nn.Linear
+// layout; q/k/v fused to one [3H][H]), biases and LayerNorm parameters fp32.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/rass_engine.h"
+#include "encoder_kernels.h"
+
+extern "C" void rassint_set_last_error(const char* msg);  // api.hip (internal, not part of the ABI)
+
+namespace {
+
+int efail(int code, const std::string& msg) {
+    rassint_set_last_error(msg.c_str());
+    return code;
+}
+
+#define EHIP_TRY(expr)                                                                                  \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess) {                                                                         \
+            char _b[512];                                                                               \
+            snprintf(_b, sizeof(_b), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,   \
+                     __LINE__);                                                                         \
+            return efail(_e == hipErrorOutOfMemory ? RASS_ERR_OOM : RASS_ERR_HIP, _b);                  \
+        }                                                                                               \
+    } while (0)
+
+struct Layer {
+    void* w_qkv = nullptr;   // bf16 [3H][H]
+    float* b_qkv = nullptr;  // [3H]
+    void* w_o = nullptr;     // bf16 [H][H]
+    float* b_o = nullptr;
+    float *ln1_g = nullptr, *ln1_b = nullptr;
+    void* w_up = nullptr;    // bf16 [I][H]
+    float* b_up = nullptr;
+    void* w_down = nullptr;  // bf16 [H][I]
+    float* b_down = nullptr;
+    float *ln2_g = nullptr, *ln2_b = nullptr;
+};
+
+}  // namespace
+
+struct rass_encoder {
+    int device = 0;
+    rass_encoder_config cfg;
+    hipStream_t own_stream = nullptr;
+    std::mutex mu;
+    std::vector<void*> allocs;
+    void *word = nullptr, *pos = nullptr, *type0 = nullptr;  // bf16
+    float *emb_g = nullptr, *emb_b = nullptr;
+    std::vector<Layer> layers;
+    std::map<std::string, bool> seen;
+    bool finalized = false;
+    // workspace (grown on demand)
+    int cap_tokens = 0, cap_seqs = 0;
+    void *x = nullptr, *qkv = nullptr, *ctx = nullptr, *y = nullptr, *h = nullptr;  // bf16 activations
+    int32_t *d_ids = nullptr, *d_cu = nullptr;
+    float* d_out = nullptr;
+    float* d_stage = nullptr;  // fp32 staging for weight upload
+    size_t stage_elems = 0;
+};
+
+namespace {
+
+int dev_alloc(rass_encoder* e, void** p, size_t bytes) {
+    EHIP_TRY(hipMalloc(p, bytes));
+    e->allocs.push_back(*p);
+    return RASS_OK;
+}
+
+// upload fp32 host -> device, optionally converting to bf16 at dst (element offset dst_off)
+int upload(rass_encoder* e, const float* host, int64_t n, void* dst, int64_t dst_off, bool to_bf16) {
+    hipStream_t st = e->own_stream;
+    if (!to_bf16) {
+        EHIP_TRY(hipMemcpyAsync(static_cast<float*>(dst) + dst_off, host, (size_t)n * 4, hipMemcpyHostToDevice, st));
+        EHIP_TRY(hipStreamSynchronize(st));
+        return RASS_OK;
+    }
+    const int64_t chunk = (int64_t)e->stage_elems;
+    for (int64_t done = 0; done < n; done += chunk) {
+        const int64_t m = std::min(chunk, n - done);
+        EHIP_TRY(hipMemcpyAsync(e->d_stage, host + done, (size_t)m * 4, hipMemcpyHostToDevice, st));
+        EHIP_TRY(rass::launch_f32_to_bf16(e->d_stage, static_cast<unsigned short*>(dst) + dst_off + done, m, st));
+        EHIP_TRY(hipStreamSynchronize(st));
+    }
+    return RASS_OK;
+}
+
+int ensure_workspace(rass_encoder* e, int tokens_pad, int nseq) {
+    const int H = e->cfg.hidden, I = e->cfg.intermediate;
+    if (tokens_pad > e->cap_tokens) {
+        for (void** p : {&e->x, &e->qkv, &e->ctx, &e->y, &e->h})
+            if (*p) {
+                (void)hipFree(*p);
+                *p = nullptr;
+            }
+        if (e->d_ids) (void)hipFree(e->d_ids);
+        e->d_ids = nullptr;
+        const size_t T = (size_t)tokens_pad;
+        EHIP_TRY(hipMalloc(&e->x, T * H * 2));
+        EHIP_TRY(hipMalloc(&e->qkv, T * 3 * H * 2));
+        EHIP_TRY(hipMalloc(&e->ctx, T * H * 2));
+        EHIP_TRY(hipMalloc(&e->y, T * H * 2));
+        EHIP_TRY(hipMalloc(&e->h, T * I * 2));
+        EHIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_ids), T * 4));
+        // padding rows are read as GEMM operands: keep them finite
+        EHIP_TRY(hipMemset(e->x, 0, T * H * 2));
+        EHIP_TRY(hipMemset(e->qkv, 0, T * 3 * H * 2));
+        EHIP_TRY(hipMemset(e->ctx, 0, T * H * 2));
+        EHIP_TRY(hipMemset(e->y, 0, T * H * 2));
+        EHIP_TRY(hipMemset(e->h, 0, T * I * 2));
+        e->cap_tokens = tokens_pad;
+    }
+    if (nseq > e->cap_seqs) {
+        if (e->d_cu) (void)hipFree(e->d_cu);
+        if (e->d_out) (void)hipFree(e->d_out);
+        e->d_cu = nullptr;
+        e->d_out = nullptr;
+        EHIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_cu), ((size_t)nseq + 1) * 4));
+        EHIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_out), (size_t)nseq * H * 4));
+        e->cap_seqs = nseq;
+    }
+    return RASS_OK;
+}
+
+int forward(rass_encoder* e, const int32_t* d_ids, const int32_t* d_cu, int nseq, int total, int max_seqlen,
+            float* d_out, hipStream_t st) {
+    const rass_encoder_config& c = e->cfg;
+    const int H = c.hidden, I = c.intermediate;
+    const int Tp = (total + 127) / 128 * 128;
+    EHIP_TRY(rass::launch_embed_layernorm(d_ids, d_cu, nseq, total, e->word, e->pos, e->type0, e->emb_g, e->emb_b,
+                                          c.layer_norm_eps, H, c.vocab_size, c.max_positions, e->x, st));
+    for (int l = 0; l < c.layers; ++l) {
+        const Layer& L = e->layers[(size_t)l];
+        EHIP_TRY(rass::launch_gemm_bf16(e->x, L.w_qkv, L.b_qkv, nullptr, e->qkv, total, Tp, 3 * H, H, 0, st));
+        EHIP_TRY(rass::launch_attention(e->qkv, d_cu, nseq, max_seqlen, H, c.heads, e->ctx, st));
+        EHIP_TRY(rass::launch_gemm_bf16(e->ctx, L.w_o, L.b_o, e->x, e->y, total, Tp, H, H, 1, st));
+        EHIP_TRY(rass::launch_layernorm(e->y, L.ln1_g, L.ln1_b, c.layer_norm_eps, total, H, e->x, st));
+        EHIP_TRY(rass::launch_gemm_bf16(e->x, L.w_up, L.b_up, nullptr, e->h, total, Tp, I, H, 2, st));
+        EHIP_TRY(rass::launch_gemm_bf16(e->h, L.w_down, L.b_down, e->x, e->y, total, Tp, H, I, 1, st));
+        EHIP_TRY(rass::launch_layernorm(e->y, L.ln2_g, L.ln2_b, c.layer_norm_eps, total, H, e->x, st));
+    }
+    EHIP_TRY(rass::launch_pool(e->x, d_cu, nseq, H, c.pooling == 1 ? 1 : 0, c.normalize ? 1 : 0, d_out, st));
+    return RASS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rass_encoder_create(int device, const rass_encoder_config* cfg, rass_encoder_t** out) {
+    if (!cfg || !out) return efail(RASS_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    if (cfg->hidden < 64 || cfg->hidden % 128 != 0 || cfg->hidden > 2048 || cfg->heads < 1 ||
+        cfg->hidden != cfg->heads * 64)
+        return efail(RASS_ERR_UNSUPPORTED, "hidden must be heads*64, a multiple of 128, <= 2048");
+    if (cfg->intermediate < 128 || cfg->intermediate % 128 != 0)
+        return efail(RASS_ERR_UNSUPPORTED, "intermediate must be a multiple of 128");
+    if (cfg->layers < 1 || cfg->vocab_size < 1 || cfg->max_positions < 1 || cfg->max_positions > 512)
+        return efail(RASS_ERR_UNSUPPORTED, "layers/vocab/max_positions out of range (max_positions <= 512)");
+    int n = 0;
+    EHIP_TRY(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return efail(RASS_ERR_INVALID, "no such HIP device");
+    rass_encoder* e = new (std::nothrow) rass_encoder();
+    if (!e) return efail(RASS_ERR_OOM, "host allocation failed");
+    e->device = device;
+    e->cfg = *cfg;
+    EHIP_TRY(hipSetDevice(device));
+    EHIP_TRY(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
+    const size_t H = (size_t)cfg->hidden, I = (size_t)cfg->intermediate;
+    e->stage_elems = std::max<size_t>(I * H, 1 << 20);
+    int rc;
+    if ((rc = dev_alloc(e, reinterpret_cast<void**>(&e->d_stage), e->stage_elems * 4)) != RASS_OK) return rc;
+    if ((rc = dev_alloc(e, &e->word, (size_t)cfg->vocab_size * H * 2)) != RASS_OK) return rc;
+    if ((rc = dev_alloc(e, &e->pos, (size_t)cfg->max_positions * H * 2)) != RASS_OK) return rc;
+    if ((rc = dev_alloc(e, &e->type0, H * 2)) != RASS_OK) return rc;
+    if ((rc = dev_alloc(e, reinterpret_cast<void**>(&e->emb_g), H * 4)) != RASS_OK) return rc;
+    if ((rc = dev_alloc(e, reinterpret_cast<void**>(&e->emb_b), H * 4)) != RASS_OK) return rc;
+    e->layers.resize((size_t)cfg->layers);
+    for (Layer& L : e->layers) {
+        if ((rc = dev_alloc(e, &L.w_qkv, 3 * H * H * 2)) != RASS_OK) return rc;
+        if ((rc = dev_alloc(e, reinterpret_cast<void**>(&L.b_qkv), 3 * H * 4)) != RASS_OK) return rc;
+        if ((rc = dev_alloc(e, &L.w_o, H * H * 2)) != RASS_OK) return rc;
+        if ((rc = dev_alloc(e, reinterpret_cast<void**>(&L.b_o), H * 4)) != RASS_OK) return rc;
+        if ((rc = dev_alloc(e, reinterpret_cast<void**>(&L.ln1_g), H * 4)) != RASS_OK) return rc;
+        if ((rc = dev_alloc(e, reinterpret_cast<void**>(&L.ln1_b), H * 4)) != RASS_OK) return rc;
+        if ((rc = dev_alloc(e, &L.w_up, I * H * 2)) != RASS_OK) return rc;
+        if ((rc = dev_alloc(e, reinterpret_cast<void**>(&L.b_up), I * 4)) != RASS_OK) return rc;
+        if ((rc = dev_alloc(e, &L.w_down, H * I * 2)) != RASS_OK) return rc;
+        if ((rc = dev_alloc(e, reinterpret_cast<void**>(&L.b_down), H * 4)) != RASS_OK) return rc;
+        if ((rc = dev_alloc(e, reinterpret_cast<void**>(&L.ln2_g), H * 4)) != RASS_OK) return rc;
+        if ((rc = dev_alloc(e, reinterpret_cast<void**>(&L.ln2_b), H * 4)) != RASS_OK) return rc;
+    }
+    *out = e;
+    return RASS_OK;
+}
+
+void rass_encoder_destroy(rass_encoder_t* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    (void)hipDeviceSynchronize();
+    for (void* p : e->allocs) (void)hipFree(p);
+    for (void* p : {e->x, e->qkv, e->ctx, e->y, e->h, (void*)e->d_ids, (void*)e->d_cu, (void*)e->d_out})
+        if (p) (void)hipFree(p);
+    if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
+    delete e;
+}
+
+int rass_encoder_set_weight(rass_encoder_t* e, const char* name, const float* data, int64_t numel) {
+    if (!e || !name || !data) return efail(RASS_ERR_INVALID, "NULL argument");
+    std::lock_guard<std::mutex> lk(e->mu);
+    EHIP_TRY(hipSetDevice(e->device));
+    const int64_t H = e->cfg.hidden, I = e->cfg.intermediate;
+    const std::string n(name);
+    auto want = [&](int64_t expect) -> int {
+        if (numel != expect) {
+            char b[256];
+            snprintf(b, sizeof(b), "%s: expected %lld elements, got %lld", name, (long long)expect, (long long)numel);
+            return efail(RASS_ERR_INVALID, b);
+        }
+        return RASS_OK;
+    };
+    int rc = RASS_ERR_NOT_FOUND;
+    if (n == "embeddings.word_embeddings.weight") {
+        if ((rc = want((int64_t)e->cfg.vocab_size * H)) == RASS_OK) rc = upload(e, data, numel, e->word, 0, true);
+    } else if (n == "embeddings.position_embeddings.weight") {
+        // a checkpoint may carry more positions than the engine serves: take the first max_positions rows
+        if (numel >= (int64_t)e->cfg.max_positions * H && numel % H == 0)
+            rc = upload(e, data, (int64_t)e->cfg.max_positions * H, e->pos, 0, true);
+        else
+            rc = want((int64_t)e->cfg.max_positions * H);
+    } else if (n == "embeddings.token_type_embeddings.weight") {
+        if (numel >= H && numel % H == 0) rc = upload(e, data, H, e->type0, 0, true);  // row 0: single-segment input
+        else rc = want(H);
+    } else if (n == "embeddings.LayerNorm.weight") {
+        if ((rc = want(H)) == RASS_OK) rc = upload(e, data, H, e->emb_g, 0, false);
+    } else if (n == "embeddings.LayerNorm.bias") {
+        if ((rc = want(H)) == RASS_OK) rc = upload(e, data, H, e->emb_b, 0, false);
+    } else if (n.rfind("encoder.layer.", 0) == 0) {
+        const size_t p0 = strlen("encoder.layer.");
+        const size_t dot = n.find('.', p0);
+        if (dot == std::string::npos) return efail(RASS_ERR_NOT_FOUND, std::string("unknown weight ") + name);
+        const int l = atoi(n.substr(p0, dot - p0).c_str());
+        if (l < 0 || l >= e->cfg.layers) return efail(RASS_ERR_NOT_FOUND, std::string("layer out of range: ") + name);
+        Layer& L = e->layers[(size_t)l];
+        const std::string s = n.substr(dot + 1);
+        if (s == "attention.self.query.weight") { if ((rc = want(H * H)) == RASS_OK) rc = upload(e, data, numel, L.w_qkv, 0, true); }
+        else if (s == "attention.self.key.weight") { if ((rc = want(H * H)) == RASS_OK) rc = upload(e, data, numel, L.w_qkv, H * H, true); }
+        else if (s == "attention.self.value.weight") { if ((rc = want(H * H)) == RASS_OK) rc = upload(e, data, numel, L.w_qkv, 2 * H * H, true); }
+        else if (s == "attention.self.query.bias") { if ((rc = want(H)) == RASS_OK) rc = upload(e, data, numel, L.b_qkv, 0, false); }
+        else if (s == "attention.self.key.bias") { if ((rc = want(H)) == RASS_OK) rc = upload(e, data, numel, L.b_qkv, H, false); }
+        else if (s == "attention.self.value.bias") { if ((rc = want(H)) == RASS_OK) rc = upload(e, data, numel, L.b_qkv, 2 * H, false); }
+        else if (s == "attention.output.dense.weight") { if ((rc = want(H * H)) == RASS_OK) rc = upload(e, data, numel, L.w_o, 0, true); }
+        else if (s == "attention.output.dense.bias") { if ((rc = want(H)) == RASS_OK) rc = upload(e, data, numel, L.b_o, 0, false); }
+        else if (s == "attention.output.LayerNorm.weight") { if ((rc = want(H)) == RASS_OK) rc = upload(e, data, numel, L.ln1_g, 0, false); }
+        else if (s == "attention.output.LayerNorm.bias") { if ((rc = want(H)) == RASS_OK) rc = upload(e, data, numel, L.ln1_b, 0, false); }
+        else if (s == "intermediate.dense.weight") { if ((rc = want(I * H)) == RASS_OK) rc = upload(e, data, numel, L.w_up, 0, true); }
+        else if (s == "intermediate.dense.bias") { if ((rc = want(I)) == RASS_OK) rc = upload(e, data, numel, L.b_up, 0, false); }
+        else if (s == "output.dense.weight") { if ((rc = want(H * I)) == RASS_OK) rc = upload(e, data, numel, L.w_down, 0, true); }
+        else if (s == "output.dense.bias") { if ((rc = want(H)) == RASS_OK) rc = upload(e, data, numel, L.b_down, 0, false); }
+        else if (s == "output.LayerNorm.weight") { if ((rc = want(H)) == RASS_OK) rc = upload(e, data, numel, L.ln2_g, 0, false); }
+        else if (s == "output.LayerNorm.bias") { if ((rc = want(H)) == RASS_OK) rc = upload(e, data, numel, L.ln2_b, 0, false); }
+    }
+    if (rc == RASS_ERR_NOT_FOUND) return efail(RASS_ERR_NOT_FOUND, std::string("unknown weight ") + name);
+    if (rc == RASS_OK) e->seen[n] = true;
+    return rc;
+}
+
+int rass_encoder_finalize(rass_encoder_t* e) {
+    if (!e) return efail(RASS_ERR_INVALID, "encoder is NULL");
+    std::lock_guard<std::mutex> lk(e->mu);
+    std::vector<std::string> need = {"embeddings.word_embeddings.weight", "embeddings.position_embeddings.weight",
+                                     "embeddings.token_type_embeddings.weight", "embeddings.LayerNorm.weight",
+                                     "embeddings.LayerNorm.bias"};
+    const char* per_layer[] = {"attention.self.query.weight", "attention.self.query.bias", "attention.self.key.weight",
+                               "attention.self.key.bias", "attention.self.value.weight", "attention.self.value.bias",
+                               "attention.output.dense.weight", "attention.output.dense.bias",
+                               "attention.output.LayerNorm.weight", "attention.output.LayerNorm.bias",
+                               "intermediate.dense.weight", "intermediate.dense.bias", "output.dense.weight",
+                               "output.dense.bias", "output.LayerNorm.weight", "output.LayerNorm.bias"};
+    for (int l = 0; l < e->cfg.layers; ++l)
+        for (const char* s : per_layer) need.push_back("encoder.layer." + std::to_string(l) + "." + s);
+    for (const std::string& n : need)
+        if (!e->seen.count(n)) return efail(RASS_ERR_NOT_FOUND, "missing weight: " + n);
+    e->finalized = true;
+    return RASS_OK;
+}
+
+int rass_encode_device(rass_encoder_t* e, const int32_t* d_token_ids, const int32_t* d_cu_seqlens, int nseq,
+                       int total_tokens, int max_seqlen, float* d_out, void* stream) {
+    if (!e || !d_token_ids || !d_cu_seqlens || !d_out) return efail(RASS_ERR_INVALID, "NULL argument");
+    if (!e->finalized) return efail(RASS_ERR_INVALID, "encoder weights not finalized");
+    if (nseq < 1 || total_tokens < 1 || max_seqlen < 1 || max_seqlen > e->cfg.max_positions)
+        return efail(RASS_ERR_INVALID, "bad nseq / total_tokens / max_seqlen");
+    std::lock_guard<std::mutex> lk(e->mu);
+    EHIP_TRY(hipSetDevice(e->device));
+    int rc = ensure_workspace(e, (total_tokens + 127) / 128 * 128, nseq);
+    if (rc != RASS_OK) return rc;
+    return forward(e, d_token_ids, d_cu_seqlens, nseq, total_tokens, max_seqlen, d_out,
+                   stream ? reinterpret_cast<hipStream_t>(stream) : e->own_stream);
+}
+
+int rass_encode(rass_encoder_t* e, const int32_t* token_ids, const int32_t* cu_seqlens, int nseq, float* out) {
+    if (!e || !token_ids || !cu_seqlens || !out) return efail(RASS_ERR_INVALID, "NULL argument");
+    if (!e->finalized) return efail(RASS_ERR_INVALID, "encoder weights not finalized");
+    if (nseq < 1) return efail(RASS_ERR_INVALID, "nseq < 1");
+    if (cu_seqlens[0] != 0) return efail(RASS_ERR_INVALID, "cu_seqlens[0] must be 0");
+    int max_len = 0;
+    for (int s = 0; s < nseq; ++s) {
+        const int len = cu_seqlens[s + 1] - cu_seqlens[s];
+        if (len < 1) return efail(RASS_ERR_INVALID, "empty sequence (blank texts are handled by the caller)");
+        max_len = std::max(max_len, len);
+    }
+    if (max_len > e->cfg.max_positions) return efail(RASS_ERR_INVALID, "sequence longer than max_positions");
+    const int total = cu_seqlens[nseq];
+    std::lock_guard<std::mutex> lk(e->mu);
+    EHIP_TRY(hipSetDevice(e->device));
+    int rc = ensure_workspace(e, (total + 127) / 128 * 128, nseq);
+    if (rc != RASS_OK) return rc;
+    hipStream_t st = e->own_stream;
+    EHIP_TRY(hipMemcpyAsync(e->d_ids, token_ids, (size_t)total * 4, hipMemcpyHostToDevice, st));
+    EHIP_TRY(hipMemcpyAsync(e->d_cu, cu_seqlens, ((size_t)nseq + 1) * 4, hipMemcpyHostToDevice, st));
+    rc = forward(e, e->d_ids, e->d_cu, nseq, total, max_len, e->d_out, st);
+    if (rc != RASS_OK) return rc;
+    EHIP_TRY(hipMemcpyAsync(out, e->d_out, (size_t)nseq * e->cfg.hidden * 4, hipMemcpyDeviceToHost, st));
+    EHIP_TRY(hipStreamSynchronize(st));
+    return RASS_OK;
+}
+
+int rass_encoder_hidden(const rass_encoder_t* e) { return e ? e->cfg.hidden : efail(RASS_ERR_INVALID, "encoder is NULL"); }
+
+/* Stand-alone launcher of the encoder GEMM (tests, micro-benchmarks). */
+int rass_gemm_bf16(const void* d_x, const void* d_w, const float* d_bias, const void* d_residual, void* d_y, int m,
+                   int m_pad, int n, int k, int epilogue, void* stream) {
+    if (!d_x || !d_w || !d_bias || !d_y) return efail(RASS_ERR_INVALID, "NULL argument");
+    hipError_t err = rass::launch_gemm_bf16(d_x, d_w, d_bias, d_residual, d_y, m, m_pad, n, k, epilogue,
+                                            reinterpret_cast<hipStream_t>(stream));
+    if (err != hipSuccess) return efail(RASS_ERR_INVALID, std::string("gemm launch: ") + hipGetErrorString(err));
+    return RASS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,39 @@
+// encoder_kernels.h — internal launcher interface of the sentence-encoder kernels (K4-K8 of
+// SURVEY §8a).  Activations are bf16 [tokens][features] row-major, tokens of all sequences
+// packed back to back (varlen, cu_seqlens), padded to a multiple of 128 rows.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rass {
+
+// K5: Y = epilogue(X[M,K] * W[N,K]^T + bias); epilogue 0 bias, 1 bias+residual, 2 bias+GELU(erf).
+// M_pad (multiple of 128) rows of X / Y / residual must be allocated; N % 128 == 0, K % 64 == 0.
+hipError_t launch_gemm_bf16(const void* X, const void* W, const float* bias, const void* residual, void* Y, int M,
+                            int M_pad, int N, int K, int epilogue, hipStream_t stream);
+
+// K4: x[t] = LayerNorm(word[ids[t]] + pos[position of t in its sequence] + type[0]) -> bf16
+hipError_t launch_embed_layernorm(const int32_t* ids, const int32_t* cu_seqlens, int nseq, int total_tokens,
+                                  const void* word_emb, const void* pos_emb, const void* type_emb,
+                                  const float* gamma, const float* beta, float eps, int hidden, int vocab,
+                                  int max_pos, void* out, hipStream_t stream);
+
+// K7: out[t] = LayerNorm(in[t]) (fp32 statistics), bf16 in/out, rows of `hidden`
+hipError_t launch_layernorm(const void* in, const float* gamma, const float* beta, float eps, int rows, int hidden,
+                            void* out, hipStream_t stream);
+
+// K6: varlen self-attention, heads of 64, S <= 512 per sequence, softmax scale 1/8.
+// qkv: [tokens][3*hidden] (q | k | v), ctx: [tokens][hidden]
+hipError_t launch_attention(const void* qkv, const int32_t* cu_seqlens, int nseq, int max_seqlen, int hidden,
+                            int heads, void* ctx, hipStream_t stream);
+
+// K8: pooled[s] = cls (first token) or mean over the sequence's tokens of x, fp32 [nseq][hidden];
+// optional L2 normalise with the reference's formula (app/main.py:1249-1251)
+hipError_t launch_pool(const void* x, const int32_t* cu_seqlens, int nseq, int hidden, int mode_mean, int normalize,
+                       float* out, hipStream_t stream);
+
+// fp32 -> bf16 (weights upload)
+hipError_t launch_f32_to_bf16(const float* in, void* out, int64_t n, hipStream_t stream);
+
+}  // namespace rass

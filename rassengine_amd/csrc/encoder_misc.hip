@@ -1,0 +1,252 @@
+// encoder_misc.hip — the HBM-bound row kernels of the sentence encoder:
+//   K4 embedding gather (word + position + token-type) + LayerNorm
+//   K7 LayerNorm (post-LN BERT: after each residual sum; eps 1e-12)
+//   K8 pooling (cls | mean over the sequence's tokens) + the reference's L2 normalise
+// One wave per row, 16 B (8 bf16) per lane per step, fp32 statistics, two-pass variance on
+// register-resident values, wave butterfly reductions, no LDS.  hidden % 8 == 0, <= 2048.
+
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+
+#include "encoder_kernels.h"
+
+namespace rass {
+
+typedef unsigned short u16;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kRowThreadsE = 256;  // 4 rows per block
+constexpr int kMaxSteps = 4;       // hidden <= 4 * 512
+
+__device__ __forceinline__ float bf2f(u16 v) { return __uint_as_float((unsigned)v << 16); }
+__device__ __forceinline__ u16 f2bf(float f) {
+    __hip_bfloat16 h = __float2bfloat16(f);
+    return *reinterpret_cast<u16*>(&h);
+}
+__device__ __forceinline__ float wave_sum_e(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+struct Vals8 {
+    float v[8];
+};
+
+__device__ __forceinline__ Vals8 load8_bf16(const u16* p) {
+    const uint4 r = *reinterpret_cast<const uint4*>(p);
+    Vals8 o;
+    o.v[0] = bf2f((u16)(r.x & 0xffff));
+    o.v[1] = bf2f((u16)(r.x >> 16));
+    o.v[2] = bf2f((u16)(r.y & 0xffff));
+    o.v[3] = bf2f((u16)(r.y >> 16));
+    o.v[4] = bf2f((u16)(r.z & 0xffff));
+    o.v[5] = bf2f((u16)(r.z >> 16));
+    o.v[6] = bf2f((u16)(r.w & 0xffff));
+    o.v[7] = bf2f((u16)(r.w >> 16));
+    return o;
+}
+
+__device__ __forceinline__ void store8_bf16(u16* p, const Vals8& x) {
+    uint4 r;
+    r.x = (unsigned)f2bf(x.v[0]) | ((unsigned)f2bf(x.v[1]) << 16);
+    r.y = (unsigned)f2bf(x.v[2]) | ((unsigned)f2bf(x.v[3]) << 16);
+    r.z = (unsigned)f2bf(x.v[4]) | ((unsigned)f2bf(x.v[5]) << 16);
+    r.w = (unsigned)f2bf(x.v[6]) | ((unsigned)f2bf(x.v[7]) << 16);
+    *reinterpret_cast<uint4*>(p) = r;
+}
+
+// LayerNorm of a register-resident row (x[s] holds columns lane*8 + 512*s .. +7), write bf16.
+__device__ __forceinline__ void layernorm_store(Vals8 (&x)[kMaxSteps], int hidden, int lane,
+                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                float eps, u16* __restrict__ dst) {
+    float sum = 0.f;
+#pragma unroll
+    for (int s = 0; s < kMaxSteps; ++s)
+        if (lane * 8 + 512 * s < hidden)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sum += x[s].v[e];
+    const float mean = wave_sum_e(sum) / (float)hidden;
+    float sq = 0.f;
+#pragma unroll
+    for (int s = 0; s < kMaxSteps; ++s)
+        if (lane * 8 + 512 * s < hidden)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = x[s].v[e] - mean;
+                sq = fmaf(d, d, sq);
+            }
+    const float rstd = rsqrtf(wave_sum_e(sq) / (float)hidden + eps);
+#pragma unroll
+    for (int s = 0; s < kMaxSteps; ++s) {
+        const int c = lane * 8 + 512 * s;
+        if (c < hidden) {
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + c), g1 = *reinterpret_cast<const f32x4*>(gamma + c + 4);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + c), b1 = *reinterpret_cast<const f32x4*>(beta + c + 4);
+            Vals8 o;
+            o.v[0] = (x[s].v[0] - mean) * rstd * g0.x + b0.x;
+            o.v[1] = (x[s].v[1] - mean) * rstd * g0.y + b0.y;
+            o.v[2] = (x[s].v[2] - mean) * rstd * g0.z + b0.z;
+            o.v[3] = (x[s].v[3] - mean) * rstd * g0.w + b0.w;
+            o.v[4] = (x[s].v[4] - mean) * rstd * g1.x + b1.x;
+            o.v[5] = (x[s].v[5] - mean) * rstd * g1.y + b1.y;
+            o.v[6] = (x[s].v[6] - mean) * rstd * g1.z + b1.z;
+            o.v[7] = (x[s].v[7] - mean) * rstd * g1.w + b1.w;
+            store8_bf16(dst + c, o);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kRowThreadsE) void embed_layernorm_kernel(
+    const int32_t* __restrict__ ids, const int32_t* __restrict__ cu, int nseq, int total, const u16* __restrict__ word,
+    const u16* __restrict__ pos, const u16* __restrict__ type0, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float eps, int hidden, int vocab, int max_pos, u16* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    for (int t = blockIdx.x * 4 + wave; t < total; t += gridDim.x * 4) {
+        // sequence of token t: largest s with cu[s] <= t (wave-uniform binary search)
+        int lo = 0, hi = nseq;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (cu[mid] <= t) lo = mid; else hi = mid;
+        }
+        int p = t - cu[lo];
+        p = p < max_pos ? p : max_pos - 1;
+        int id = ids[t];
+        id = (id < 0 || id >= vocab) ? 0 : id;
+        Vals8 x[kMaxSteps];
+#pragma unroll
+        for (int s = 0; s < kMaxSteps; ++s) {
+            const int c = lane * 8 + 512 * s;
+            if (c < hidden) {
+                const Vals8 w = load8_bf16(word + (int64_t)id * hidden + c);
+                const Vals8 pe = load8_bf16(pos + (int64_t)p * hidden + c);
+                const Vals8 te = load8_bf16(type0 + c);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[s].v[e] = (w.v[e] + te.v[e]) + pe.v[e];
+            }
+        }
+        layernorm_store(x, hidden, lane, gamma, beta, eps, out + (int64_t)t * hidden);
+    }
+}
+
+hipError_t launch_embed_layernorm(const int32_t* ids, const int32_t* cu_seqlens, int nseq, int total_tokens,
+                                  const void* word_emb, const void* pos_emb, const void* type_emb,
+                                  const float* gamma, const float* beta, float eps, int hidden, int vocab,
+                                  int max_pos, void* out, hipStream_t stream) {
+    if (hidden % 8 != 0 || hidden > 512 * kMaxSteps || nseq < 1) return hipErrorInvalidValue;
+    if (total_tokens <= 0) return hipSuccess;
+    int blocks = (total_tokens + 3) / 4;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(embed_layernorm_kernel, dim3(blocks), dim3(kRowThreadsE), 0, stream, ids, cu_seqlens, nseq,
+                       total_tokens, static_cast<const u16*>(word_emb), static_cast<const u16*>(pos_emb),
+                       static_cast<const u16*>(type_emb), gamma, beta, eps, hidden, vocab, max_pos,
+                       static_cast<u16*>(out));
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(kRowThreadsE) void layernorm_kernel(const u16* __restrict__ in,
+                                                                 const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, float eps, int rows,
+                                                                 int hidden, u16* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    for (int r = blockIdx.x * 4 + wave; r < rows; r += gridDim.x * 4) {
+        Vals8 x[kMaxSteps];
+#pragma unroll
+        for (int s = 0; s < kMaxSteps; ++s) {
+            const int c = lane * 8 + 512 * s;
+            if (c < hidden) x[s] = load8_bf16(in + (int64_t)r * hidden + c);
+        }
+        layernorm_store(x, hidden, lane, gamma, beta, eps, out + (int64_t)r * hidden);
+    }
+}
+
+hipError_t launch_layernorm(const void* in, const float* gamma, const float* beta, float eps, int rows, int hidden,
+                            void* out, hipStream_t stream) {
+    if (hidden % 8 != 0 || hidden > 512 * kMaxSteps) return hipErrorInvalidValue;
+    if (rows <= 0) return hipSuccess;
+    int blocks = (rows + 3) / 4;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(layernorm_kernel, dim3(blocks), dim3(kRowThreadsE), 0, stream, static_cast<const u16*>(in),
+                       gamma, beta, eps, rows, hidden, static_cast<u16*>(out));
+    return hipGetLastError();
+}
+
+// K8: one wave per sequence.  mean: fp32 sum over the sequence's tokens in token order, then
+// / n_tokens (what sentence-transformers' mean pooling does with an all-ones mask on real
+// tokens); cls: the first token.  Optional reference normalise e / (||e|| + 1e-9).
+__global__ __launch_bounds__(kRowThreadsE) void pool_kernel(const u16* __restrict__ x, const int32_t* __restrict__ cu,
+                                                            int nseq, int hidden, int mode_mean, int normalize,
+                                                            float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    for (int s = blockIdx.x * 4 + wave; s < nseq; s += gridDim.x * 4) {
+        const int t0 = cu[s], t1 = cu[s + 1];
+        Vals8 acc[kMaxSteps];
+#pragma unroll
+        for (int st = 0; st < kMaxSteps; ++st)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[st].v[e] = 0.f;
+        const int last = mode_mean ? t1 : (t1 > t0 ? t0 + 1 : t0);
+        for (int t = t0; t < last; ++t) {
+#pragma unroll
+            for (int st = 0; st < kMaxSteps; ++st) {
+                const int c = lane * 8 + 512 * st;
+                if (c < hidden) {
+                    const Vals8 v = load8_bf16(x + (int64_t)t * hidden + c);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[st].v[e] += v.v[e];
+                }
+            }
+        }
+        const float inv_n = (mode_mean && t1 > t0) ? 1.f / (float)(t1 - t0) : 1.f;
+        float ss = 0.f;
+#pragma unroll
+        for (int st = 0; st < kMaxSteps; ++st)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                acc[st].v[e] *= inv_n;
+                if (lane * 8 + 512 * st < hidden) ss = fmaf(acc[st].v[e], acc[st].v[e], ss);
+            }
+        const float denom = normalize ? sqrtf(wave_sum_e(ss)) + 1e-9f : 1.f;
+#pragma unroll
+        for (int st = 0; st < kMaxSteps; ++st) {
+            const int c = lane * 8 + 512 * st;
+            if (c < hidden) {
+                float* dst = out + (int64_t)s * hidden + c;
+                *reinterpret_cast<f32x4*>(dst) = f32x4{acc[st].v[0] / denom, acc[st].v[1] / denom, acc[st].v[2] / denom,
+                                                       acc[st].v[3] / denom};
+                *reinterpret_cast<f32x4*>(dst + 4) = f32x4{acc[st].v[4] / denom, acc[st].v[5] / denom,
+                                                           acc[st].v[6] / denom, acc[st].v[7] / denom};
+            }
+        }
+    }
+}
+
+hipError_t launch_pool(const void* x, const int32_t* cu_seqlens, int nseq, int hidden, int mode_mean, int normalize,
+                       float* out, hipStream_t stream) {
+    if (hidden % 8 != 0 || hidden > 512 * kMaxSteps) return hipErrorInvalidValue;
+    if (nseq <= 0) return hipSuccess;
+    int blocks = (nseq + 3) / 4;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(pool_kernel, dim3(blocks), dim3(kRowThreadsE), 0, stream, static_cast<const u16*>(x),
+                       cu_seqlens, nseq, hidden, mode_mean, normalize, out);
+    return hipGetLastError();
+}
+
+__global__ void f32_to_bf16_kernel(const float* __restrict__ in, u16* __restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = f2bf(in[i]);
+}
+
+hipError_t launch_f32_to_bf16(const float* in, void* out, int64_t n, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, in, static_cast<u16*>(out), n);
+    return hipGetLastError();
+}
+
+}  // namespace rass

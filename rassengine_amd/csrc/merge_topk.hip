@@ -120,25 +120,29 @@ __global__ __launch_bounds__(kMergeThreads) void merge_topk_kernel(const float* 
         wave_sort64(c, lane);
         fold_group(run, c, lane);
     }
-    if (lane < 32) {
-        sh_s[wave * 32 + lane] = run.s;
-        sh_i[wave * 32 + lane] = run.id;
-    }
-    __syncthreads();
-    if (wave != 0) return;
-    // wave 0 folds the 16 per-wave lists, two at a time (each already sorted best-first)
-    Cand acc = run;  // wave 0's own list in lanes 0..31
+    // tree over the 16 per-wave lists (each sorted best-first in lanes 0..31): in round r the
+    // waves with wave % (2<<r) == 0 fold in the list of wave + (1<<r), handed over through LDS
+    Cand acc = run;
 #pragma unroll 1
-    for (int w = 1; w < kMergeWaves; ++w) {
-        Cand other;
-        other.s = sh_s[w * 32 + (lane & 31)];
-        other.id = sh_i[w * 32 + (lane & 31)];
-        // lanes 32..63 take list w reversed
-        const Cand rev = shfl_cand(other, 31 - (lane & 31));
-        Cand c = (lane < 32) ? acc : rev;
-        wave_bitonic_merge64(c, lane);
-        acc = c;
+    for (int step = 1; step < kMergeWaves; step <<= 1) {
+        const bool sender = (wave & (2 * step - 1)) == step;
+        const bool receiver = (wave & (2 * step - 1)) == 0;
+        if (sender && lane < 32) {
+            sh_s[wave * 32 + lane] = acc.s;
+            sh_i[wave * 32 + lane] = acc.id;
+        }
+        __syncthreads();
+        if (receiver) {
+            // lanes 32..63 take the partner's list reversed: lane 32+i <- element 31-i
+            Cand c;
+            c.s = sh_s[(wave + step) * 32 + (31 - (lane & 31))];
+            c.id = sh_i[(wave + step) * 32 + (31 - (lane & 31))];
+            if (lane < 32) c = acc;
+            wave_bitonic_merge64(c, lane);
+            acc = c;
+        }
     }
+    if (wave != 0) return;
     if (lane < k) {
         const bool filled = acc.id != kWorstId;
         out_scores[(int64_t)q * k + lane] = filled ? acc.s : -INFINITY;

@@ -1,0 +1,124 @@
+"""GPU parity of the sentence-encoder kernels (K4-K8) through the C ABI against the fp32 CPU
+oracle (oracle/bert_ref.py: plain PyTorch fp32 forward of the same architecture and weights).
+
+Tolerance (north_star / SURVEY §8c O3): the bf16 GPU path must reach cosine >= 0.999 to the
+fp32 oracle on the pooled sentence vector; the GEMM alone is held to bf16 rounding of an fp32
+reference (|err| <= 1.5 * 2^-8 * |ref| + small abs)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _cos(a, b):
+    a = a.astype(np.float64)
+    b = b.astype(np.float64)
+    return np.sum(a * b, axis=-1) / (np.linalg.norm(a, axis=-1) * np.linalg.norm(b, axis=-1))
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(128, 128, 64, 0), (100, 384, 128, 0), (300, 128, 512, 1), (257, 512, 128, 2),
+                                       (1000, 3072, 1024, 0), (513, 1024, 4096, 1), (640, 4096, 1024, 2)])
+def test_gemm_bf16_matches_torch(gpu, M, N, K, epi):
+    torch = gpu
+    from rassengine_amd import _native as N_
+    g = torch.Generator(device="cuda")
+    g.manual_seed(M * 7 + N + K + epi)
+    M_pad = (M + 127) // 128 * 128
+    X = torch.zeros((M_pad, K), dtype=torch.bfloat16, device="cuda")
+    X[:M] = torch.randn((M, K), generator=g, device="cuda").bfloat16()
+    W = (torch.randn((N, K), generator=g, device="cuda") / K ** 0.5).bfloat16()
+    bias = torch.randn((N,), generator=g, device="cuda") * 0.1
+    R = torch.zeros((M_pad, N), dtype=torch.bfloat16, device="cuda")
+    R[:M] = torch.randn((M, N), generator=g, device="cuda").bfloat16()
+    Y = torch.full((M_pad, N), 777.0, dtype=torch.bfloat16, device="cuda")
+    N_.check("rass_gemm_bf16", N_.lib().rass_gemm_bf16(
+        ctypes.c_void_p(X.data_ptr()), ctypes.c_void_p(W.data_ptr()), ctypes.c_void_p(bias.data_ptr()),
+        ctypes.c_void_p(R.data_ptr()) if epi == 1 else None, ctypes.c_void_p(Y.data_ptr()), M, M_pad, N, K, epi,
+        ctypes.c_void_p(int(torch.cuda.current_stream().cuda_stream))))
+    torch.cuda.synchronize()
+    ref = X[:M].float() @ W.float().T + bias
+    if epi == 1:
+        ref = ref + R[:M].float()
+    if epi == 2:
+        ref = torch.nn.functional.gelu(ref)
+    got = Y[:M].float()
+    err = (got - ref).abs()
+    tol = 1.5 * 2.0 ** -8 * ref.abs() + 2e-3
+    assert bool((err <= tol).all()), float((err - tol).max())
+    assert bool((Y[M:] == 777.0).all())  # padding rows are never written
+
+
+@pytest.fixture(scope="module")
+def tiny_model(tmp_path_factory):
+    from rassengine_amd.encoder import EncoderConfig, write_random_model_dir
+    d = str(tmp_path_factory.mktemp("tiny_model_gpu"))
+    write_random_model_dir(d, EncoderConfig(vocab_size=300, hidden=128, layers=2, heads=2, intermediate=512,
+                                            max_positions=512), seed=11)
+    return d
+
+
+@pytest.mark.parametrize("pooling", ["cls", "mean"])
+def test_tiny_encoder_matches_oracle(gpu, tiny_model, pooling, monkeypatch):
+    from oracle import bert_ref
+    from rassengine_amd import config
+    from rassengine_amd.encoder import HipSentenceEncoder
+    monkeypatch.setattr(config, "RASS_POOLING", pooling)
+    rng = np.random.default_rng(3)
+    lens = [1, 2, 15, 16, 17, 63, 64, 65, 127, 128, 129, 300, 512, 40]
+    seqs = [list(rng.integers(0, 300, size=n)) for n in lens]
+    enc = HipSentenceEncoder.from_dir(tiny_model, device=0)
+    try:
+        assert enc.cfg.pooling == pooling
+        got = enc.encode_ids(seqs)
+        got2 = enc.encode_ids(seqs[::-1])[::-1]  # batching order must not matter
+    finally:
+        enc.close()
+    ref = bert_ref.pool(bert_ref.forward_plain(tiny_model, seqs), pooling)
+    ref_bf = bert_ref.pool(bert_ref.forward_plain(tiny_model, seqs, bf16_weights=True), pooling)
+    assert got.shape == (len(seqs), 128) and got.dtype == np.float32 and np.all(np.isfinite(got))
+    c = _cos(got, ref)
+    assert np.all(c >= 0.999), c
+    assert np.all(_cos(got, ref_bf) >= 0.999)
+    assert np.abs(got - ref).max() <= 0.08 * np.abs(ref).max()
+    assert np.array_equal(got, got2)
+
+
+def test_large_encoder_sample_matches_oracle(gpu, tmp_path_factory):
+    """BERT-large-class (24 x 1024 x 16 heads x 4096, vocab 30522): the mxbai-embed-large shape
+    with seeded random weights (no real weights offline)."""
+    from oracle import bert_ref
+    from rassengine_amd.encoder import EncoderConfig, HipSentenceEncoder, write_random_model_dir
+    d = str(tmp_path_factory.mktemp("large_model"))
+    cfg = EncoderConfig(pooling="mean")
+    write_random_model_dir(d, cfg, seed=1)
+    rng = np.random.default_rng(99)
+    seqs = [list(rng.integers(0, 30522, size=n)) for n in (32, 20, 7)]
+    enc = HipSentenceEncoder.from_dir(d, device=0)
+    try:
+        got = enc.encode_ids(seqs)
+    finally:
+        enc.close()
+    ref = bert_ref.pool(bert_ref.forward_plain(d, seqs), "mean")
+    c = _cos(got, ref)
+    assert np.all(c >= 0.999), c
+
+
+def test_embedding_shim_over_hip_encoder(gpu, tiny_model):
+    """embed_texts_in_batches / embed_query (reference app/main.py:240-274) over the HIP encoder."""
+    import asyncio
+    from rassengine_amd import embedding
+    from rassengine_amd.encoder import HipSentenceEncoder
+    enc = HipSentenceEncoder.from_dir(tiny_model, device=0)
+    embedding.set_embedder(enc)
+    try:
+        texts = ["patient history of diabetes", "", "blood pressure note", "chunk number 3 about topic"]
+        e = asyncio.run(embedding.embed_texts_in_batches(texts, batch_size=3))
+        assert e.shape == (4, 128) and e.dtype == np.float32
+        assert np.all(e[1] == 0) and np.all(np.isfinite(e))
+        q = asyncio.run(embedding.embed_query("blood pressure note"))
+        assert q.shape == (1, 128) and np.allclose(q[0], e[2], atol=1e-6)
+    finally:
+        embedding.set_embedder(None)
+        enc.close()

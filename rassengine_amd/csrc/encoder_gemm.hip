@@ -43,6 +43,22 @@ __device__ __forceinline__ u16 f32_to_bf16(float f) {
     return *reinterpret_cast<u16*>(&h);
 }
 
+// GELU(x) = x/2 * (1 + erf(x/sqrt2)) with erf by Abramowitz-Stegun 7.1.26 (|err| < 1.5e-7 in
+// exact arithmetic, 5e-7 in fp32: two orders below bf16 resolution of the output).  libm's
+// erff costs ~3x the epilogue budget: the FFN-up GEMM ran at 510 TF/s with it vs 780 without.
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    p *= t;
+    const float e = __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);
+    const float erf_abs = fmaf(-p, e, 1.0f);
+    return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+}
+
 // Stage one 128 x 64 bf16 operand tile (rows row0.., columns k0..k0+63 of a [rows][ld] matrix)
 // into LDS: 16 wave-instructions of 1 KiB; wave w issues pieces w, w+4, w+8, w+12.
 __device__ __forceinline__ void stage_tile(const u16* __restrict__ g, int64_t ld, int row0, int k0,
@@ -138,10 +154,10 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_bf16_kernel(const u16* _
                 v.w += bf16_to_f32((u16)(r.y >> 16));
             }
             if (EPI == 2) {
-                v.x = 0.5f * v.x * (1.f + erff(v.x * 0.70710678118654752440f));
-                v.y = 0.5f * v.y * (1.f + erff(v.y * 0.70710678118654752440f));
-                v.z = 0.5f * v.z * (1.f + erff(v.z * 0.70710678118654752440f));
-                v.w = 0.5f * v.w * (1.f + erff(v.w * 0.70710678118654752440f));
+                v.x = gelu_erf(v.x);
+                v.y = gelu_erf(v.y);
+                v.z = gelu_erf(v.z);
+                v.w = gelu_erf(v.w);
             }
             uint2 o;
             o.x = (unsigned)f32_to_bf16(v.x) | ((unsigned)f32_to_bf16(v.y) << 16);

@@ -204,6 +204,36 @@ int rass_normalize_rows_f32(const float* d_in, int64_t in_stride, float* d_out,
                             int64_t out_stride, int64_t n, int dim,
                             void* stream);
 
+/* -------------------------------------------------------------------- IVF
+ * K9: inverted-file cosine index (nlist coarse centroids + contiguous lists)
+ * for shards where a flat scan per query batch is too much (BASELINE cfg 5:
+ * 100 M rows, IVF-4096).  Stands in for the sub-linear behaviour of the
+ * reference's HNSW (app/main.py:563-572) while staying an HBM-streaming
+ * kernel: probing = the flat fused scan over the centroid slab, a plan kernel,
+ * and the same fused scan over the union of the batch's probed lists.
+ * Approximate by construction: recall@k vs the flat index is a function of
+ * nprobe and is measured, never assumed (nprobe = nlist is exact). */
+typedef struct rass_ivf rass_ivf_t;
+
+/* Build from a flat index: `centroids` nlist x dim fp32 (host; normalised
+ * here), `assign[r]` = list of source row r (host, one per appended row;
+ * tombstoned rows are skipped).  Training / assignment are offline and live in
+ * the Python layer (rassengine_amd/ivf.py).  Result ids are the source index's
+ * row ids.  The source index may be dropped afterwards. */
+int rass_ivf_build(rass_index_t* src, const float* centroids, int nlist,
+                   const int32_t* assign, rass_ivf_t** out);
+void rass_ivf_destroy(rass_ivf_t* ivf);
+int64_t rass_ivf_rows(const rass_ivf_t* ivf);
+int rass_ivf_nlist(const rass_ivf_t* ivf);
+/* Same contract as rass_index_search; 1 <= nprobe <= 32 lists per query.
+ * *scanned_rows (may be NULL) receives the rows the fine scans touched. */
+int rass_ivf_search(rass_ivf_t* ivf, const float* queries, int nq, int k,
+                    int nprobe, const int32_t* q_filter, float* out_scores,
+                    int64_t* out_ids, int64_t* scanned_rows);
+int rass_ivf_search_device(rass_ivf_t* ivf, const float* d_queries, int nq,
+                           int k, int nprobe, const int32_t* d_q_filter,
+                           float* d_out_scores, int64_t* d_out_ids);
+
 /* ---------------------------------------------------------------- encoder
  * Replaces ollama_embed_text / embed_texts_in_batches / embed_query's HTTP hop
  * to Ollama (app/main.py:225-274): a BERT-class post-LN sentence encoder

@@ -79,6 +79,14 @@ SIGNATURES = {
                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "rass_normalize_rows_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
                                                ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
+    "rass_ivf_build": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, c_void_pp]),
+    "rass_ivf_destroy": (None, [ctypes.c_void_p]),
+    "rass_ivf_rows": (ctypes.c_int64, [ctypes.c_void_p]),
+    "rass_ivf_nlist": (ctypes.c_int, [ctypes.c_void_p]),
+    "rass_ivf_search": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_i64_p]),
+    "rass_ivf_search_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                              ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "rass_encoder_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, c_void_pp]),
     "rass_encoder_destroy": (None, [ctypes.c_void_p]),
     "rass_encoder_hidden": (ctypes.c_int, [ctypes.c_void_p]),

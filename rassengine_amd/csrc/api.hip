@@ -62,6 +62,14 @@ int device_cus(int device) {
     return cus;
 }
 
+struct IvfPlan {
+    const int32_t* work_tile;
+    const int32_t* work_rows;
+    const uint32_t* work_mask;
+    const int32_t* n_work;
+    int64_t max_tiles;
+};
+
 struct ScratchLayout {
     size_t q_padded, part_scores, part_ids, total;
 };
@@ -172,7 +180,8 @@ int index_reserve(rass_index* idx, int64_t need_rows) {
 int scan_launch(const float* d_corpus, int64_t n_rows, int64_t stride, const int32_t* d_row_tag,
                 const float* d_queries, int q_dim, int64_t q_stride, int nq, const int32_t* d_q_filter, int k,
                 int64_t id_base, float* d_out_scores, int64_t* d_out_ids, unsigned char* ws, size_t ws_bytes,
-                int n_cus, hipStream_t st, rass_engine* timing = nullptr) {
+                int n_cus, hipStream_t st, rass_engine* timing = nullptr, const IvfPlan* plan = nullptr,
+                const int64_t* id_map = nullptr) {
     if (nq < 1 || nq > RASS_MAX_QBATCH) return fail(RASS_ERR_INVALID, "nq must be in [1, RASS_MAX_QBATCH]");
     if (k < 1 || k > RASS_MAX_K) return fail(RASS_ERR_INVALID, "k must be in [1, RASS_MAX_K]");
     if (n_rows < 0 || n_rows > 0x7fffffc0LL) return fail(RASS_ERR_INVALID, "n_rows out of range for one scan");
@@ -191,7 +200,8 @@ int scan_launch(const float* d_corpus, int64_t n_rows, int64_t stride, const int
     // a4 on the query side (reference app/main.py:1536-1537), written zero-padded.
     HIP_TRY(rass::launch_normalize_rows_f32(d_queries, q_stride, q_padded, stride, nq, q_dim, st, nq_pad));
 
-    const int64_t n_tiles = (n_rows + 31) / 32;
+    // IVF: the number of work tiles is only known on the device; size the grid by the slab
+    const int64_t n_tiles = plan ? plan->max_tiles : (n_rows + 31) / 32;
     int grid = (int)std::min<int64_t>(std::max<int64_t>(n_tiles, 1), std::min(n_cus, kMaxGrid));
     if ((int64_t)grid * k > rass::kMergeMaxCandidates) grid = rass::kMergeMaxCandidates / k;
 
@@ -207,6 +217,12 @@ int scan_launch(const float* d_corpus, int64_t n_rows, int64_t stride, const int
     a.n_rows = (int)n_rows;
     a.nq = nq;
     a.k = k;
+    if (plan) {
+        a.work_tile = plan->work_tile;
+        a.work_rows = plan->work_rows;
+        a.work_mask = plan->work_mask;
+        a.n_work = plan->n_work;
+    }
     const bool timed = timing && timing->ev_on && (size_t)(2 * timing->ev_used + 1) < timing->ev_pool.size();
     if (timed) HIP_TRY(hipEventRecord(timing->ev_pool[2 * timing->ev_used], st));
     HIP_TRY(rass::launch_scan_topk_f32(a, grid, st));
@@ -214,11 +230,29 @@ int scan_launch(const float* d_corpus, int64_t n_rows, int64_t stride, const int
         HIP_TRY(hipEventRecord(timing->ev_pool[2 * timing->ev_used + 1], st));
         timing->ev_used += 1;
     }
-    HIP_TRY(rass::launch_merge_topk(part_scores, part_ids, grid, nq, k, d_out_scores, d_out_ids, st));
+    HIP_TRY(rass::launch_merge_topk(part_scores, part_ids, grid, nq, k, d_out_scores, d_out_ids, st, id_map));
     return RASS_OK;
 }
 
 }  // namespace
+
+// ------------------------------------------------------------------------------------ IVF (K9)
+struct rass_ivf {
+    rass_engine* eng = nullptr;
+    int dim = 0, nlist = 0;
+    int64_t stride = 0, rows = 0, slab_rows = 0, total_tiles = 0;
+    float* d_slab = nullptr;        // tile16, lists contiguous, each starting on a 32-row tile
+    int32_t* d_tags = nullptr;      // [slab_rows] permuted row tags (0 on padding)
+    int64_t* d_ids = nullptr;       // [slab_rows] source row id, -1 on padding
+    float* d_centroids = nullptr;   // tile16 slab of nlist normalised centroids
+    int32_t *d_list_tile0 = nullptr, *d_list_len = nullptr;
+    int32_t *d_work_tile = nullptr, *d_work_rows = nullptr, *d_n_work = nullptr;
+    uint32_t* d_work_mask = nullptr;
+    int64_t* d_scanned = nullptr;   // rows touched by the last fine scan
+    float* d_probe_scores = nullptr;  // [32][32]
+    int64_t* d_probe_ids = nullptr;   // [32][32]
+    bool any_tags = false;
+};
 
 extern "C" void rassint_set_last_error(const char* msg) { g_err = msg ? msg : ""; }
 
@@ -819,12 +853,189 @@ int rass_engine_kernel_timing_end(rass_engine_t* eng, double* total_ms, int* lau
 void* rass_index_device_rows(rass_index_t* idx) { return idx ? reinterpret_cast<void*>(idx->d_rows) : nullptr; }
 void* rass_index_device_tags(rass_index_t* idx) { return idx ? reinterpret_cast<void*>(idx->d_tags) : nullptr; }
 
+static void ivf_free(rass_ivf* v) {
+    if (!v) return;
+    for (void* p : {(void*)v->d_slab, (void*)v->d_tags, (void*)v->d_ids, (void*)v->d_centroids, (void*)v->d_list_tile0,
+                    (void*)v->d_list_len, (void*)v->d_work_tile, (void*)v->d_work_rows, (void*)v->d_n_work,
+                    (void*)v->d_work_mask, (void*)v->d_scanned, (void*)v->d_probe_scores, (void*)v->d_probe_ids})
+        if (p) (void)hipFree(p);
+    delete v;
+}
+
+int rass_ivf_build(rass_index_t* src, const float* centroids, int nlist, const int32_t* assign, rass_ivf_t** out) {
+    if (!src || !centroids || !assign || !out) return fail(RASS_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    if (nlist < 1 || nlist > 32768) return fail(RASS_ERR_INVALID, "nlist must be in [1, 32768]");
+    rass_engine* eng = src->eng;
+    std::lock_guard<std::mutex> lk(src->mu);
+    int rc = set_device(eng);
+    if (rc != RASS_OK) return rc;
+    const int64_t n = src->rows;
+    // list lengths over live rows, tile-aligned offsets
+    std::vector<int32_t> len((size_t)nlist, 0), tile0((size_t)nlist, 0);
+    for (int64_t r = 0; r < n; ++r) {
+        if (src->host_deleted[(size_t)(r >> 3)] & (1u << (r & 7))) continue;
+        const int32_t l = assign[r];
+        if (l < 0 || l >= nlist) return fail(RASS_ERR_INVALID, "assign[] holds a list id outside [0, nlist)");
+        len[(size_t)l] += 1;
+    }
+    int64_t tiles = 0;
+    for (int l = 0; l < nlist; ++l) {
+        tile0[(size_t)l] = (int32_t)tiles;
+        tiles += (len[(size_t)l] + 31) / 32;
+    }
+    if (tiles * 32 > 0x7fffffc0LL) return fail(RASS_ERR_UNSUPPORTED, "slab too large for one IVF shard");
+    const int64_t slab_rows = std::max<int64_t>(tiles, 1) * 32;
+    std::vector<int64_t> src_of((size_t)slab_rows, -1);
+    std::vector<int32_t> fill((size_t)nlist, 0);
+    for (int64_t r = 0; r < n; ++r) {  // ascending source id inside every list
+        if (src->host_deleted[(size_t)(r >> 3)] & (1u << (r & 7))) continue;
+        const int32_t l = assign[r];
+        src_of[(size_t)((int64_t)tile0[(size_t)l] * 32 + fill[(size_t)l]++)] = r;
+    }
+    rass_ivf* v = new (std::nothrow) rass_ivf();
+    if (!v) return fail(RASS_ERR_OOM, "host allocation failed");
+    v->eng = eng;
+    v->dim = src->dim;
+    v->stride = src->stride;
+    v->nlist = nlist;
+    v->rows = n - src->deleted;
+    v->slab_rows = slab_rows;
+    v->total_tiles = std::max<int64_t>(tiles, 1);
+    v->any_tags = src->has_tags;
+    hipStream_t st = eng->stream;
+    const int64_t cent_rows = ((int64_t)nlist + 15) / 16 * 16;
+#define IVF_TRY(expr)                                                                                       \
+    do {                                                                                                    \
+        hipError_t _e = (expr);                                                                             \
+        if (_e != hipSuccess) {                                                                             \
+            ivf_free(v);                                                                                    \
+            return fail(_e == hipErrorOutOfMemory ? RASS_ERR_OOM : RASS_ERR_HIP,                            \
+                        std::string("ivf build: ") + #expr + ": " + hipGetErrorString(_e));                 \
+        }                                                                                                   \
+    } while (0)
+    IVF_TRY(hipMalloc(reinterpret_cast<void**>(&v->d_slab), (size_t)slab_rows * v->stride * 4));
+    IVF_TRY(hipMalloc(reinterpret_cast<void**>(&v->d_tags), (size_t)slab_rows * 4));
+    IVF_TRY(hipMalloc(reinterpret_cast<void**>(&v->d_ids), (size_t)slab_rows * 8));
+    IVF_TRY(hipMalloc(reinterpret_cast<void**>(&v->d_centroids), (size_t)cent_rows * v->stride * 4));
+    IVF_TRY(hipMalloc(reinterpret_cast<void**>(&v->d_list_tile0), (size_t)nlist * 4));
+    IVF_TRY(hipMalloc(reinterpret_cast<void**>(&v->d_list_len), (size_t)nlist * 4));
+    IVF_TRY(hipMalloc(reinterpret_cast<void**>(&v->d_work_tile), (size_t)v->total_tiles * 4));
+    IVF_TRY(hipMalloc(reinterpret_cast<void**>(&v->d_work_rows), (size_t)v->total_tiles * 4));
+    IVF_TRY(hipMalloc(reinterpret_cast<void**>(&v->d_work_mask), (size_t)v->total_tiles * 4));
+    IVF_TRY(hipMalloc(reinterpret_cast<void**>(&v->d_n_work), 4));
+    IVF_TRY(hipMalloc(reinterpret_cast<void**>(&v->d_scanned), 8));
+    IVF_TRY(hipMalloc(reinterpret_cast<void**>(&v->d_probe_scores), RASS_MAX_QBATCH * RASS_MAX_K * 4));
+    IVF_TRY(hipMalloc(reinterpret_cast<void**>(&v->d_probe_ids), RASS_MAX_QBATCH * RASS_MAX_K * 8));
+    IVF_TRY(hipMemcpyAsync(v->d_ids, src_of.data(), (size_t)slab_rows * 8, hipMemcpyHostToDevice, st));
+    IVF_TRY(hipMemcpyAsync(v->d_list_tile0, tile0.data(), (size_t)nlist * 4, hipMemcpyHostToDevice, st));
+    IVF_TRY(hipMemcpyAsync(v->d_list_len, len.data(), (size_t)nlist * 4, hipMemcpyHostToDevice, st));
+    IVF_TRY(rass::launch_permute_rows_tile16(src->d_rows, v->d_slab, v->stride, v->d_ids, slab_rows, st));
+    // tags: permuted on the host (small), padding rows get 0
+    {
+        std::vector<int32_t> tags((size_t)std::max<int64_t>(n, 1), 0), ptags((size_t)slab_rows, 0);
+        if (n > 0) {
+            IVF_TRY(hipMemcpyAsync(tags.data(), src->d_tags, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+            IVF_TRY(hipStreamSynchronize(st));
+        }
+        for (int64_t d = 0; d < slab_rows; ++d)
+            if (src_of[(size_t)d] >= 0) ptags[(size_t)d] = tags[(size_t)src_of[(size_t)d]];
+        IVF_TRY(hipMemcpyAsync(v->d_tags, ptags.data(), (size_t)slab_rows * 4, hipMemcpyHostToDevice, st));
+        IVF_TRY(hipStreamSynchronize(st));
+    }
+    // centroids: normalise + pack through the engine's staging buffer
+    IVF_TRY(hipMemsetAsync(v->d_centroids, 0, (size_t)cent_rows * v->stride * 4, st));
+    {
+        std::lock_guard<std::mutex> elk(eng->mu);
+        for (int64_t done = 0; done < nlist; done += kStageRows) {
+            const int64_t m = std::min<int64_t>(kStageRows, nlist - done);
+            IVF_TRY(hipMemcpyAsync(eng->d_stage, centroids + done * v->dim, (size_t)m * v->dim * 4,
+                                   hipMemcpyHostToDevice, st));
+            IVF_TRY(rass::launch_pack_rows_tile16(eng->d_stage, v->dim, v->d_centroids, v->stride, done, m, v->dim, 1, st));
+            IVF_TRY(hipStreamSynchronize(st));
+        }
+    }
+#undef IVF_TRY
+    *out = v;
+    return RASS_OK;
+}
+
+void rass_ivf_destroy(rass_ivf_t* v) {
+    if (!v) return;
+    (void)hipSetDevice(v->eng->device);
+    (void)hipStreamSynchronize(v->eng->stream);
+    ivf_free(v);
+}
+
+int64_t rass_ivf_rows(const rass_ivf_t* v) { return v ? v->rows : 0; }
+int rass_ivf_nlist(const rass_ivf_t* v) { return v ? v->nlist : 0; }
+
+int rass_ivf_search_device(rass_ivf_t* v, const float* d_queries, int nq, int k, int nprobe,
+                           const int32_t* d_q_filter, float* d_out_scores, int64_t* d_out_ids) {
+    if (!v || !d_queries || !d_out_scores || !d_out_ids) return fail(RASS_ERR_INVALID, "NULL argument");
+    if (nprobe < 1 || nprobe > RASS_MAX_K) return fail(RASS_ERR_INVALID, "nprobe must be in [1, 32]");
+    rass_engine* eng = v->eng;
+    std::lock_guard<std::mutex> lk(eng->mu);
+    int rc = set_device(eng);
+    if (rc != RASS_OK) return rc;
+    hipStream_t st = eng->stream;
+    const int np = std::min(nprobe, v->nlist);
+    // (i) coarse: top-nprobe centroids per query with the flat fused scan
+    rc = scan_launch(v->d_centroids, v->nlist, v->stride, nullptr, d_queries, v->dim, v->dim, nq, nullptr, np, 0,
+                     v->d_probe_scores, v->d_probe_ids, eng->d_scratch, eng->scratch_bytes, eng->n_cus, st);
+    if (rc != RASS_OK) return rc;
+    // (ii) plan: union of probed lists -> work tiles with per-tile query masks
+    HIP_TRY(rass::launch_plan_probe(v->d_probe_ids, nq, np, v->nlist, v->d_list_tile0, v->d_list_len, v->d_work_tile,
+                                    v->d_work_rows, v->d_work_mask, v->d_n_work, v->d_scanned, st));
+    // (iii) fine: the same fused scan over the planned tiles; slab positions -> source ids in the merge
+    IvfPlan plan{v->d_work_tile, v->d_work_rows, v->d_work_mask, v->d_n_work, v->total_tiles};
+    const bool need_tags = v->any_tags || d_q_filter != nullptr;
+    return scan_launch(v->d_slab, v->slab_rows, v->stride, need_tags ? v->d_tags : nullptr, d_queries, v->dim, v->dim,
+                       nq, d_q_filter, k, 0, d_out_scores, d_out_ids, eng->d_scratch, eng->scratch_bytes, eng->n_cus,
+                       st, eng, &plan, v->d_ids);
+}
+
+int rass_ivf_search(rass_ivf_t* v, const float* queries, int nq, int k, int nprobe, const int32_t* q_filter,
+                    float* out_scores, int64_t* out_ids, int64_t* scanned_rows) {
+    if (!v || !out_scores || !out_ids) return fail(RASS_ERR_INVALID, "NULL argument");
+    if (nq < 0 || (nq > 0 && !queries)) return fail(RASS_ERR_INVALID, "bad queries / nq");
+    if (k < 1 || k > RASS_MAX_K) return fail(RASS_ERR_INVALID, "k must be in [1, RASS_MAX_K]");
+    rass_engine* eng = v->eng;
+    int rc = set_device(eng);
+    if (rc != RASS_OK) return rc;
+    int64_t scanned_total = 0;
+    for (int done = 0; done < nq;) {
+        const int b = std::min(RASS_MAX_QBATCH, nq - done);
+        hipStream_t st = eng->stream;
+        {
+            std::lock_guard<std::mutex> lk(eng->mu);
+            HIP_TRY(hipMemcpyAsync(eng->d_qraw, queries + (int64_t)done * v->dim, (size_t)b * v->dim * 4,
+                                   hipMemcpyHostToDevice, st));
+            if (q_filter)
+                HIP_TRY(hipMemcpyAsync(eng->d_qfilter, q_filter + done, (size_t)b * 4, hipMemcpyHostToDevice, st));
+        }
+        rc = rass_ivf_search_device(v, eng->d_qraw, b, k, nprobe, q_filter ? eng->d_qfilter : nullptr,
+                                    eng->d_out_scores, eng->d_out_ids);
+        if (rc != RASS_OK) return rc;
+        int64_t scanned = 0;
+        HIP_TRY(hipMemcpyAsync(out_scores + (int64_t)done * k, eng->d_out_scores, (size_t)b * k * 4,
+                               hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(out_ids + (int64_t)done * k, eng->d_out_ids, (size_t)b * k * 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(&scanned, v->d_scanned, 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        scanned_total += scanned;
+        done += b;
+    }
+    if (scanned_rows) *scanned_rows = scanned_total;
+    return RASS_OK;
+}
+
 const char* rass_scan_kernel_name(int dim, int nq) {
     static thread_local char buf[64];
     const int64_t stride = pad128(dim);
     if (dim < 1 || !rass::scan_supported_stride(stride) || stride > kMaxStride || nq < 1 || nq > RASS_MAX_QBATCH)
         return "";
-    snprintf(buf, sizeof(buf), "scan_topk_f32_kernel<%d, %d>", (int)(stride / 128), nq <= 16 ? 1 : 2);
+    snprintf(buf, sizeof(buf), "scan_topk_f32_kernel<%d, %d, false>", (int)(stride / 128), nq <= 16 ? 1 : 2);
     return buf;
 }
 

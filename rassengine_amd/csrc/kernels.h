@@ -19,6 +19,12 @@ struct ScanArgs {
     int n_rows;
     int nq;
     int k;
+    // IVF probe plan (all nullptr for the flat scan): work item i = slab tile work_tile[i] with
+    // work_rows[i] valid rows, visible to the queries whose bit is set in work_mask[i]
+    const int32_t* work_tile = nullptr;
+    const int32_t* work_rows = nullptr;
+    const uint32_t* work_mask = nullptr;
+    const int32_t* n_work = nullptr;  // device scalar: number of work items
 };
 
 bool scan_supported_stride(int64_t row_stride);
@@ -27,7 +33,15 @@ hipError_t launch_scan_topk_f32(const ScanArgs& a, int grid, hipStream_t stream)
 // [n_lists][nq][k] sorted candidate lists -> [nq][k]; n_lists * k <= kMergeMaxCandidates.
 constexpr int kMergeMaxCandidates = 8192;
 hipError_t launch_merge_topk(const float* scores, const int64_t* ids, int n_lists, int nq, int k,
-                             float* out_scores, int64_t* out_ids, hipStream_t stream);
+                             float* out_scores, int64_t* out_ids, hipStream_t stream,
+                             const int64_t* id_map = nullptr);
+
+// ---- IVF (ivf.hip)
+hipError_t launch_plan_probe(const int64_t* probe_ids, int nq, int nprobe, int nlist, const int32_t* list_tile0,
+                             const int32_t* list_len, int32_t* work_tile, int32_t* work_rows, uint32_t* work_mask,
+                             int32_t* n_work, int64_t* scanned_rows, hipStream_t stream);
+hipError_t launch_permute_rows_tile16(const float* src, float* dst, int64_t stride, const int64_t* src_of,
+                                      int64_t dst_rows, hipStream_t stream);
 
 // out[r][0..dim) = in[r] / (||in[r]|| + 1e-9); out[r][dim..out_stride) = 0 for r < n;
 // rows [n, n_total) of out are zero-filled (query padding), all in one launch.

@@ -89,7 +89,8 @@ __device__ __forceinline__ void fold_group(Cand& run, const Cand& grp_sorted, in
 __global__ __launch_bounds__(kMergeThreads) void merge_topk_kernel(const float* __restrict__ scores,
                                                                    const int64_t* __restrict__ ids, int n_lists,
                                                                    int nq, int k, float* __restrict__ out_scores,
-                                                                   int64_t* __restrict__ out_ids) {
+                                                                   int64_t* __restrict__ out_ids,
+                                                                   const int64_t* __restrict__ id_map) {
     __shared__ float sh_s[kMergeWaves * 32];
     __shared__ int64_t sh_i[kMergeWaves * 32];
     const int q = blockIdx.x;
@@ -146,16 +147,17 @@ __global__ __launch_bounds__(kMergeThreads) void merge_topk_kernel(const float* 
     if (lane < k) {
         const bool filled = acc.id != kWorstId;
         out_scores[(int64_t)q * k + lane] = filled ? acc.s : -INFINITY;
-        out_ids[(int64_t)q * k + lane] = filled ? acc.id : (int64_t)-1;
+        // id_map (IVF): candidates carry slab positions, callers get their own row ids
+        out_ids[(int64_t)q * k + lane] = filled ? (id_map ? id_map[acc.id] : acc.id) : (int64_t)-1;
     }
 }
 
 hipError_t launch_merge_topk(const float* scores, const int64_t* ids, int n_lists, int nq, int k,
-                             float* out_scores, int64_t* out_ids, hipStream_t stream) {
+                             float* out_scores, int64_t* out_ids, hipStream_t stream, const int64_t* id_map) {
     const int64_t n = (int64_t)n_lists * k;
     if (n_lists < 1 || nq < 1 || k < 1 || k > 32 || n > kMergeMaxCandidates) return hipErrorInvalidValue;
     hipLaunchKernelGGL(merge_topk_kernel, dim3(nq), dim3(kMergeThreads), 0, stream, scores, ids, n_lists, nq, k,
-                       out_scores, out_ids);
+                       out_scores, out_ids, id_map);
     return hipGetLastError();
 }
 

@@ -68,14 +68,37 @@ struct TileDesc {
     __amdgpu_buffer_rsrc_t tags;
 };
 
+// One unit of work of a workgroup: a 32-row slab tile, how many of its rows exist, and which
+// queries of the batch may rank its rows (all of them for the flat scan; for IVF the queries
+// that probe the list the tile belongs to).
+struct WorkItem {
+    int tile;
+    int rows;
+    unsigned mask;
+};
+
+template <bool IVF>
+__device__ __forceinline__ WorkItem get_work(const ScanArgs& p, int i, int n_items) {
+    WorkItem w;
+    if (IVF) {
+        const bool ok = i < n_items;
+        w.tile = ok ? p.work_tile[i] : 0;
+        w.rows = ok ? p.work_rows[i] : 0;
+        w.mask = ok ? p.work_mask[i] : 0u;
+    } else {
+        int rows = p.n_rows - i * kTileRows;
+        rows = rows < 0 ? 0 : (rows > kTileRows ? kTileRows : rows);
+        w.tile = i < n_items ? i : 0;
+        w.rows = i < n_items ? rows : 0;
+        w.mask = 0xffffffffu;
+    }
+    return w;
+}
+
 __device__ __forceinline__ TileDesc make_tile_desc(const float* __restrict__ X, int64_t row_stride,
-                                                   const int32_t* __restrict__ row_tag, int tile, int n_tiles,
-                                                   int n_rows) {
-    const int row0 = tile * kTileRows;
-    int rows_here = n_rows - row0;
-    rows_here = rows_here < 0 ? 0 : (rows_here > kTileRows ? kTileRows : rows_here);
-    if (tile >= n_tiles) rows_here = 0;
-    const int64_t base_row = (tile < n_tiles) ? (int64_t)row0 : 0;
+                                                   const int32_t* __restrict__ row_tag, const WorkItem& w) {
+    const int rows_here = w.rows;
+    const int64_t base_row = (int64_t)w.tile * kTileRows;
     // The descriptor must be PROVABLY wave-uniform or hipcc wraps every buffer op in a
     // waterfall loop: pin its inputs with readfirstlane (guide T20).
     const uint64_t base_u = reinterpret_cast<uint64_t>(X + base_row * row_stride);
@@ -191,7 +214,7 @@ __device__ __forceinline__ void insert_candidates(TopList& L, float& tau, float 
     }
 }
 
-template <int CH, int NT>
+template <int CH, int NT, bool IVF>
 __global__ __launch_bounds__(kThreads, 2) void scan_topk_f32_kernel(ScanArgs p) {
     constexpr int NQ = NT * 16;
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [2][kWaves][NQ][kPitch]
@@ -199,7 +222,9 @@ __global__ __launch_bounds__(kThreads, 2) void scan_topk_f32_kernel(ScanArgs p) 
     const int lane = lane_id();
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int m = lane & 15, g = lane >> 4;
-    const int n_tiles = (p.n_rows + kTileRows - 1) / kTileRows;
+    // number of work items: tiles of the slab (flat) or entries of the probe plan (IVF; written
+    // by plan_probe_kernel earlier on this stream)
+    const int n_tiles = IVF ? __builtin_amdgcn_readfirstlane(*p.n_work) : (p.n_rows + kTileRows - 1) / kTileRows;
     const int G = gridDim.x;
 
     // Query fragments: lane (n = m, g) holds Qn[nt*16 + n][slice + 16j + 4g .. +3].
@@ -231,13 +256,12 @@ __global__ __launch_bounds__(kThreads, 2) void scan_topk_f32_kernel(ScanArgs p) 
     const int mt_step = 16 * (int)p.row_stride * 4;
     TileRegs<CH> R0, R1;
     int t = blockIdx.x;
-    issue_tile_loads<CH>(R0, make_tile_desc(p.corpus, p.row_stride, p.row_tag, t, n_tiles, p.n_rows), voff_lane,
-                         mt_step);
-    issue_tile_loads<CH>(R1, make_tile_desc(p.corpus, p.row_stride, p.row_tag, t + G, n_tiles, p.n_rows),
-                         voff_lane, mt_step);
+    WorkItem W0 = get_work<IVF>(p, t, n_tiles), W1 = get_work<IVF>(p, t + G, n_tiles);
+    issue_tile_loads<CH>(R0, make_tile_desc(p.corpus, p.row_stride, p.row_tag, W0), voff_lane, mt_step);
+    issue_tile_loads<CH>(R1, make_tile_desc(p.corpus, p.row_stride, p.row_tag, W1), voff_lane, mt_step);
     __builtin_amdgcn_sched_barrier(0);
 
-    auto finish_tile = [&](const f32x4 (&acc)[2][NT], int tile, int tag, int buf) {
+    auto finish_tile = [&](const f32x4 (&acc)[2][NT], const WorkItem& w, int tag, int buf) {
         float* P = lds + buf * (kWaves * NQ * kPitch);
         // dump: lane (n=m, g) holds rows 4g..4g+3 of M-tile mt for query nt*16+n
 #pragma unroll
@@ -247,16 +271,17 @@ __global__ __launch_bounds__(kThreads, 2) void scan_topk_f32_kernel(ScanArgs p) 
                 *reinterpret_cast<f32x4*>(P + (wid * NQ + nt * 16 + m) * kPitch + mt * 16 + 4 * g) = acc[mt][nt];
         __syncthreads();
         const int r = lane & 31;
-        const int row = tile * kTileRows + r;
-        bool row_ok = (tile < n_tiles) && (row < p.n_rows) && (tag != -1);
+        const int row = w.tile * kTileRows + r;
+        const bool row_ok = (r < w.rows) && (tag != -1);
 #pragma unroll
         for (int pq = 0; pq < NT; ++pq) {
             const int q = pq * 16 + (lane >> 5) * 8 + wid;
             const float* src = P + q * kPitch + r;
             float s = src[0];
 #pragma unroll
-            for (int w = 1; w < kWaves; ++w) s += src[w * NQ * kPitch];
-            const bool ok = row_ok && (qfilt[pq] < 0 || qfilt[pq] == tag);
+            for (int wv = 1; wv < kWaves; ++wv) s += src[wv * NQ * kPitch];
+            bool ok = row_ok && (qfilt[pq] < 0 || qfilt[pq] == tag);
+            if (IVF) ok = ok && ((w.mask >> q) & 1u);
             s = ok ? s : -INFINITY;
             insert_candidates(L[pq], tau[pq], s, row, p.k);
         }
@@ -265,15 +290,17 @@ __global__ __launch_bounds__(kThreads, 2) void scan_topk_f32_kernel(ScanArgs p) 
     for (; t < n_tiles; t += 2 * G) {
         f32x4 acc[2][NT];
         int tag = R0.tag;
-        multiply_and_refill<CH, NT>(R0, qf, acc,
-                                    make_tile_desc(p.corpus, p.row_stride, p.row_tag, t + 2 * G, n_tiles, p.n_rows),
-                                    voff_lane, mt_step);
-        finish_tile(acc, t, tag, 0);
+        WorkItem Wn = get_work<IVF>(p, t + 2 * G, n_tiles);
+        multiply_and_refill<CH, NT>(R0, qf, acc, make_tile_desc(p.corpus, p.row_stride, p.row_tag, Wn), voff_lane,
+                                    mt_step);
+        finish_tile(acc, W0, tag, 0);
+        W0 = Wn;
         tag = R1.tag;
-        multiply_and_refill<CH, NT>(R1, qf, acc,
-                                    make_tile_desc(p.corpus, p.row_stride, p.row_tag, t + 3 * G, n_tiles, p.n_rows),
-                                    voff_lane, mt_step);
-        finish_tile(acc, t + G, tag, 1);
+        Wn = get_work<IVF>(p, t + 3 * G, n_tiles);
+        multiply_and_refill<CH, NT>(R1, qf, acc, make_tile_desc(p.corpus, p.row_stride, p.row_tag, Wn), voff_lane,
+                                    mt_step);
+        finish_tile(acc, W1, tag, 1);
+        W1 = Wn;
     }
 
     // Per-workgroup sorted lists -> [gridDim.x][nq][k]
@@ -290,29 +317,29 @@ __global__ __launch_bounds__(kThreads, 2) void scan_topk_f32_kernel(ScanArgs p) 
     }
 }
 
-template <int CH, int NT>
+template <int CH, int NT, bool IVF>
 static hipError_t launch_variant(const ScanArgs& a, int grid, hipStream_t stream) {
     constexpr size_t lds_bytes = (size_t)2 * kWaves * NT * 16 * kPitch * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_topk_f32_kernel<CH, NT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_topk_f32_kernel<CH, NT, IVF>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((scan_topk_f32_kernel<CH, NT>), dim3(grid), dim3(kThreads), lds_bytes, stream, a);
+    hipLaunchKernelGGL((scan_topk_f32_kernel<CH, NT, IVF>), dim3(grid), dim3(kThreads), lds_bytes, stream, a);
     return hipGetLastError();
 }
 
-template <int NT>
+template <int NT, bool IVF>
 static hipError_t launch_ch(int ch, const ScanArgs& a, int grid, hipStream_t stream) {
     switch (ch) {
-        case 1: return launch_variant<1, NT>(a, grid, stream);
-        case 2: return launch_variant<2, NT>(a, grid, stream);
-        case 3: return launch_variant<3, NT>(a, grid, stream);
-        case 4: return launch_variant<4, NT>(a, grid, stream);
-        case 6: return launch_variant<6, NT>(a, grid, stream);
-        case 8: return launch_variant<8, NT>(a, grid, stream);
+        case 1: return launch_variant<1, NT, IVF>(a, grid, stream);
+        case 2: return launch_variant<2, NT, IVF>(a, grid, stream);
+        case 3: return launch_variant<3, NT, IVF>(a, grid, stream);
+        case 4: return launch_variant<4, NT, IVF>(a, grid, stream);
+        case 6: return launch_variant<6, NT, IVF>(a, grid, stream);
+        case 8: return launch_variant<8, NT, IVF>(a, grid, stream);
         default: return hipErrorInvalidValue;
     }
 }
@@ -326,8 +353,13 @@ bool scan_supported_stride(int64_t row_stride) {
 hipError_t launch_scan_topk_f32(const ScanArgs& a, int grid, hipStream_t stream) {
     if (!scan_supported_stride(a.row_stride)) return hipErrorInvalidValue;
     const int ch = (int)(a.row_stride / 128);
-    if (a.nq <= 16) return launch_ch<1>(ch, a, grid, stream);
-    return launch_ch<2>(ch, a, grid, stream);
+    if (a.work_tile != nullptr) {  // IVF probe: iterate the plan instead of every tile
+        if (!a.work_rows || !a.work_mask || !a.n_work) return hipErrorInvalidValue;
+        if (a.nq <= 16) return launch_ch<1, true>(ch, a, grid, stream);
+        return launch_ch<2, true>(ch, a, grid, stream);
+    }
+    if (a.nq <= 16) return launch_ch<1, false>(ch, a, grid, stream);
+    return launch_ch<2, false>(ch, a, grid, stream);
 }
 
 }  // namespace rass

@@ -1,0 +1,113 @@
+"""GPU tests of the IVF index (K9): probing every list reproduces the exact flat result,
+recall@10 grows with nprobe on clustered data, filters / tombstones carry over, and the
+fine scan touches only the probed lists."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _clustered(rng, n, dim, centres, sigma):
+    c = rng.standard_normal((centres, dim)).astype(np.float32)
+    c /= np.linalg.norm(c, axis=1, keepdims=True)
+    lab = rng.integers(0, centres, size=n)
+    x = c[lab] + sigma * rng.standard_normal((n, dim)).astype(np.float32) / np.sqrt(dim)
+    return x.astype(np.float32), c, lab
+
+
+@pytest.fixture(scope="module")
+def built(gpu):
+    from rassengine_amd.engine import Engine
+    from rassengine_amd.ivf import IvfIndex
+    rng = np.random.default_rng(42)
+    n, dim = 30000, 1024
+    x, centres, _ = _clustered(rng, n, dim, 200, 1.0)
+    tags = rng.integers(1, 5, size=n).astype(np.int32)
+    eng = Engine(0, dim)
+    flat = eng.open_index("ivf-src")
+    flat.add(x, tags=tags)
+    for r in (5, 77, 12345):
+        flat.delete(r)
+    ivf = IvfIndex.build(flat, nlist=128, iters=8, seed=3)
+    q = centres[rng.integers(0, 200, size=50)] + 0.8 * rng.standard_normal((50, dim)).astype(np.float32) / np.sqrt(dim)
+    yield eng, flat, ivf, q.astype(np.float32), tags
+    ivf.close()
+    eng.close()
+
+
+def test_probe_all_lists_equals_flat(built):
+    eng, flat, ivf, q, _ = built
+    assert ivf.nlist == 128 and ivf.rows == flat.count
+    # nlist = 128 > 32 lists per probe: cover all lists in 4 disjoint probes?  Not possible through
+    # the API (probe picks the best lists), so compare at the largest nprobe against flat recall
+    # and, for exactness, on a second index with nlist <= 32.
+    from rassengine_amd.ivf import IvfIndex
+    ivf32 = IvfIndex.build(flat, nlist=32, iters=5, seed=1)
+    try:
+        s_f, i_f = flat.search(q, 10)
+        s_i, i_i, scanned = ivf32.search(q, 10, nprobe=32)
+        assert np.array_equal(i_i, i_f)
+        assert np.array_equal(s_i, s_f)       # same kernel, same fmaf order: bit-identical scores
+        assert scanned == 2 * flat.count      # 50 queries = 2 batches, each touching every live row once
+    finally:
+        ivf32.close()
+
+
+def test_recall_grows_with_nprobe(built):
+    eng, flat, ivf, q, _ = built
+    s_f, i_f = flat.search(q, 10)
+    recalls, scanned = [], []
+    for nprobe in (1, 2, 4, 8, 16, 32):
+        s, i, sc = ivf.search(q, 10, nprobe=nprobe)
+        recalls.append(np.mean([len(set(i[r]) & set(i_f[r])) / 10 for r in range(q.shape[0])]))
+        scanned.append(sc)
+        found = i >= 0
+        # every returned score is the true cosine of that row: compare with the flat scores of the same ids
+        for r in range(q.shape[0]):
+            common = {int(a): float(b) for a, b in zip(i_f[r], s_f[r])}
+            for a, b in zip(i[r][found[r]], s[r][found[r]]):
+                if int(a) in common:
+                    assert b == common[int(a)]
+    assert all(b >= a - 1e-9 for a, b in zip(recalls, recalls[1:])), recalls
+    assert recalls[-1] >= 0.95, recalls
+    assert recalls[0] >= 0.3, recalls
+    assert all(b >= a for a, b in zip(scanned, scanned[1:]))
+    # one list per query: at most 32 of the 128 lists per batch are touched
+    assert scanned[0] < 0.3 * 2 * flat.count
+
+
+def test_ivf_filters_and_tombstones(built):
+    eng, flat, ivf, q, tags = built
+    qf = np.array([(r % 4) + 1 for r in range(q.shape[0])], dtype=np.int32)
+    s, i, _ = ivf.search(q, 10, nprobe=32, q_filter=qf)
+    for r in range(q.shape[0]):
+        live = i[r][i[r] >= 0]
+        assert np.all(tags[live] == qf[r])
+        assert not set(live.tolist()) & {5, 77, 12345}
+    s_f, i_f = flat.search(q, 10, q_filter=qf)
+    rec = np.mean([len(set(i[r]) & set(i_f[r])) / 10 for r in range(q.shape[0])])
+    assert rec >= 0.9
+
+
+def test_ivf_empty_lists_and_small_index(gpu):
+    """More lists than distinct points: empty lists must be harmless."""
+    from rassengine_amd.engine import Engine
+    from rassengine_amd.ivf import IvfIndex
+    import torch
+    rng = np.random.default_rng(1)
+    base = rng.standard_normal((8, 1024)).astype(np.float32)
+    x = np.repeat(base, 20, axis=0) + 1e-3 * rng.standard_normal((160, 1024)).astype(np.float32)
+    eng = Engine(0, 1024)
+    try:
+        flat = eng.open_index("ivf-small")
+        flat.add(x)
+        cent = torch.from_numpy(np.concatenate([base, rng.standard_normal((24, 1024)).astype(np.float32)])).cuda()
+        cent = cent / cent.norm(dim=1, keepdim=True)
+        ivf = IvfIndex.build(flat, nlist=32, centroids=cent)
+        assert int((ivf.list_sizes == 0).sum()) >= 20
+        s, i, scanned = ivf.search(base, 5, nprobe=3)
+        s_f, i_f = flat.search(base, 5)
+        assert np.array_equal(i, i_f)
+        ivf.close()
+    finally:
+        eng.close()

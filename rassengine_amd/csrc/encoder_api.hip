@@ -145,7 +145,7 @@ int forward(rass_encoder* e, const int32_t* d_ids, const int32_t* d_cu, int nseq
             float* d_out, hipStream_t st) {
     const rass_encoder_config& c = e->cfg;
     const int H = c.hidden, I = c.intermediate;
-    const int Tp = (total + 127) / 128 * 128;
+    const int Tp = (total + 255) / 256 * 256;  // whole 256-token GEMM tiles
     EHIP_TRY(rass::launch_embed_layernorm(d_ids, d_cu, nseq, total, e->word, e->pos, e->type0, e->emb_g, e->emb_b,
                                           c.layer_norm_eps, H, c.vocab_size, c.max_positions, e->x, st));
     for (int l = 0; l < c.layers; ++l) {
@@ -312,7 +312,7 @@ int rass_encode_device(rass_encoder_t* e, const int32_t* d_token_ids, const int3
         return efail(RASS_ERR_INVALID, "bad nseq / total_tokens / max_seqlen");
     std::lock_guard<std::mutex> lk(e->mu);
     EHIP_TRY(hipSetDevice(e->device));
-    int rc = ensure_workspace(e, (total_tokens + 127) / 128 * 128, nseq);
+    int rc = ensure_workspace(e, (total_tokens + 255) / 256 * 256, nseq);
     if (rc != RASS_OK) return rc;
     return forward(e, d_token_ids, d_cu_seqlens, nseq, total_tokens, max_seqlen, d_out,
                    stream ? reinterpret_cast<hipStream_t>(stream) : e->own_stream);
@@ -333,7 +333,7 @@ int rass_encode(rass_encoder_t* e, const int32_t* token_ids, const int32_t* cu_s
     const int total = cu_seqlens[nseq];
     std::lock_guard<std::mutex> lk(e->mu);
     EHIP_TRY(hipSetDevice(e->device));
-    int rc = ensure_workspace(e, (total + 127) / 128 * 128, nseq);
+    int rc = ensure_workspace(e, (total + 255) / 256 * 256, nseq);
     if (rc != RASS_OK) return rc;
     hipStream_t st = e->own_stream;
     EHIP_TRY(hipMemcpyAsync(e->d_ids, token_ids, (size_t)total * 4, hipMemcpyHostToDevice, st));

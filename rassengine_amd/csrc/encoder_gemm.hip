@@ -167,9 +167,260 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_bf16_kernel(const u16* _
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Large-shape kernel: 256 (N) x 256 (M) x 32 (K) tiles, 512 threads = 2 (N) x 4 (M) waves, each
+// wave 128 x 64 = 8 x 4 MFMA tiles (128 accumulator VGPRs).  Versus the 128^2 kernel above
+// it halves the staging instructions per MFMA (4 global_load_lds per 32 MFMAs per wave
+// instead of 8) and replaces "vmcnt(0) + barrier every K step" by a 3-slot LDS ring with a
+// COUNTED wait: while step t is multiplied, the DMAs of steps t+1 and t+2 are in flight;
+// `s_waitcnt vmcnt(4)` (= all but the 4 pieces this wave just issued for t+2) retires t+1,
+// then ONE raw s_barrier per step publishes it (guide §5 "Pipelining across barriers": never
+// __syncthreads() here, its fence drains vmcnt(0)).  Hazards: RAW — a slot is read one
+// iteration after the wait+barrier that retired it; WAR — slot (t+2)%3 == (t-1)%3 was last
+// read in iteration t-1, and every wave passed that iteration's closing barrier before any
+// wave issues the t+2 DMAs.
+// LDS image: rows of 64 B (32 bf16), 16 rows per 1 KiB DMA piece, lane-linear; the
+// bank-conflict swizzle chunk ^= 3*((row>>3)&1) lives on the SOURCE address and on the read.
+constexpr int RBM = 256, RBN = 256, RBK = 32;
+constexpr int kRingThreads = 512;
+constexpr int kRingTileBytes = 256 * RBK * 2;        // 16 KiB per operand per slot
+constexpr int kRingSlotBytes = 2 * kRingTileBytes;   // W tile | X tile
+constexpr int kRingSlots = 3;
+
+__device__ __forceinline__ void ring_stage(const u16* __restrict__ g, int64_t ld, int row0, int k0,
+                                           unsigned char* lds_tile, int wave, int lane) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int piece = wave + 8 * p;          // 16 rows per piece
+        const int r = piece * 16 + (lane >> 2);  // tile row this lane fills
+        const int c_src = (lane & 3) ^ (((r >> 3) & 1) * 3);
+        const u16* src = g + (int64_t)(row0 + r) * ld + k0 + c_src * 8;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(lds_tile + piece * 1024), 16, 0, 0);
+    }
+}
+
+__device__ __forceinline__ bf16x8 ring_frag(const unsigned char* lds_tile, int row, int g) {
+    const int c = g ^ (((row >> 3) & 1) * 3);
+    return *reinterpret_cast<const bf16x8*>(lds_tile + row * 64 + c * 16);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(kRingThreads, 2) void gemm_bf16_ring_kernel(const u16* __restrict__ X,
+                                                                        const u16* __restrict__ W,
+                                                                        const float* __restrict__ bias,
+                                                                        const u16* __restrict__ residual,
+                                                                        u16* __restrict__ Y, int M, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // [3 slots][W tile | X tile]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wn = wave >> 2, wm = wave & 3;
+    const int nblk = gridDim.x, orig = blockIdx.x;
+    const int q = nblk / 8, rr = nblk % 8, xcd = orig % 8;
+    const int bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + orig / 8;
+    const int tiles_n = N / RBN;
+    const int bn = bid % tiles_n, bm = bid / tiles_n;
+    const int n0 = bn * RBN, m0 = bm * RBM;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = K / RBK;
+    // Loop-invariant addressing, hoisted: the K loop then issues ~1 VALU per 4 MFMAs instead of
+    // ~2 per MFMA (measured: SQ_INSTS_VALU / MFMA = 1.8 with the addresses recomputed per step).
+    //   DMA: this wave moves pieces {wave, wave+8} of each operand tile; per lane one source
+    //   pointer per piece, advanced by RBK elements per step; LDS destination = slot + piece*1024.
+    //   Fragments: byte offset inside a slot of each of the 8 A (W) and 4 B (X) fragments.
+    const u16* srcW[2];
+    const u16* srcX[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int r = (wave + 8 * p) * 16 + (lane >> 2);
+        const int c_src = (lane & 3) ^ (((r >> 3) & 1) * 3);
+        srcW[p] = W + (int64_t)(n0 + r) * K + c_src * 8;
+        srcX[p] = X + (int64_t)(m0 + r) * K + c_src * 8;
+    }
+    int offA[8], offB[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = wn * 128 + i * 16 + (lane & 15);
+        offA[i] = row * 64 + (((lane >> 4) ^ (((row >> 3) & 1) * 3)) * 16);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = wm * 64 + j * 16 + (lane & 15);
+        offB[j] = kRingTileBytes + row * 64 + (((lane >> 4) ^ (((row >> 3) & 1) * 3)) * 16);
+    }
+    auto stage_step = [&](unsigned char* slot_base) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)srcW[p],
+                                             (__attribute__((address_space(3))) void*)(slot_base + (wave + 8 * p) * 1024),
+                                             16, 0, 0);
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)srcX[p],
+                (__attribute__((address_space(3))) void*)(slot_base + kRingTileBytes + (wave + 8 * p) * 1024), 16, 0, 0);
+            srcW[p] += RBK;
+            srcX[p] += RBK;
+        }
+    };
+    stage_step(lds);
+    if (nk > 1) {
+        stage_step(lds + kRingSlotBytes);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+
+    // Stagger (MI355X_MICROARCH "two waves per SIMD" item 9): every K step is a LOAD phase (DMA
+    // issue for step t+2 + this step's 12 LDS fragment reads) and a COMPUTE phase (32 MFMAs),
+    // each closed by a barrier.  Waves 4-7 (the SIMD partners of waves 0-3) run ONE phase behind:
+    // while a SIMD's older wave multiplies, its partner issues DMAs and LDS reads, instead of
+    // both doing the same thing at the same time.  Step t+1 must be complete before the FIRST
+    // reader (group A, interval 2t+2): group A retires its pieces at the end of its compute
+    // phase, group B at the end of its load phase — both are interval 2t+1.  WAR on slot
+    // (t+2)%3 == (t-1)%3: its last reads (group B's load phase of step t-1, drained by
+    // lgkmcnt(0) before the barrier) end in interval 2t-1, the first new DMA is interval 2t.
+    const bool grpB = wave >= 4;
+    if (grpB) __builtin_amdgcn_s_barrier();
+    int slot = 0;
+    for (int t = 0; t < nk; ++t) {
+        const bool more = t + 2 < nk;
+        // ---- load phase
+        if (more) {
+            int s2 = slot + 2;
+            s2 = s2 >= kRingSlots ? s2 - kRingSlots : s2;
+            stage_step(lds + s2 * kRingSlotBytes);
+        }
+        const unsigned char* buf = lds + slot * kRingSlotBytes;
+        bf16x8 a[8], b[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bf16x8*>(buf + offB[j]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] = *reinterpret_cast<const bf16x8*>(buf + offA[i]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (grpB) {
+            if (more) {
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- compute phase
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        if (!grpB) {
+            if (more) {
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        slot = slot + 1 >= kRingSlots ? 0 : slot + 1;
+    }
+    if (!grpB) __builtin_amdgcn_s_barrier();  // both groups execute the same number of barriers
+
+    // Epilogue through LDS (free after the last barrier).  The accumulator layout gives every
+    // lane 4 consecutive features of ONE token per tile, i.e. 8-byte stores scattered over 16
+    // token rows per instruction: measured 1.7 TB/s, ~45 % of a K=1024 GEMM's time.  Instead
+    // each wave transposes 32-token x 64-feature chunks (fp32, 8.5 KiB of its private 12 KiB
+    // LDS region) and writes them back as 16-byte stores, 8 lanes = 128 contiguous bytes per
+    // token row; bias / residual / GELU are applied on the coalesced side.
+    {
+        constexpr int kPitchF = 68;  // floats per token row of the chunk image (64 + pad)
+        float* stg = reinterpret_cast<float*>(lds + wave * (kRingSlots * kRingSlotBytes / 8));
+        const int tl = lane >> 3, nq = lane & 7;  // read-back: token row (of 8 per pass), 8-feature group
+#pragma unroll
+        for (int jc = 0; jc < 2; ++jc) {
+#pragma unroll
+            for (int ic = 0; ic < 2; ++ic) {
+                // stage: tiles i = 4ic..4ic+3, j = 2jc..2jc+1
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int ii = 0; ii < 4; ++ii)
+                        *reinterpret_cast<f32x4*>(stg + (jj * 16 + (lane & 15)) * kPitchF + ii * 16 + (lane >> 4) * 4) =
+                            acc[4 * ic + ii][2 * jc + jj];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same-wave LDS write -> read
+                const int nbase = n0 + wn * 128 + ic * 64 + nq * 8;
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + nbase);
+                const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias + nbase + 4);
+#pragma unroll
+                for (int pass = 0; pass < 4; ++pass) {
+                    const int tok = pass * 8 + tl;
+                    const int m = m0 + wm * 64 + jc * 32 + tok;
+                    f32x4 v0 = *reinterpret_cast<const f32x4*>(stg + tok * kPitchF + nq * 8);
+                    f32x4 v1 = *reinterpret_cast<const f32x4*>(stg + tok * kPitchF + nq * 8 + 4);
+                    v0 += b0;
+                    v1 += b1;
+                    if (m < M) {
+                        if (EPI == 1) {
+                            const uint4 r = *reinterpret_cast<const uint4*>(residual + (int64_t)m * N + nbase);
+                            v0.x += bf16_to_f32((u16)(r.x & 0xffff));
+                            v0.y += bf16_to_f32((u16)(r.x >> 16));
+                            v0.z += bf16_to_f32((u16)(r.y & 0xffff));
+                            v0.w += bf16_to_f32((u16)(r.y >> 16));
+                            v1.x += bf16_to_f32((u16)(r.z & 0xffff));
+                            v1.y += bf16_to_f32((u16)(r.z >> 16));
+                            v1.z += bf16_to_f32((u16)(r.w & 0xffff));
+                            v1.w += bf16_to_f32((u16)(r.w >> 16));
+                        }
+                        if (EPI == 2) {
+                            v0.x = gelu_erf(v0.x); v0.y = gelu_erf(v0.y); v0.z = gelu_erf(v0.z); v0.w = gelu_erf(v0.w);
+                            v1.x = gelu_erf(v1.x); v1.y = gelu_erf(v1.y); v1.z = gelu_erf(v1.z); v1.w = gelu_erf(v1.w);
+                        }
+                        uint4 o;
+                        o.x = (unsigned)f32_to_bf16(v0.x) | ((unsigned)f32_to_bf16(v0.y) << 16);
+                        o.y = (unsigned)f32_to_bf16(v0.z) | ((unsigned)f32_to_bf16(v0.w) << 16);
+                        o.z = (unsigned)f32_to_bf16(v1.x) | ((unsigned)f32_to_bf16(v1.y) << 16);
+                        o.w = (unsigned)f32_to_bf16(v1.z) | ((unsigned)f32_to_bf16(v1.w) << 16);
+                        *reinterpret_cast<uint4*>(Y + (int64_t)m * N + nbase) = o;
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the next chunk overwrites
+            }
+        }
+    }
+}
+
+template <int EPI>
+static hipError_t launch_ring(const u16* X, const u16* W, const float* bias, const u16* residual, u16* Y, int M,
+                              int M_pad, int N, int K, hipStream_t stream) {
+    constexpr int lds_bytes = kRingSlots * kRingSlotBytes;  // 96 KiB
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_ring_kernel<EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int grid = (N / RBN) * (M_pad / RBM);
+    hipLaunchKernelGGL((gemm_bf16_ring_kernel<EPI>), dim3(grid), dim3(kRingThreads), lds_bytes, stream, X, W, bias,
+                       residual, Y, M, N, K);
+    return hipGetLastError();
+}
+
 template <int EPI>
 static hipError_t launch_epi(const u16* X, const u16* W, const float* bias, const u16* residual, u16* Y, int M,
                              int M_pad, int N, int K, hipStream_t stream) {
+    // big shapes: the 256^2 ring kernel; small / odd shapes: the 128^2 kernel
+    if (N % RBN == 0 && M_pad % RBM == 0 && K % RBK == 0 && M >= 1024)
+        return launch_ring<EPI>(X, W, bias, residual, Y, M, M_pad, N, K, stream);
     constexpr int lds_bytes = 4 * kTileBytes;  // 64 KiB
     static bool attr_set = false;
     if (!attr_set) {
@@ -186,8 +437,9 @@ static hipError_t launch_epi(const u16* X, const u16* W, const float* bias, cons
 
 hipError_t launch_gemm_bf16(const void* X, const void* W, const float* bias, const void* residual, void* Y, int M,
                             int M_pad, int N, int K, int epilogue, hipStream_t stream) {
-    if (M < 0 || M_pad < M || M_pad % GBM != 0 || N % GBN != 0 || K % GBK != 0 || N <= 0 || K <= 0)
-        return hipErrorInvalidValue;
+    if (M < 0 || M_pad < M || N <= 0 || K <= 0) return hipErrorInvalidValue;
+    const bool ring_ok = N % RBN == 0 && M_pad % RBM == 0 && K % RBK == 0 && M >= 1024;
+    if (!ring_ok && (M_pad % GBM != 0 || N % GBN != 0 || K % GBK != 0)) return hipErrorInvalidValue;
     if (M == 0) return hipSuccess;
     const u16* x = static_cast<const u16*>(X);
     const u16* w = static_cast<const u16*>(W);

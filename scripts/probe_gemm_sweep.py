@@ -1,0 +1,26 @@
+"""K sweep at fixed N: slope = mainloop rate, intercept = per-tile fixed cost."""
+import ctypes, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from rassengine_amd import _native as N
+L = N.lib()
+g = torch.Generator(device="cuda"); g.manual_seed(0)
+M = 131072
+stream = ctypes.c_void_p(int(torch.cuda.current_stream().cuda_stream))
+for Nn, epi in [(1024, 0), (1024, 1), (4096, 2), (4096, 0)]:
+    for K in (32, 256, 512, 1024, 2048, 4096):
+        X = torch.randn((M, K), generator=g, device="cuda").bfloat16()
+        W = (torch.randn((Nn, K), generator=g, device="cuda") / K ** 0.5).bfloat16()
+        b = torch.randn((Nn,), generator=g, device="cuda")
+        R = torch.randn((M, Nn), generator=g, device="cuda").bfloat16()
+        Y = torch.empty((M, Nn), dtype=torch.bfloat16, device="cuda")
+        def run():
+            N.check("g", L.rass_gemm_bf16(ctypes.c_void_p(X.data_ptr()), ctypes.c_void_p(W.data_ptr()), ctypes.c_void_p(b.data_ptr()),
+                    ctypes.c_void_p(R.data_ptr()), ctypes.c_void_p(Y.data_ptr()), M, M, Nn, K, epi, stream))
+        run(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5): run()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 5
+        print(f"N={Nn} epi={epi} K={K:5d}: {dt*1e6:7.0f} us  {2*M*Nn*K/dt/1e12:6.0f} TF/s", flush=True)
+        del X, W, R, Y

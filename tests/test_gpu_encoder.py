@@ -19,13 +19,16 @@ def _cos(a, b):
 
 
 @pytest.mark.parametrize("M,N,K,epi", [(128, 128, 64, 0), (100, 384, 128, 0), (300, 128, 512, 1), (257, 512, 128, 2),
-                                       (1000, 3072, 1024, 0), (513, 1024, 4096, 1), (640, 4096, 1024, 2)])
+                                       (1000, 3072, 1024, 0), (513, 1024, 4096, 1), (640, 4096, 1024, 2),
+                                       # >= 1024 rows, N % 256 == 0: the 256^2 ring kernel
+                                       (1024, 256, 32, 0), (1500, 1024, 1024, 1), (4096, 3072, 1024, 0),
+                                       (1100, 4096, 1024, 2), (1300, 1024, 4096, 1), (2048, 512, 96, 0)])
 def test_gemm_bf16_matches_torch(gpu, M, N, K, epi):
     torch = gpu
     from rassengine_amd import _native as N_
     g = torch.Generator(device="cuda")
     g.manual_seed(M * 7 + N + K + epi)
-    M_pad = (M + 127) // 128 * 128
+    M_pad = (M + 255) // 256 * 256 if M >= 1024 else (M + 127) // 128 * 128
     X = torch.zeros((M_pad, K), dtype=torch.bfloat16, device="cuda")
     X[:M] = torch.randn((M, K), generator=g, device="cuda").bfloat16()
     W = (torch.randn((N, K), generator=g, device="cuda") / K ** 0.5).bfloat16()

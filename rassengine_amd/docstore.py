@@ -53,9 +53,36 @@ class IndexState:
         self.doc_row: Dict[str, int] = {}        # doc_id -> live row
         self.structured: Dict[str, dict] = {}    # structured docs carry no embedding (app/main.py:1222-1240)
         self.patients = PatientDictionary()
+        self.batcher = None                      # QueryBatcher, created on first async search
 
     def live_count(self) -> int:
         return len(self.doc_row) + len(self.structured)
+
+    # ---- persistence: the vectors go to `<prefix>.rass` (rass_index_save), the
+    # host-side metadata OpenSearch used to hold (docs, doc_id map, patient dictionary) to
+    # `<prefix>.meta.json`.  Replaces OpenSearch's durability for this path.
+    def save(self, prefix: str) -> None:
+        import json
+        with self.lock:
+            self.index.save(prefix + ".rass")
+            meta = {"version": 1, "name": self.name, "row_doc": self.row_doc, "structured": self.structured,
+                    "patients": self.patients._name[1:]}
+            with open(prefix + ".meta.json", "w", encoding="utf-8") as f:
+                json.dump(meta, f)
+
+    @classmethod
+    def load(cls, name: str, prefix: str, index_loader) -> "IndexState":
+        """``index_loader(name, path) -> FlatIndex-like`` (e.g. ``Engine.load_index``)."""
+        import json
+        with open(prefix + ".meta.json", encoding="utf-8") as f:
+            meta = json.load(f)
+        st = cls(name, index_loader(name, prefix + ".rass"))
+        st.row_doc = meta["row_doc"]
+        st.structured = meta["structured"]
+        for p in meta["patients"]:
+            st.patients.encode(p)
+        st.doc_row = {d["doc_id"]: r for r, d in enumerate(st.row_doc) if d is not None}
+        return st
 
 
 class Registry:
@@ -83,6 +110,10 @@ class Registry:
                 factory = self._factory or self._default_factory
                 st = self._states[name] = IndexState(name, factory(name))
             return st
+
+    def put(self, st: IndexState) -> None:
+        with self._lock:
+            self._states[st.name] = st
 
     def exists(self, name: str) -> bool:
         with self._lock:

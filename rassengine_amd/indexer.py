@@ -103,11 +103,35 @@ class HipIndexer:
             return []  # 1570-1571
         return self.knn_scores(query_emb, k, boost=2.0, filter_clause=filter_clause, patient_id=patient_id)
 
-    # ---------------------------------------------------------------------------- internals
-    def _knn(self, query_emb, k, filter_clause, patient_id, boost, score_mode) -> List[Tuple[Dict, float]]:
-        st: Optional[IndexState] = REGISTRY.get(self.index_name, create=False)
-        if st is None:
+    async def asemantic_search(self, query_emb: np.ndarray, k: int = TOP_K, filter_clause: Optional[Dict] = None,
+                               patient_id: Optional[str] = None, query: Optional[str] = None, **_ignored
+                               ) -> List[Tuple[Dict, float]]:
+        """Awaitable ``semantic_search``: concurrent callers on one event loop share scans
+        through the index's ``QueryBatcher`` (up to 32 queries per HBM pass) instead of
+        blocking the loop with one scan each (the reference calls the sync client inline,
+        app/main.py:1552)."""
+        if query_emb is None or np.size(query_emb) == 0:
             return []
+        try:
+            st: Optional[IndexState] = REGISTRY.get(self.index_name, create=False)
+            if st is None:
+                return []
+            prep = self._prepare(st, query_emb, k, filter_clause, patient_id)
+            if prep is None:
+                return []
+            q, k_eff, q_filter = prep
+            if st.batcher is None:
+                from .batcher import QueryBatcher
+                st.batcher = QueryBatcher(st.index)
+            scores, ids = await st.batcher.search(q[0], k_eff, int(q_filter[0]) if q_filter is not None else -1)
+            return self._hits(st, scores, ids, 1.0, None)
+        except Exception as e:
+            logger.error(f"Semantic search error: {e}")
+            return []
+
+    # ---------------------------------------------------------------------------- internals
+    @staticmethod
+    def _prepare(st: IndexState, query_emb, k, filter_clause, patient_id):
         q = np.asarray(query_emb, dtype=np.float32)
         if q.ndim == 1:
             q = q[None, :]
@@ -117,13 +141,26 @@ class HipIndexer:
         if pid:
             code = st.patients.lookup(pid)
             if code is None:
-                return []  # term filter on a patient that was never indexed
+                return None  # term filter on a patient that was never indexed
             q_filter = np.array([code], dtype=np.int32)
-        k_eff = max(1, min(int(k), 32))
+        return q, max(1, min(int(k), 32)), q_filter
+
+    def _knn(self, query_emb, k, filter_clause, patient_id, boost, score_mode) -> List[Tuple[Dict, float]]:
+        st: Optional[IndexState] = REGISTRY.get(self.index_name, create=False)
+        if st is None:
+            return []
+        prep = self._prepare(st, query_emb, k, filter_clause, patient_id)
+        if prep is None:
+            return []
+        q, k_eff, q_filter = prep
         scores, ids = st.index.search(q, k_eff, q_filter=q_filter)
+        return self._hits(st, scores[0], ids[0], boost, score_mode)
+
+    @staticmethod
+    def _hits(st: IndexState, scores, ids, boost, score_mode) -> List[Tuple[Dict, float]]:
         out: List[Tuple[Dict, float]] = []
         with st.lock:
-            for cos, row in zip(scores[0], ids[0]):
+            for cos, row in zip(scores, ids):
                 if row < 0:
                     break
                 doc = st.row_doc[int(row)] if int(row) < len(st.row_doc) else None

@@ -1,0 +1,146 @@
+"""CPU tests: the cross-request query micro-batcher and the metadata persistence, on the
+oracle-backed index double (the HIP index has the same surface)."""
+import asyncio
+
+import numpy as np
+import pytest
+
+from rassengine_amd import embedding, indexer
+from rassengine_amd.batcher import QueryBatcher
+from rassengine_amd.docstore import REGISTRY, IndexState
+from tests.helpers import HashEmbedder, OracleIndex
+
+
+class CountingIndex(OracleIndex):
+    def __init__(self, dim):
+        super().__init__(dim)
+        self.calls = []
+
+    def search(self, queries, k, q_filter=None):
+        self.calls.append((queries.shape[0], k, None if q_filter is None else q_filter.copy()))
+        return super().search(queries, k, q_filter)
+
+
+def test_batcher_coalesces_and_matches_individual_searches():
+    rng = np.random.default_rng(0)
+    idx = CountingIndex(64)
+    idx.add(rng.standard_normal((500, 64), dtype=np.float32), tags=rng.integers(1, 4, size=500).astype(np.int32))
+    qs = rng.standard_normal((100, 64), dtype=np.float32)
+    ks = rng.integers(1, 11, size=100)
+    codes = rng.integers(-1, 4, size=100)
+
+    async def main():
+        b = QueryBatcher(idx, max_batch=32, max_delay_ms=20.0)
+        res = await asyncio.gather(*[b.search(qs[i], int(ks[i]), int(codes[i])) for i in range(100)])
+        await b.close()
+        return b, res
+
+    b, res = asyncio.run(main())
+    assert b.served == 100 and b.scans <= 8          # >= 13x fewer scans than requests
+    assert all(c[0] <= 32 for c in idx.calls)
+    ref = OracleIndex(64)
+    ref._rows, ref._tags = idx._rows, idx._tags
+    for i, (s, ids) in enumerate(res):
+        f = None if codes[i] < 0 else np.array([codes[i]], dtype=np.int32)
+        rs, ri = ref.search(qs[i:i + 1], int(ks[i]), f)
+        assert ids.shape == (ks[i],) and np.array_equal(ids, ri[0]) and np.allclose(s, rs[0], atol=1e-6)
+
+
+def test_batcher_single_request_latency_bound_and_errors():
+    idx = CountingIndex(16)
+    idx.add(np.eye(16, dtype=np.float32))
+
+    async def one():
+        b = QueryBatcher(idx, max_delay_ms=1.0)
+        s, i = await b.search(np.eye(16, dtype=np.float32)[3], 2)
+        await b.close()
+        return s, i
+
+    s, i = asyncio.run(one())
+    assert i[0] == 3 and idx.calls[-1][0] == 1
+
+    class Boom:
+        def search(self, *a, **k):
+            raise RuntimeError("device lost")
+
+    async def failing():
+        b = QueryBatcher(Boom(), max_delay_ms=1.0)
+        with pytest.raises(RuntimeError):
+            await b.search(np.zeros(4, dtype=np.float32), 1)
+        await b.close()
+
+    asyncio.run(failing())
+    with pytest.raises(ValueError):
+        QueryBatcher(idx, max_batch=64)
+
+
+def test_async_semantic_search_shares_scans():
+    REGISTRY.clear()
+    idx = CountingIndex(1024)
+    REGISTRY.set_index_factory(lambda name: idx)
+    emb = HashEmbedder(1024)
+    embedding.set_embedder(emb)
+    try:
+        docs = [{"doc_id": f"d{i}", "doc_type": "unstructured", "patientId": f"p{i % 2}",
+                 "unstructuredText": f"note {i} topic{i % 9}"} for i in range(120)]
+
+        async def main():
+            await indexer.store_fhir_docs_in_opensearch([], docs, None, "idx-b")
+            ix = indexer.HipIndexer(None, "idx-b")
+            qs = [await embedding.embed_query(f"note {i} topic{i % 9}") for i in range(40)]
+            idx.calls.clear()
+            out = await asyncio.gather(*[ix.asemantic_search(query_emb=qs[i], k=3, patient_id=f"p{i % 2}", query="x")
+                                         for i in range(40)])
+            sync = [ix.semantic_search(qs[i], k=3, patient_id=f"p{i % 2}") for i in range(40)]
+            await REGISTRY.get("idx-b").batcher.close()
+            return out, sync
+
+        out, sync = asyncio.run(main())
+        assert len(idx.calls) - 40 <= 14                     # 40 async requests share scans (+40 sync calls)
+        for a, b in zip(out, sync):
+            assert [d["doc_id"] for d, _ in a] == [d["doc_id"] for d, _ in b]
+            assert np.allclose([s for _, s in a], [s for _, s in b])
+        assert out[5][0][0]["doc_id"] == "d5"
+    finally:
+        embedding.set_embedder(None)
+        REGISTRY.set_index_factory(None)
+        REGISTRY.clear()
+
+
+def test_metadata_persistence_roundtrip(tmp_path):
+    class SavingIndex(OracleIndex):
+        def save(self, path):
+            np.savez(path + ".npz", rows=self._rows, tags=self._tags)
+
+    def loader(name, path):
+        z = np.load(path + ".npz")
+        i = SavingIndex(z["rows"].shape[1])
+        i._rows, i._tags = z["rows"], z["tags"]
+        return i
+
+    REGISTRY.clear()
+    REGISTRY.set_index_factory(lambda name: SavingIndex(1024))
+    embedding.set_embedder(HashEmbedder(1024))
+    try:
+        docs = [{"doc_id": f"d{i}", "doc_type": "unstructured", "patientId": f"p{i % 3}",
+                 "unstructuredText": f"text {i} alpha{i % 5}"} for i in range(30)]
+        structured = [{"doc_id": "Patient-1", "doc_type": "structured", "patientId": "p1"}]
+        asyncio.run(indexer.store_fhir_docs_in_opensearch(structured, docs, None, "idx-p"))
+        asyncio.run(indexer.store_fhir_docs_in_opensearch([], [dict(docs[4], unstructuredText="rewritten")], None, "idx-p"))
+        st = REGISTRY.get("idx-p")
+        prefix = str(tmp_path / "shard0")
+        st.save(prefix)
+        st2 = IndexState.load("idx-p", prefix, loader)
+        assert st2.doc_row == st.doc_row and st2.structured == st.structured
+        assert st2.patients.lookup("p2") == st.patients.lookup("p2") and len(st2.patients) == 3
+        REGISTRY.clear()
+        REGISTRY.put(st2)
+        ix = indexer.HipIndexer(None, "idx-p")
+        q = asyncio.run(embedding.embed_query("rewritten"))
+        hits = ix.semantic_search(q, k=2, patient_id="p1")
+        assert hits[0][0]["doc_id"] == "d4" and hits[0][0]["unstructuredText"] == "rewritten"
+        assert ix.has_any_data()
+    finally:
+        embedding.set_embedder(None)
+        REGISTRY.set_index_factory(None)
+        REGISTRY.clear()

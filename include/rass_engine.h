@@ -283,6 +283,28 @@ int rass_gemm_bf16(const void* d_x, const void* d_w, const float* d_bias,
                    const void* d_residual, void* d_y, int m, int m_pad, int n,
                    int k, int epilogue, void* stream);
 
+/* -------------------------------------------------------------- tokenizer
+ * BERT (uncased) BasicTokenizer + WordPiece on the host (C++), replacing the
+ * tokenisation Ollama / llama.cpp performs on every chunk the reference posts
+ * (app/main.py:225-237): lower-case, NFD + accent strip, punctuation split,
+ * CJK spacing, greedy longest-match-first pieces, [CLS] ... [SEP], truncated
+ * to max_len.  Unicode tables are generated from Python's unicodedata. */
+typedef struct rass_tokenizer rass_tokenizer_t;
+int rass_tokenizer_create(const char* vocab_path, int lower_case,
+                          rass_tokenizer_t** out);
+void rass_tokenizer_destroy(rass_tokenizer_t* tok);
+int rass_tokenizer_vocab_size(const rass_tokenizer_t* tok);
+/* Returns the number of ids written (<= max_len) or a negative status. */
+int rass_tokenizer_encode(const rass_tokenizer_t* tok, const char* text,
+                          int64_t text_len, int max_len, int32_t* out_ids);
+/* n UTF-8 texts -> packed ids (capacity n*max_len) + cu_seqlens[n+1], fanned
+ * out over n_threads (<= 0: all cores).  Returns the total token count. */
+int64_t rass_tokenizer_encode_batch(const rass_tokenizer_t* tok,
+                                    const char* const* texts,
+                                    const int64_t* lens, int n, int max_len,
+                                    int32_t* out_ids, int32_t* out_cu,
+                                    int n_threads);
+
 /* HIP-event timing on an explicit stream (bench.py measures kernels on the
  * stream they run on; torch.cuda.Event only sees torch's current stream). */
 typedef struct rass_timer rass_timer_t;

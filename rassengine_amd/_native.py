@@ -98,6 +98,14 @@ SIGNATURES = {
     "rass_gemm_bf16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                       ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                       ctypes.c_int, ctypes.c_void_p]),
+    "rass_tokenizer_create": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int, c_void_pp]),
+    "rass_tokenizer_destroy": (None, [ctypes.c_void_p]),
+    "rass_tokenizer_vocab_size": (ctypes.c_int, [ctypes.c_void_p]),
+    "rass_tokenizer_encode": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64, ctypes.c_int,
+                                             ctypes.c_void_p]),
+    "rass_tokenizer_encode_batch": (ctypes.c_int64, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_char_p),
+                                                     ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                                     ctypes.c_void_p, ctypes.c_int]),
     "rass_timer_create": (ctypes.c_int, [c_void_pp]),
     "rass_timer_destroy": (None, [ctypes.c_void_p]),
     "rass_timer_start": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),

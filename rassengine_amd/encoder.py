@@ -261,6 +261,55 @@ class WordPieceTokenizer:
         return [self.cls] + ids[: max_len - 2] + [self.sep]
 
 
+class CppWordPieceTokenizer:
+    """The same tokenizer in host C++ behind the C ABI (``rass_tokenizer_*``), multi-threaded
+    over a batch; used by ``HipSentenceEncoder`` so ingest is not bottlenecked on Python."""
+
+    def __init__(self, vocab_path: str, lower_case: bool = True):
+        self._L = N.lib()
+        h = ctypes.c_void_p()
+        N.check("rass_tokenizer_create",
+                self._L.rass_tokenizer_create(vocab_path.encode(), 1 if lower_case else 0, ctypes.byref(h)))
+        self._h = h
+
+    @property
+    def vocab_size(self) -> int:
+        return int(self._L.rass_tokenizer_vocab_size(self._h))
+
+    def encode(self, text: str, max_len: int = 512) -> List[int]:
+        raw = text.encode("utf-8", "replace")
+        out = np.empty(max_len, dtype=np.int32)
+        n = N.check("rass_tokenizer_encode",
+                    self._L.rass_tokenizer_encode(self._h, raw, len(raw), int(max_len),
+                                                  out.ctypes.data_as(ctypes.c_void_p)))
+        return out[:n].tolist()
+
+    def encode_batch(self, texts: Sequence[str], max_len: int = 512, n_threads: int = 0):
+        """-> (ids int32 [total], cu_seqlens int32 [n+1]) ready for ``rass_encode``."""
+        n = len(texts)
+        raws = [t.encode("utf-8", "replace") for t in texts]
+        arr = (ctypes.c_char_p * n)(*raws)
+        lens = np.array([len(r) for r in raws], dtype=np.int64)
+        ids = np.empty(max(n, 1) * max_len, dtype=np.int32)
+        cu = np.zeros(n + 1, dtype=np.int32)
+        total = self._L.rass_tokenizer_encode_batch(self._h, arr, lens.ctypes.data_as(ctypes.c_void_p), n,
+                                                    int(max_len), ids.ctypes.data_as(ctypes.c_void_p),
+                                                    cu.ctypes.data_as(ctypes.c_void_p), int(n_threads))
+        N.check("rass_tokenizer_encode_batch", int(total) if total < 0 else 0)
+        return ids[:int(total)], cu
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._L.rass_tokenizer_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 # ---------------------------------------------------------------------------------- encoder
 class HipSentenceEncoder:
     """texts -> pooled fp32 vectors [n, hidden] on one GPU (an ``Embedder`` for embedding.py)."""
@@ -290,7 +339,7 @@ class HipSentenceEncoder:
     def from_dir(cls, path: str, device: int = 0, **kw) -> "HipSentenceEncoder":
         cfg = EncoderConfig.from_dir(path)
         vocab_path = os.path.join(path, "vocab.txt")
-        tok = WordPieceTokenizer.from_file(vocab_path) if os.path.exists(vocab_path) else None
+        tok = CppWordPieceTokenizer(vocab_path) if os.path.exists(vocab_path) else None
         return cls(cfg, load_weights(path), tok, device=device, **kw)
 
     def close(self) -> None:
@@ -330,4 +379,7 @@ class HipSentenceEncoder:
     def encode(self, texts: List[str]) -> np.ndarray:
         if self.tokenizer is None:
             raise RuntimeError("this model directory has no vocab.txt: use encode_ids()")
+        if hasattr(self.tokenizer, "encode_batch"):  # C++: one multi-threaded call per batch
+            ids, cu = self.tokenizer.encode_batch(texts, self.cfg.max_positions)
+            return self.encode_ids([ids[cu[i]:cu[i + 1]] for i in range(len(texts))])
         return self.encode_ids([self.tokenizer.encode(t, self.cfg.max_positions) for t in texts])

@@ -39,6 +39,8 @@ def main():
     ap.add_argument("--query-pool", type=int, default=4096)
     ap.add_argument("--cpu-sample-rows", type=int, default=200_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--prefilter", action="store_true",
+                    help="flagged mode (not the parity default): bf16 candidate scan + exact fp32 re-rank")
     args = ap.parse_args()
 
     import numpy as np
@@ -50,11 +52,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    # one rank per GPU; RASS_BENCH_SHARE_GPU=1 (rehearsal on a 1-GPU box, gloo) lets ranks share a device
+    share = os.environ.get("RASS_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from rassengine_amd.dist import HipShard, ShardedSearch
     from rassengine_amd.engine import Engine, scan_kernel_name
@@ -64,6 +73,8 @@ def main():
     idx = eng.open_index("bench", capacity_rows=n_local)
     # Philox rows keyed by the GLOBAL row id: shard r regenerates rows [r*n_local, (r+1)*n_local)
     idx.fill_synthetic(n_local, seed=1234, row_id_base=rank * n_local)
+    if args.prefilter:
+        idx.set_prefilter(True)
     eng.synchronize()
 
     shard = HipShard(idx, id_base=rank * n_local)  # switches the engine to torch's current stream
@@ -102,7 +113,9 @@ def main():
 
     ms_per_step = elapsed / args.steps * 1e3
     qps = B * args.steps / elapsed
-    bytes_per_launch = n_local * idx.row_stride * 4  # algorithmic: N_loc * D * 4
+    # algorithmic bytes of the dominant kernel: N_loc * D * 4 (fp32 scan); the bf16
+    # candidate scan of the prefilter mode reads N_loc * D * 2
+    bytes_per_launch = n_local * idx.row_stride * (2 if args.prefilter else 4)
     achieved = bytes_per_launch * scan_launches / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
 
     result = {
@@ -122,19 +135,31 @@ def main():
             "workload": f"{n_local * world} x {dim}-d flat cosine top-{k}, {world} x MI355X, precomputed embeddings "
                         f"(BASELINE configs[1] shard per GPU)",
             "rows_per_gpu": n_local, "rows_global": n_local * world, "dim": dim, "k": k, "query_batch": B,
-            "corpus_dtype": "f32", "layout": "tile16", "sharding": f"row-sharded x{world}, RCCL all-gather merge"
+            "corpus_dtype": "f32" if not args.prefilter else "f32 + bf16 candidate copy (exact fp32 re-rank)",
+            "layout": "tile16", "mode": "prefilter" if args.prefilter else "flat", "sharding": f"row-sharded x{world}, RCCL all-gather merge"
             if world > 1 else "single shard",
             "aggregate_scan_GBps": round(bytes_per_launch * world * args.steps / elapsed / 1e9, 1),
         },
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
-            "kernel": scan_kernel_name(dim, B), "bytes_per_launch": bytes_per_launch,
+            "kernel": scan_kernel_name(dim, B) if not args.prefilter else
+            f"scan_bf16_topk_kernel<{idx.row_stride // 256}, {1 if B <= 16 else 2}>", "bytes_per_launch": bytes_per_launch,
             "avg_launch_us": round(scan_ms / max(scan_launches, 1) * 1e3, 2), "launches": scan_launches,
         },
     }
 
     result["roofline"]["traffic"] = pmc_traffic(result["roofline"]["kernel"], bytes_per_launch)
+
+    if rank == 0 and world == 1 and args.prefilter:
+        # the flagged mode is approximate in principle: measure it against the exact flat scan
+        qh = pool[:B].cpu().numpy()
+        s_p, i_p = idx.search(qh, k)
+        idx.set_prefilter(False)
+        s_f, i_f = idx.search(qh, k)
+        idx.set_prefilter(True)
+        result["prefilter_recall_vs_flat"] = float(np.mean([len(set(i_p[r]) & set(i_f[r])) / k for r in range(B)]))
+        result["prefilter_scores_bit_identical"] = bool(np.array_equal(s_p[i_p == i_f], s_f[i_p == i_f]))
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result.update(cpu_baseline_and_recall(np, torch, eng, idx, pool, args, n_local, dim, B, k))

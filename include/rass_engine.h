@@ -144,6 +144,17 @@ int rass_index_search_device(rass_index_t* idx, const float* d_queries, int nq,
                              int k, const int32_t* d_q_filter, int64_t id_base,
                              float* d_out_scores, int64_t* d_out_ids);
 
+/* Prefilter mode, OFF by default: keep a bf16 copy of the slab,
+ * scan IT (half the HBM bytes per pass, bf16 MFMA) for the 32 best candidates
+ * per query, then recompute those candidates' scores exactly from the fp32
+ * slab in the flat kernel's fmaf order and return the exact top-k among them.
+ * Returned scores are bit-identical to the flat path; the id set equals the
+ * flat result whenever the true top-k lies inside the bf16 top-32 (measured
+ * as recall, not guaranteed).  Used for k <= 16 only (k > 16 takes the exact
+ * flat scan).  Needs dim padded to a multiple of 256. */
+int rass_index_set_prefilter(rass_index_t* idx, int enable);
+int rass_index_get_prefilter(const rass_index_t* idx);
+
 /* Shard persistence: raw rows + tags + manifest header. */
 int rass_index_save(rass_index_t* idx, const char* path);
 int rass_index_load(rass_engine_t* eng, const char* name, const char* path,

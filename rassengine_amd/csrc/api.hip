@@ -42,6 +42,7 @@ int fail(int code, const std::string& msg) {
         }                                                                                               \
     } while (0)
 
+constexpr int kPrefilterMaxK = 16;     // prefilter keeps 32 bf16 candidates: only k <= 16 uses it, wider k scans fp32
 constexpr int kMaxGrid = 1024;        // upper bound on scan workgroups (sizing of scratch)
 constexpr int kMaxStride = 1024;      // dim_padded limit of the fused scan (CH <= 8)
 constexpr int64_t kStageRows = 8192;  // host -> device staging granule for add()
@@ -71,7 +72,7 @@ struct IvfPlan {
 };
 
 struct ScratchLayout {
-    size_t q_padded, part_scores, part_ids, total;
+    size_t q_padded, part_scores, part_ids, q_bf16, cand_scores, cand_ids, total;
 };
 
 ScratchLayout scratch_layout(int nq, int k) {
@@ -84,6 +85,15 @@ ScratchLayout scratch_layout(int nq, int k) {
     off = (off + 255) / 256 * 256;
     L.part_ids = off;
     off += (size_t)kMaxGrid * nq * k * sizeof(int64_t);
+    off = (off + 255) / 256 * 256;
+    // prefilter mode: bf16 queries + the 32 candidates per query handed to the exact re-rank
+    L.q_bf16 = off;
+    off += (size_t)RASS_MAX_QBATCH * kMaxStride * 2;
+    L.cand_scores = off;
+    off += (size_t)RASS_MAX_QBATCH * RASS_MAX_K * sizeof(float);
+    off = (off + 255) / 256 * 256;
+    L.cand_ids = off;
+    off += (size_t)RASS_MAX_QBATCH * RASS_MAX_K * sizeof(int64_t);
     off = (off + 255) / 256 * 256;
     L.total = off;
     return L;
@@ -127,6 +137,8 @@ struct rass_index {
     bool has_tags = false;  // any non-zero tag ever stored
     float* d_rows = nullptr;
     int32_t* d_tags = nullptr;
+    unsigned short* d_rows_bf16 = nullptr;  // tile16b copy for the prefilter mode (nullptr = off)
+    bool prefilter = false;
     std::vector<uint8_t> host_deleted;  // tombstone bitmap mirror (host)
     std::mutex mu;
 };
@@ -168,11 +180,26 @@ int index_reserve(rass_index* idx, int64_t need_rows) {
         HIP_TRY(hipMemcpyAsync(ntags, idx->d_tags, (size_t)idx->rows * sizeof(int32_t), hipMemcpyDeviceToDevice,
                                st));
     }
+    unsigned short* nb16 = nullptr;
+    if (idx->prefilter) {
+        e = hipMalloc(reinterpret_cast<void**>(&nb16), (size_t)cap * idx->stride * 2);
+        if (e != hipSuccess) {
+            (void)hipFree(nrows);
+            (void)hipFree(ntags);
+            return fail(RASS_ERR_OOM, "index grow: hipMalloc of bf16 slab failed");
+        }
+        HIP_TRY(hipMemsetAsync(nb16, 0, (size_t)cap * idx->stride * 2, st));
+        if (idx->rows > 0)
+            HIP_TRY(hipMemcpyAsync(nb16, idx->d_rows_bf16, (size_t)used_rows * idx->stride * 2,
+                                   hipMemcpyDeviceToDevice, st));
+    }
     HIP_TRY(hipStreamSynchronize(st));
     if (idx->d_rows) (void)hipFree(idx->d_rows);
     if (idx->d_tags) (void)hipFree(idx->d_tags);
+    if (idx->d_rows_bf16) (void)hipFree(idx->d_rows_bf16);
     idx->d_rows = nrows;
     idx->d_tags = ntags;
+    idx->d_rows_bf16 = nb16;
     idx->capacity = cap;
     return RASS_OK;
 }
@@ -231,6 +258,52 @@ int scan_launch(const float* d_corpus, int64_t n_rows, int64_t stride, const int
         timing->ev_used += 1;
     }
     HIP_TRY(rass::launch_merge_topk(part_scores, part_ids, grid, nq, k, d_out_scores, d_out_ids, st, id_map));
+    return RASS_OK;
+}
+
+// Prefilter mode: bf16 candidate scan (32 per query) -> merge -> exact fp32 re-rank.
+int prefilter_launch(rass_index* idx, const float* d_queries, int nq, const int32_t* d_q_filter, int k,
+                     int64_t id_base, float* d_out_scores, int64_t* d_out_ids, const int32_t* d_row_tag,
+                     rass_engine* eng, hipStream_t st) {
+    if (nq < 1 || nq > RASS_MAX_QBATCH) return fail(RASS_ERR_INVALID, "nq must be in [1, RASS_MAX_QBATCH]");
+    if (k < 1 || k > RASS_MAX_K) return fail(RASS_ERR_INVALID, "k must be in [1, RASS_MAX_K]");
+    const int64_t stride = idx->stride;
+    const ScratchLayout L = scratch_layout(RASS_MAX_QBATCH, RASS_MAX_K);
+    unsigned char* ws = eng->d_scratch;
+    float* q_padded = reinterpret_cast<float*>(ws + L.q_padded);
+    float* part_scores = reinterpret_cast<float*>(ws + L.part_scores);
+    int64_t* part_ids = reinterpret_cast<int64_t*>(ws + L.part_ids);
+    unsigned short* q_bf16 = reinterpret_cast<unsigned short*>(ws + L.q_bf16);
+    float* cand_scores = reinterpret_cast<float*>(ws + L.cand_scores);
+    int64_t* cand_ids = reinterpret_cast<int64_t*>(ws + L.cand_ids);
+    const int nq_pad = nq <= 16 ? 16 : 32;
+    const int kc = RASS_MAX_K;  // candidates per query
+    HIP_TRY(rass::launch_normalize_rows_f32(d_queries, idx->dim, q_padded, stride, nq, idx->dim, st, nq_pad));
+    HIP_TRY(rass::launch_queries_to_bf16(q_padded, q_bf16, (int64_t)nq_pad * stride, st));
+    const int64_t n_tiles = (idx->rows + 63) / 64;
+    int grid = (int)std::min<int64_t>(std::max<int64_t>(n_tiles, 1), std::min(eng->n_cus, kMaxGrid));
+    if ((int64_t)grid * kc > rass::kMergeMaxCandidates) grid = rass::kMergeMaxCandidates / kc;
+    rass::ScanBf16Args a;
+    a.corpus = idx->d_rows_bf16;
+    a.row_tag = d_row_tag;
+    a.q_bf16 = q_bf16;
+    a.q_filter = d_q_filter;
+    a.part_scores = part_scores;
+    a.part_ids = part_ids;
+    a.row_stride = stride;
+    a.n_rows = (int)idx->rows;
+    a.nq = nq;
+    a.k = kc;
+    const bool timed = eng->ev_on && (size_t)(2 * eng->ev_used + 1) < eng->ev_pool.size();
+    if (timed) HIP_TRY(hipEventRecord(eng->ev_pool[2 * eng->ev_used], st));
+    HIP_TRY(rass::launch_scan_bf16_topk(a, grid, st));
+    if (timed) {
+        HIP_TRY(hipEventRecord(eng->ev_pool[2 * eng->ev_used + 1], st));
+        eng->ev_used += 1;
+    }
+    HIP_TRY(rass::launch_merge_topk(part_scores, part_ids, grid, nq, kc, cand_scores, cand_ids, st));
+    HIP_TRY(rass::launch_rerank_f32(idx->d_rows, stride, q_padded, cand_ids, nq, kc, k, id_base, d_out_scores,
+                                    d_out_ids, st));
     return RASS_OK;
 }
 
@@ -305,6 +378,7 @@ void rass_engine_destroy(rass_engine_t* eng) {
         rass_index* idx = kv.second;
         if (idx->d_rows) (void)hipFree(idx->d_rows);
         if (idx->d_tags) (void)hipFree(idx->d_tags);
+        if (idx->d_rows_bf16) (void)hipFree(idx->d_rows_bf16);
         delete idx;
     }
     eng->indices.clear();
@@ -395,10 +469,41 @@ int rass_index_drop(rass_engine_t* eng, const char* name) {
     rass_index* idx = it->second;
     if (idx->d_rows) (void)hipFree(idx->d_rows);
     if (idx->d_tags) (void)hipFree(idx->d_tags);
+    if (idx->d_rows_bf16) (void)hipFree(idx->d_rows_bf16);
     delete idx;
     eng->indices.erase(it);
     return RASS_OK;
 }
+
+int rass_index_set_prefilter(rass_index_t* idx, int enable) {
+    if (!idx) return fail(RASS_ERR_INVALID, "index is NULL");
+    rass_engine* eng = idx->eng;
+    std::lock_guard<std::mutex> lk(idx->mu);
+    std::lock_guard<std::mutex> elk(eng->mu);
+    int rc = set_device(eng);
+    if (rc != RASS_OK) return rc;
+    hipStream_t st = eng->stream;
+    if (!enable) {
+        HIP_TRY(hipStreamSynchronize(st));
+        if (idx->d_rows_bf16) (void)hipFree(idx->d_rows_bf16);
+        idx->d_rows_bf16 = nullptr;
+        idx->prefilter = false;
+        return RASS_OK;
+    }
+    if (idx->prefilter) return RASS_OK;
+    if (idx->stride % 256 != 0) return fail(RASS_ERR_UNSUPPORTED, "prefilter needs dim padded to a multiple of 256");
+    if (idx->capacity > 0) {
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&idx->d_rows_bf16), (size_t)idx->capacity * idx->stride * 2));
+        HIP_TRY(hipMemsetAsync(idx->d_rows_bf16, 0, (size_t)idx->capacity * idx->stride * 2, st));
+        HIP_TRY(rass::launch_convert_tile16_bf16(idx->d_rows, idx->d_rows_bf16, idx->stride, 0, (idx->rows + 15) >> 4,
+                                                 st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    idx->prefilter = true;
+    return RASS_OK;
+}
+
+int rass_index_get_prefilter(const rass_index_t* idx) { return (idx && idx->prefilter) ? 1 : 0; }
 
 int64_t rass_index_count(const rass_index_t* idx) { return idx ? idx->rows - idx->deleted : 0; }
 int64_t rass_index_rows(const rass_index_t* idx) { return idx ? idx->rows : 0; }
@@ -449,6 +554,9 @@ static int add_common(rass_index_t* idx, const float* vecs, const int32_t* tags,
         if (!device_src) HIP_TRY(hipStreamSynchronize(st));
         done += m;
     }
+    if (idx->prefilter)
+        HIP_TRY(rass::launch_convert_tile16_bf16(idx->d_rows, idx->d_rows_bf16, idx->stride, idx->rows >> 4,
+                                                 (idx->rows + n + 15) >> 4, st));
     if (tags) idx->has_tags = true;
     idx->rows += n;
     idx->host_deleted.resize((size_t)((idx->rows + 7) / 8), 0);
@@ -524,6 +632,9 @@ int rass_index_search_device(rass_index_t* idx, const float* d_queries, int nq, 
     int rc = set_device(eng);
     if (rc != RASS_OK) return rc;
     const bool need_tags = (idx->deleted > 0) || (d_q_filter != nullptr);
+    if (idx->prefilter && idx->rows > 0 && k <= kPrefilterMaxK)
+        return prefilter_launch(idx, d_queries, nq, d_q_filter, k, id_base, d_out_scores, d_out_ids,
+                                need_tags ? idx->d_tags : nullptr, eng, eng->stream);
     return scan_launch(idx->d_rows ? idx->d_rows : reinterpret_cast<const float*>(eng->d_scratch), idx->rows,
                        idx->stride, need_tags ? idx->d_tags : nullptr, d_queries, idx->dim, idx->dim, nq,
                        d_q_filter, k, id_base, d_out_scores, d_out_ids, eng->d_scratch, eng->scratch_bytes,
@@ -555,6 +666,10 @@ int rass_index_search(rass_index_t* idx, const float* queries, int nq, int k, co
                 d_filter = eng->d_qfilter;
             }
             const bool need_tags = (idx->deleted > 0) || (d_filter != nullptr);
+            if (idx->prefilter && idx->rows > 0 && k <= kPrefilterMaxK)
+                rc = prefilter_launch(idx, eng->d_qraw, b, d_filter, k, 0, eng->d_out_scores, eng->d_out_ids,
+                                      need_tags ? idx->d_tags : nullptr, eng, st);
+            else
             rc = scan_launch(idx->d_rows ? idx->d_rows : reinterpret_cast<const float*>(eng->d_scratch), idx->rows,
                              idx->stride, need_tags ? idx->d_tags : nullptr, eng->d_qraw, dim, dim, b, d_filter, k,
                              0, eng->d_out_scores, eng->d_out_ids, eng->d_scratch, eng->scratch_bytes, eng->n_cus,
@@ -714,6 +829,9 @@ int rass_index_fill_synthetic(rass_index_t* idx, int64_t n, uint64_t seed, int64
     hipStream_t st = eng->stream;
     HIP_TRY(rass::launch_fill_synthetic_f32(idx->d_rows, idx->stride, idx->rows, n, idx->dim, seed, row_id_base, st));
     HIP_TRY(rass::launch_fill_i32(idx->d_tags + idx->rows, n, 0, st));
+    if (idx->prefilter)
+        HIP_TRY(rass::launch_convert_tile16_bf16(idx->d_rows, idx->d_rows_bf16, idx->stride, idx->rows >> 4,
+                                                 (idx->rows + n + 15) >> 4, st));
     idx->rows += n;
     idx->host_deleted.resize((size_t)((idx->rows + 7) / 8), 0);
     return RASS_OK;

@@ -36,6 +36,27 @@ hipError_t launch_merge_topk(const float* scores, const int64_t* ids, int n_list
                              float* out_scores, int64_t* out_ids, hipStream_t stream,
                              const int64_t* id_map = nullptr);
 
+// ---- bf16 candidate scan + exact re-rank (scan_bf16.hip)
+struct ScanBf16Args {
+    const unsigned short* corpus;   // tile16b bf16 slab
+    const int32_t* row_tag;
+    const unsigned short* q_bf16;   // [16*NT][row_stride] normalised queries as bf16
+    const int32_t* q_filter;
+    float* part_scores;             // [grid][nq][k]
+    int64_t* part_ids;              // [grid][nq][k]  LOCAL rows
+    int64_t row_stride;             // elements, multiple of 256
+    int n_rows;
+    int nq;
+    int k;                          // candidates kept per query (<= 32)
+};
+hipError_t launch_scan_bf16_topk(const ScanBf16Args& a, int grid, hipStream_t stream);
+hipError_t launch_convert_tile16_bf16(const float* src, void* dst, int64_t stride, int64_t block0, int64_t block1,
+                                      hipStream_t stream);
+hipError_t launch_queries_to_bf16(const float* src, void* dst, int64_t n, hipStream_t stream);
+hipError_t launch_rerank_f32(const float* slab, int64_t stride, const float* q_padded, const int64_t* cand_rows, int nq,
+                             int n_cand, int k, int64_t id_base, float* out_scores, int64_t* out_ids,
+                             hipStream_t stream);
+
 // ---- IVF (ivf.hip)
 hipError_t launch_plan_probe(const int64_t* probe_ids, int nq, int nprobe, int nlist, const int32_t* list_tile0,
                              const int32_t* list_len, int32_t* work_tile, int32_t* work_rows, uint32_t* work_mask,

@@ -1,0 +1,388 @@
+// scan_bf16.hip — SURVEY §8f-4: bf16 candidate scan + exact fp32 re-rank ("prefilter" mode of
+// a flat index).  NOT the parity path: the fp32 fused scan (scan_topk.hip) stays the default.
+//
+//   1. scan_bf16_topk_kernel: the same persistent, K-split, register-streaming structure as the
+//      fp32 scan, over a bf16 copy of the slab (half the HBM bytes per pass) with
+//      v_mfma_f32_16x16x32_bf16 (16x the fp32 MFMA rate, so the pass is purely HBM-bound even at
+//      32 queries); keeps the 32 best candidates per query and workgroup by bf16 score.
+//   2. merge (merge_topk.hip) -> 32 candidates per query.
+//   3. rerank_f32_kernel: exact fp32 scores of those candidates from the fp32 slab, in the flat
+//      kernel's fmaf order (bit-identical scores for every returned row), then the exact
+//      (score desc, id asc) top-k among them.
+// The result equals the flat result whenever the true top-k is inside the bf16 top-32 — measured
+// (recall vs the flat kernel), never assumed.
+//
+// bf16 slab layout ("tile16b"): 16-row blocks; chunk jb (columns 32jb..32jb+31) of the 16 rows
+// is one contiguous 1 KiB in MFMA lane order, lane (m = lane&15, g = lane>>4) holding
+// X[16b+m][32jb + 8g .. +7]: element (r, c) at
+//   (r>>4)*16*stride + (c>>5)*512 + ((((c>>3)&3)*16 + (r&15))*8) + (c&7)      [bf16 elements]
+
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+
+#include "kernels.h"
+
+namespace rass {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16;
+
+constexpr int kBWaves = 8;
+constexpr int kBThreads = kBWaves * 64;
+constexpr int kBTileRows = 64;  // 4 blocks of 16 rows
+constexpr int kBPitch = 68;     // floats per query row of the LDS partial image (64 rows + pad)
+
+__device__ __forceinline__ u16 f2bf_s(float f) {
+    __hip_bfloat16 h = __float2bfloat16(f);
+    return *reinterpret_cast<u16*>(&h);
+}
+
+struct BList {
+    float s;
+    int i;
+};
+
+__device__ __forceinline__ void binsert(BList& L, float& tau, float s, int row, int k) {
+    unsigned long long mask = __ballot(s > tau);
+    const int lane = threadIdx.x & 63;
+    const int lpos = lane & 31;
+    while (mask) {
+        const int c = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        const float cs = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), c));
+        const int ci = __builtin_amdgcn_readlane(row, c);
+        const bool mine = ((lane ^ c) & 32) == 0;
+        const bool better = (L.s > cs) || (L.s == cs && L.i < ci);
+        const int pos = __builtin_popcountll(__ballot(better && mine));
+        if (pos < k) {
+            const float us = __shfl_up(L.s, 1, 64);
+            const int ui = __shfl_up(L.i, 1, 64);
+            if (mine) {
+                if (lpos == pos) {
+                    L.s = cs;
+                    L.i = ci;
+                } else if (lpos > pos) {
+                    L.s = us;
+                    L.i = ui;
+                }
+            }
+            tau = __shfl(L.s, (lane & 32) + k - 1, 64);
+        }
+    }
+}
+
+struct BDesc {
+    __amdgpu_buffer_rsrc_t rows;
+    __amdgpu_buffer_rsrc_t tags;
+};
+
+__device__ __forceinline__ BDesc make_bdesc(const u16* __restrict__ X, int64_t stride, const int32_t* __restrict__ tag,
+                                            int tile, int n_tiles, int n_rows) {
+    int rows_here = n_rows - tile * kBTileRows;
+    rows_here = rows_here < 0 ? 0 : (rows_here > kBTileRows ? kBTileRows : rows_here);
+    if (tile >= n_tiles) rows_here = 0;
+    const int64_t base_row = tile < n_tiles ? (int64_t)tile * kBTileRows : 0;
+    const uint64_t bu = reinterpret_cast<uint64_t>(X + base_row * stride);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)bu), hi = __builtin_amdgcn_readfirstlane((uint32_t)(bu >> 32));
+    const unsigned blocks = (unsigned)(rows_here + 15) >> 4;
+    const unsigned bytes = __builtin_amdgcn_readfirstlane(blocks * 16u * (unsigned)stride * 2u);
+    BDesc d;
+    d.rows = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<u16*>(((uint64_t)hi << 32) | lo), 0, (int)bytes, 0x00020000);
+    const bool has = tag != nullptr;
+    const uint64_t tu = has ? reinterpret_cast<uint64_t>(tag + base_row) : bu;
+    const uint32_t tlo = __builtin_amdgcn_readfirstlane((uint32_t)tu), thi = __builtin_amdgcn_readfirstlane((uint32_t)(tu >> 32));
+    const unsigned tb = __builtin_amdgcn_readfirstlane(has ? (unsigned)(rows_here * 4) : 0u);
+    d.tags = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<int32_t*>(((uint64_t)thi << 32) | tlo), 0, (int)tb, 0x00020000);
+    return d;
+}
+
+template <int CHB>
+struct BTile {
+    bf16x8 a[4][CHB];
+    int tag;  // tag of row lane (0..63) of the tile
+};
+
+template <int CHB, int NT>
+__global__ __launch_bounds__(kBThreads, 2) void scan_bf16_topk_kernel(ScanBf16Args p) {
+    constexpr int NQ = NT * 16;
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // [2][kBWaves][NQ][kBPitch]
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m = lane & 15, g = lane >> 4;
+    const int n_tiles = (p.n_rows + kBTileRows - 1) / kBTileRows;
+    const int G = gridDim.x;
+
+    bf16x8 qf[NT][CHB];
+    {
+        const u16* qb = p.q_bf16 + (int64_t)m * p.row_stride + wid * 32 * CHB + 8 * g;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int j = 0; j < CHB; ++j)
+                qf[nt][j] = *reinterpret_cast<const bf16x8*>(qb + (int64_t)nt * 16 * p.row_stride + 32 * j);
+    }
+    const int voff_lane = wid * CHB * 1024 + lane * 16;
+    const int blk_step = 16 * (int)p.row_stride * 2;
+
+    BList L[NT];
+    float tau[NT];
+    int qfilt[NT];
+#pragma unroll
+    for (int pq = 0; pq < NT; ++pq) {
+        L[pq].s = -INFINITY;
+        L[pq].i = 0x7fffffff;
+        tau[pq] = -INFINITY;
+        const int q = pq * 16 + (lane >> 5) * 8 + wid;
+        qfilt[pq] = (p.q_filter != nullptr && q < p.nq) ? p.q_filter[q] : -1;
+    }
+
+    auto issue = [&](BTile<CHB>& r, const BDesc& d) {
+        r.tag = (int)__builtin_amdgcn_raw_buffer_load_b32(d.tags, lane * 4, 0, 0);
+#pragma unroll
+        for (int j = 0; j < CHB; ++j)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                r.a[b][j] = __builtin_bit_cast(
+                    bf16x8, __builtin_amdgcn_raw_buffer_load_b128(d.rows, voff_lane + b * blk_step + j * 1024, 0, 2));
+    };
+    auto mul_refill = [&](BTile<CHB>& r, f32x4 (&acc)[4][NT], const BDesc& next) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[b][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        r.tag = (int)__builtin_amdgcn_raw_buffer_load_b32(next.tags, lane * 4, 0, 0);
+#pragma unroll
+        for (int j = 0; j < CHB; ++j) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const bf16x8 a = r.a[b][j];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[b][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[nt][j], acc[b][nt], 0, 0, 0);
+                r.a[b][j] = __builtin_bit_cast(
+                    bf16x8, __builtin_amdgcn_raw_buffer_load_b128(next.rows, voff_lane + b * blk_step + j * 1024, 0, 2));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto finish = [&](const f32x4 (&acc)[4][NT], int tile, int tag, int buf) {
+        float* P = lds + buf * (kBWaves * NQ * kBPitch);
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                *reinterpret_cast<f32x4*>(P + (wid * NQ + nt * 16 + m) * kBPitch + b * 16 + 4 * g) = acc[b][nt];
+        __syncthreads();
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int r = (lane & 31) + 32 * half;
+            const int row = tile * kBTileRows + r;
+            const int rtag = __shfl(tag, r, 64);
+            const bool row_ok = (tile < n_tiles) && (row < p.n_rows) && (rtag != -1);
+#pragma unroll
+            for (int pq = 0; pq < NT; ++pq) {
+                const int q = pq * 16 + (lane >> 5) * 8 + wid;
+                const float* src = P + q * kBPitch + r;
+                float s = src[0];
+#pragma unroll
+                for (int w = 1; w < kBWaves; ++w) s += src[w * NQ * kBPitch];
+                const bool ok = row_ok && (qfilt[pq] < 0 || qfilt[pq] == rtag);
+                binsert(L[pq], tau[pq], ok ? s : -INFINITY, row, p.k);
+            }
+        }
+    };
+
+    BTile<CHB> R0, R1;
+    int t = blockIdx.x;
+    issue(R0, make_bdesc(p.corpus, p.row_stride, p.row_tag, t, n_tiles, p.n_rows));
+    issue(R1, make_bdesc(p.corpus, p.row_stride, p.row_tag, t + G, n_tiles, p.n_rows));
+    __builtin_amdgcn_sched_barrier(0);
+    for (; t < n_tiles; t += 2 * G) {
+        f32x4 acc[4][NT];
+        int tag = R0.tag;
+        mul_refill(R0, acc, make_bdesc(p.corpus, p.row_stride, p.row_tag, t + 2 * G, n_tiles, p.n_rows));
+        finish(acc, t, tag, 0);
+        tag = R1.tag;
+        mul_refill(R1, acc, make_bdesc(p.corpus, p.row_stride, p.row_tag, t + 3 * G, n_tiles, p.n_rows));
+        finish(acc, t + G, tag, 1);
+    }
+    const int lpos = lane & 31;
+#pragma unroll
+    for (int pq = 0; pq < NT; ++pq) {
+        const int q = pq * 16 + (lane >> 5) * 8 + wid;
+        if (q < p.nq && lpos < p.k) {
+            const int64_t o = ((int64_t)blockIdx.x * p.nq + q) * p.k + lpos;
+            const bool filled = L[pq].i != 0x7fffffff;
+            p.part_scores[o] = filled ? L[pq].s : -INFINITY;
+            p.part_ids[o] = filled ? (int64_t)L[pq].i : (int64_t)-1;  // LOCAL rows: the re-rank needs them
+        }
+    }
+}
+
+template <int CHB, int NT>
+static hipError_t launch_bvariant(const ScanBf16Args& a, int grid, hipStream_t stream) {
+    constexpr size_t lds_bytes = (size_t)2 * kBWaves * NT * 16 * kBPitch * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_bf16_topk_kernel<CHB, NT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((scan_bf16_topk_kernel<CHB, NT>), dim3(grid), dim3(kBThreads), lds_bytes, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_scan_bf16_topk(const ScanBf16Args& a, int grid, hipStream_t stream) {
+    if (a.row_stride % 256 != 0) return hipErrorInvalidValue;  // 8 waves x 32-column chunks
+    const int chb = (int)(a.row_stride / 256);
+    const bool two = a.nq > 16;
+    switch (chb) {
+        case 1: return two ? launch_bvariant<1, 2>(a, grid, stream) : launch_bvariant<1, 1>(a, grid, stream);
+        case 2: return two ? launch_bvariant<2, 2>(a, grid, stream) : launch_bvariant<2, 1>(a, grid, stream);
+        case 3: return two ? launch_bvariant<3, 2>(a, grid, stream) : launch_bvariant<3, 1>(a, grid, stream);
+        case 4: return two ? launch_bvariant<4, 2>(a, grid, stream) : launch_bvariant<4, 1>(a, grid, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// fp32 tile16 slab -> bf16 tile16b slab, blocks [b0, b1).  bf16 lane (m, g) of chunk jb holds
+// columns 32jb + 8g .. +7 = fp32 chunk 2jb + (g>>1), lane groups 2(g&1) and 2(g&1)+1.
+__global__ __launch_bounds__(256) void convert_tile16_bf16_kernel(const float* __restrict__ src, u16* __restrict__ dst,
+                                                                  int64_t stride, int64_t b0, int64_t b1) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = lane & 15, g = lane >> 4;
+    const int nchb = (int)(stride >> 5);
+    for (int64_t b = b0 + (int64_t)blockIdx.x * 4 + wave; b < b1; b += (int64_t)gridDim.x * 4) {
+        const float* sb = src + b * 16 * stride;
+        u16* db = dst + b * 16 * stride;
+        for (int jb = 0; jb < nchb; ++jb) {
+            const float* sc = sb + (int64_t)(2 * jb + (g >> 1)) * 256;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(sc + ((2 * (g & 1)) * 16 + m) * 4);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(sc + ((2 * (g & 1) + 1) * 16 + m) * 4);
+            uint4 o;
+            o.x = (unsigned)f2bf_s(v0.x) | ((unsigned)f2bf_s(v0.y) << 16);
+            o.y = (unsigned)f2bf_s(v0.z) | ((unsigned)f2bf_s(v0.w) << 16);
+            o.z = (unsigned)f2bf_s(v1.x) | ((unsigned)f2bf_s(v1.y) << 16);
+            o.w = (unsigned)f2bf_s(v1.z) | ((unsigned)f2bf_s(v1.w) << 16);
+            *reinterpret_cast<uint4*>(db + (int64_t)jb * 512 + lane * 8) = o;
+        }
+    }
+}
+
+hipError_t launch_convert_tile16_bf16(const float* src, void* dst, int64_t stride, int64_t block0, int64_t block1,
+                                      hipStream_t stream) {
+    if (block1 <= block0) return hipSuccess;
+    if (stride % 32 != 0) return hipErrorInvalidValue;
+    int64_t blocks = (block1 - block0 + 3) / 4;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(convert_tile16_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, src,
+                       static_cast<u16*>(dst), stride, block0, block1);
+    return hipGetLastError();
+}
+
+// queries: normalised fp32 [nq_pad][stride] (q_padded of the fp32 path) -> bf16 [nq_pad][stride]
+__global__ void queries_to_bf16_kernel(const float* __restrict__ src, u16* __restrict__ dst, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = f2bf_s(src[i]);
+}
+
+hipError_t launch_queries_to_bf16(const float* src, void* dst, int64_t n, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(queries_to_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, src, static_cast<u16*>(dst), n);
+    return hipGetLastError();
+}
+
+// Exact re-rank.  One workgroup per query: thread (c = tid>>3, w = tid&7) recomputes K-slice w of
+// candidate c's score in the flat kernel's order (chunk j, component i, lane group g: the fmaf
+// chain of v_mfma_f32_16x16x4_f32), the 8 slice partials are added in slice order, then the 32
+// exact (score, id) pairs are ranked by counting and the best k are written.
+__global__ __launch_bounds__(256) void rerank_f32_kernel(const float* __restrict__ slab, int64_t stride,
+                                                         const float* __restrict__ q_padded,
+                                                         const int64_t* __restrict__ cand_rows, int n_cand, int k,
+                                                         int64_t id_base, float* __restrict__ out_scores,
+                                                         int64_t* __restrict__ out_ids) {
+    __shared__ float part[32][9];
+    __shared__ float sc[32];
+    __shared__ int64_t rw[32];
+    const int q = blockIdx.x;
+    const int c = threadIdx.x >> 3, w = threadIdx.x & 7;
+    const int ch = (int)(stride >> 7);
+    const int64_t row = c < n_cand ? cand_rows[(int64_t)q * n_cand + c] : -1;
+    float acc = 0.f;
+    if (row >= 0) {
+        const float* xb = slab + (row >> 4) * 16 * stride;
+        const float* qv = q_padded + (int64_t)q * stride;
+        const int mrow = (int)(row & 15);
+        for (int j = 0; j < ch; ++j) {
+            const int chunk = w * ch + j;
+            f32x4 xv[4];
+            f32x4 qq[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                xv[g] = *reinterpret_cast<const f32x4*>(xb + (int64_t)chunk * 256 + (g * 16 + mrow) * 4);
+                qq[g] = *reinterpret_cast<const f32x4*>(qv + chunk * 16 + 4 * g);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc = fmaf(xv[g][i], qq[g][i], acc);
+        }
+    }
+    part[c][w] = acc;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        const int cc = threadIdx.x;
+        float s = part[cc][0];
+#pragma unroll
+        for (int ww = 1; ww < 8; ++ww) s += part[cc][ww];
+        const int64_t r = cc < n_cand ? cand_rows[(int64_t)q * n_cand + cc] : -1;
+        sc[cc] = r >= 0 ? s : -INFINITY;
+        rw[cc] = r;
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        const int cc = threadIdx.x;
+        const float s = sc[cc];
+        const int64_t r = rw[cc];
+        int rank = 0;
+        for (int o = 0; o < 32; ++o) {
+            const float so = sc[o];
+            const int64_t ro = rw[o];
+            const bool o_valid = ro >= 0, me_valid = r >= 0;
+            const bool better = o_valid && (!me_valid || so > s || (so == s && ro < r));
+            rank += (o != cc && better) ? 1 : 0;
+        }
+        if (r < 0) rank = 32 + cc;  // invalid entries never land in [0, k)
+        if (rank < k) {
+            out_scores[(int64_t)q * k + rank] = s;
+            out_ids[(int64_t)q * k + rank] = id_base + r;
+        }
+    }
+    // slots beyond the number of valid candidates
+    if (threadIdx.x < 32) {
+        int valid = 0;
+        for (int o = 0; o < 32; ++o) valid += rw[o] >= 0 ? 1 : 0;
+        const int e = threadIdx.x;
+        if (e >= valid && e < k) {
+            out_scores[(int64_t)q * k + e] = -INFINITY;
+            out_ids[(int64_t)q * k + e] = -1;
+        }
+    }
+}
+
+hipError_t launch_rerank_f32(const float* slab, int64_t stride, const float* q_padded, const int64_t* cand_rows, int nq,
+                             int n_cand, int k, int64_t id_base, float* out_scores, int64_t* out_ids,
+                             hipStream_t stream) {
+    if (nq < 1 || n_cand < 1 || n_cand > 32 || k < 1 || k > n_cand || stride % 128 != 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(rerank_f32_kernel, dim3(nq), dim3(256), 0, stream, slab, stride, q_padded, cand_rows, n_cand, k,
+                       id_base, out_scores, out_ids);
+    return hipGetLastError();
+}
+
+}  // namespace rass

@@ -187,6 +187,14 @@ class FlatIndex:
         N.check("rass_index_get_rows", self._L.rass_index_get_rows(self._h, int(first_row), int(n), _np_ptr(out)))
         return out
 
+    def set_prefilter(self, enable: bool = True) -> None:
+        """bf16 candidate scan + exact fp32 re-rank; off by default."""
+        N.check("rass_index_set_prefilter", self._L.rass_index_set_prefilter(self._h, 1 if enable else 0))
+
+    @property
+    def prefilter(self) -> bool:
+        return bool(self._L.rass_index_get_prefilter(self._h))
+
     def save(self, path: str) -> None:
         N.check("rass_index_save", self._L.rass_index_save(self._h, path.encode()))
 

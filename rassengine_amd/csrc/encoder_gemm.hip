@@ -23,6 +23,8 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_bf16.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include "encoder_kernels.h"
 
@@ -415,12 +417,217 @@ static hipError_t launch_ring(const u16* X, const u16* W, const float* bias, con
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------
+// "Duo" kernel: the ring pipeline with 4-wave blocks so that TWO blocks share a CU.
+// 128 (N) x 256 (M) x 32 (K) tiles, 256 threads = 2 (N) x 2 (M) waves, each wave 64 x 128 =
+// 4 x 8 MFMA tiles (the same 32 MFMAs / 12 fragment reads per step as the ring kernel, 6 DMA
+// pieces per wave and step instead of 4), 3 LDS slots of 24 KiB = 72 KiB per block.  The two
+// blocks of a CU have separate barriers, so their phases drift apart: one block's epilogue
+// (the output write, ~25 % of a K=1024 GEMM when nothing overlaps it) and prologue run beside
+// the other block's mainloop, and on each SIMD the two waves (one per block) interleave MFMA
+// with DMA issue / LDS reads without an explicit stagger.
+constexpr int DBN = 128, DBM = 256;
+constexpr int kDuoThreads = 256;
+constexpr int kDuoWBytes = DBN * RBK * 2;             // 8 KiB
+constexpr int kDuoXBytes = DBM * RBK * 2;             // 16 KiB
+constexpr int kDuoSlotBytes = kDuoWBytes + kDuoXBytes;  // 24 KiB
+
+template <int EPI>
+__global__ __launch_bounds__(kDuoThreads, 2) void gemm_bf16_duo_kernel(const u16* __restrict__ X,
+                                                                      const u16* __restrict__ W,
+                                                                      const float* __restrict__ bias,
+                                                                      const u16* __restrict__ residual,
+                                                                      u16* __restrict__ Y, int M, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // [3 slots][W tile | X tile]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wn = wave >> 1, wm = wave & 1;
+    const int nblk = gridDim.x, orig = blockIdx.x;
+    const int q = nblk / 8, rr = nblk % 8, xcd = orig % 8;
+    const int bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + orig / 8;
+    const int tiles_n = N / DBN;
+    const int bn = bid % tiles_n, bm = bid / tiles_n;
+    const int n0 = bn * DBN, m0 = bm * DBM;
+
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = K / RBK;
+    // DMA pieces of 16 rows: W tile has 8 (wave moves 2), X tile has 16 (wave moves 4)
+    const u16* srcW[2];
+    const u16* srcX[4];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int r = (wave + 4 * p) * 16 + (lane >> 2);
+        srcW[p] = W + (int64_t)(n0 + r) * K + ((lane & 3) ^ (((r >> 3) & 1) * 3)) * 8;
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int r = (wave + 4 * p) * 16 + (lane >> 2);
+        srcX[p] = X + (int64_t)(m0 + r) * K + ((lane & 3) ^ (((r >> 3) & 1) * 3)) * 8;
+    }
+    int offA[4], offB[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = wn * 64 + i * 16 + (lane & 15);
+        offA[i] = row * 64 + (((lane >> 4) ^ (((row >> 3) & 1) * 3)) * 16);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int row = wm * 128 + j * 16 + (lane & 15);
+        offB[j] = kDuoWBytes + row * 64 + (((lane >> 4) ^ (((row >> 3) & 1) * 3)) * 16);
+    }
+    auto stage_step = [&](unsigned char* slot_base) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)srcW[p],
+                                             (__attribute__((address_space(3))) void*)(slot_base + (wave + 4 * p) * 1024),
+                                             16, 0, 0);
+            srcW[p] += RBK;
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)srcX[p],
+                (__attribute__((address_space(3))) void*)(slot_base + kDuoWBytes + (wave + 4 * p) * 1024), 16, 0, 0);
+            srcX[p] += RBK;
+        }
+    };
+    stage_step(lds);
+    if (nk > 1) {
+        stage_step(lds + kDuoSlotBytes);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+
+    // RAW: slot t+1 is read one iteration after the counted wait + barrier that retired it.
+    // WAR: slot (t+2)%3 == (t-1)%3 was last read in iteration t-1, whose closing barrier every
+    // wave has passed (with its LDS reads drained: lgkmcnt(0)) before any wave issues the DMAs.
+    int slot = 0;
+    for (int t = 0; t < nk; ++t) {
+        const bool more = t + 2 < nk;
+        if (more) {
+            int s2 = slot + 2;
+            s2 = s2 >= 3 ? s2 - 3 : s2;
+            stage_step(lds + s2 * kDuoSlotBytes);
+        }
+        const unsigned char* buf = lds + slot * kDuoSlotBytes;
+        bf16x8 a[4], b[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8*>(buf + offA[i]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) b[j] = *reinterpret_cast<const bf16x8*>(buf + offB[j]);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        if (more) {
+            asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        slot = slot + 1 >= 3 ? 0 : slot + 1;
+    }
+
+    // Epilogue through LDS: 32-token x 64-feature fp32 chunks per wave (18 KiB private region),
+    // written back as 16-byte stores, 128 contiguous bytes per token row.
+    {
+        constexpr int kPitchF = 68;
+        float* stg = reinterpret_cast<float*>(lds + wave * (3 * kDuoSlotBytes / 4));
+        const int tl = lane >> 3, nq = lane & 7;
+#pragma unroll
+        for (int jc = 0; jc < 4; ++jc) {  // 4 x 32 tokens = the wave's 128 tokens
+            // stage: all 4 i tiles (64 features), j = 2jc, 2jc+1
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii)
+                    *reinterpret_cast<f32x4*>(stg + (jj * 16 + (lane & 15)) * kPitchF + ii * 16 + (lane >> 4) * 4) =
+                        acc[ii][2 * jc + jj];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int nbase = n0 + wn * 64 + nq * 8;
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + nbase);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias + nbase + 4);
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int tok = pass * 8 + tl;
+                const int m = m0 + wm * 128 + jc * 32 + tok;
+                f32x4 v0 = *reinterpret_cast<const f32x4*>(stg + tok * kPitchF + nq * 8);
+                f32x4 v1 = *reinterpret_cast<const f32x4*>(stg + tok * kPitchF + nq * 8 + 4);
+                v0 += b0;
+                v1 += b1;
+                if (m < M) {
+                    if (EPI == 1) {
+                        const uint4 r = *reinterpret_cast<const uint4*>(residual + (int64_t)m * N + nbase);
+                        v0.x += bf16_to_f32((u16)(r.x & 0xffff));
+                        v0.y += bf16_to_f32((u16)(r.x >> 16));
+                        v0.z += bf16_to_f32((u16)(r.y & 0xffff));
+                        v0.w += bf16_to_f32((u16)(r.y >> 16));
+                        v1.x += bf16_to_f32((u16)(r.z & 0xffff));
+                        v1.y += bf16_to_f32((u16)(r.z >> 16));
+                        v1.z += bf16_to_f32((u16)(r.w & 0xffff));
+                        v1.w += bf16_to_f32((u16)(r.w >> 16));
+                    }
+                    if (EPI == 2) {
+                        v0.x = gelu_erf(v0.x); v0.y = gelu_erf(v0.y); v0.z = gelu_erf(v0.z); v0.w = gelu_erf(v0.w);
+                        v1.x = gelu_erf(v1.x); v1.y = gelu_erf(v1.y); v1.z = gelu_erf(v1.z); v1.w = gelu_erf(v1.w);
+                    }
+                    uint4 o;
+                    o.x = (unsigned)f32_to_bf16(v0.x) | ((unsigned)f32_to_bf16(v0.y) << 16);
+                    o.y = (unsigned)f32_to_bf16(v0.z) | ((unsigned)f32_to_bf16(v0.w) << 16);
+                    o.z = (unsigned)f32_to_bf16(v1.x) | ((unsigned)f32_to_bf16(v1.y) << 16);
+                    o.w = (unsigned)f32_to_bf16(v1.z) | ((unsigned)f32_to_bf16(v1.w) << 16);
+                    *reinterpret_cast<uint4*>(Y + (int64_t)m * N + nbase) = o;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    }
+}
+
+template <int EPI>
+static hipError_t launch_duo(const u16* X, const u16* W, const float* bias, const u16* residual, u16* Y, int M,
+                             int M_pad, int N, int K, hipStream_t stream) {
+    constexpr int lds_bytes = 3 * kDuoSlotBytes;  // 72 KiB: two blocks per CU
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_duo_kernel<EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int grid = (N / DBN) * (M_pad / DBM);
+    hipLaunchKernelGGL((gemm_bf16_duo_kernel<EPI>), dim3(grid), dim3(kDuoThreads), lds_bytes, stream, X, W, bias,
+                       residual, Y, M, N, K);
+    return hipGetLastError();
+}
+
 template <int EPI>
 static hipError_t launch_epi(const u16* X, const u16* W, const float* bias, const u16* residual, u16* Y, int M,
                              int M_pad, int N, int K, hipStream_t stream) {
     // big shapes: the 256^2 ring kernel; small / odd shapes: the 128^2 kernel
-    if (N % RBN == 0 && M_pad % RBM == 0 && K % RBK == 0 && M >= 1024)
+    if (N % RBN == 0 && M_pad % RBM == 0 && K % RBK == 0 && M >= 1024) {
+        // Default: the 8-wave 256x256 ring kernel.  RASS_GEMM_VARIANT=duo selects the two-blocks-
+        // per-CU variant for A/B runs (measured slower: 720-935 vs 817-1105 TF/s; its 6 DMA pieces
+        // per 32 MFMAs cost more than the overlapped epilogue wins back).
+        static const bool use_duo = [] {
+            const char* v = getenv("RASS_GEMM_VARIANT");
+            return v != nullptr && strcmp(v, "duo") == 0;
+        }();
+        if (use_duo) return launch_duo<EPI>(X, W, bias, residual, Y, M, M_pad, N, K, stream);
         return launch_ring<EPI>(X, W, bias, residual, Y, M, M_pad, N, K, stream);
+    }
     constexpr int lds_bytes = 4 * kTileBytes;  // 64 KiB
     static bool attr_set = false;
     if (!attr_set) {

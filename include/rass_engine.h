@@ -208,6 +208,14 @@ int rass_topk_merge(const float* d_scores, const int64_t* d_ids, int n_lists,
                     int nq, int k, float* d_out_scores, int64_t* d_out_ids,
                     void* stream);
 
+/* Same with explicit list strides (in elements): lets the merge read the G
+ * per-rank records of ONE all-gather, each packed as nq*k f32 scores followed
+ * by nq*k i64 ids, without unpacking (rassengine_amd/dist.py). */
+int rass_topk_merge_strided(const float* d_scores, const int64_t* d_ids,
+                            int64_t score_list_stride, int64_t id_list_stride,
+                            int n_lists, int nq, int k, float* d_out_scores,
+                            int64_t* d_out_ids, void* stream);
+
 /* a4 (app/main.py:1249-1251, 1536-1537): out = in / (||in||_2 + 1e-9), rows
  * of `dim` floats read at in_stride, written at out_stride (elements); the
  * out_stride - dim tail of each output row is zero-filled. */

@@ -887,6 +887,21 @@ int rass_topk_merge(const float* d_scores, const int64_t* d_ids, int n_lists, in
     return RASS_OK;
 }
 
+int rass_topk_merge_strided(const float* d_scores, const int64_t* d_ids, int64_t score_list_stride,
+                            int64_t id_list_stride, int n_lists, int nq, int k, float* d_out_scores,
+                            int64_t* d_out_ids, void* stream) {
+    if (!d_scores || !d_ids || !d_out_scores || !d_out_ids) return fail(RASS_ERR_INVALID, "NULL argument");
+    if (n_lists < 1 || nq < 1 || k < 1 || k > RASS_MAX_K) return fail(RASS_ERR_INVALID, "bad n_lists / nq / k");
+    if (score_list_stride < (int64_t)nq * k || id_list_stride < (int64_t)nq * k)
+        return fail(RASS_ERR_INVALID, "list strides must be >= nq * k elements");
+    if ((int64_t)n_lists * k > rass::kMergeMaxCandidates)
+        return fail(RASS_ERR_UNSUPPORTED, "n_lists * k exceeds 8192 candidates");
+    HIP_TRY(rass::launch_merge_topk(d_scores, d_ids, n_lists, nq, k, d_out_scores, d_out_ids,
+                                    reinterpret_cast<hipStream_t>(stream), nullptr, score_list_stride,
+                                    id_list_stride));
+    return RASS_OK;
+}
+
 int rass_normalize_rows_f32(const float* d_in, int64_t in_stride, float* d_out, int64_t out_stride, int64_t n,
                             int dim, void* stream) {
     if (n < 0 || dim < 1 || in_stride < dim || out_stride < dim) return fail(RASS_ERR_INVALID, "bad shape");

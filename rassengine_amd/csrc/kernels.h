@@ -34,7 +34,8 @@ hipError_t launch_scan_topk_f32(const ScanArgs& a, int grid, hipStream_t stream)
 constexpr int kMergeMaxCandidates = 8192;
 hipError_t launch_merge_topk(const float* scores, const int64_t* ids, int n_lists, int nq, int k,
                              float* out_scores, int64_t* out_ids, hipStream_t stream,
-                             const int64_t* id_map = nullptr);
+                             const int64_t* id_map = nullptr, int64_t score_list_stride = 0,
+                             int64_t id_list_stride = 0);
 
 // ---- bf16 candidate scan + exact re-rank (scan_bf16.hip)
 struct ScanBf16Args {

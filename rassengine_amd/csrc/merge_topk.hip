@@ -90,7 +90,8 @@ __global__ __launch_bounds__(kMergeThreads) void merge_topk_kernel(const float* 
                                                                    const int64_t* __restrict__ ids, int n_lists,
                                                                    int nq, int k, float* __restrict__ out_scores,
                                                                    int64_t* __restrict__ out_ids,
-                                                                   const int64_t* __restrict__ id_map) {
+                                                                   const int64_t* __restrict__ id_map,
+                                                                   int64_t score_list_stride, int64_t id_list_stride) {
     __shared__ float sh_s[kMergeWaves * 32];
     __shared__ int64_t sh_i[kMergeWaves * 32];
     const int q = blockIdx.x;
@@ -109,9 +110,11 @@ __global__ __launch_bounds__(kMergeThreads) void merge_topk_kernel(const float* 
         c.id = kWorstId;
         if (e < n) {
             const int list = e / k, kk = e - list * k;
-            const int64_t o = ((int64_t)list * nq + q) * k + kk;
-            const int64_t gi = ids[o];
-            const float gs = scores[o];
+            // list strides in elements: nq*k for dense [n_lists][nq][k] arrays, larger when each
+            // list is one rank's packed (scores | ids) record of the single all-gather
+            const int64_t o = (int64_t)q * k + kk;
+            const int64_t gi = ids[(int64_t)list * id_list_stride + o];
+            const float gs = scores[(int64_t)list * score_list_stride + o];
             // NaN and -inf never rank (the scan never emits them; foreign lists might)
             if (gi >= 0 && gs > -INFINITY) {
                 c.s = gs;
@@ -153,11 +156,14 @@ __global__ __launch_bounds__(kMergeThreads) void merge_topk_kernel(const float* 
 }
 
 hipError_t launch_merge_topk(const float* scores, const int64_t* ids, int n_lists, int nq, int k,
-                             float* out_scores, int64_t* out_ids, hipStream_t stream, const int64_t* id_map) {
+                             float* out_scores, int64_t* out_ids, hipStream_t stream, const int64_t* id_map,
+                             int64_t score_list_stride, int64_t id_list_stride) {
     const int64_t n = (int64_t)n_lists * k;
     if (n_lists < 1 || nq < 1 || k < 1 || k > 32 || n > kMergeMaxCandidates) return hipErrorInvalidValue;
+    if (score_list_stride <= 0) score_list_stride = (int64_t)nq * k;
+    if (id_list_stride <= 0) id_list_stride = (int64_t)nq * k;
     hipLaunchKernelGGL(merge_topk_kernel, dim3(nq), dim3(kMergeThreads), 0, stream, scores, ids, n_lists, nq, k,
-                       out_scores, out_ids, id_map);
+                       out_scores, out_ids, id_map, score_list_stride, id_list_stride);
     return hipGetLastError();
 }
 

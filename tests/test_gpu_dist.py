@@ -1,0 +1,68 @@
+"""Multi-rank sharded search on real HIP shards: 2 ranks share the one GPU of the test box
+(gloo rendezvous; the collectives move device tensors), each owns half of the rows; every rank
+must end with exactly the single-index result (ids AND scores bit-identical) — the invariant
+the 8-GPU RCCL path relies on."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n_local, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from rassengine_amd.dist import HipShard, ShardedSearch
+        from rassengine_amd.engine import Engine
+        torch.cuda.set_device(0)
+        eng = Engine(0, 1024)
+        idx = eng.open_index("shard", capacity_rows=n_local)
+        idx.fill_synthetic(n_local, seed=77, row_id_base=rank * n_local)
+        eng.synchronize()
+        search = ShardedSearch(HipShard(idx, id_base=rank * n_local))
+        g = torch.Generator(device="cuda")
+        g.manual_seed(5)
+        q_all = torch.randn((20, 1024), generator=g, device="cuda")
+        q = q_all.clone() if rank == 0 else torch.zeros_like(q_all)   # only rank 0 holds the batch
+        s, i = search.search(q, 10)
+        torch.cuda.synchronize()
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), s=s.cpu().numpy(), i=i.cpu().numpy(), q=q.cpu().numpy())
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_sharded_search_equals_single_index(gpu, tmp_path):
+    import torch.multiprocessing as mp
+    from rassengine_amd.engine import Engine
+    n_local, world = 30000, 2
+    mp.spawn(_worker, args=(world, _free_port(), n_local, str(tmp_path)), nprocs=world, join=True)
+    r0 = np.load(os.path.join(str(tmp_path), "rank0.npz"))
+    r1 = np.load(os.path.join(str(tmp_path), "rank1.npz"))
+    assert np.array_equal(r0["q"], r1["q"])                       # broadcast reached rank 1
+    assert np.array_equal(r0["i"], r1["i"]) and np.array_equal(r0["s"], r1["s"])
+    eng = Engine(0, 1024)
+    try:
+        whole = eng.open_index("whole", capacity_rows=world * n_local)
+        whole.fill_synthetic(world * n_local, seed=77, row_id_base=0)   # Philox rows keyed by global id
+        s, i = whole.search(r0["q"], 10)
+    finally:
+        eng.close()
+    assert np.array_equal(r0["i"], i)
+    assert np.array_equal(r0["s"], s)
+    assert (r0["i"] >= n_local).any() and (r0["i"] < n_local).any()   # hits come from both shards

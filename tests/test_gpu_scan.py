@@ -256,3 +256,30 @@ def test_normalize_rows(gpu, oracle, n, dim, stride):
     np.testing.assert_allclose(out[:, :dim], ref, rtol=3e-7, atol=1e-30)
     if n > 3:
         assert np.all(out[3] == 0.0)
+
+
+def test_strided_merge_of_packed_records(gpu, oracle):
+    """The single-all-gather path: G packed (scores | ids) records merged in place."""
+    import ctypes
+    from rassengine_amd import _native as N
+    from rassengine_amd.dist import HipShard
+    rng = np.random.default_rng(12)
+    G, nq, k = 5, 7, 10
+    ids_off, size = HipShard.record_bytes(nq, k)
+    assert ids_off % 8 == 0 and size % 8 == 0
+    s = -np.sort(-rng.standard_normal((G, nq, k)).astype(np.float32), axis=2)
+    ids = rng.permutation(G * nq * k).reshape(G, nq, k).astype(np.int64)
+    buf = np.zeros((G, size), dtype=np.uint8)
+    for g in range(G):
+        buf[g, : nq * k * 4] = s[g].view(np.uint8).reshape(-1)
+        buf[g, ids_off: ids_off + nq * k * 8] = ids[g].view(np.uint8).reshape(-1)
+    d = gpu.from_numpy(buf.reshape(-1)).cuda()
+    out_s = gpu.empty((nq, k), dtype=gpu.float32, device="cuda")
+    out_i = gpu.empty((nq, k), dtype=gpu.int64, device="cuda")
+    N.check("m", N.lib().rass_topk_merge_strided(ctypes.c_void_p(d.data_ptr()), ctypes.c_void_p(d.data_ptr() + ids_off),
+                                                 size // 4, size // 8, G, nq, k, ctypes.c_void_p(out_s.data_ptr()),
+                                                 ctypes.c_void_p(out_i.data_ptr()), None))
+    gpu.cuda.synchronize()
+    rs, ri = oracle.merge(s.astype(np.float64), ids)
+    assert np.array_equal(out_i.cpu().numpy(), ri)
+    assert np.array_equal(out_s.cpu().numpy(), rs.astype(np.float32))

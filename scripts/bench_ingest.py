@@ -15,6 +15,9 @@ ap.add_argument("--chunks", type=int, default=16384)
 ap.add_argument("--batch", type=int, default=256)
 ap.add_argument("--profile", choices=["fixed512", "varlen"], default="fixed512")
 ap.add_argument("--layers", type=int, default=24)
+ap.add_argument("--cpu-baseline-chunks", type=int, default=0,
+                help="also time the fp32 PyTorch-CPU forward of the same architecture (stand-in for Ollama's "
+                     "CPU embed path, BASELINE.md s3) on this many 512-token chunks, batch 1 and batch 8")
 a = ap.parse_args()
 
 cfg = EncoderConfig(layers=a.layers, pooling="mean")
@@ -68,7 +71,28 @@ q = torch.randn((32, H), device="cuda")
 os_ = torch.empty((32, 10), device="cuda"); oi = torch.empty((32, 10), dtype=torch.int64, device="cuda")
 idx.search_device(q.data_ptr(), 32, 10, os_.data_ptr(), oi.data_ptr()); torch.cuda.synchronize()
 flops_tok = cfg.layers * 2 * (4 * H * H + 2 * H * I)
-print(json.dumps({"workload": f"ingest {chunks} chunks, batch {a.batch}, {a.profile}, BERT-large-class bf16 (random weights)",
+cpu = None
+if a.cpu_baseline_chunks > 0:
+    from transformers import BertConfig, BertModel
+    torch.manual_seed(0)
+    hf = BertModel(BertConfig(vocab_size=cfg.vocab_size, hidden_size=H, num_hidden_layers=cfg.layers,
+                              num_attention_heads=cfg.heads, intermediate_size=I, max_position_embeddings=512),
+                   add_pooling_layer=False).eval()
+    n = a.cpu_baseline_chunks
+    ids_cpu = torch.randint(0, cfg.vocab_size, (n, 512))
+    with torch.no_grad():
+        hf(input_ids=ids_cpu[:1])  # warm
+        t0 = time.perf_counter()
+        for i in range(n):          # one request per text, like the reference (app/main.py:252-260)
+            hf(input_ids=ids_cpu[i:i + 1])
+        t_b1 = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        for i in range(0, n, 8):
+            hf(input_ids=ids_cpu[i:i + 8])
+        t_b8 = time.perf_counter() - t0
+    cpu = {"kind": "port (PyTorch-CPU fp32 BertModel, same architecture, random weights)", "threads": torch.get_num_threads(),
+           "chunks": n, "chunks_per_s_batch1": round(n / t_b1, 3), "chunks_per_s_batch8": round(n / t_b8, 3)}
+print(json.dumps({"cpu_baseline": cpu, "workload": f"ingest {chunks} chunks, batch {a.batch}, {a.profile}, BERT-large-class bf16 (random weights)",
                   "chunks_per_s": round(chunks / dt, 1), "tokens_per_s": round(tokens / dt), "seconds": round(dt, 3),
                   "linear_TFLOPs": round(tokens * flops_tok / dt / 1e12, 1), "index_rows": idx.rows,
                   "extrapolated_1M_chunks_s": round(1e6 / (chunks / dt), 1)}))

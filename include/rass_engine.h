@@ -244,7 +244,8 @@ int rass_ivf_build(rass_index_t* src, const float* centroids, int nlist,
 void rass_ivf_destroy(rass_ivf_t* ivf);
 int64_t rass_ivf_rows(const rass_ivf_t* ivf);
 int rass_ivf_nlist(const rass_ivf_t* ivf);
-/* Same contract as rass_index_search; 1 <= nprobe <= 32 lists per query.
+/* Same contract as rass_index_search; nprobe >= 1 lists per query (capped at
+ * nlist; nprobe > 32 selects by a per-query score threshold, ties may add lists).
  * *scanned_rows (may be NULL) receives the rows the fine scans touched. */
 int rass_ivf_search(rass_ivf_t* ivf, const float* queries, int nq, int k,
                     int nprobe, const int32_t* q_filter, float* out_scores,

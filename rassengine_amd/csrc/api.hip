@@ -324,6 +324,8 @@ struct rass_ivf {
     int64_t* d_scanned = nullptr;   // rows touched by the last fine scan
     float* d_probe_scores = nullptr;  // [32][32]
     int64_t* d_probe_ids = nullptr;   // [32][32]
+    uint32_t* d_tau = nullptr;        // [32] nprobe > 32: per-query threshold keys
+    uint32_t* d_list_mask = nullptr;  // [nlist] nprobe > 32: probe masks from the score matrix
     bool any_tags = false;
 };
 
@@ -990,7 +992,8 @@ static void ivf_free(rass_ivf* v) {
     if (!v) return;
     for (void* p : {(void*)v->d_slab, (void*)v->d_tags, (void*)v->d_ids, (void*)v->d_centroids, (void*)v->d_list_tile0,
                     (void*)v->d_list_len, (void*)v->d_work_tile, (void*)v->d_work_rows, (void*)v->d_n_work,
-                    (void*)v->d_work_mask, (void*)v->d_scanned, (void*)v->d_probe_scores, (void*)v->d_probe_ids})
+                    (void*)v->d_work_mask, (void*)v->d_scanned, (void*)v->d_probe_scores, (void*)v->d_probe_ids,
+                    (void*)v->d_tau, (void*)v->d_list_mask})
         if (p) (void)hipFree(p);
     delete v;
 }
@@ -1060,6 +1063,8 @@ int rass_ivf_build(rass_index_t* src, const float* centroids, int nlist, const i
     IVF_TRY(hipMalloc(reinterpret_cast<void**>(&v->d_scanned), 8));
     IVF_TRY(hipMalloc(reinterpret_cast<void**>(&v->d_probe_scores), RASS_MAX_QBATCH * RASS_MAX_K * 4));
     IVF_TRY(hipMalloc(reinterpret_cast<void**>(&v->d_probe_ids), RASS_MAX_QBATCH * RASS_MAX_K * 8));
+    IVF_TRY(hipMalloc(reinterpret_cast<void**>(&v->d_tau), RASS_MAX_QBATCH * 4));
+    IVF_TRY(hipMalloc(reinterpret_cast<void**>(&v->d_list_mask), (size_t)nlist * 4));
     IVF_TRY(hipMemcpyAsync(v->d_ids, src_of.data(), (size_t)slab_rows * 8, hipMemcpyHostToDevice, st));
     IVF_TRY(hipMemcpyAsync(v->d_list_tile0, tile0.data(), (size_t)nlist * 4, hipMemcpyHostToDevice, st));
     IVF_TRY(hipMemcpyAsync(v->d_list_len, len.data(), (size_t)nlist * 4, hipMemcpyHostToDevice, st));
@@ -1106,20 +1111,54 @@ int rass_ivf_nlist(const rass_ivf_t* v) { return v ? v->nlist : 0; }
 int rass_ivf_search_device(rass_ivf_t* v, const float* d_queries, int nq, int k, int nprobe,
                            const int32_t* d_q_filter, float* d_out_scores, int64_t* d_out_ids) {
     if (!v || !d_queries || !d_out_scores || !d_out_ids) return fail(RASS_ERR_INVALID, "NULL argument");
-    if (nprobe < 1 || nprobe > RASS_MAX_K) return fail(RASS_ERR_INVALID, "nprobe must be in [1, 32]");
+    if (nprobe < 1) return fail(RASS_ERR_INVALID, "nprobe must be >= 1");
+    if (nq < 1 || nq > RASS_MAX_QBATCH) return fail(RASS_ERR_INVALID, "nq must be in [1, RASS_MAX_QBATCH]");
     rass_engine* eng = v->eng;
     std::lock_guard<std::mutex> lk(eng->mu);
     int rc = set_device(eng);
     if (rc != RASS_OK) return rc;
     hipStream_t st = eng->stream;
     const int np = std::min(nprobe, v->nlist);
-    // (i) coarse: top-nprobe centroids per query with the flat fused scan
-    rc = scan_launch(v->d_centroids, v->nlist, v->stride, nullptr, d_queries, v->dim, v->dim, nq, nullptr, np, 0,
-                     v->d_probe_scores, v->d_probe_ids, eng->d_scratch, eng->scratch_bytes, eng->n_cus, st);
-    if (rc != RASS_OK) return rc;
-    // (ii) plan: union of probed lists -> work tiles with per-tile query masks
-    HIP_TRY(rass::launch_plan_probe(v->d_probe_ids, nq, np, v->nlist, v->d_list_tile0, v->d_list_len, v->d_work_tile,
-                                    v->d_work_rows, v->d_work_mask, v->d_n_work, v->d_scanned, st));
+    const int n_ctiles = (v->nlist + 31) / 32;
+    if (np <= RASS_MAX_K || n_ctiles > kMaxGrid) {
+        // (i) coarse: top-nprobe centroids per query with the flat fused scan
+        rc = scan_launch(v->d_centroids, v->nlist, v->stride, nullptr, d_queries, v->dim, v->dim, nq, nullptr,
+                         std::min(np, RASS_MAX_K), 0, v->d_probe_scores, v->d_probe_ids, eng->d_scratch,
+                         eng->scratch_bytes, eng->n_cus, st);
+        if (rc != RASS_OK) return rc;
+        // (ii) plan: union of probed lists -> work tiles with per-tile query masks
+        HIP_TRY(rass::launch_plan_probe(v->d_probe_ids, nq, std::min(np, RASS_MAX_K), v->nlist, v->d_list_tile0,
+                                        v->d_list_len, v->d_work_tile, v->d_work_rows, v->d_work_mask, v->d_n_work,
+                                        v->d_scanned, st));
+    } else {
+        // nprobe > 32: one workgroup per 32-centroid tile with k = 32 leaves EVERY centroid score in
+        // the per-workgroup lists; radix-select the nprobe-th best per query, mask by threshold
+        const ScratchLayout L = scratch_layout(nq, RASS_MAX_K);
+        unsigned char* ws = eng->d_scratch;
+        float* q_padded = reinterpret_cast<float*>(ws + L.q_padded);
+        float* part_scores = reinterpret_cast<float*>(ws + L.part_scores);
+        int64_t* part_ids = reinterpret_cast<int64_t*>(ws + L.part_ids);
+        const int nq_pad = nq <= 16 ? 16 : 32;
+        HIP_TRY(rass::launch_normalize_rows_f32(d_queries, v->dim, q_padded, v->stride, nq, v->dim, st, nq_pad));
+        rass::ScanArgs a;
+        a.corpus = v->d_centroids;
+        a.row_tag = nullptr;
+        a.q_padded = q_padded;
+        a.q_filter = nullptr;
+        a.part_scores = part_scores;
+        a.part_ids = part_ids;
+        a.row_stride = v->stride;
+        a.id_base = 0;
+        a.n_rows = v->nlist;
+        a.nq = nq;
+        a.k = RASS_MAX_K;
+        HIP_TRY(rass::launch_scan_topk_f32(a, n_ctiles, st));
+        HIP_TRY(rass::launch_ivf_threshold(part_scores, part_ids, n_ctiles, nq, np, v->d_tau, st));
+        HIP_TRY(rass::launch_ivf_mask_from_scores(part_scores, part_ids, n_ctiles, nq, v->nlist, v->d_tau,
+                                                  v->d_list_mask, st));
+        HIP_TRY(rass::launch_plan_probe(v->d_probe_ids, nq, 1, v->nlist, v->d_list_tile0, v->d_list_len, v->d_work_tile,
+                                        v->d_work_rows, v->d_work_mask, v->d_n_work, v->d_scanned, st, v->d_list_mask));
+    }
     // (iii) fine: the same fused scan over the planned tiles; slab positions -> source ids in the merge
     IvfPlan plan{v->d_work_tile, v->d_work_rows, v->d_work_mask, v->d_n_work, v->total_tiles};
     const bool need_tags = v->any_tags || d_q_filter != nullptr;

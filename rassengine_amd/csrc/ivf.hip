@@ -30,16 +30,19 @@ __global__ __launch_bounds__(kPlanThreads) void plan_probe_kernel(const int64_t*
                                                                   int32_t* __restrict__ work_rows,
                                                                   uint32_t* __restrict__ work_mask,
                                                                   int32_t* __restrict__ n_work,
-                                                                  int64_t* __restrict__ scanned_rows) {
+                                                                  int64_t* __restrict__ scanned_rows,
+                                                                  const uint32_t* __restrict__ preset_mask) {
     extern __shared__ uint32_t sh[];   // [nlist] query masks, then [kPlanThreads] scan scratch
     uint32_t* mask = sh;
     uint32_t* part = sh + nlist;
     const int tid = threadIdx.x;
-    for (int l = tid; l < nlist; l += kPlanThreads) mask[l] = 0u;
+    for (int l = tid; l < nlist; l += kPlanThreads) mask[l] = preset_mask ? preset_mask[l] : 0u;
     __syncthreads();
-    for (int e = tid; e < nq * nprobe; e += kPlanThreads) {
-        const int64_t l = probe_ids[e];
-        if (l >= 0 && l < nlist) atomicOr(&mask[(int)l], 1u << (e / nprobe));
+    if (!preset_mask) {
+        for (int e = tid; e < nq * nprobe; e += kPlanThreads) {
+            const int64_t l = probe_ids[e];
+            if (l >= 0 && l < nlist) atomicOr(&mask[(int)l], 1u << (e / nprobe));
+        }
     }
     __syncthreads();
     // each thread owns a contiguous chunk of lists; exclusive scan of the chunks' tile counts
@@ -87,7 +90,7 @@ __global__ __launch_bounds__(kPlanThreads) void plan_probe_kernel(const int64_t*
 
 hipError_t launch_plan_probe(const int64_t* probe_ids, int nq, int nprobe, int nlist, const int32_t* list_tile0,
                              const int32_t* list_len, int32_t* work_tile, int32_t* work_rows, uint32_t* work_mask,
-                             int32_t* n_work, int64_t* scanned_rows, hipStream_t stream) {
+                             int32_t* n_work, int64_t* scanned_rows, hipStream_t stream, const uint32_t* preset_mask) {
     if (nq < 1 || nq > 32 || nprobe < 1 || nlist < 1 || nlist > 32768) return hipErrorInvalidValue;
     const size_t lds = ((size_t)nlist + kPlanThreads) * sizeof(uint32_t);
     static size_t attr = 0;
@@ -98,7 +101,88 @@ hipError_t launch_plan_probe(const int64_t* probe_ids, int nq, int nprobe, int n
         attr = lds;
     }
     hipLaunchKernelGGL(plan_probe_kernel, dim3(1), dim3(kPlanThreads), lds, stream, probe_ids, nq, nprobe, nlist,
-                       list_tile0, list_len, work_tile, work_rows, work_mask, n_work, scanned_rows);
+                       list_tile0, list_len, work_tile, work_rows, work_mask, n_work, scanned_rows, preset_mask);
+    return hipGetLastError();
+}
+
+// ---- nprobe > 32: threshold select + plan from the full centroid score matrix ------------------
+// The coarse scan is launched with one workgroup per 32-centroid tile and k = 32, so its
+// per-workgroup lists [n_ctiles][nq][32] hold EVERY centroid's score.  tau[q] = the nprobe-th
+// largest of them (radix select on order-preserving integer keys, 4 passes of 8 bits).
+__device__ __forceinline__ uint32_t desc_key(float s, int64_t id) {
+    if (id < 0 || !(s > -INFINITY)) return 0xffffffffu;          // never selected
+    const uint32_t b = __float_as_uint(s);
+    const uint32_t asc = (b & 0x80000000u) ? ~b : (b | 0x80000000u);  // ascending in s
+    return ~asc;                                                  // ascending key = descending score
+}
+
+__global__ __launch_bounds__(256) void ivf_threshold_kernel(const float* __restrict__ part_scores,
+                                                            const int64_t* __restrict__ part_ids, int n_ctiles,
+                                                            int nq, int nprobe, uint32_t* __restrict__ tau_key) {
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t sel_prefix, sel_remaining;
+    const int q = blockIdx.x;
+    const int n = n_ctiles * 32;
+    if (threadIdx.x == 0) {
+        sel_prefix = 0;
+        sel_remaining = (uint32_t)nprobe;
+    }
+    __syncthreads();
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        hist[threadIdx.x] = 0;
+        __syncthreads();
+        const uint32_t prefix = sel_prefix;
+        const uint32_t himask = shift == 24 ? 0u : (0xffffffffu << (shift + 8));
+        for (int e = threadIdx.x; e < n; e += 256) {
+            const int64_t o = ((int64_t)(e >> 5) * nq + q) * 32 + (e & 31);
+            const uint32_t key = desc_key(part_scores[o], part_ids[o]);
+            if ((key & himask) == (prefix & himask)) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t rem = sel_remaining, b = 0;
+            for (; b < 255; ++b) {
+                if (hist[b] >= rem) break;
+                rem -= hist[b];
+            }
+            sel_prefix = prefix | (b << shift);
+            sel_remaining = rem;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) tau_key[q] = sel_prefix;  // keys <= tau are probed (ties may add a few lists)
+}
+
+hipError_t launch_ivf_threshold(const float* part_scores, const int64_t* part_ids, int n_ctiles, int nq, int nprobe,
+                                uint32_t* tau_key, hipStream_t stream) {
+    if (n_ctiles < 1 || nq < 1 || nprobe < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ivf_threshold_kernel, dim3(nq), dim3(256), 0, stream, part_scores, part_ids, n_ctiles, nq, nprobe,
+                       tau_key);
+    return hipGetLastError();
+}
+
+// Probe masks from the score matrix + thresholds, written to a global mask array that
+// plan_probe_kernel then consumes through its `preset_mask` input.
+__global__ void ivf_mask_from_scores_kernel(const float* __restrict__ part_scores,
+                                            const int64_t* __restrict__ part_ids, int n_ctiles, int nq, int nlist,
+                                            const uint32_t* __restrict__ tau_key, uint32_t* __restrict__ mask) {
+    const int64_t total = (int64_t)n_ctiles * nq * 32;
+    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
+        const int q = (int)((o >> 5) % nq);
+        const int64_t l = part_ids[o];
+        if (l >= 0 && l < nlist && desc_key(part_scores[o], l) <= tau_key[q]) atomicOr(&mask[l], 1u << q);
+    }
+}
+
+hipError_t launch_ivf_mask_from_scores(const float* part_scores, const int64_t* part_ids, int n_ctiles, int nq,
+                                       int nlist, const uint32_t* tau_key, uint32_t* mask, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(mask, 0, (size_t)nlist * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    const int64_t total = (int64_t)n_ctiles * nq * 32;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(ivf_mask_from_scores_kernel, dim3(blocks), dim3(256), 0, stream, part_scores, part_ids, n_ctiles,
+                       nq, nlist, tau_key, mask);
     return hipGetLastError();
 }
 

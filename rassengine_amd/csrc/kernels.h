@@ -61,7 +61,12 @@ hipError_t launch_rerank_f32(const float* slab, int64_t stride, const float* q_p
 // ---- IVF (ivf.hip)
 hipError_t launch_plan_probe(const int64_t* probe_ids, int nq, int nprobe, int nlist, const int32_t* list_tile0,
                              const int32_t* list_len, int32_t* work_tile, int32_t* work_rows, uint32_t* work_mask,
-                             int32_t* n_work, int64_t* scanned_rows, hipStream_t stream);
+                             int32_t* n_work, int64_t* scanned_rows, hipStream_t stream,
+                             const uint32_t* preset_mask = nullptr);
+hipError_t launch_ivf_threshold(const float* part_scores, const int64_t* part_ids, int n_ctiles, int nq, int nprobe,
+                                uint32_t* tau_key, hipStream_t stream);
+hipError_t launch_ivf_mask_from_scores(const float* part_scores, const int64_t* part_ids, int n_ctiles, int nq,
+                                       int nlist, const uint32_t* tau_key, uint32_t* mask, hipStream_t stream);
 hipError_t launch_permute_rows_tile16(const float* src, float* dst, int64_t stride, const int64_t* src_of,
                                       int64_t dst_rows, hipStream_t stream);
 

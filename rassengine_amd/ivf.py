@@ -13,7 +13,8 @@ Division of labour:
   batch's probed lists (``csrc/ivf.hip``, IVF mode of ``csrc/scan_topk.hip``).
 
 IVF is approximate: recall@k against the flat index is measured per nprobe
-(``scripts/bench_ivf.py``, ``tests/test_gpu_ivf.py``); ``nprobe = nlist`` reproduces the flat result.
+(``scripts/bench_ivf.py``, ``tests/test_gpu_ivf.py``); ``nprobe = nlist`` reproduces the flat result (nprobe > 32 selects lists by a per-query score
+threshold from the full centroid score matrix).
 """
 from __future__ import annotations
 

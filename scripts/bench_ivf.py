@@ -69,7 +69,7 @@ res = {"workload": f"IVF-{a.nlist} over {a.rows} x {dim} {'iid' if a.iid else 'c
        "list_len_max": int(sizes.max()), "empty_lists": int((sizes == 0).sum()),
        "flat_qps": round(a.queries / flat_ms * 1e3, 1), "sweep": []}
 got = torch.empty((a.queries, k), dtype=torch.int64, device=dev)
-for nprobe in (1, 2, 4, 8, 16, 32):
+for nprobe in (1, 2, 4, 8, 16, 32, 64, 128):
     for b in range(0, min(a.queries, 4 * B), B):  # warm-up
         ivf.search_device(q[b:b + B].data_ptr(), B, k, nprobe, out_s.data_ptr(), got[b:b + B].data_ptr())
     eng.synchronize()

@@ -76,6 +76,24 @@ def test_recall_grows_with_nprobe(built):
     assert scanned[0] < 0.3 * 2 * flat.count
 
 
+def test_wide_probe_threshold_path(built):
+    """nprobe > 32 goes through the full centroid-score matrix + radix-select threshold: probing
+    all 128 lists must reproduce the flat result exactly; 64 lists must not be worse than 32."""
+    eng, flat, ivf, q, _ = built
+    s_f, i_f = flat.search(q, 10)
+    s_all, i_all, scanned = ivf.search(q, 10, nprobe=128)
+    assert np.array_equal(i_all, i_f) and np.array_equal(s_all, s_f)
+    assert scanned == 2 * flat.count
+    s_big, i_big, _ = ivf.search(q, 10, nprobe=100000)      # capped at nlist
+    assert np.array_equal(i_big, i_f)
+    rec = {}
+    for nprobe in (32, 33, 64, 96):
+        s, i, sc = ivf.search(q, 10, nprobe=nprobe)
+        rec[nprobe] = (np.mean([len(set(i[r]) & set(i_f[r])) / 10 for r in range(q.shape[0])]), sc)
+    assert rec[33][0] >= rec[32][0] - 1e-9 and rec[64][0] >= rec[33][0] - 1e-9 and rec[96][0] >= rec[64][0] - 1e-9
+    assert rec[32][1] <= rec[33][1] <= rec[64][1] <= rec[96][1] <= 2 * flat.count
+
+
 def test_ivf_filters_and_tombstones(built):
     eng, flat, ivf, q, tags = built
     qf = np.array([(r % 4) + 1 for r in range(q.shape[0])], dtype=np.int32)

@@ -128,6 +128,10 @@ def main():
         "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True,
         "scaling": "weak",
+        # weak scaling in CORPUS ROWS (every GPU keeps rows_per_gpu rows, every query is answered over all
+        # N shards): the ideal is CONSTANT queries/s while rows_global grows N x; the quantity that grows
+        # N x is row_queries_per_s = value * rows_global (and config.aggregate_scan_GBps)
+        "row_queries_per_s": round(qps * n_local * world, 1),
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",

@@ -33,6 +33,9 @@ def main():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--rows-per-gpu", type=int, default=1_000_000)
+    ap.add_argument("--rows-global", type=int, default=0,
+                    help="STRONG scaling instead: a fixed global corpus (BASELINE configs[3]: 10000000) split "
+                         "into contiguous row ranges over the ranks; overrides --rows-per-gpu")
     ap.add_argument("--dim", type=int, default=1024)
     ap.add_argument("--batch", type=int, default=32, help="queries per scan (<= 32)")
     ap.add_argument("--k", type=int, default=10)
@@ -65,19 +68,23 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    from rassengine_amd.dist import HipShard, ShardedSearch
+    from rassengine_amd.dist import HipShard, ShardedSearch, shard_bounds
     from rassengine_amd.engine import Engine, scan_kernel_name
 
-    n_local, dim, B, k = args.rows_per_gpu, args.dim, args.batch, args.k
+    dim, B, k = args.dim, args.batch, args.k
+    strong = args.rows_global > 0
+    rows_global = args.rows_global if strong else args.rows_per_gpu * world
+    row_lo, row_hi = shard_bounds(rows_global, world)[rank]
+    n_local = row_hi - row_lo
     eng = Engine(device=local_rank, dim=dim)
     idx = eng.open_index("bench", capacity_rows=n_local)
-    # Philox rows keyed by the GLOBAL row id: shard r regenerates rows [r*n_local, (r+1)*n_local)
-    idx.fill_synthetic(n_local, seed=1234, row_id_base=rank * n_local)
+    # Philox rows keyed by the GLOBAL row id: shard r regenerates exactly rows [row_lo, row_hi)
+    idx.fill_synthetic(n_local, seed=1234, row_id_base=row_lo)
     if args.prefilter:
         idx.set_prefilter(True)
     eng.synchronize()
 
-    shard = HipShard(idx, id_base=rank * n_local)  # switches the engine to torch's current stream
+    shard = HipShard(idx, id_base=row_lo)  # switches the engine to torch's current stream
     search = ShardedSearch(shard)
     gen = torch.Generator(device=dev)
     gen.manual_seed(4321)
@@ -127,18 +134,19 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if strong else "weak",
         # weak scaling in CORPUS ROWS (every GPU keeps rows_per_gpu rows, every query is answered over all
         # N shards): the ideal is CONSTANT queries/s while rows_global grows N x; the quantity that grows
         # N x is row_queries_per_s = value * rows_global (and config.aggregate_scan_GBps)
-        "row_queries_per_s": round(qps * n_local * world, 1),
+        "row_queries_per_s": round(qps * rows_global, 1),
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": f"{n_local * world} x {dim}-d flat cosine top-{k}, {world} x MI355X, precomputed embeddings "
-                        f"(BASELINE configs[1] shard per GPU)",
-            "rows_per_gpu": n_local, "rows_global": n_local * world, "dim": dim, "k": k, "query_batch": B,
+            "workload": f"{rows_global} x {dim}-d flat cosine top-{k}, {world} x MI355X, precomputed embeddings "
+                        + ("(BASELINE configs[3] corpus, fixed, row-sharded)" if strong else
+                           "(BASELINE configs[1] shard per GPU)"),
+            "rows_per_gpu": n_local, "rows_global": rows_global, "dim": dim, "k": k, "query_batch": B,
             "corpus_dtype": "f32" if not args.prefilter else "f32 + bf16 candidate copy (exact fp32 re-rank)",
             "layout": "tile16", "mode": "prefilter" if args.prefilter else "flat", "sharding": f"row-sharded x{world}, RCCL all-gather merge"
             if world > 1 else "single shard",

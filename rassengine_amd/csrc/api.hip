@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -204,6 +205,24 @@ int index_reserve(rass_index* idx, int64_t need_rows) {
     return RASS_OK;
 }
 
+// XCD skew of the scan's tile order (kernels.h ScanArgs::xcd_skew; measured in
+// scripts/microbench/scan_tail.hip and with bench.py).  RASS_SCAN_XCD_SKEW="a" or "a,b" overrides
+// the defaults for query batches <= 16 / > 16 (0 = plain round-robin).
+int scan_xcd_skew(int nq) {
+    static int skew16 = -1, skew32 = -1;
+    if (skew16 < 0) {
+        int a = 4, b = 0;  // bench.py sweeps: B<=16 603 -> 582 us at skew 4; no gain at B=32 (MFMA/power-bound)
+        if (const char* e = getenv("RASS_SCAN_XCD_SKEW")) {
+            const int n = sscanf(e, "%d,%d", &a, &b);
+            if (n == 1) b = a;
+            if (n < 1 || a < 0 || b < 0 || a > 4096 || b > 4096) a = 4, b = 0;
+        }
+        skew32 = b;
+        skew16 = a;
+    }
+    return nq <= 16 ? skew16 : skew32;
+}
+
 int scan_launch(const float* d_corpus, int64_t n_rows, int64_t stride, const int32_t* d_row_tag,
                 const float* d_queries, int q_dim, int64_t q_stride, int nq, const int32_t* d_q_filter, int k,
                 int64_t id_base, float* d_out_scores, int64_t* d_out_ids, unsigned char* ws, size_t ws_bytes,
@@ -244,6 +263,8 @@ int scan_launch(const float* d_corpus, int64_t n_rows, int64_t stride, const int
     a.n_rows = (int)n_rows;
     a.nq = nq;
     a.k = k;
+    // one workgroup per CU on every XCD: only then does blockIdx parity = XCD parity
+    a.xcd_skew = (grid == n_cus && grid % 8 == 0) ? scan_xcd_skew(nq) : 0;
     if (plan) {
         a.work_tile = plan->work_tile;
         a.work_rows = plan->work_rows;

@@ -25,6 +25,11 @@ struct ScanArgs {
     const int32_t* work_rows = nullptr;
     const uint32_t* work_mask = nullptr;
     const int32_t* n_work = nullptr;  // device scalar: number of work items
+    // XCD skew (0 = plain round-robin).  Workgroups land on XCD blockIdx % 8; measured on MI355X
+    // (scripts/microbench/scan_tail.hip) the odd XCDs stream ~14 % slower than the even ones when
+    // the scan is purely HBM-bound (B <= 16).  With skew s > 0 the even workgroups take s+1 items
+    // for every s the odd ones take, so all of them finish together.  Needs an even grid.
+    int xcd_skew = 0;
 };
 
 bool scan_supported_stride(int64_t row_stride);

@@ -53,6 +53,29 @@ constexpr int kPitch = 36;  // floats per query row of the LDS partial image (32
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
+#ifdef RASS_SCAN_CLOCKS  // scripts/microbench/scan_tail.hip only: per-workgroup start / end wall clocks
+__device__ unsigned long long g_scan_clocks[2 * 1024];
+#endif
+
+// The ascending sequence of work-item indices one workgroup handles.  Plain: b, b+G, b+2G, ...
+// With XCD skew s: the items are cut into super-rounds of s*G + G/2; in each, every workgroup
+// takes s items round-robin (j*G + b) and the even workgroups one more (s*G + b/2).
+struct ItemSeq {
+    int base, j, lim, skew, G, b, period;
+    __device__ __forceinline__ ItemSeq(int b_, int G_, int skew_) : base(0), j(0), skew(skew_), G(G_), b(b_) {
+        lim = skew == 0 ? 1 : ((b & 1) ? skew : skew + 1);
+        period = skew == 0 ? G : skew * G + (G >> 1);
+    }
+    __device__ __forceinline__ int next() {
+        const int r = (skew == 0 || j < skew) ? base + j * G + b : base + skew * G + (b >> 1);
+        if (++j == lim) {
+            j = 0;
+            base += period;
+        }
+        return r;
+    }
+};
+
 // One tile's A fragments for one wave: 2 M-tiles x CH chunks of 16 B per lane.
 template <int CH>
 struct TileRegs {
@@ -226,6 +249,9 @@ __global__ __launch_bounds__(kThreads, 2) void scan_topk_f32_kernel(ScanArgs p) 
     // by plan_probe_kernel earlier on this stream)
     const int n_tiles = IVF ? __builtin_amdgcn_readfirstlane(*p.n_work) : (p.n_rows + kTileRows - 1) / kTileRows;
     const int G = gridDim.x;
+#ifdef RASS_SCAN_CLOCKS
+    if (threadIdx.x == 0) g_scan_clocks[2 * blockIdx.x] = wall_clock64();
+#endif
 
     // Query fragments: lane (n = m, g) holds Qn[nt*16 + n][slice + 16j + 4g .. +3].
     f32x4 qf[NT][CH];
@@ -255,8 +281,9 @@ __global__ __launch_bounds__(kThreads, 2) void scan_topk_f32_kernel(ScanArgs p) 
 
     const int mt_step = 16 * (int)p.row_stride * 4;
     TileRegs<CH> R0, R1;
-    int t = blockIdx.x;
-    WorkItem W0 = get_work<IVF>(p, t, n_tiles), W1 = get_work<IVF>(p, t + G, n_tiles);
+    ItemSeq seq((int)blockIdx.x, G, (G & 1) ? 0 : p.xcd_skew);
+    int t = seq.next();  // the item R0 holds; R1 holds the one after it
+    WorkItem W0 = get_work<IVF>(p, t, n_tiles), W1 = get_work<IVF>(p, seq.next(), n_tiles);
     issue_tile_loads<CH>(R0, make_tile_desc(p.corpus, p.row_stride, p.row_tag, W0), voff_lane, mt_step);
     issue_tile_loads<CH>(R1, make_tile_desc(p.corpus, p.row_stride, p.row_tag, W1), voff_lane, mt_step);
     __builtin_amdgcn_sched_barrier(0);
@@ -287,22 +314,26 @@ __global__ __launch_bounds__(kThreads, 2) void scan_topk_f32_kernel(ScanArgs p) 
         }
     };
 
-    for (; t < n_tiles; t += 2 * G) {
+    while (t < n_tiles) {
         f32x4 acc[2][NT];
         int tag = R0.tag;
-        WorkItem Wn = get_work<IVF>(p, t + 2 * G, n_tiles);
+        t = seq.next();
+        WorkItem Wn = get_work<IVF>(p, t, n_tiles);
         multiply_and_refill<CH, NT>(R0, qf, acc, make_tile_desc(p.corpus, p.row_stride, p.row_tag, Wn), voff_lane,
                                     mt_step);
         finish_tile(acc, W0, tag, 0);
         W0 = Wn;
         tag = R1.tag;
-        Wn = get_work<IVF>(p, t + 3 * G, n_tiles);
+        Wn = get_work<IVF>(p, seq.next(), n_tiles);
         multiply_and_refill<CH, NT>(R1, qf, acc, make_tile_desc(p.corpus, p.row_stride, p.row_tag, Wn), voff_lane,
                                     mt_step);
         finish_tile(acc, W1, tag, 1);
         W1 = Wn;
     }
 
+#ifdef RASS_SCAN_CLOCKS
+    if (threadIdx.x == 0) g_scan_clocks[2 * blockIdx.x + 1] = wall_clock64();
+#endif
     // Per-workgroup sorted lists -> [gridDim.x][nq][k]
     const int lpos = lane & 31;
 #pragma unroll

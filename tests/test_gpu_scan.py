@@ -59,6 +59,9 @@ def _run_scan(torch, xn, q_raw, k, dim, stride, tags=None, qfilter=None, id_base
     (3000, 100, 4, 5),     # dim padded to 128
     (2500, 768, 20, 10),
     (5, 1024, 2, 10),      # fewer rows than k
+    (45000, 256, 8, 10),   # full grid, B <= 16: XCD-skewed tile order, 1.2 super-rounds
+    (100003, 128, 16, 7),  # ... 2.7 super-rounds, ragged last tile
+    (70000, 128, 1, 32),
 ])
 def test_scan_matches_oracle(gpu, oracle, n, dim, nq, k):
     rng = np.random.default_rng(1000 + n + dim + nq + k)

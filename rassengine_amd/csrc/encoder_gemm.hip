@@ -183,11 +183,28 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_bf16_kernel(const u16* _
 // wave issues the t+2 DMAs.
 // LDS image: rows of 64 B (32 bf16), 16 rows per 1 KiB DMA piece, lane-linear; the
 // bank-conflict swizzle chunk ^= 3*((row>>3)&1) lives on the SOURCE address and on the read.
+#ifdef RASS_GEMM_CLOCKS
+__device__ unsigned long long g_gemm_clocks[4 * 16384];
+__device__ unsigned long long g_gemm_core_cycles[64];
+#endif
 constexpr int RBM = 256, RBN = 256, RBK = 32;
 constexpr int kRingThreads = 512;
 constexpr int kRingTileBytes = 256 * RBK * 2;        // 16 KiB per operand per slot
 constexpr int kRingSlotBytes = 2 * kRingTileBytes;   // W tile | X tile
-constexpr int kRingSlots = 3;
+constexpr int kRingSlots = 3;             // 96 KiB: steps t+1, t+2 in flight while t is multiplied (a 4th
+                                          // slot measured no gain: the K loop is not latency-bound)
+constexpr int kRingAhead = kRingSlots - 1;
+
+// Wait until at most `steps` whole K steps of this wave's DMAs (4 pieces each) are outstanding.
+__device__ __forceinline__ void ring_wait_steps(int steps) {
+    if (steps >= 2) {
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else if (steps == 1) {
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+}
 
 __device__ __forceinline__ void ring_stage(const u16* __restrict__ g, int64_t ld, int row0, int k0,
                                            unsigned char* lds_tile, int wave, int lane) {
@@ -218,6 +235,9 @@ __global__ __launch_bounds__(kRingThreads, 2) void gemm_bf16_ring_kernel(const u
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wn = wave >> 2, wm = wave & 3;
     const int nblk = gridDim.x, orig = blockIdx.x;
+#ifdef RASS_GEMM_CLOCKS  // scripts/microbench/gemm_phases.hip only
+    if (threadIdx.x == 0) g_gemm_clocks[4 * blockIdx.x] = wall_clock64();
+#endif
     const int q = nblk / 8, rr = nblk % 8, xcd = orig % 8;
     const int bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + orig / 8;
     const int tiles_n = N / RBN;
@@ -269,15 +289,17 @@ __global__ __launch_bounds__(kRingThreads, 2) void gemm_bf16_ring_kernel(const u
             srcX[p] += RBK;
         }
     };
-    stage_step(lds);
-    if (nk > 1) {
-        stage_step(lds + kRingSlotBytes);
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    {
+        const int pre = nk < kRingAhead ? nk : kRingAhead;  // steps 0 .. pre-1 go out; step 0 must land
+        for (int s0 = 0; s0 < pre; ++s0) stage_step(lds + s0 * kRingSlotBytes);
+        ring_wait_steps(pre - 1);
     }
     __builtin_amdgcn_s_barrier();
 
+#ifdef RASS_GEMM_CLOCKS
+    if (threadIdx.x == 0) g_gemm_clocks[4 * blockIdx.x + 1] = wall_clock64();
+    const unsigned long long core0 = clock64();
+#endif
     // Stagger (MI355X_MICROARCH "two waves per SIMD" item 9): every K step is a LOAD phase (DMA
     // issue for step t+2 + this step's 12 LDS fragment reads) and a COMPUTE phase (32 MFMAs),
     // each closed by a barrier.  Waves 4-7 (the SIMD partners of waves 0-3) run ONE phase behind:
@@ -291,10 +313,12 @@ __global__ __launch_bounds__(kRingThreads, 2) void gemm_bf16_ring_kernel(const u
     if (grpB) __builtin_amdgcn_s_barrier();
     int slot = 0;
     for (int t = 0; t < nk; ++t) {
-        const bool more = t + 2 < nk;
+        const bool more = t + kRingAhead < nk;
+        // steps still in flight once step t+1 has been retired: t+2 .. min(t+kRingAhead, nk-1)
+        const int keep = more ? kRingAhead - 1 : (nk - 2 - t > 0 ? nk - 2 - t : 0);
         // ---- load phase
         if (more) {
-            int s2 = slot + 2;
+            int s2 = slot + kRingAhead;
             s2 = s2 >= kRingSlots ? s2 - kRingSlots : s2;
             stage_step(lds + s2 * kRingSlotBytes);
         }
@@ -305,13 +329,7 @@ __global__ __launch_bounds__(kRingThreads, 2) void gemm_bf16_ring_kernel(const u
 #pragma unroll
         for (int i = 0; i < 8; ++i) a[i] = *reinterpret_cast<const bf16x8*>(buf + offA[i]);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (grpB) {
-            if (more) {
-                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-        }
+        if (grpB) ring_wait_steps(keep);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -323,19 +341,17 @@ __global__ __launch_bounds__(kRingThreads, 2) void gemm_bf16_ring_kernel(const u
             for (int j = 0; j < 4; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
-        if (!grpB) {
-            if (more) {
-                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-        }
+        if (!grpB) ring_wait_steps(keep);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         slot = slot + 1 >= kRingSlots ? 0 : slot + 1;
     }
     if (!grpB) __builtin_amdgcn_s_barrier();  // both groups execute the same number of barriers
+#ifdef RASS_GEMM_CLOCKS
+    if (threadIdx.x == 0) g_gemm_clocks[4 * blockIdx.x + 2] = wall_clock64();
+    if (threadIdx.x == 0 && blockIdx.x < 64) g_gemm_core_cycles[blockIdx.x] = clock64() - core0;
+#endif
 
     // Epilogue through LDS (free after the last barrier).  The accumulator layout gives every
     // lane 4 consecutive features of ONE token per tile, i.e. 8-byte stores scattered over 16
@@ -347,10 +363,30 @@ __global__ __launch_bounds__(kRingThreads, 2) void gemm_bf16_ring_kernel(const u
         constexpr int kPitchF = 68;  // floats per token row of the chunk image (64 + pad)
         float* stg = reinterpret_cast<float*>(lds + wave * (kRingSlots * kRingSlotBytes / 8));
         const int tl = lane >> 3, nq = lane & 7;  // read-back: token row (of 8 per pass), 8-feature group
+        // Every global read of the epilogue is issued before it is needed (a dependent load costs
+        // 0.5-1 us here and there would be 4 bias + 16 residual ones per wave in a row): bias for
+        // both feature halves up front, the residual rows of a chunk before its LDS staging.
+        f32x4 bv[2][2];
+#pragma unroll
+        for (int ic = 0; ic < 2; ++ic) {
+            const int nb = n0 + wn * 128 + ic * 64 + nq * 8;
+            bv[ic][0] = *reinterpret_cast<const f32x4*>(bias + nb);
+            bv[ic][1] = *reinterpret_cast<const f32x4*>(bias + nb + 4);
+        }
 #pragma unroll
         for (int jc = 0; jc < 2; ++jc) {
 #pragma unroll
             for (int ic = 0; ic < 2; ++ic) {
+                const int nbase = n0 + wn * 128 + ic * 64 + nq * 8;
+                uint4 res[4];
+                if (EPI == 1) {
+#pragma unroll
+                    for (int pass = 0; pass < 4; ++pass) {
+                        const int m = m0 + wm * 64 + jc * 32 + pass * 8 + tl;
+                        res[pass] = m < M ? *reinterpret_cast<const uint4*>(residual + (int64_t)m * N + nbase)
+                                          : uint4{0u, 0u, 0u, 0u};
+                    }
+                }
                 // stage: tiles i = 4ic..4ic+3, j = 2jc..2jc+1
 #pragma unroll
                 for (int jj = 0; jj < 2; ++jj)
@@ -359,33 +395,30 @@ __global__ __launch_bounds__(kRingThreads, 2) void gemm_bf16_ring_kernel(const u
                         *reinterpret_cast<f32x4*>(stg + (jj * 16 + (lane & 15)) * kPitchF + ii * 16 + (lane >> 4) * 4) =
                             acc[4 * ic + ii][2 * jc + jj];
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same-wave LDS write -> read
-                const int nbase = n0 + wn * 128 + ic * 64 + nq * 8;
-                const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + nbase);
-                const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias + nbase + 4);
 #pragma unroll
                 for (int pass = 0; pass < 4; ++pass) {
                     const int tok = pass * 8 + tl;
                     const int m = m0 + wm * 64 + jc * 32 + tok;
                     f32x4 v0 = *reinterpret_cast<const f32x4*>(stg + tok * kPitchF + nq * 8);
                     f32x4 v1 = *reinterpret_cast<const f32x4*>(stg + tok * kPitchF + nq * 8 + 4);
-                    v0 += b0;
-                    v1 += b1;
+                    v0 += bv[ic][0];
+                    v1 += bv[ic][1];
+                    if (EPI == 1) {
+                        const uint4 r = res[pass];
+                        v0.x += bf16_to_f32((u16)(r.x & 0xffff));
+                        v0.y += bf16_to_f32((u16)(r.x >> 16));
+                        v0.z += bf16_to_f32((u16)(r.y & 0xffff));
+                        v0.w += bf16_to_f32((u16)(r.y >> 16));
+                        v1.x += bf16_to_f32((u16)(r.z & 0xffff));
+                        v1.y += bf16_to_f32((u16)(r.z >> 16));
+                        v1.z += bf16_to_f32((u16)(r.w & 0xffff));
+                        v1.w += bf16_to_f32((u16)(r.w >> 16));
+                    }
+                    if (EPI == 2) {
+                        v0.x = gelu_erf(v0.x); v0.y = gelu_erf(v0.y); v0.z = gelu_erf(v0.z); v0.w = gelu_erf(v0.w);
+                        v1.x = gelu_erf(v1.x); v1.y = gelu_erf(v1.y); v1.z = gelu_erf(v1.z); v1.w = gelu_erf(v1.w);
+                    }
                     if (m < M) {
-                        if (EPI == 1) {
-                            const uint4 r = *reinterpret_cast<const uint4*>(residual + (int64_t)m * N + nbase);
-                            v0.x += bf16_to_f32((u16)(r.x & 0xffff));
-                            v0.y += bf16_to_f32((u16)(r.x >> 16));
-                            v0.z += bf16_to_f32((u16)(r.y & 0xffff));
-                            v0.w += bf16_to_f32((u16)(r.y >> 16));
-                            v1.x += bf16_to_f32((u16)(r.z & 0xffff));
-                            v1.y += bf16_to_f32((u16)(r.z >> 16));
-                            v1.z += bf16_to_f32((u16)(r.w & 0xffff));
-                            v1.w += bf16_to_f32((u16)(r.w >> 16));
-                        }
-                        if (EPI == 2) {
-                            v0.x = gelu_erf(v0.x); v0.y = gelu_erf(v0.y); v0.z = gelu_erf(v0.z); v0.w = gelu_erf(v0.w);
-                            v1.x = gelu_erf(v1.x); v1.y = gelu_erf(v1.y); v1.z = gelu_erf(v1.z); v1.w = gelu_erf(v1.w);
-                        }
                         uint4 o;
                         o.x = (unsigned)f32_to_bf16(v0.x) | ((unsigned)f32_to_bf16(v0.y) << 16);
                         o.y = (unsigned)f32_to_bf16(v0.z) | ((unsigned)f32_to_bf16(v0.w) << 16);
@@ -398,12 +431,16 @@ __global__ __launch_bounds__(kRingThreads, 2) void gemm_bf16_ring_kernel(const u
             }
         }
     }
+#ifdef RASS_GEMM_CLOCKS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0) g_gemm_clocks[4 * blockIdx.x + 3] = wall_clock64();
+#endif
 }
 
 template <int EPI>
 static hipError_t launch_ring(const u16* X, const u16* W, const float* bias, const u16* residual, u16* Y, int M,
                               int M_pad, int N, int K, hipStream_t stream) {
-    constexpr int lds_bytes = kRingSlots * kRingSlotBytes;  // 96 KiB
+    constexpr int lds_bytes = kRingSlots * kRingSlotBytes;  // 96 KiB at 3 slots
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_ring_kernel<EPI>),

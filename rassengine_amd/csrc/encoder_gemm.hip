@@ -186,6 +186,9 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_bf16_kernel(const u16* _
 #ifdef RASS_GEMM_CLOCKS
 __device__ unsigned long long g_gemm_clocks[4 * 16384];
 __device__ unsigned long long g_gemm_core_cycles[64];
+#ifdef RASS_GEMM_PHASE_TIMERS
+__device__ unsigned long long g_gemm_phase_cycles[64 * 2 * 4];
+#endif
 #endif
 constexpr int RBM = 256, RBN = 256, RBK = 32;
 constexpr int kRingThreads = 512;
@@ -311,11 +314,17 @@ __global__ __launch_bounds__(kRingThreads, 2) void gemm_bf16_ring_kernel(const u
     // lgkmcnt(0) before the barrier) end in interval 2t-1, the first new DMA is interval 2t.
     const bool grpB = wave >= 4;
     if (grpB) __builtin_amdgcn_s_barrier();
+#ifdef RASS_GEMM_PHASE_TIMERS
+    unsigned long long ph_load = 0, ph_bar1 = 0, ph_comp = 0, ph_bar2 = 0;
+#endif
     int slot = 0;
     for (int t = 0; t < nk; ++t) {
         const bool more = t + kRingAhead < nk;
         // steps still in flight once step t+1 has been retired: t+2 .. min(t+kRingAhead, nk-1)
         const int keep = more ? kRingAhead - 1 : (nk - 2 - t > 0 ? nk - 2 - t : 0);
+#ifdef RASS_GEMM_PHASE_TIMERS
+        const unsigned long long pt0 = clock64();
+#endif
         // ---- load phase
         if (more) {
             int s2 = slot + kRingAhead;
@@ -331,7 +340,13 @@ __global__ __launch_bounds__(kRingThreads, 2) void gemm_bf16_ring_kernel(const u
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (grpB) ring_wait_steps(keep);
         __builtin_amdgcn_sched_barrier(0);
+#ifdef RASS_GEMM_PHASE_TIMERS
+        const unsigned long long pt1 = clock64();
+#endif
         __builtin_amdgcn_s_barrier();
+#ifdef RASS_GEMM_PHASE_TIMERS
+        const unsigned long long pt2 = clock64();
+#endif
         __builtin_amdgcn_sched_barrier(0);
         // ---- compute phase
         __builtin_amdgcn_s_setprio(1);
@@ -343,14 +358,29 @@ __global__ __launch_bounds__(kRingThreads, 2) void gemm_bf16_ring_kernel(const u
         __builtin_amdgcn_s_setprio(0);
         if (!grpB) ring_wait_steps(keep);
         __builtin_amdgcn_sched_barrier(0);
+#ifdef RASS_GEMM_PHASE_TIMERS
+        const unsigned long long pt3 = clock64();
+#endif
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+#ifdef RASS_GEMM_PHASE_TIMERS
+        {
+            const unsigned long long pt4 = clock64();
+            ph_load += pt1 - pt0; ph_bar1 += pt2 - pt1; ph_comp += pt3 - pt2; ph_bar2 += pt4 - pt3;
+        }
+#endif
         slot = slot + 1 >= kRingSlots ? 0 : slot + 1;
     }
     if (!grpB) __builtin_amdgcn_s_barrier();  // both groups execute the same number of barriers
 #ifdef RASS_GEMM_CLOCKS
     if (threadIdx.x == 0) g_gemm_clocks[4 * blockIdx.x + 2] = wall_clock64();
     if (threadIdx.x == 0 && blockIdx.x < 64) g_gemm_core_cycles[blockIdx.x] = clock64() - core0;
+#endif
+#ifdef RASS_GEMM_PHASE_TIMERS
+    if (lane == 0 && (wave == 0 || wave == 4) && blockIdx.x < 64) {
+        unsigned long long* o = g_gemm_phase_cycles + (blockIdx.x * 2 + (wave >> 2)) * 4;
+        o[0] = ph_load; o[1] = ph_bar1; o[2] = ph_comp; o[3] = ph_bar2;
+    }
 #endif
 
     // Epilogue through LDS (free after the last barrier).  The accumulator layout gives every

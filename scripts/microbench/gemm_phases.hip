@@ -47,6 +47,19 @@ int main() {
         for (int i = 0; i < 64; ++i) { cyc += (double)core[i]; lp += (c[4 * i + 2] - c[4 * i + 1]) * 0.01; }
         printf("  K loop of blocks 0-63: %.0f s_memtime ticks in %.1f us -> %.0f MHz; per K step %.0f ticks\n", cyc / 64, lp / 64,
                cyc / lp, cyc / 64 / (K / 32));
+#ifdef RASS_GEMM_PHASE_TIMERS
+        {
+            unsigned long long ph[64 * 2 * 4];
+            CK(hipMemcpyFromSymbol(ph, HIP_SYMBOL(rass::g_gemm_phase_cycles), sizeof(ph)));
+            for (int g = 0; g < 2; ++g) {
+                double v[4] = {0, 0, 0, 0};
+                for (int b = 0; b < 64; ++b) for (int x = 0; x < 4; ++x) v[x] += (double)ph[(b * 2 + g) * 4 + x];
+                const double steps = 64.0 * (K / 32);
+                printf("  group %c per K step (s_memtime ticks, timers perturb): load %.0f  barrier1 %.0f  compute+wait %.0f  barrier2 %.0f\n",
+                       g ? 'B' : 'A', v[0] / steps, v[1] / steps, v[2] / steps, v[3] / steps);
+            }
+        }
+#endif
         double pro = 0, loop = 0, ep = 0, tot = 0;
         unsigned long long t0 = ~0ull, t1 = 0;
         for (int i = 0; i < grid; ++i) {

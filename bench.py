@@ -31,7 +31,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--rows-per-gpu", type=int, default=1_000_000)
     ap.add_argument("--rows-global", type=int, default=0,
                     help="STRONG scaling instead: a fixed global corpus (BASELINE configs[3]: 10000000) split "

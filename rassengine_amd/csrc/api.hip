@@ -209,18 +209,19 @@ int index_reserve(rass_index* idx, int64_t need_rows) {
 // scripts/microbench/scan_tail.hip and with bench.py).  RASS_SCAN_XCD_SKEW="a" or "a,b" overrides
 // the defaults for query batches <= 16 / > 16 (0 = plain round-robin).
 int scan_xcd_skew(int nq) {
-    static int skew16 = -1, skew32 = -1;
-    if (skew16 < 0) {
-        int a = 4, b = 0;  // bench.py sweeps: B<=16 603 -> 582 us at skew 4; no gain at B=32 (MFMA/power-bound)
-        if (const char* e = getenv("RASS_SCAN_XCD_SKEW")) {
-            const int n = sscanf(e, "%d,%d", &a, &b);
-            if (n == 1) b = a;
-            if (n < 1 || a < 0 || b < 0 || a > 4096 || b > 4096) a = 4, b = 0;
+    struct Skew {
+        int b16 = 4, b32 = 0;  // bench.py sweeps: B<=16 603 -> 582 us at skew 4; no gain at B=32 (MFMA/power-bound)
+        Skew() {
+            if (const char* e = getenv("RASS_SCAN_XCD_SKEW")) {
+                int a = 0, b = 0;
+                const int n = sscanf(e, "%d,%d", &a, &b);
+                if (n == 1) b = a;
+                if (n >= 1 && a >= 0 && b >= 0 && a <= 4096 && b <= 4096) b16 = a, b32 = b;
+            }
         }
-        skew32 = b;
-        skew16 = a;
-    }
-    return nq <= 16 ? skew16 : skew32;
+    };
+    static const Skew skew;  // C++11: initialised once, thread-safe
+    return nq <= 16 ? skew.b16 : skew.b32;
 }
 
 int scan_launch(const float* d_corpus, int64_t n_rows, int64_t stride, const int32_t* d_row_tag,
@@ -779,6 +780,16 @@ int rass_index_load(rass_engine_t* eng, const char* name, const char* path, rass
     if (h.dim != eng->dim || h.dtype != RASS_F32 || h.rows < 0) {
         fclose(f);
         return fail(RASS_ERR_INVALID, "index file does not match the engine (dim / dtype)");
+    }
+    {   // the header's row count must agree with the file length before anything is allocated from it
+        const long body = ftell(f);
+        int64_t file_len = -1;
+        if (body >= 0 && fseek(f, 0, SEEK_END) == 0) file_len = (int64_t)ftell(f);
+        const int64_t need = (int64_t)sizeof(SaveHeader) + h.rows * ((int64_t)h.dim * 4 + 4);
+        if (body < 0 || h.rows > ((int64_t)1 << 40) || file_len < need || fseek(f, body, SEEK_SET) != 0) {
+            fclose(f);
+            return fail(RASS_ERR_IO, "truncated index file (shorter than its header says)");
+        }
     }
     {
         std::lock_guard<std::mutex> lk(eng->mu);

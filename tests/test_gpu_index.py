@@ -107,6 +107,23 @@ def test_save_load_roundtrip(engine, oracle, tmp_path):
     assert np.array_equal(i1, i2) and np.array_equal(s1, s2)
     for r in (0, 5, 776):
         assert np.array_equal(idx.get_row(r), idx2.get_row(r))
+    # a file shorter than its header claims, or with an absurd row count, is refused before any
+    # allocation is sized from it
+    from rassengine_amd._native import RassError
+    blob = open(path, "rb").read()
+    cut = os.path.join(str(tmp_path), "cut.rass")
+    open(cut, "wb").write(blob[: len(blob) // 2])
+    with pytest.raises(RassError, match="truncated"):
+        engine.load_index("t-save-cut", cut)
+    huge = bytearray(blob)
+    huge[24:32] = (1 << 45).to_bytes(8, "little")          # SaveHeader.rows
+    bad = os.path.join(str(tmp_path), "huge.rass")
+    open(bad, "wb").write(bytes(huge))
+    with pytest.raises(RassError, match="truncated"):
+        engine.load_index("t-save-huge", bad)
+    with pytest.raises(RassError, match="not a rass index"):
+        open(bad, "wb").write(b"garbage" * 10)
+        engine.load_index("t-save-garbage", bad)
 
 
 def test_errors_are_reported_not_thrown(engine):

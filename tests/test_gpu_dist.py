@@ -66,3 +66,75 @@ def test_two_rank_sharded_search_equals_single_index(gpu, tmp_path):
     assert np.array_equal(r0["i"], i)
     assert np.array_equal(r0["s"], s)
     assert (r0["i"] >= n_local).any() and (r0["i"] < n_local).any()   # hits come from both shards
+
+
+def _ivf_worker(rank, world, port, n_local, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from rassengine_amd.dist import ShardedSearch
+        from rassengine_amd.engine import Engine
+        from rassengine_amd.ivf import IvfIndex, IvfShard, train_centroids
+        torch.cuda.set_device(0)
+        eng = Engine(0, 1024)
+        idx = eng.open_index("shard", capacity_rows=n_local)
+        idx.fill_synthetic(n_local, seed=78, row_id_base=rank * n_local)
+        idx.delete(3)                                       # one tombstone per shard
+        eng.synchronize()
+        # shared centroids: k-means sums all-reduced over the ranks (every rank ends with the same ones)
+        cent = train_centroids(idx, nlist=64, iters=4, seed=2)
+        ivf = IvfIndex.build(idx, nlist=64, centroids=cent)
+        g = torch.Generator(device="cuda")
+        g.manual_seed(6)
+        q_all = torch.randn((12, 1024), generator=g, device="cuda")
+        q = q_all.clone() if rank == 0 else torch.zeros_like(q_all)
+        out = {"cent": cent.cpu().numpy()}
+        for nprobe in (64, 4):
+            s, i = ShardedSearch(IvfShard(ivf, id_base=rank * n_local, nprobe=nprobe)).search(q, 10)
+            torch.cuda.synchronize()
+            out[f"s{nprobe}"] = s.cpu().numpy()
+            out[f"i{nprobe}"] = i.cpu().numpy()
+        out["q"] = q.cpu().numpy()
+        np.savez(os.path.join(out_dir, f"ivf_rank{rank}.npz"), **out)
+        ivf.close()
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_ivf_shards_share_centroids_and_match_flat(gpu, tmp_path):
+    """cfg 5's structure on 2 ranks: centroids trained with an all-reduce, per-rank inverted lists
+    over the rank's own rows, per-shard top-k merged after one all-gather.  Probing every list
+    must reproduce the flat single-index answer (tombstones included); a partial probe must be
+    identical on both ranks and contain only true scores."""
+    import torch.multiprocessing as mp
+    from rassengine_amd.engine import Engine
+    n_local, world = 20000, 2
+    mp.spawn(_ivf_worker, args=(world, _free_port(), n_local, str(tmp_path)), nprocs=world, join=True)
+    r0 = np.load(os.path.join(str(tmp_path), "ivf_rank0.npz"))
+    r1 = np.load(os.path.join(str(tmp_path), "ivf_rank1.npz"))
+    assert np.array_equal(r0["cent"], r1["cent"])
+    for key in ("i64", "s64", "i4", "s4", "q"):
+        assert np.array_equal(r0[key], r1[key]), key
+    eng = Engine(0, 1024)
+    try:
+        whole = eng.open_index("whole", capacity_rows=world * n_local)
+        whole.fill_synthetic(world * n_local, seed=78, row_id_base=0)
+        whole.delete(3)
+        whole.delete(n_local + 3)
+        s, i = whole.search(r0["q"], 10)
+    finally:
+        eng.close()
+    assert np.array_equal(r0["i64"], i) and np.array_equal(r0["s64"], s)
+    truth = {(qq, int(a)): float(b) for qq in range(i.shape[0]) for a, b in zip(i[qq], s[qq])}
+    hits = 0
+    for qq in range(i.shape[0]):
+        for a, b in zip(r0["i4"][qq], r0["s4"][qq]):
+            if (qq, int(a)) in truth:
+                assert truth[(qq, int(a))] == float(b)
+                hits += 1
+    assert hits > 0

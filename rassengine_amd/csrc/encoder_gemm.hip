@@ -49,16 +49,19 @@ __device__ __forceinline__ u16 f32_to_bf16(float f) {
 // exact arithmetic, 5e-7 in fp32: two orders below bf16 resolution of the output).  libm's
 // erff costs ~3x the epilogue budget: the FFN-up GEMM ran at 510 TF/s with it vs 780 without.
 __device__ __forceinline__ float gelu_erf(float x) {
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    // With h = |x|/2, z = |x|/sqrt2 = h*sqrt2:  GELU(x) = max(x, 0) - h * (1 - erf(z)), and
+    // 1 - erf(z) = p(t) * exp(-z^2), t = 1/(1 + 0.3275911 z).  All constants folded onto h:
+    // 12 VALU + rcp + exp2 per element (the plain transcription costs 16 + 2).
+    const float h = 0.5f * fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.46328375849f, h, 1.0f));   // 0.3275911 * sqrt2
     float p = fmaf(1.061405429f, t, -1.453152027f);
     p = fmaf(p, t, 1.421413741f);
     p = fmaf(p, t, -0.284496736f);
     p = fmaf(p, t, 0.254829592f);
     p *= t;
-    const float e = __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);
-    const float erf_abs = fmaf(-p, e, 1.0f);
-    return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+    const float zz = h * 1.69864357838f;                                   // sqrt(2 * log2(e)) * h: zz^2 = z^2 * log2(e)
+    const float e = __builtin_amdgcn_exp2f(-zz * zz);
+    return fmaf(-h, p * e, fmaxf(x, 0.0f));
 }
 
 // Stage one 128 x 64 bf16 operand tile (rows row0.., columns k0..k0+63 of a [rows][ld] matrix)
@@ -485,198 +488,271 @@ static hipError_t launch_ring(const u16* X, const u16* W, const float* bias, con
 }
 
 // ------------------------------------------------------------------------------------------
-// "Duo" kernel: the ring pipeline with 4-wave blocks so that TWO blocks share a CU.
-// 128 (N) x 256 (M) x 32 (K) tiles, 256 threads = 2 (N) x 2 (M) waves, each wave 64 x 128 =
-// 4 x 8 MFMA tiles (the same 32 MFMAs / 12 fragment reads per step as the ring kernel, 6 DMA
-// pieces per wave and step instead of 4), 3 LDS slots of 24 KiB = 72 KiB per block.  The two
-// blocks of a CU have separate barriers, so their phases drift apart: one block's epilogue
-// (the output write, ~25 % of a K=1024 GEMM when nothing overlaps it) and prologue run beside
-// the other block's mainloop, and on each SIMD the two waves (one per block) interleave MFMA
-// with DMA issue / LDS reads without an explicit stagger.
-constexpr int DBN = 128, DBM = 256;
-constexpr int kDuoThreads = 256;
-constexpr int kDuoWBytes = DBN * RBK * 2;             // 8 KiB
-constexpr int kDuoXBytes = DBM * RBK * 2;             // 16 KiB
-constexpr int kDuoSlotBytes = kDuoWBytes + kDuoXBytes;  // 24 KiB
+// Persistent form of the ring kernel: one workgroup per CU walks tiles pos, pos+G, pos+2G, ...
+// Per tile the non-persistent kernel pays ~2 us of pipeline prologue (first DMAs in flight, MFMA
+// idle) and ~2 us of block turnover (wave launch, drain of the last stores before the block
+// retires) on top of a ~28 us K loop and a 6-9 us epilogue (scripts/microbench/gemm_phases.hip).
+// Here the first kRingAhead K steps of the NEXT tile are put in flight right after the K loop and
+// land during the epilogue, and the epilogue's stores drain under the next tile's K loop.
+// LDS: the ring (3 x 32 KiB) + epilogue staging that must not overlap slots 0/1 (prefetch target):
+// waves 0-2 stage in slot 2, waves 3-7 behind the ring.
+constexpr int kPringStageBytes = 32 * 68 * 4;                                          // 8704 B per wave
+constexpr int kPringLdsBytes = kRingSlots * kRingSlotBytes + 5 * kPringStageBytes;     // 141 824 B
+static_assert(kRingSlots == 3 && 3 * kPringStageBytes <= kRingSlotBytes, "epilogue staging layout assumes a 3-slot ring");
+
+// K-loop fragment read as opaque asm: hipcc's waitcnt pass orders every LDS access it can see after
+// the LDS-DMA (global_load_lds) ops still in flight — in two of the three epilogue variants of the
+// persistent kernel it put a vmcnt(0) in front of the fragment reads of EVERY K step (K loop 45 us
+// instead of 28).  The DMA / read ordering is this kernel's own protocol (counted vmcnt + barrier).
+#define RASS_DS_READ_B128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
 
 template <int EPI>
-__global__ __launch_bounds__(kDuoThreads, 2) void gemm_bf16_duo_kernel(const u16* __restrict__ X,
-                                                                      const u16* __restrict__ W,
-                                                                      const float* __restrict__ bias,
-                                                                      const u16* __restrict__ residual,
-                                                                      u16* __restrict__ Y, int M, int N, int K) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // [3 slots][W tile | X tile]
+__global__ __launch_bounds__(kRingThreads, 2) void gemm_bf16_pring_kernel(const u16* __restrict__ X,
+                                                                         const u16* __restrict__ W,
+                                                                         const float* __restrict__ bias,
+                                                                         const u16* __restrict__ residual,
+                                                                         u16* __restrict__ Y, int M, int N, int K,
+                                                                         int tiles_total) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wn = wave >> 1, wm = wave & 1;
-    const int nblk = gridDim.x, orig = blockIdx.x;
-    const int q = nblk / 8, rr = nblk % 8, xcd = orig % 8;
-    const int bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + orig / 8;
-    const int tiles_n = N / DBN;
-    const int bn = bid % tiles_n, bm = bid / tiles_n;
-    const int n0 = bn * DBN, m0 = bm * DBM;
-
-    f32x4 acc[4][8];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
+    const int wn = wave >> 2, wm = wave & 3;
+    const int G = gridDim.x, orig = blockIdx.x;
+    // position inside a round of G tiles: XCD x (= blockIdx % 8) owns a contiguous eighth, so the
+    // N tiles that share an X panel run on one XCD (one L2) at the same time
+    const int pos = (G % 8 == 0) ? (orig % 8) * (G / 8) + orig / 8 : orig;
+    int tile = pos;
+    if (tile >= tiles_total) return;
+    const int tiles_n = N / RBN;
     const int nk = K / RBK;
-    // DMA pieces of 16 rows: W tile has 8 (wave moves 2), X tile has 16 (wave moves 4)
+    const int pre = nk < kRingAhead ? nk : kRingAhead;
+
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    unsigned offA0, offB0;
+    {
+        const int rowA = wn * 128 + (lane & 15), rowB = wm * 64 + (lane & 15);
+        offA0 = rowA * 64 + (((lane >> 4) ^ (((rowA >> 3) & 1) * 3)) * 16);
+        offB0 = kRingTileBytes + rowB * 64 + (((lane >> 4) ^ (((rowB >> 3) & 1) * 3)) * 16);
+    }
     const u16* srcW[2];
-    const u16* srcX[4];
+    const u16* srcX[2];
+    auto point_at = [&](int t) {
+        const int tn0 = (t % tiles_n) * RBN, tm0 = (t / tiles_n) * RBM;
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const int r = (wave + 4 * p) * 16 + (lane >> 2);
-        srcW[p] = W + (int64_t)(n0 + r) * K + ((lane & 3) ^ (((r >> 3) & 1) * 3)) * 8;
-    }
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int r = (wave + 4 * p) * 16 + (lane >> 2);
-        srcX[p] = X + (int64_t)(m0 + r) * K + ((lane & 3) ^ (((r >> 3) & 1) * 3)) * 8;
-    }
-    int offA[4], offB[8];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = wn * 64 + i * 16 + (lane & 15);
-        offA[i] = row * 64 + (((lane >> 4) ^ (((row >> 3) & 1) * 3)) * 16);
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int row = wm * 128 + j * 16 + (lane & 15);
-        offB[j] = kDuoWBytes + row * 64 + (((lane >> 4) ^ (((row >> 3) & 1) * 3)) * 16);
-    }
+        for (int p = 0; p < 2; ++p) {
+            const int r = (wave + 8 * p) * 16 + (lane >> 2);
+            const int c_src = (lane & 3) ^ (((r >> 3) & 1) * 3);
+            srcW[p] = W + (int64_t)(tn0 + r) * K + c_src * 8;
+            srcX[p] = X + (int64_t)(tm0 + r) * K + c_src * 8;
+        }
+    };
     auto stage_step = [&](unsigned char* slot_base) {
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)srcW[p],
-                                             (__attribute__((address_space(3))) void*)(slot_base + (wave + 4 * p) * 1024),
+                                             (__attribute__((address_space(3))) void*)(slot_base + (wave + 8 * p) * 1024),
                                              16, 0, 0);
-            srcW[p] += RBK;
-        }
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
             __builtin_amdgcn_global_load_lds(
                 (const __attribute__((address_space(1))) void*)srcX[p],
-                (__attribute__((address_space(3))) void*)(slot_base + kDuoWBytes + (wave + 4 * p) * 1024), 16, 0, 0);
+                (__attribute__((address_space(3))) void*)(slot_base + kRingTileBytes + (wave + 8 * p) * 1024), 16, 0, 0);
+            srcW[p] += RBK;
             srcX[p] += RBK;
         }
     };
-    stage_step(lds);
-    if (nk > 1) {
-        stage_step(lds + kDuoSlotBytes);
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    float* const stg = reinterpret_cast<float*>(wave < 3 ? lds + 2 * kRingSlotBytes + wave * kPringStageBytes
+                                                         : lds + kRingSlots * kRingSlotBytes + (wave - 3) * kPringStageBytes);
+    const bool grpB = wave >= 4;
+
+    point_at(tile);
+    for (int s0 = 0; s0 < pre; ++s0) stage_step(lds + s0 * kRingSlotBytes);
+    ring_wait_steps(pre - 1);
     __builtin_amdgcn_s_barrier();
 
-    // RAW: slot t+1 is read one iteration after the counted wait + barrier that retired it.
-    // WAR: slot (t+2)%3 == (t-1)%3 was last read in iteration t-1, whose closing barrier every
-    // wave has passed (with its LDS reads drained: lgkmcnt(0)) before any wave issues the DMAs.
-    int slot = 0;
-    for (int t = 0; t < nk; ++t) {
-        const bool more = t + 2 < nk;
-        if (more) {
-            int s2 = slot + 2;
-            s2 = s2 >= 3 ? s2 - 3 : s2;
-            stage_step(lds + s2 * kDuoSlotBytes);
-        }
-        const unsigned char* buf = lds + slot * kDuoSlotBytes;
-        bf16x8 a[4], b[8];
+    for (;;) {
+        const int n0 = (tile % tiles_n) * RBN, m0 = (tile / tiles_n) * RBM;
+#ifdef RASS_GEMM_CLOCKS
+        if (threadIdx.x == 0) g_gemm_clocks[4 * tile] = g_gemm_clocks[4 * tile + 1] = wall_clock64();
+#endif
+        f32x4 acc[8][4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8*>(buf + offA[i]);
+        for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) b[j] = *reinterpret_cast<const bf16x8*>(buf + offB[j]);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        if (more) {
-            asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        slot = slot + 1 >= 3 ? 0 : slot + 1;
-    }
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // Epilogue through LDS: 32-token x 64-feature fp32 chunks per wave (18 KiB private region),
-    // written back as 16-byte stores, 128 contiguous bytes per token row.
-    {
-        constexpr int kPitchF = 68;
-        float* stg = reinterpret_cast<float*>(lds + wave * (3 * kDuoSlotBytes / 4));
-        const int tl = lane >> 3, nq = lane & 7;
-#pragma unroll
-        for (int jc = 0; jc < 4; ++jc) {  // 4 x 32 tokens = the wave's 128 tokens
-            // stage: all 4 i tiles (64 features), j = 2jc, 2jc+1
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                for (int ii = 0; ii < 4; ++ii)
-                    *reinterpret_cast<f32x4*>(stg + (jj * 16 + (lane & 15)) * kPitchF + ii * 16 + (lane >> 4) * 4) =
-                        acc[ii][2 * jc + jj];
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            const int nbase = n0 + wn * 64 + nq * 8;
-            const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + nbase);
-            const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias + nbase + 4);
-#pragma unroll
-            for (int pass = 0; pass < 4; ++pass) {
-                const int tok = pass * 8 + tl;
-                const int m = m0 + wm * 128 + jc * 32 + tok;
-                f32x4 v0 = *reinterpret_cast<const f32x4*>(stg + tok * kPitchF + nq * 8);
-                f32x4 v1 = *reinterpret_cast<const f32x4*>(stg + tok * kPitchF + nq * 8 + 4);
-                v0 += b0;
-                v1 += b1;
-                if (m < M) {
-                    if (EPI == 1) {
-                        const uint4 r = *reinterpret_cast<const uint4*>(residual + (int64_t)m * N + nbase);
-                        v0.x += bf16_to_f32((u16)(r.x & 0xffff));
-                        v0.y += bf16_to_f32((u16)(r.x >> 16));
-                        v0.z += bf16_to_f32((u16)(r.y & 0xffff));
-                        v0.w += bf16_to_f32((u16)(r.y >> 16));
-                        v1.x += bf16_to_f32((u16)(r.z & 0xffff));
-                        v1.y += bf16_to_f32((u16)(r.z >> 16));
-                        v1.z += bf16_to_f32((u16)(r.w & 0xffff));
-                        v1.w += bf16_to_f32((u16)(r.w >> 16));
-                    }
-                    if (EPI == 2) {
-                        v0.x = gelu_erf(v0.x); v0.y = gelu_erf(v0.y); v0.z = gelu_erf(v0.z); v0.w = gelu_erf(v0.w);
-                        v1.x = gelu_erf(v1.x); v1.y = gelu_erf(v1.y); v1.z = gelu_erf(v1.z); v1.w = gelu_erf(v1.w);
-                    }
-                    uint4 o;
-                    o.x = (unsigned)f32_to_bf16(v0.x) | ((unsigned)f32_to_bf16(v0.y) << 16);
-                    o.y = (unsigned)f32_to_bf16(v0.z) | ((unsigned)f32_to_bf16(v0.w) << 16);
-                    o.z = (unsigned)f32_to_bf16(v1.x) | ((unsigned)f32_to_bf16(v1.y) << 16);
-                    o.w = (unsigned)f32_to_bf16(v1.z) | ((unsigned)f32_to_bf16(v1.w) << 16);
-                    *reinterpret_cast<uint4*>(Y + (int64_t)m * N + nbase) = o;
-                }
+        // ---- K loop: identical to gemm_bf16_ring_kernel (group B one phase behind group A)
+        if (grpB) __builtin_amdgcn_s_barrier();
+        int slot = 0;
+        for (int t = 0; t < nk; ++t) {
+            const bool more = t + kRingAhead < nk;
+            const int keep = more ? kRingAhead - 1 : (nk - 2 - t > 0 ? nk - 2 - t : 0);
+            if (more) {
+                int s2 = slot + kRingAhead;
+                s2 = s2 >= kRingSlots ? s2 - kRingSlots : s2;
+                stage_step(lds + s2 * kRingSlotBytes);
+            }
+            bf16x8 a[8], b[4];
+            {
+                // fragment i / j of a slot sits i / j KiB after fragment 0 (16 rows x 64 B; the swizzle
+                // term only depends on lane bits)
+                const unsigned ab = lds_base + slot * kRingSlotBytes + offA0;
+                const unsigned bb = lds_base + slot * kRingSlotBytes + offB0;
+                RASS_DS_READ_B128(b[0], bb, 0);
+                RASS_DS_READ_B128(b[1], bb, 1024);
+                RASS_DS_READ_B128(b[2], bb, 2048);
+                RASS_DS_READ_B128(b[3], bb, 3072);
+                RASS_DS_READ_B128(a[0], ab, 0);
+                RASS_DS_READ_B128(a[1], ab, 1024);
+                RASS_DS_READ_B128(a[2], ab, 2048);
+                RASS_DS_READ_B128(a[3], ab, 3072);
+                RASS_DS_READ_B128(a[4], ab, 4096);
+                RASS_DS_READ_B128(a[5], ab, 5120);
+                RASS_DS_READ_B128(a[6], ab, 6144);
+                RASS_DS_READ_B128(a[7], ab, 7168);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (grpB) ring_wait_steps(keep);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            if (!grpB) ring_wait_steps(keep);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            slot = slot + 1 >= kRingSlots ? 0 : slot + 1;
         }
+        if (!grpB) __builtin_amdgcn_s_barrier();  // groups re-aligned: every ring read is done, no DMA in flight
+#ifdef RASS_GEMM_CLOCKS
+        if (threadIdx.x == 0) g_gemm_clocks[4 * tile + 2] = wall_clock64();
+#endif
+
+        // ---- next tile's first K steps go out now and land under the epilogue (slots 0 .. pre-1)
+        const int next = tile + G;
+        const bool has_next = next < tiles_total;
+        if (has_next) {
+            point_at(next);
+            for (int s0 = 0; s0 < pre; ++s0) stage_step(lds + s0 * kRingSlotBytes);
+        }
+
+        // ---- epilogue (see gemm_bf16_ring_kernel): LDS transpose per wave, coalesced 16-B stores
+        {
+            constexpr int kPitchF = 68;
+            const int tl = lane >> 3, nq = lane & 7;
+            // Bias through opaque asm loads, retired by the explicit vmcnt(0) below: a load hipcc can
+            // see stays "possibly pending" on its destination registers across the tile loop, and
+            // when the K loop's fragment reads get the same registers the waitcnt pass protects them
+            // with a vmcnt(0) in EVERY K step (seen in two of the three epilogue variants).
+            f32x4 bv[2][2];
+#pragma unroll
+            for (int ic = 0; ic < 2; ++ic) {
+                const float* bp = bias + n0 + wn * 128 + ic * 64 + nq * 8;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bv[ic][0]) : "v"(bp));
+                asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(bv[ic][1]) : "v"(bp));
+            }
+#pragma unroll
+            for (int jc = 0; jc < 2; ++jc) {
+#pragma unroll
+                for (int ic = 0; ic < 2; ++ic) {
+                    const int nbase = n0 + wn * 128 + ic * 64 + nq * 8;
+                    uint4 res[4];
+                    if (EPI == 1) {
+#pragma unroll
+                        for (int pass = 0; pass < 4; ++pass) {
+                            const int m = m0 + wm * 64 + jc * 32 + pass * 8 + tl;
+                            res[pass] = m < M ? *reinterpret_cast<const uint4*>(residual + (int64_t)m * N + nbase)
+                                              : uint4{0u, 0u, 0u, 0u};
+                        }
+                    }
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                        for (int ii = 0; ii < 4; ++ii)
+                            *reinterpret_cast<f32x4*>(stg + (jj * 16 + (lane & 15)) * kPitchF + ii * 16 + (lane >> 4) * 4) =
+                                acc[4 * ic + ii][2 * jc + jj];
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (jc == 0 && ic == 0) {
+                        // Explicit: this wave's prefetch DMAs (and the bias / first residual reads issued
+                        // after them) are complete before anything below consumes them and before the
+                        // publishing barrier after the epilogue.  No store is outstanding yet.
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
+#pragma unroll
+                    for (int pass = 0; pass < 4; ++pass) {
+                        const int tok = pass * 8 + tl;
+                        const int m = m0 + wm * 64 + jc * 32 + tok;
+                        f32x4 v0 = *reinterpret_cast<const f32x4*>(stg + tok * kPitchF + nq * 8);
+                        f32x4 v1 = *reinterpret_cast<const f32x4*>(stg + tok * kPitchF + nq * 8 + 4);
+                        v0 += bv[ic][0];
+                        v1 += bv[ic][1];
+                        if (EPI == 1) {
+                            const uint4 r = res[pass];
+                            v0.x += bf16_to_f32((u16)(r.x & 0xffff));
+                            v0.y += bf16_to_f32((u16)(r.x >> 16));
+                            v0.z += bf16_to_f32((u16)(r.y & 0xffff));
+                            v0.w += bf16_to_f32((u16)(r.y >> 16));
+                            v1.x += bf16_to_f32((u16)(r.z & 0xffff));
+                            v1.y += bf16_to_f32((u16)(r.z >> 16));
+                            v1.z += bf16_to_f32((u16)(r.w & 0xffff));
+                            v1.w += bf16_to_f32((u16)(r.w >> 16));
+                        }
+                        if (EPI == 2) {
+                            v0.x = gelu_erf(v0.x); v0.y = gelu_erf(v0.y); v0.z = gelu_erf(v0.z); v0.w = gelu_erf(v0.w);
+                            v1.x = gelu_erf(v1.x); v1.y = gelu_erf(v1.y); v1.z = gelu_erf(v1.z); v1.w = gelu_erf(v1.w);
+                        }
+                        if (m < M) {
+                            uint4 o;
+                            o.x = (unsigned)f32_to_bf16(v0.x) | ((unsigned)f32_to_bf16(v0.y) << 16);
+                            o.y = (unsigned)f32_to_bf16(v0.z) | ((unsigned)f32_to_bf16(v0.w) << 16);
+                            o.z = (unsigned)f32_to_bf16(v1.x) | ((unsigned)f32_to_bf16(v1.y) << 16);
+                            o.w = (unsigned)f32_to_bf16(v1.z) | ((unsigned)f32_to_bf16(v1.w) << 16);
+                            *reinterpret_cast<uint4*>(Y + (int64_t)m * N + nbase) = o;
+                        }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+            }
+        }
+#ifdef RASS_GEMM_CLOCKS
+        if (threadIdx.x == 0) g_gemm_clocks[4 * tile + 3] = wall_clock64();
+#endif
+        if (!has_next) break;
+        // The epilogue's stores stay in flight: they are older than every DMA of the next K loop in the
+        // in-order vmcnt queue, so the first counted wait there also retires them (they have had the
+        // whole first K step to drain).
+        // publish the next tile's first steps: every wave retired its own pieces (vmcnt(0) above)
+        // and finished reading its staging area (slot 2 is a DMA target again from step 0 on)
+        __builtin_amdgcn_s_barrier();
+        tile = next;
     }
 }
 
 template <int EPI>
-static hipError_t launch_duo(const u16* X, const u16* W, const float* bias, const u16* residual, u16* Y, int M,
-                             int M_pad, int N, int K, hipStream_t stream) {
-    constexpr int lds_bytes = 3 * kDuoSlotBytes;  // 72 KiB: two blocks per CU
+static hipError_t launch_pring(const u16* X, const u16* W, const float* bias, const u16* residual, u16* Y, int M,
+                               int M_pad, int N, int K, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_duo_kernel<EPI>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_pring_kernel<EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kPringLdsBytes);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    const int grid = (N / DBN) * (M_pad / DBM);
-    hipLaunchKernelGGL((gemm_bf16_duo_kernel<EPI>), dim3(grid), dim3(kDuoThreads), lds_bytes, stream, X, W, bias,
-                       residual, Y, M, N, K);
+    static int n_cus = 0;
+    if (n_cus == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cus <= 0)
+            n_cus = 256;
+    }
+    const int tiles_total = (N / RBN) * (M_pad / RBM);
+    const int grid = tiles_total < n_cus ? tiles_total : n_cus;
+    hipLaunchKernelGGL((gemm_bf16_pring_kernel<EPI>), dim3(grid), dim3(kRingThreads), kPringLdsBytes, stream, X, W, bias,
+                       residual, Y, M, N, K, tiles_total);
     return hipGetLastError();
 }
 
@@ -685,15 +761,14 @@ static hipError_t launch_epi(const u16* X, const u16* W, const float* bias, cons
                              int M_pad, int N, int K, hipStream_t stream) {
     // big shapes: the 256^2 ring kernel; small / odd shapes: the 128^2 kernel
     if (N % RBN == 0 && M_pad % RBM == 0 && K % RBK == 0 && M >= 1024) {
-        // Default: the 8-wave 256x256 ring kernel.  RASS_GEMM_VARIANT=duo selects the two-blocks-
-        // per-CU variant for A/B runs (measured slower: 720-935 vs 817-1105 TF/s; its 6 DMA pieces
-        // per 32 MFMAs cost more than the overlapped epilogue wins back).
-        static const bool use_duo = [] {
+        // Default: the persistent form of the 8-wave 256x256 ring kernel; RASS_GEMM_VARIANT=ring
+        // selects the one-tile-per-block form for A/B runs (scripts/microbench/gemm_phases.hip).
+        static const bool one_tile_blocks = [] {
             const char* v = getenv("RASS_GEMM_VARIANT");
-            return v != nullptr && strcmp(v, "duo") == 0;
+            return v != nullptr && strcmp(v, "ring") == 0;
         }();
-        if (use_duo) return launch_duo<EPI>(X, W, bias, residual, Y, M, M_pad, N, K, stream);
-        return launch_ring<EPI>(X, W, bias, residual, Y, M, M_pad, N, K, stream);
+        if (one_tile_blocks) return launch_ring<EPI>(X, W, bias, residual, Y, M, M_pad, N, K, stream);
+        return launch_pring<EPI>(X, W, bias, residual, Y, M, M_pad, N, K, stream);
     }
     constexpr int lds_bytes = 4 * kTileBytes;  // 64 KiB
     static bool attr_set = false;

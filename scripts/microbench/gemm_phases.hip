@@ -19,10 +19,14 @@ __global__ void fill_bf16(unsigned short* x, size_t n, unsigned seed) {
     }
 }
 
-int main() {
+int main(int argc, char**) {
     const int M = 131072;
-    const int shapes[4][3] = {{3072, 1024, 0}, {1024, 1024, 1}, {4096, 1024, 2}, {1024, 4096, 1}};
-    for (auto& sh : shapes) {
+    // the encoder's four GEMMs, then (with any argument) the epilogue / N cross terms
+    const int shapes[8][3] = {{3072, 1024, 0}, {1024, 1024, 1}, {4096, 1024, 2}, {1024, 4096, 1},
+                              {1024, 1024, 0}, {1024, 1024, 2}, {4096, 1024, 1}, {4096, 1024, 0}};
+    const int n_shapes = argc > 1 ? 8 : 4;
+    for (int si = 0; si < n_shapes; ++si) {
+        const int* sh = shapes[si];
         const int N = sh[0], K = sh[1], epi = sh[2];
         unsigned short *X, *W, *R, *Y; float* b;
         CK(hipMalloc(&X, (size_t)M * K * 2)); CK(hipMalloc(&W, (size_t)N * K * 2));

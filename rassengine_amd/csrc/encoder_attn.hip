@@ -2,18 +2,21 @@
 // encoder (BERT: bidirectional, heads of 64, S <= 512, softmax scale 1/8, key padding never
 // materialised because sequences are packed).  Replaces llama.cpp's attention behind Ollama.
 //
-// One workgroup (4 waves) per (sequence, head); the head's K [S][64] and V^T [64][S] live in
-// LDS for the whole workgroup (S <= 512: 64 KiB + 65 KiB), so K/V are fetched from HBM/L2
-// once per (sequence, head).  Each wave owns 16 queries per pass and streams 64-key blocks
-// with an online softmax.
+// One workgroup (16 waves) per (sequence, head); the head's K [S][64] and V [S][64] live in LDS
+// for the whole workgroup (S <= 512: 64 KiB + 80 KiB), so K/V are fetched from HBM/L2 once per
+// (sequence, head).  Each wave owns 16 queries per pass and streams 64-key blocks with an online
+// softmax.
 //
 // MFMA orientation (v_mfma_f32_16x16x32_bf16), chosen so NOTHING is transposed between the
 // two products (guide §3 "an accumulator tile as the next MFMA's operand"):
 //   S^T[key][q] = K[key][:] . Q[q][:]     A = K rows from LDS, B = Q (registers)
 //       -> lane (q = lane&15, g = lane>>4) holds scores of keys 16*kt + 4g + {0..3}
 //   O^T[d][q]  += V^T[d][key] . P^T[key][q]  B = the lane's own exponentiated scores packed
-//       to bf16 (k index 8g+j <-> key 32*kk + (j<4 ? 4g+j : 16+4g+j-4)), A = V^T read with
-//       the same k permutation (two 8-byte LDS reads).
+//       to bf16 (k index 8g+j <-> key 32*kk + (j<4 ? 4g+j : 16+4g+j-4)), A = V^T taken from the
+//       ROW-major V image with two ds_read_b64_tr_b16 (gfx950 transposing LDS read: a 16-lane
+//       group reads 4 keys x 16 d and lane i receives column d = i of the 4 keys) — V is staged
+//       with plain 16-byte writes like K, no transposed copy is built (the 2-byte scattered
+//       writes of a V^T image were 8-way bank conflicted: ~20 % of the kernel).
 // The softmax statistics of query q live in the 4 lanes that share lane&15.
 
 #include <hip/hip_runtime.h>
@@ -35,6 +38,7 @@ typedef unsigned short u16;
 constexpr int kAttnThreads = 1024;
 constexpr int kAttnWaves = kAttnThreads / 64;
 constexpr int kHeadDim = 64;
+constexpr int kVPitch = 160;  // bytes per V row in LDS (128 B of data)
 
 __device__ __forceinline__ u16 f2bf_a(float f) {
     __hip_bfloat16 h = __float2bfloat16(f);
@@ -43,10 +47,12 @@ __device__ __forceinline__ u16 f2bf_a(float f) {
 
 __global__ __launch_bounds__(kAttnThreads) void attention_kernel(const u16* __restrict__ qkv,
                                                                  const int32_t* __restrict__ cu, int hidden, int heads,
-                                                                 int s_pad, int vt_pitch, u16* __restrict__ ctx) {
+                                                                 int s_pad, u16* __restrict__ ctx) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    unsigned char* Kl = lds;                                          // [s_pad][128 B], chunk-swizzled
-    u16* Vt = reinterpret_cast<u16*>(lds + (size_t)s_pad * 128);      // [64][vt_pitch]
+    unsigned char* Kl = lds;                              // [s_pad][128 B], chunk-swizzled
+    unsigned char* Vl = lds + (size_t)s_pad * 128;        // [s_pad][kVPitch B]: row stride 40 dwords, so the 8
+                                                          // rows x 32 B one half-wave's transposed read touches
+                                                          // fall on 64 distinct banks
     const int seq = blockIdx.x / heads, head = blockIdx.x % heads;
     const int t0 = cu[seq];
     int S = cu[seq + 1] - t0;
@@ -58,7 +64,7 @@ __global__ __launch_bounds__(kAttnThreads) void attention_kernel(const u16* __re
     const u16* kbase = qbase + hidden;
     const u16* vbase = qbase + 2 * hidden;
 
-    // ---- stage K (swizzled rows) and V^T; keys >= S are zero (masked later, must be finite)
+    // ---- stage K (swizzled rows) and V (padded rows); keys >= S are zero (masked later, must be finite)
     for (int e = threadIdx.x; e < s_pad * 8; e += kAttnThreads) {
         const int key = e >> 3, c = e & 7;
         uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
@@ -67,12 +73,7 @@ __global__ __launch_bounds__(kAttnThreads) void attention_kernel(const u16* __re
             vv = *reinterpret_cast<const uint4*>(vbase + (int64_t)key * ld + c * 8);
         }
         *reinterpret_cast<uint4*>(Kl + key * 128 + ((c ^ ((key >> 1) & 7)) * 16)) = kv;
-        const unsigned w[4] = {vv.x, vv.y, vv.z, vv.w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            Vt[(c * 8 + 2 * i) * vt_pitch + key] = (u16)(w[i] & 0xffff);
-            Vt[(c * 8 + 2 * i + 1) * vt_pitch + key] = (u16)(w[i] >> 16);
-        }
+        *reinterpret_cast<uint4*>(Vl + key * kVPitch + c * 16) = vv;
     }
     __syncthreads();
 
@@ -105,37 +106,45 @@ __global__ __launch_bounds__(kAttnThreads) void attention_kernel(const u16* __re
                     s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[ks], s[kt], 0, 0, 0);
                 }
             }
-            // scale + mask; s[kt][r] is key kb*64 + kt*16 + 4g + r
-            float mx = -INFINITY;
+            // s[kt][r] is the raw score of key kb*64 + kt*16 + 4g + r.  The softmax runs in the exp2
+            // domain with the scale (1/8 * log2 e) folded into the exponent's fma, and is written to
+            // keep the VALU count per score low (this kernel is VALU-bound: 16 x 512 scores per wave
+            // and pass against 2 x 32 MFMAs): no per-score mask outside the last key block, max3
+            // chains, packed adds, and the O / l rescale only in blocks where some query's max grew.
+            constexpr float kScale = 0.18033688011112042f;
+            if (kb * 64 + 64 > S) {  // wave-uniform: only the last block of a ragged sequence
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
+                for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = kb * 64 + kt * 16 + 4 * g + r;
-                    // softmax in the exp2 domain: scale 1/8 and log2(e) folded into one multiply
-                    const float v = key < S ? s[kt][r] * 0.18033688011112042f : -INFINITY;
-                    s[kt][r] = v;
-                    mx = fmaxf(mx, v);
-                }
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                    for (int r = 0; r < 4; ++r)
+                        if (kb * 64 + kt * 16 + 4 * g + r >= S) s[kt][r] = -INFINITY;
+            }
+            float mx = fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3]));
+#pragma unroll
+            for (int kt = 1; kt < 4; ++kt) mx = fmaxf(fmaxf(mx, fmaxf(s[kt][0], s[kt][1])), fmaxf(s[kt][2], s[kt][3]));
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));  // (gfx950's v_permlane16/32_swap measured the same)
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run, mx);  // finite: key 0 of block 0 is always valid
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-            float rs = 0.f;
+            const float m_new = fmaxf(m_run, mx * kScale);  // finite: key 0 of block 0 is always valid
+            if (__any(m_new > m_run)) {
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // 1 where the max did not move
+                l_run *= alpha;
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
+                for (int dt = 0; dt < 4; ++dt) O[dt] *= alpha;
+                m_run = m_new;
+            }
+            const f32x4 negm = f32x4{-m_run, -m_run, -m_run, -m_run};
+            f32x4 rs4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(s[kt][r] - m_new);
-                    s[kt][r] = p;
-                    rs += p;
-                }
+            for (int kt = 0; kt < 4; ++kt) {
+                const f32x4 e = s[kt] * kScale + negm;  // v_pk_fma_f32 x2
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[kt][r] = __builtin_amdgcn_exp2f(e[r]);
+                rs4 += s[kt];
+            }
+            float rs = (rs4[0] + rs4[1]) + (rs4[2] + rs4[3]);
             rs += __shfl_xor(rs, 16, 64);
             rs += __shfl_xor(rs, 32, 64);
-            l_run = l_run * alpha + rs;
-            m_run = m_new;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) O[dt] *= alpha;
+            l_run += rs;
             // P^T fragments (B operand) for the two 32-key steps of this block
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
@@ -145,12 +154,14 @@ __global__ __launch_bounds__(kAttnThreads) void attention_kernel(const u16* __re
                     pf[r] = (short)f2bf_a(s[2 * kk][r]);
                     pf[4 + r] = (short)f2bf_a(s[2 * kk + 1][r]);
                 }
-                const int key0 = kb * 64 + kk * 32 + 4 * g;
+                // transposed read: lane 4q+p of a 16-lane group addresses key row q, columns 4p..4p+3
+                const unsigned char* vblk = Vl + (kb * 64 + kk * 32 + 4 * g + (qi >> 2)) * kVPitch + (qi & 3) * 8;
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
-                    const u16* vrow = Vt + (dt * 16 + qi) * vt_pitch + key0;  // A operand row = d (lane&15)
-                    const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vrow);
-                    const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vrow + 16);
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) bf16x4*)(vblk + dt * 32));
+                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) bf16x4*)(vblk + 16 * kVPitch + dt * 32));
                     bf16x8 vf;
                     vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
                     vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
@@ -178,8 +189,7 @@ hipError_t launch_attention(const void* qkv, const int32_t* cu_seqlens, int nseq
     if (hidden != heads * kHeadDim || max_seqlen < 1 || max_seqlen > 512) return hipErrorInvalidValue;
     if (nseq <= 0) return hipSuccess;
     const int s_pad = (max_seqlen + 63) / 64 * 64;
-    const int vt_pitch = (s_pad + 127) / 128 * 128 + 8;  // +8: conflict-free 8-byte column reads
-    const size_t lds_bytes = (size_t)s_pad * 128 + (size_t)kHeadDim * vt_pitch * 2;
+    const size_t lds_bytes = (size_t)s_pad * 128 + (size_t)s_pad * kVPitch;  // 144 KiB at S = 512
     static size_t attr_bytes = 0;
     if (lds_bytes > attr_bytes) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel),
@@ -188,8 +198,7 @@ hipError_t launch_attention(const void* qkv, const int32_t* cu_seqlens, int nseq
         attr_bytes = lds_bytes;
     }
     hipLaunchKernelGGL(attention_kernel, dim3(nseq * heads), dim3(kAttnThreads), lds_bytes, stream,
-                       static_cast<const u16*>(qkv), cu_seqlens, hidden, heads, s_pad, vt_pitch,
-                       static_cast<u16*>(ctx));
+                       static_cast<const u16*>(qkv), cu_seqlens, hidden, heads, s_pad, static_cast<u16*>(ctx));
     return hipGetLastError();
 }
 

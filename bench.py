@@ -163,6 +163,32 @@ def main():
 
     result["roofline"]["traffic"] = pmc_traffic(result["roofline"]["kernel"], bytes_per_launch)
 
+    # Outside the timed region, single GPU only: the same scan at the other batch sizes SURVEY §8d
+    # asks for (B <= 16 runs the NT=1 kernel variant, purely HBM-bound; B = 32 sits at the HBM / fp32-
+    # MFMA corner).  Reported next to the headline, never as `value`.
+    if world == 1 and not args.prefilter and rank == 0:
+        others = []
+        for Bo in (16, 1):
+            if Bo == B:
+                continue
+            qo = pool[:Bo].contiguous()
+            for _ in range(10):
+                search.search(qo, k)
+            torch.cuda.synchronize()
+            n_o = 100
+            eng.kernel_timing_begin(n_o)
+            t0 = time.perf_counter()
+            for _ in range(n_o):
+                search.search(qo, k)
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            ms_o, launches_o = eng.kernel_timing_end()
+            ach = bytes_per_launch * launches_o / (ms_o * 1e-3) / 1e9 if ms_o > 0 else 0.0
+            others.append({"query_batch": Bo, "queries_per_s": round(Bo * n_o / el, 1), "kernel": scan_kernel_name(dim, Bo),
+                           "avg_launch_us": round(ms_o / max(launches_o, 1) * 1e3, 2), "achieved": round(ach, 1),
+                           "frac": round(ach / HBM_PEAK_GBPS, 4)})
+        result["roofline_other_batches"] = others
+
     if rank == 0 and world == 1 and args.prefilter:
         # the flagged mode is approximate in principle: measure it against the exact flat scan
         qh = pool[:B].cpu().numpy()

@@ -22,7 +22,11 @@ def _cos(a, b):
                                        (1000, 3072, 1024, 0), (513, 1024, 4096, 1), (640, 4096, 1024, 2),
                                        # >= 1024 rows, N % 256 == 0: the 256^2 ring kernel
                                        (1024, 256, 32, 0), (1500, 1024, 1024, 1), (4096, 3072, 1024, 0),
-                                       (1100, 4096, 1024, 2), (1300, 1024, 4096, 1), (2048, 512, 96, 0)])
+                                       (1100, 4096, 1024, 2), (1300, 1024, 4096, 1), (2048, 512, 96, 0),
+                                       # more tiles than CUs: the persistent kernel walks several tiles per
+                                       # workgroup (next-tile prefetch under the epilogue), ragged last M tile
+                                       (70000, 1024, 1024, 1), (33000, 3072, 256, 0), (66000, 512, 64, 2),
+                                       (65537, 256, 32, 1)])
 def test_gemm_bf16_matches_torch(gpu, M, N, K, epi):
     torch = gpu
     from rassengine_amd import _native as N_

@@ -97,6 +97,11 @@ def main():
             q_buf.copy_(pool[(i % n_batches) * B:(i % n_batches + 1) * B])
         return search.search(q_buf, k)  # broadcast (N>1) + scan + all-gather + merge
 
+    # Initialisation, not a step: the first ~30 scans after the Philox fill kernel run 5-40 % slow while
+    # the clocks settle (profiles/r01_bench_1M_B32_kernel_stats.csv: 703 .. 989 .. 680 us); a caller's small
+    # --warmup would leave that transient inside the timed region.
+    for i in range(40):
+        step(i)
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()

@@ -58,6 +58,8 @@ def _run_scan(torch, xn, q_raw, k, dim, stride, tags=None, qfilter=None, id_base
     (3000, 384, 8, 10),
     (3000, 100, 4, 5),     # dim padded to 128
     (2500, 768, 20, 10),
+    (3000, 512, 32, 10),   # CH = 4
+    (9000, 500, 9, 4),     # dim padded to 512
     (5, 1024, 2, 10),      # fewer rows than k
     (45000, 256, 8, 10),   # full grid, B <= 16: XCD-skewed tile order, 1.2 super-rounds
     (100003, 128, 16, 7),  # ... 2.7 super-rounds, ragged last tile
@@ -286,3 +288,17 @@ def test_strided_merge_of_packed_records(gpu, oracle):
     rs, ri = oracle.merge(s.astype(np.float64), ids)
     assert np.array_equal(out_i.cpu().numpy(), ri)
     assert np.array_equal(out_s.cpu().numpy(), rs.astype(np.float32))
+
+
+def test_unsupported_row_stride_is_an_error_not_a_wrong_answer(gpu):
+    """dim 640 pads to a stride of 640 = 5 x 128, which no kernel variant covers: refused, loudly."""
+    from rassengine_amd._native import RassError
+    from rassengine_amd.engine import Engine
+    with pytest.raises((RassError, ValueError)):
+        eng = Engine(0, 640)
+        try:
+            idx = eng.open_index("odd")
+            idx.add(np.ones((4, 640), dtype=np.float32))
+            idx.search(np.ones((1, 640), dtype=np.float32), 1)
+        finally:
+            eng.close()

@@ -233,7 +233,7 @@ int scan_launch(const float* d_corpus, int64_t n_rows, int64_t stride, const int
     if (k < 1 || k > RASS_MAX_K) return fail(RASS_ERR_INVALID, "k must be in [1, RASS_MAX_K]");
     if (n_rows < 0 || n_rows > 0x7fffffc0LL) return fail(RASS_ERR_INVALID, "n_rows out of range for one scan");
     if (!rass::scan_supported_stride(stride) || stride > kMaxStride)
-        return fail(RASS_ERR_UNSUPPORTED, "row_stride must be 128*{1,2,3,4,6,8} elements");
+        return fail(RASS_ERR_UNSUPPORTED, "row_stride must be 128*{1..8} elements (dim <= 1024)");
     if (q_dim > stride) return fail(RASS_ERR_INVALID, "dim exceeds row_stride");
     const ScratchLayout L = scratch_layout(nq, k);
     if (ws == nullptr || ws_bytes < L.total) return fail(RASS_ERR_INVALID, "scan workspace too small");

@@ -369,7 +369,9 @@ static hipError_t launch_ch(int ch, const ScanArgs& a, int grid, hipStream_t str
         case 2: return launch_variant<2, NT, IVF>(a, grid, stream);
         case 3: return launch_variant<3, NT, IVF>(a, grid, stream);
         case 4: return launch_variant<4, NT, IVF>(a, grid, stream);
+        case 5: return launch_variant<5, NT, IVF>(a, grid, stream);
         case 6: return launch_variant<6, NT, IVF>(a, grid, stream);
+        case 7: return launch_variant<7, NT, IVF>(a, grid, stream);
         case 8: return launch_variant<8, NT, IVF>(a, grid, stream);
         default: return hipErrorInvalidValue;
     }
@@ -378,7 +380,7 @@ static hipError_t launch_ch(int ch, const ScanArgs& a, int grid, hipStream_t str
 bool scan_supported_stride(int64_t row_stride) {
     if (row_stride % 128 != 0) return false;
     const int64_t ch = row_stride / 128;
-    return ch == 1 || ch == 2 || ch == 3 || ch == 4 || ch == 6 || ch == 8;
+    return ch >= 1 && ch <= 8;
 }
 
 hipError_t launch_scan_topk_f32(const ScanArgs& a, int grid, hipStream_t stream) {

@@ -59,6 +59,9 @@ def _run_scan(torch, xn, q_raw, k, dim, stride, tags=None, qfilter=None, id_base
     (3000, 100, 4, 5),     # dim padded to 128
     (2500, 768, 20, 10),
     (3000, 512, 32, 10),   # CH = 4
+    (3000, 640, 32, 10),   # CH = 5
+    (2000, 896, 7, 5),     # CH = 7
+    (2000, 600, 32, 8),    # dim padded to 640
     (9000, 500, 9, 4),     # dim padded to 512
     (5, 1024, 2, 10),      # fewer rows than k
     (45000, 256, 8, 10),   # full grid, B <= 16: XCD-skewed tile order, 1.2 super-rounds
@@ -290,15 +293,15 @@ def test_strided_merge_of_packed_records(gpu, oracle):
     assert np.array_equal(out_s.cpu().numpy(), rs.astype(np.float32))
 
 
-def test_unsupported_row_stride_is_an_error_not_a_wrong_answer(gpu):
-    """dim 640 pads to a stride of 640 = 5 x 128, which no kernel variant covers: refused, loudly."""
+def test_dims_above_1024_are_refused_not_answered_wrongly(gpu):
+    """The scan covers row strides of 128 x {1..8}: dim 1100 has no kernel variant and must be refused."""
     from rassengine_amd._native import RassError
     from rassengine_amd.engine import Engine
     with pytest.raises((RassError, ValueError)):
-        eng = Engine(0, 640)
+        eng = Engine(0, 1100)
         try:
             idx = eng.open_index("odd")
-            idx.add(np.ones((4, 640), dtype=np.float32))
-            idx.search(np.ones((1, 640), dtype=np.float32), 1)
+            idx.add(np.ones((4, 1100), dtype=np.float32))
+            idx.search(np.ones((1, 1100), dtype=np.float32), 1)
         finally:
             eng.close()

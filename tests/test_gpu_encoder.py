@@ -112,6 +112,30 @@ def test_large_encoder_sample_matches_oracle(gpu, tmp_path_factory):
     assert np.all(c >= 0.999), c
 
 
+def test_base_shape_encoder_through_the_persistent_gemm(gpu, tmp_path_factory):
+    """BERT-base-class layers (768 x 12 heads x 3072, the bge-base / nomic class) with > 1024 packed
+    tokens: every linear goes through the persistent 256 x 256 ring GEMM (N % 256 == 0, M >= 1024),
+    attention through full 512-token and ragged sequences; pooled vectors vs the fp32 oracle."""
+    from oracle import bert_ref
+    from rassengine_amd.encoder import EncoderConfig, HipSentenceEncoder, write_random_model_dir
+    d = str(tmp_path_factory.mktemp("base_model"))
+    cfg = EncoderConfig(vocab_size=2000, hidden=768, layers=2, heads=12, intermediate=3072, max_positions=512,
+                        pooling="mean")
+    write_random_model_dir(d, cfg, seed=4)
+    rng = np.random.default_rng(5)
+    lens = (512, 300, 200, 129, 64, 17, 1)
+    seqs = [list(rng.integers(0, 2000, size=n)) for n in lens]
+    enc = HipSentenceEncoder.from_dir(d, device=0)
+    try:
+        got = enc.encode_ids(seqs)
+    finally:
+        enc.close()
+    ref = bert_ref.pool(bert_ref.forward_plain(d, seqs), "mean")
+    c = _cos(got, ref)
+    assert got.shape == (len(lens), 768) and np.all(np.isfinite(got))
+    assert np.all(c >= 0.999), c
+
+
 def test_embedding_shim_over_hip_encoder(gpu, tiny_model):
     """embed_texts_in_batches / embed_query (reference app/main.py:240-274) over the HIP encoder."""
     import asyncio

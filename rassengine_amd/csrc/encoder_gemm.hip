@@ -212,24 +212,6 @@ __device__ __forceinline__ void ring_wait_steps(int steps) {
     }
 }
 
-__device__ __forceinline__ void ring_stage(const u16* __restrict__ g, int64_t ld, int row0, int k0,
-                                           unsigned char* lds_tile, int wave, int lane) {
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const int piece = wave + 8 * p;          // 16 rows per piece
-        const int r = piece * 16 + (lane >> 2);  // tile row this lane fills
-        const int c_src = (lane & 3) ^ (((r >> 3) & 1) * 3);
-        const u16* src = g + (int64_t)(row0 + r) * ld + k0 + c_src * 8;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(lds_tile + piece * 1024), 16, 0, 0);
-    }
-}
-
-__device__ __forceinline__ bf16x8 ring_frag(const unsigned char* lds_tile, int row, int g) {
-    const int c = g ^ (((row >> 3) & 1) * 3);
-    return *reinterpret_cast<const bf16x8*>(lds_tile + row * 64 + c * 16);
-}
-
 template <int EPI>
 __global__ __launch_bounds__(kRingThreads, 2) void gemm_bf16_ring_kernel(const u16* __restrict__ X,
                                                                         const u16* __restrict__ W,

@@ -88,7 +88,7 @@ __device__ __forceinline__ void fold_group(Cand& run, const Cand& grp_sorted, in
 
 __global__ __launch_bounds__(kMergeThreads) void merge_topk_kernel(const float* __restrict__ scores,
                                                                    const int64_t* __restrict__ ids, int n_lists,
-                                                                   int nq, int k, float* __restrict__ out_scores,
+                                                                   int /*nq = gridDim.x*/, int k, float* __restrict__ out_scores,
                                                                    int64_t* __restrict__ out_ids,
                                                                    const int64_t* __restrict__ id_map,
                                                                    int64_t score_list_stride, int64_t id_list_stride) {

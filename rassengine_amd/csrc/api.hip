@@ -826,13 +826,18 @@ int rass_index_load(rass_engine_t* eng, const char* name, const char* path, rass
             (void)rass_index_drop(eng, name);
             return fail(RASS_ERR_IO, "truncated index file (tags)");
         }
-        std::lock_guard<std::mutex> lk(idx->mu);
-        hipError_t e = hipMemcpyAsync(idx->d_tags, tags.data(), (size_t)h.rows * 4, hipMemcpyHostToDevice, eng->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(eng->stream);
+        hipError_t e;
+        {
+            std::lock_guard<std::mutex> lk(idx->mu);
+            e = hipMemcpyAsync(idx->d_tags, tags.data(), (size_t)h.rows * 4, hipMemcpyHostToDevice, eng->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(eng->stream);
+        }
         if (e != hipSuccess) {
             fclose(f);
+            (void)rass_index_drop(eng, name);
             return fail(RASS_ERR_HIP, std::string("load: tag upload failed: ") + hipGetErrorString(e));
         }
+        std::lock_guard<std::mutex> lk(idx->mu);
         for (int64_t r = 0; r < h.rows; ++r) {
             if (tags[(size_t)r] == RASS_ROW_TAG_DELETED) {
                 idx->host_deleted[(size_t)(r >> 3)] |= (uint8_t)(1u << (r & 7));

@@ -173,28 +173,34 @@ int index_reserve(rass_index* idx, int64_t need_rows) {
     // rows of a block past the last appended one must read as finite zeros (they are masked,
     // never ranked): zero the part of the slab the copy below does not overwrite
     const int64_t used_rows = (idx->rows + 15) / 16 * 16;
-    HIP_TRY(hipMemsetAsync(nrows + used_rows * idx->stride, 0, (size_t)(cap - used_rows) * idx->stride * sizeof(float),
-                           st));
-    if (idx->rows > 0) {
-        HIP_TRY(hipMemcpyAsync(nrows, idx->d_rows, (size_t)used_rows * idx->stride * sizeof(float),
-                               hipMemcpyDeviceToDevice, st));
-        HIP_TRY(hipMemcpyAsync(ntags, idx->d_tags, (size_t)idx->rows * sizeof(int32_t), hipMemcpyDeviceToDevice,
-                               st));
-    }
     unsigned short* nb16 = nullptr;
-    if (idx->prefilter) {
-        e = hipMalloc(reinterpret_cast<void**>(&nb16), (size_t)cap * idx->stride * 2);
-        if (e != hipSuccess) {
-            (void)hipFree(nrows);
-            (void)hipFree(ntags);
-            return fail(RASS_ERR_OOM, "index grow: hipMalloc of bf16 slab failed");
+    auto copy_over = [&]() -> hipError_t {
+        hipError_t c = hipMemsetAsync(nrows + used_rows * idx->stride, 0,
+                                      (size_t)(cap - used_rows) * idx->stride * sizeof(float), st);
+        if (c == hipSuccess && idx->rows > 0)
+            c = hipMemcpyAsync(nrows, idx->d_rows, (size_t)used_rows * idx->stride * sizeof(float),
+                               hipMemcpyDeviceToDevice, st);
+        if (c == hipSuccess && idx->rows > 0)
+            c = hipMemcpyAsync(ntags, idx->d_tags, (size_t)idx->rows * sizeof(int32_t), hipMemcpyDeviceToDevice, st);
+        if (c == hipSuccess && idx->prefilter) {
+            c = hipMalloc(reinterpret_cast<void**>(&nb16), (size_t)cap * idx->stride * 2);
+            if (c == hipSuccess) c = hipMemsetAsync(nb16, 0, (size_t)cap * idx->stride * 2, st);
+            if (c == hipSuccess && idx->rows > 0)
+                c = hipMemcpyAsync(nb16, idx->d_rows_bf16, (size_t)used_rows * idx->stride * 2,
+                                   hipMemcpyDeviceToDevice, st);
         }
-        HIP_TRY(hipMemsetAsync(nb16, 0, (size_t)cap * idx->stride * 2, st));
-        if (idx->rows > 0)
-            HIP_TRY(hipMemcpyAsync(nb16, idx->d_rows_bf16, (size_t)used_rows * idx->stride * 2,
-                                   hipMemcpyDeviceToDevice, st));
+        if (c == hipSuccess) c = hipStreamSynchronize(st);
+        return c;
+    };
+    e = copy_over();
+    if (e != hipSuccess) {  // nothing of the old index was touched: release the new allocations and report
+        (void)hipStreamSynchronize(st);
+        (void)hipFree(nrows);
+        (void)hipFree(ntags);
+        if (nb16) (void)hipFree(nb16);
+        return fail(e == hipErrorOutOfMemory ? RASS_ERR_OOM : RASS_ERR_HIP,
+                    std::string("index grow failed: ") + hipGetErrorString(e));
     }
-    HIP_TRY(hipStreamSynchronize(st));
     if (idx->d_rows) (void)hipFree(idx->d_rows);
     if (idx->d_tags) (void)hipFree(idx->d_tags);
     if (idx->d_rows_bf16) (void)hipFree(idx->d_rows_bf16);
@@ -378,18 +384,27 @@ int rass_engine_create(int device, int dim, rass_engine_t** out) {
     if (!eng) return fail(RASS_ERR_OOM, "host allocation failed");
     eng->device = device;
     eng->dim = dim;
-    HIP_TRY(hipSetDevice(device));
-    eng->n_cus = device_cus(device);
-    HIP_TRY(hipStreamCreateWithFlags(&eng->own_stream, hipStreamNonBlocking));
-    eng->stream = eng->own_stream;
-    eng->scratch_bytes = scratch_layout(RASS_MAX_QBATCH, RASS_MAX_K).total;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&eng->d_scratch), eng->scratch_bytes));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&eng->d_qraw), (size_t)RASS_MAX_QBATCH * dim * sizeof(float)));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&eng->d_qfilter), RASS_MAX_QBATCH * sizeof(int32_t)));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&eng->d_out_scores), RASS_MAX_QBATCH * RASS_MAX_K * sizeof(float)));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&eng->d_out_ids), RASS_MAX_QBATCH * RASS_MAX_K * sizeof(int64_t)));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&eng->d_stage), (size_t)kStageRows * dim * sizeof(float)));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&eng->d_stage_tags), (size_t)kStageRows * sizeof(int32_t)));
+    auto init = [&]() -> int {
+        HIP_TRY(hipSetDevice(device));
+        eng->n_cus = device_cus(device);
+        HIP_TRY(hipStreamCreateWithFlags(&eng->own_stream, hipStreamNonBlocking));
+        eng->stream = eng->own_stream;
+        eng->scratch_bytes = scratch_layout(RASS_MAX_QBATCH, RASS_MAX_K).total;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&eng->d_scratch), eng->scratch_bytes));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&eng->d_qraw), (size_t)RASS_MAX_QBATCH * dim * sizeof(float)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&eng->d_qfilter), RASS_MAX_QBATCH * sizeof(int32_t)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&eng->d_out_scores), RASS_MAX_QBATCH * RASS_MAX_K * sizeof(float)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&eng->d_out_ids), RASS_MAX_QBATCH * RASS_MAX_K * sizeof(int64_t)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&eng->d_stage), (size_t)kStageRows * dim * sizeof(float)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&eng->d_stage_tags), (size_t)kStageRows * sizeof(int32_t)));
+        return RASS_OK;
+    };
+    const int rc = init();
+    if (rc != RASS_OK) {
+        const std::string why = g_err;  // destroy() must not lose the reason
+        rass_engine_destroy(eng);
+        return fail(rc, why);
+    }
     *out = eng;
     return RASS_OK;
 }
@@ -562,6 +577,10 @@ static int add_common(rass_index_t* idx, const float* vecs, const int32_t* tags,
         int32_t* tdst = idx->d_tags + idx->rows + done;
         const float* src = vecs + done * dim;
         const float* dsrc = src;
+        // host source: the staging buffer is ENGINE scratch, shared with the other indices (users) of
+        // this engine and with get_row(s) / save — hold the engine lock for the chunk's round trip
+        std::unique_lock<std::mutex> elk(eng->mu, std::defer_lock);
+        if (!device_src) elk.lock();
         if (!device_src) {
             HIP_TRY(hipMemcpyAsync(eng->d_stage, src, (size_t)m * dim * sizeof(float), hipMemcpyHostToDevice, st));
             dsrc = eng->d_stage;

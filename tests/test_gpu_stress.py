@@ -70,3 +70,37 @@ def test_concurrent_add_delete_search(gpu, oracle):
         assert np.max(np.abs(s.astype(np.float64) - rs)) <= 2e-6
     finally:
         eng.close()
+
+
+def test_concurrent_adds_to_different_indices_share_the_engine_staging_buffer(gpu):
+    """Two users ingesting at once (one engine, two indices): the host -> device staging buffer is
+    engine scratch, so each chunk's upload + pack must be atomic with respect to the other index."""
+    from rassengine_amd.engine import Engine
+    dim, n, batch = 128, 20000, 37          # many small uploads to maximise interleaving
+    eng = Engine(0, dim)
+    errors = []
+    try:
+        data = {}
+        for name, seed in (("user-a", 1), ("user-b", 2)):
+            rng = np.random.default_rng(seed)
+            data[name] = rng.standard_normal((n, dim)).astype(np.float32)
+        idxs = {name: eng.open_index(name) for name in data}
+
+        def ingest(name):
+            try:
+                for lo in range(0, n, batch):
+                    idxs[name].add(data[name][lo:lo + batch], normalize=False)
+            except Exception as e:  # noqa: BLE001
+                errors.append((name, repr(e)))
+
+        threads = [threading.Thread(target=ingest, args=(name,)) for name in data]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=120)
+        assert not errors, errors
+        for name in data:
+            assert idxs[name].rows == n
+            assert np.array_equal(idxs[name].get_rows(0, n), data[name]), name
+    finally:
+        eng.close()

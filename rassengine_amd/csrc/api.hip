@@ -977,8 +977,12 @@ int rass_timer_create(rass_timer_t** out) {
     if (!out) return fail(RASS_ERR_INVALID, "out is NULL");
     rass_timer* t = new (std::nothrow) rass_timer();
     if (!t) return fail(RASS_ERR_OOM, "host allocation failed");
-    HIP_TRY(hipEventCreate(&t->start));
-    HIP_TRY(hipEventCreate(&t->stop));
+    hipError_t e = hipEventCreate(&t->start);
+    if (e == hipSuccess) e = hipEventCreate(&t->stop);
+    if (e != hipSuccess) {
+        rass_timer_destroy(t);
+        return fail(RASS_ERR_HIP, std::string("hipEventCreate: ") + hipGetErrorString(e));
+    }
     *out = t;
     return RASS_OK;
 }
@@ -1164,13 +1168,13 @@ void rass_ivf_destroy(rass_ivf_t* v) {
 int64_t rass_ivf_rows(const rass_ivf_t* v) { return v ? v->rows : 0; }
 int rass_ivf_nlist(const rass_ivf_t* v) { return v ? v->nlist : 0; }
 
-int rass_ivf_search_device(rass_ivf_t* v, const float* d_queries, int nq, int k, int nprobe,
-                           const int32_t* d_q_filter, float* d_out_scores, int64_t* d_out_ids) {
+// Caller holds eng->mu (the probe scratch of the IVF object and the engine scratch are shared).
+static int ivf_search_locked(rass_ivf_t* v, const float* d_queries, int nq, int k, int nprobe,
+                             const int32_t* d_q_filter, float* d_out_scores, int64_t* d_out_ids) {
     if (!v || !d_queries || !d_out_scores || !d_out_ids) return fail(RASS_ERR_INVALID, "NULL argument");
     if (nprobe < 1) return fail(RASS_ERR_INVALID, "nprobe must be >= 1");
     if (nq < 1 || nq > RASS_MAX_QBATCH) return fail(RASS_ERR_INVALID, "nq must be in [1, RASS_MAX_QBATCH]");
     rass_engine* eng = v->eng;
-    std::lock_guard<std::mutex> lk(eng->mu);
     int rc = set_device(eng);
     if (rc != RASS_OK) return rc;
     hipStream_t st = eng->stream;
@@ -1223,6 +1227,13 @@ int rass_ivf_search_device(rass_ivf_t* v, const float* d_queries, int nq, int k,
                        st, eng, &plan, v->d_ids);
 }
 
+int rass_ivf_search_device(rass_ivf_t* v, const float* d_queries, int nq, int k, int nprobe,
+                           const int32_t* d_q_filter, float* d_out_scores, int64_t* d_out_ids) {
+    if (!v) return fail(RASS_ERR_INVALID, "NULL argument");
+    std::lock_guard<std::mutex> lk(v->eng->mu);
+    return ivf_search_locked(v, d_queries, nq, k, nprobe, d_q_filter, d_out_scores, d_out_ids);
+}
+
 int rass_ivf_search(rass_ivf_t* v, const float* queries, int nq, int k, int nprobe, const int32_t* q_filter,
                     float* out_scores, int64_t* out_ids, int64_t* scanned_rows) {
     if (!v || !out_scores || !out_ids) return fail(RASS_ERR_INVALID, "NULL argument");
@@ -1234,16 +1245,15 @@ int rass_ivf_search(rass_ivf_t* v, const float* queries, int nq, int k, int npro
     int64_t scanned_total = 0;
     for (int done = 0; done < nq;) {
         const int b = std::min(RASS_MAX_QBATCH, nq - done);
+        // staging buffers are per engine: hold the lock across the whole batch round trip
+        std::lock_guard<std::mutex> lk(eng->mu);
         hipStream_t st = eng->stream;
-        {
-            std::lock_guard<std::mutex> lk(eng->mu);
-            HIP_TRY(hipMemcpyAsync(eng->d_qraw, queries + (int64_t)done * v->dim, (size_t)b * v->dim * 4,
-                                   hipMemcpyHostToDevice, st));
-            if (q_filter)
-                HIP_TRY(hipMemcpyAsync(eng->d_qfilter, q_filter + done, (size_t)b * 4, hipMemcpyHostToDevice, st));
-        }
-        rc = rass_ivf_search_device(v, eng->d_qraw, b, k, nprobe, q_filter ? eng->d_qfilter : nullptr,
-                                    eng->d_out_scores, eng->d_out_ids);
+        HIP_TRY(hipMemcpyAsync(eng->d_qraw, queries + (int64_t)done * v->dim, (size_t)b * v->dim * 4,
+                               hipMemcpyHostToDevice, st));
+        if (q_filter)
+            HIP_TRY(hipMemcpyAsync(eng->d_qfilter, q_filter + done, (size_t)b * 4, hipMemcpyHostToDevice, st));
+        rc = ivf_search_locked(v, eng->d_qraw, b, k, nprobe, q_filter ? eng->d_qfilter : nullptr, eng->d_out_scores,
+                               eng->d_out_ids);
         if (rc != RASS_OK) return rc;
         int64_t scanned = 0;
         HIP_TRY(hipMemcpyAsync(out_scores + (int64_t)done * k, eng->d_out_scores, (size_t)b * k * 4,

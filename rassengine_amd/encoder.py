@@ -356,30 +356,62 @@ class HipSentenceEncoder:
     def encode_ids(self, seqs: Sequence[Sequence[int]]) -> np.ndarray:
         """Pooled embeddings of already-tokenised sequences (each ``[CLS] ... [SEP]``)."""
         n = len(seqs)
+        if n == 0:
+            return np.empty((0, self.dim), dtype=np.float32)
+        lens = np.fromiter((len(s) for s in seqs), dtype=np.int64, count=n)
+        cu = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(lens, out=cu[1:])
+        ids = np.concatenate([np.asarray(s, dtype=np.int32) for s in seqs]) if cu[-1] else np.empty(0, np.int32)
+        return self._encode_flat(ids, cu)
+
+    def _encode_flat(self, ids: np.ndarray, cu: np.ndarray) -> np.ndarray:
+        """Packed token ids + cumulative sequence offsets -> pooled vectors; greedy batches of at most
+        ``max_batch_seqs`` sequences / ``max_batch_tokens`` tokens, no per-token Python work."""
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        cu = np.asarray(cu, dtype=np.int64)
+        n = cu.shape[0] - 1
         out = np.empty((n, self.dim), dtype=np.float32)
+        lens = np.diff(cu)
+        bad = np.nonzero((lens < 1) | (lens > self.cfg.max_positions))[0]
+        if bad.size:
+            j = int(bad[0])
+            raise ValueError(f"sequence {j} has {int(lens[j])} tokens (1..{self.cfg.max_positions} allowed)")
         i = 0
         while i < n:
-            j, tokens = i, 0
-            while j < n and j - i < self.max_batch_seqs and tokens + len(seqs[j]) <= self.max_batch_tokens:
-                if not 1 <= len(seqs[j]) <= self.cfg.max_positions:
-                    raise ValueError(f"sequence {j} has {len(seqs[j])} tokens (1..{self.cfg.max_positions} allowed)")
-                tokens += len(seqs[j])
-                j += 1
-            if j == i:
+            j_tok = int(np.searchsorted(cu, cu[i] + self.max_batch_tokens, side="right")) - 1
+            j = min(n, i + self.max_batch_seqs, j_tok)
+            if j <= i:
                 raise ValueError("a single sequence exceeds max_batch_tokens")
-            ids = np.fromiter((t for s in seqs[i:j] for t in s), dtype=np.int32, count=tokens)
-            cu = np.zeros(j - i + 1, dtype=np.int32)
-            np.cumsum([len(s) for s in seqs[i:j]], out=cu[1:])
+            sub_ids = ids[cu[i]:cu[j]]
+            sub_cu = np.ascontiguousarray(cu[i:j + 1] - cu[i], dtype=np.int32)
             N.check("rass_encode",
-                    self._L.rass_encode(self._h, ids.ctypes.data_as(ctypes.c_void_p), cu.ctypes.data_as(ctypes.c_void_p),
-                                        j - i, out[i:j].ctypes.data_as(ctypes.c_void_p)))
+                    self._L.rass_encode(self._h, sub_ids.ctypes.data_as(ctypes.c_void_p),
+                                        sub_cu.ctypes.data_as(ctypes.c_void_p), j - i,
+                                        out[i:j].ctypes.data_as(ctypes.c_void_p)))
             i = j
         return out
 
     def encode(self, texts: List[str]) -> np.ndarray:
         if self.tokenizer is None:
             raise RuntimeError("this model directory has no vocab.txt: use encode_ids()")
-        if hasattr(self.tokenizer, "encode_batch"):  # C++: one multi-threaded call per batch
-            ids, cu = self.tokenizer.encode_batch(texts, self.cfg.max_positions)
-            return self.encode_ids([ids[cu[i]:cu[i + 1]] for i in range(len(texts))])
-        return self.encode_ids([self.tokenizer.encode(t, self.cfg.max_positions) for t in texts])
+        if not hasattr(self.tokenizer, "encode_batch"):
+            return self.encode_ids([self.tokenizer.encode(t, self.cfg.max_positions) for t in texts])
+        # C++ tokenizer: one multi-threaded call per slice of texts; the next slice is tokenised on a
+        # worker thread while the GPU encodes the current one (both calls release the GIL).
+        step = self.max_batch_seqs
+        slices = [texts[a:a + step] for a in range(0, len(texts), step)]
+        if not slices:
+            return np.empty((0, self.dim), dtype=np.float32)
+        if len(slices) == 1:
+            ids, cu = self.tokenizer.encode_batch(slices[0], self.cfg.max_positions)
+            return self._encode_flat(ids, cu)
+        from concurrent.futures import ThreadPoolExecutor
+        outs = []
+        with ThreadPoolExecutor(max_workers=1) as pool:
+            fut = pool.submit(self.tokenizer.encode_batch, slices[0], self.cfg.max_positions)
+            for nxt in slices[1:] + [None]:
+                ids, cu = fut.result()
+                if nxt is not None:
+                    fut = pool.submit(self.tokenizer.encode_batch, nxt, self.cfg.max_positions)
+                outs.append(self._encode_flat(ids, cu))
+        return np.concatenate(outs, axis=0)

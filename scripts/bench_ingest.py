@@ -15,6 +15,9 @@ ap.add_argument("--chunks", type=int, default=16384)
 ap.add_argument("--batch", type=int, default=256)
 ap.add_argument("--profile", choices=["fixed512", "varlen"], default="fixed512")
 ap.add_argument("--layers", type=int, default=24)
+ap.add_argument("--from-text", action="store_true",
+                help="start from raw text: C++ WordPiece tokenisation (overlapped with the GPU) -> encode -> host "
+                     "embeddings -> index add, i.e. what store_fhir_docs_in_opensearch does per upload")
 ap.add_argument("--cpu-baseline-chunks", type=int, default=0,
                 help="also time the fp32 PyTorch-CPU forward of the same architecture (stand-in for Ollama's "
                      "CPU embed path, BASELINE.md s3) on this many 512-token chunks, batch 1 and batch 8")
@@ -36,7 +39,16 @@ for name in weight_names(cfg.layers):
     t = rng.standard_normal(shape, dtype=np.float32) * (0.03 if len(shape) == 2 else 0.05)
     if "LayerNorm.weight" in name: t = 1 + t
     w[name] = t
-enc = HipSentenceEncoder(cfg, w, None, device=0)
+tok = None
+if a.from_text:
+    import tempfile
+    from rassengine_amd.encoder import CppWordPieceTokenizer, synthetic_vocab
+    vocab = synthetic_vocab(cfg.vocab_size)
+    vdir = tempfile.mkdtemp()
+    with open(os.path.join(vdir, "vocab.txt"), "w", encoding="utf-8") as f:
+        f.write("\n".join(vocab) + "\n")
+    tok = CppWordPieceTokenizer(os.path.join(vdir, "vocab.txt"))
+enc = HipSentenceEncoder(cfg, w, tok, device=0)
 eng = Engine(0, H)
 idx = eng.open_index("ingest", capacity_rows=a.chunks)
 stream = int(torch.cuda.current_stream().cuda_stream)
@@ -60,6 +72,24 @@ def ingest_one(b):
                                         nb, total, mx, ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(stream)))
     idx.add_device(out.data_ptr(), nb, normalize=True)
     return nb, total
+if a.from_text:
+    words = [v for v in vocab if v.isalpha() and len(v) > 2][:5000]
+    trng = np.random.default_rng(5)
+    n_words = 380 if a.profile == "fixed512" else None
+    texts = [" ".join(trng.choice(words, size=n_words or int(trng.integers(40, 400)))) + ". BP 120/80 mmHg, HbA1c 7.2%."
+             for _ in range(a.chunks)]
+    enc.encode(texts[:a.batch])
+    t0 = time.perf_counter()
+    emb = enc.encode(texts)                       # tokenise (worker thread) || GPU encode, host embeddings out
+    t_embed = time.perf_counter() - t0
+    idx.add(emb, normalize=True)
+    eng.synchronize()
+    dt = time.perf_counter() - t0
+    n_tok = None
+    print(json.dumps({"workload": f"text ingest {a.chunks} chunks (~{n_words or 'varlen'} words), tokenise + encode + add",
+                      "chunks_per_s": round(a.chunks / dt, 1), "embed_only_chunks_per_s": round(a.chunks / t_embed, 1),
+                      "seconds": round(dt, 3), "index_rows": idx.rows}))
+    sys.exit(0)
 ingest_one(0); torch.cuda.synchronize()
 eng.drop_index("ingest"); idx = eng.open_index("ingest", capacity_rows=a.chunks)
 t0 = time.perf_counter(); chunks = tokens = 0

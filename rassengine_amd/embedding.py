@@ -84,10 +84,14 @@ async def embed_texts_in_batches(texts: List[str], batch_size: int = BATCH_SIZE)
     """Embeds a list of texts in batches (app/main.py:240-263)."""
     if not texts:
         return np.array([])
+    # The reference's batch_size bounds how many HTTP requests are gathered at once (one per text).
+    # Here a slice is ONE encoder call that batches on its own (<= 256 sequences / 131 072 tokens per
+    # forward, tokenisation overlapped), so slices are made large enough to keep the GPU busy; the
+    # result does not depend on the slicing (order-preserving, each text embedded independently).
+    step = max(int(batch_size), 2048)
     all_embeddings = []
-    for i in range(0, len(texts), batch_size):
-        batch = texts[i:i + batch_size]
-        all_embeddings.append(await asyncio.to_thread(_encode_nonblank, batch))
+    for i in range(0, len(texts), step):
+        all_embeddings.append(await asyncio.to_thread(_encode_nonblank, texts[i:i + step]))
     return np.ascontiguousarray(np.concatenate(all_embeddings, axis=0), dtype=np.float32)
 
 

@@ -50,7 +50,9 @@ def test_embed_contract_matches_reference(shim):
     assert e.shape == (5, 1024) and e.dtype == np.float32 and e.flags["C_CONTIGUOUS"]
     assert np.all(e[1] == 0) and np.all(e[3] == 0) and np.any(e[0] != 0)
     assert np.array_equal(e[2], np.asarray(run(embedding.ollama_embed_text("gamma")), dtype=np.float32))
-    assert [len(c) for c in shim.calls[:3]] == [1, 1, 1]  # blanks never reach the encoder, batches of <= 2
+    # blanks never reach the encoder; the three non-blank texts of one call go out as ONE encoder
+    # batch whatever batch_size says (the encoder batches for the GPU on its own)
+    assert [len(c) for c in shim.calls[:3]] == [1, 3, 1]
     # a3: blank query -> size 0; else [1, dim] fp32, no prompt prefix
     assert run(embedding.embed_query(" ")).size == 0
     q = run(embedding.embed_query("gamma"))

@@ -55,6 +55,7 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
 #ifdef RASS_SCAN_CLOCKS  // scripts/microbench/scan_tail.hip only: per-workgroup start / end wall clocks
 __device__ unsigned long long g_scan_clocks[2 * 1024];
+__device__ unsigned long long g_scan_core[2];
 #endif
 
 // The ascending sequence of work-item indices one workgroup handles.  Plain: b, b+G, b+2G, ...
@@ -251,6 +252,7 @@ __global__ __launch_bounds__(kThreads, 2) void scan_topk_f32_kernel(ScanArgs p) 
     const int G = gridDim.x;
 #ifdef RASS_SCAN_CLOCKS
     if (threadIdx.x == 0) g_scan_clocks[2 * blockIdx.x] = wall_clock64();
+    if (threadIdx.x == 0 && blockIdx.x == 0) g_scan_core[0] = clock64();
 #endif
 
     // Query fragments: lane (n = m, g) holds Qn[nt*16 + n][slice + 16j + 4g .. +3].
@@ -333,6 +335,7 @@ __global__ __launch_bounds__(kThreads, 2) void scan_topk_f32_kernel(ScanArgs p) 
 
 #ifdef RASS_SCAN_CLOCKS
     if (threadIdx.x == 0) g_scan_clocks[2 * blockIdx.x + 1] = wall_clock64();
+    if (threadIdx.x == 0 && blockIdx.x == 0) g_scan_core[1] = clock64();
 #endif
     // Per-workgroup sorted lists -> [gridDim.x][nq][k]
     const int lpos = lane & 31;

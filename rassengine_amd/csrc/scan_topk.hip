@@ -241,7 +241,7 @@ __device__ __forceinline__ void insert_candidates(TopList& L, float& tau, float 
 template <int CH, int NT, bool IVF>
 __global__ __launch_bounds__(kThreads, 2) void scan_topk_f32_kernel(ScanArgs p) {
     constexpr int NQ = NT * 16;
-    extern __shared__ __attribute__((aligned(16))) float lds[];  // [2][kWaves][NQ][kPitch]
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // [4][kWaves][NQ][kPitch]
 
     const int lane = lane_id();
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -290,15 +290,21 @@ __global__ __launch_bounds__(kThreads, 2) void scan_topk_f32_kernel(ScanArgs p) 
     issue_tile_loads<CH>(R1, make_tile_desc(p.corpus, p.row_stride, p.row_tag, W1), voff_lane, mt_step);
     __builtin_amdgcn_sched_barrier(0);
 
-    auto finish_tile = [&](const f32x4 (&acc)[2][NT], const WorkItem& w, int tag, int buf) {
+    // A tile's 8 K-partials meet in LDS.  Two tiles share ONE barrier: both are dumped (four LDS
+    // images: two per loop iteration, alternating between iterations so a fast wave's next dump never
+    // lands on an image a slow wave is still reading — it would have to pass the next barrier first),
+    // then ranked in ascending row order.
+    auto dump_tile = [&](const f32x4 (&acc)[2][NT], int buf) {
         float* P = lds + buf * (kWaves * NQ * kPitch);
-        // dump: lane (n=m, g) holds rows 4g..4g+3 of M-tile mt for query nt*16+n
+        // lane (n=m, g) holds rows 4g..4g+3 of M-tile mt for query nt*16+n
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
                 *reinterpret_cast<f32x4*>(P + (wid * NQ + nt * 16 + m) * kPitch + mt * 16 + 4 * g) = acc[mt][nt];
-        __syncthreads();
+    };
+    auto rank_tile = [&](const WorkItem& w, int tag, int buf) {
+        const float* P = lds + buf * (kWaves * NQ * kPitch);
         const int r = lane & 31;
         const int row = w.tile * kTileRows + r;
         const bool row_ok = (r < w.rows) && (tag != -1);
@@ -316,21 +322,28 @@ __global__ __launch_bounds__(kThreads, 2) void scan_topk_f32_kernel(ScanArgs p) 
         }
     };
 
+    int pair = 0;  // 0 / 2: which two LDS images this iteration uses
     while (t < n_tiles) {
         f32x4 acc[2][NT];
-        int tag = R0.tag;
+        const int tag0 = R0.tag;
+        const WorkItem Wa = W0;
         t = seq.next();
         WorkItem Wn = get_work<IVF>(p, t, n_tiles);
         multiply_and_refill<CH, NT>(R0, qf, acc, make_tile_desc(p.corpus, p.row_stride, p.row_tag, Wn), voff_lane,
                                     mt_step);
-        finish_tile(acc, W0, tag, 0);
+        dump_tile(acc, pair);
         W0 = Wn;
-        tag = R1.tag;
+        const int tag1 = R1.tag;
+        const WorkItem Wb = W1;
         Wn = get_work<IVF>(p, seq.next(), n_tiles);
         multiply_and_refill<CH, NT>(R1, qf, acc, make_tile_desc(p.corpus, p.row_stride, p.row_tag, Wn), voff_lane,
                                     mt_step);
-        finish_tile(acc, W1, tag, 1);
+        dump_tile(acc, pair + 1);
         W1 = Wn;
+        __syncthreads();
+        rank_tile(Wa, tag0, pair);
+        rank_tile(Wb, tag1, pair + 1);
+        pair ^= 2;
     }
 
 #ifdef RASS_SCAN_CLOCKS
@@ -353,7 +366,7 @@ __global__ __launch_bounds__(kThreads, 2) void scan_topk_f32_kernel(ScanArgs p) 
 
 template <int CH, int NT, bool IVF>
 static hipError_t launch_variant(const ScanArgs& a, int grid, hipStream_t stream) {
-    constexpr size_t lds_bytes = (size_t)2 * kWaves * NT * 16 * kPitch * sizeof(float);
+    constexpr size_t lds_bytes = (size_t)4 * kWaves * NT * 16 * kPitch * sizeof(float);  // 144 KiB at NT = 2
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_topk_f32_kernel<CH, NT, IVF>),

@@ -42,7 +42,11 @@ typedef enum rass_status {
     RASS_ERR_IO = -6           /* save/load failure */
 } rass_status;
 
-/* Corpus storage dtype (fp32 is the parity path). */
+/* Corpus storage dtype (fp32 is the parity path and the only one
+ * rass_index_open accepts in ABI version 1).  RASS_BF16 is reserved for a bf16-only
+ * corpus (half the HBM per row): today it is refused with RASS_ERR_UNSUPPORTED; the
+ * bf16 scan exists as the candidate copy of an fp32 index (rass_index_set_prefilter),
+ * whose results are re-ranked in fp32 and stay exact. */
 typedef enum rass_dtype {
     RASS_F32 = 0,
     RASS_BF16 = 1

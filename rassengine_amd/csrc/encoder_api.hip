@@ -76,6 +76,12 @@ struct rass_encoder {
     float* d_out = nullptr;
     float* d_stage = nullptr;  // fp32 staging for weight upload
     size_t stage_elems = 0;
+    // The activation workspace is ONE set per encoder: a forward enqueued on stream A must finish
+    // before a forward on stream B (or a reallocation) touches it.  `done` is recorded at the end of
+    // every forward on `last_stream`.
+    hipEvent_t done = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool done_recorded = false;
 };
 
 namespace {
@@ -106,7 +112,12 @@ int upload(rass_encoder* e, const float* host, int64_t n, void* dst, int64_t dst
 
 int ensure_workspace(rass_encoder* e, int tokens_pad, int nseq) {
     const int H = e->cfg.hidden, I = e->cfg.intermediate;
+    if ((tokens_pad > e->cap_tokens || nseq > e->cap_seqs) && e->done_recorded)
+        EHIP_TRY(hipEventSynchronize(e->done));  // a forward still in flight reads what is freed below
     if (tokens_pad > e->cap_tokens) {
+        // the capacity is withdrawn BEFORE anything is freed and published only after every
+        // allocation succeeded: a failed grow leaves cap_tokens = 0 and the next call re-allocates
+        e->cap_tokens = 0;
         for (void** p : {&e->x, &e->qkv, &e->ctx, &e->y, &e->h})
             if (*p) {
                 (void)hipFree(*p);
@@ -130,6 +141,7 @@ int ensure_workspace(rass_encoder* e, int tokens_pad, int nseq) {
         e->cap_tokens = tokens_pad;
     }
     if (nseq > e->cap_seqs) {
+        e->cap_seqs = 0;
         if (e->d_cu) (void)hipFree(e->d_cu);
         if (e->d_out) (void)hipFree(e->d_out);
         e->d_cu = nullptr;
@@ -146,6 +158,10 @@ int forward(rass_encoder* e, const int32_t* d_ids, const int32_t* d_cu, int nseq
     const rass_encoder_config& c = e->cfg;
     const int H = c.hidden, I = c.intermediate;
     const int Tp = (total + 255) / 256 * 256;  // whole 256-token GEMM tiles
+    if (!e->x || !e->qkv || !e->ctx || !e->y || !e->h || Tp > e->cap_tokens)
+        return efail(RASS_ERR_INVALID, "encoder workspace is not allocated for this batch");
+    // one workspace per encoder: order this forward after the previous one when the stream differs
+    if (e->done_recorded && e->last_stream != st) EHIP_TRY(hipStreamWaitEvent(st, e->done, 0));
     EHIP_TRY(rass::launch_embed_layernorm(d_ids, d_cu, nseq, total, e->word, e->pos, e->type0, e->emb_g, e->emb_b,
                                           c.layer_norm_eps, H, c.vocab_size, c.max_positions, e->x, st));
     for (int l = 0; l < c.layers; ++l) {
@@ -159,6 +175,9 @@ int forward(rass_encoder* e, const int32_t* d_ids, const int32_t* d_cu, int nseq
         EHIP_TRY(rass::launch_layernorm(e->y, L.ln2_g, L.ln2_b, c.layer_norm_eps, total, H, e->x, st));
     }
     EHIP_TRY(rass::launch_pool(e->x, d_cu, nseq, H, c.pooling == 1 ? 1 : 0, c.normalize ? 1 : 0, d_out, st));
+    EHIP_TRY(hipEventRecord(e->done, st));
+    e->last_stream = st;
+    e->done_recorded = true;
     return RASS_OK;
 }
 
@@ -183,31 +202,41 @@ int rass_encoder_create(int device, const rass_encoder_config* cfg, rass_encoder
     if (!e) return efail(RASS_ERR_OOM, "host allocation failed");
     e->device = device;
     e->cfg = *cfg;
-    EHIP_TRY(hipSetDevice(device));
-    EHIP_TRY(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
-    const size_t H = (size_t)cfg->hidden, I = (size_t)cfg->intermediate;
-    e->stage_elems = std::max<size_t>(I * H, 1 << 20);
-    int rc;
-    if ((rc = dev_alloc(e, reinterpret_cast<void**>(&e->d_stage), e->stage_elems * 4)) != RASS_OK) return rc;
-    if ((rc = dev_alloc(e, &e->word, (size_t)cfg->vocab_size * H * 2)) != RASS_OK) return rc;
-    if ((rc = dev_alloc(e, &e->pos, (size_t)cfg->max_positions * H * 2)) != RASS_OK) return rc;
-    if ((rc = dev_alloc(e, &e->type0, H * 2)) != RASS_OK) return rc;
-    if ((rc = dev_alloc(e, reinterpret_cast<void**>(&e->emb_g), H * 4)) != RASS_OK) return rc;
-    if ((rc = dev_alloc(e, reinterpret_cast<void**>(&e->emb_b), H * 4)) != RASS_OK) return rc;
-    e->layers.resize((size_t)cfg->layers);
-    for (Layer& L : e->layers) {
-        if ((rc = dev_alloc(e, &L.w_qkv, 3 * H * H * 2)) != RASS_OK) return rc;
-        if ((rc = dev_alloc(e, reinterpret_cast<void**>(&L.b_qkv), 3 * H * 4)) != RASS_OK) return rc;
-        if ((rc = dev_alloc(e, &L.w_o, H * H * 2)) != RASS_OK) return rc;
-        if ((rc = dev_alloc(e, reinterpret_cast<void**>(&L.b_o), H * 4)) != RASS_OK) return rc;
-        if ((rc = dev_alloc(e, reinterpret_cast<void**>(&L.ln1_g), H * 4)) != RASS_OK) return rc;
-        if ((rc = dev_alloc(e, reinterpret_cast<void**>(&L.ln1_b), H * 4)) != RASS_OK) return rc;
-        if ((rc = dev_alloc(e, &L.w_up, I * H * 2)) != RASS_OK) return rc;
-        if ((rc = dev_alloc(e, reinterpret_cast<void**>(&L.b_up), I * 4)) != RASS_OK) return rc;
-        if ((rc = dev_alloc(e, &L.w_down, H * I * 2)) != RASS_OK) return rc;
-        if ((rc = dev_alloc(e, reinterpret_cast<void**>(&L.b_down), H * 4)) != RASS_OK) return rc;
-        if ((rc = dev_alloc(e, reinterpret_cast<void**>(&L.ln2_g), H * 4)) != RASS_OK) return rc;
-        if ((rc = dev_alloc(e, reinterpret_cast<void**>(&L.ln2_b), H * 4)) != RASS_OK) return rc;
+    auto init = [&]() -> int {
+        EHIP_TRY(hipSetDevice(device));
+        EHIP_TRY(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
+        EHIP_TRY(hipEventCreateWithFlags(&e->done, hipEventDisableTiming));
+        const size_t H = (size_t)cfg->hidden, I = (size_t)cfg->intermediate;
+        e->stage_elems = std::max<size_t>(I * H, 1 << 20);
+        int rc;
+        if ((rc = dev_alloc(e, reinterpret_cast<void**>(&e->d_stage), e->stage_elems * 4)) != RASS_OK) return rc;
+        if ((rc = dev_alloc(e, &e->word, (size_t)cfg->vocab_size * H * 2)) != RASS_OK) return rc;
+        if ((rc = dev_alloc(e, &e->pos, (size_t)cfg->max_positions * H * 2)) != RASS_OK) return rc;
+        if ((rc = dev_alloc(e, &e->type0, H * 2)) != RASS_OK) return rc;
+        if ((rc = dev_alloc(e, reinterpret_cast<void**>(&e->emb_g), H * 4)) != RASS_OK) return rc;
+        if ((rc = dev_alloc(e, reinterpret_cast<void**>(&e->emb_b), H * 4)) != RASS_OK) return rc;
+        e->layers.resize((size_t)cfg->layers);
+        for (Layer& L : e->layers) {
+            if ((rc = dev_alloc(e, &L.w_qkv, 3 * H * H * 2)) != RASS_OK) return rc;
+            if ((rc = dev_alloc(e, reinterpret_cast<void**>(&L.b_qkv), 3 * H * 4)) != RASS_OK) return rc;
+            if ((rc = dev_alloc(e, &L.w_o, H * H * 2)) != RASS_OK) return rc;
+            if ((rc = dev_alloc(e, reinterpret_cast<void**>(&L.b_o), H * 4)) != RASS_OK) return rc;
+            if ((rc = dev_alloc(e, reinterpret_cast<void**>(&L.ln1_g), H * 4)) != RASS_OK) return rc;
+            if ((rc = dev_alloc(e, reinterpret_cast<void**>(&L.ln1_b), H * 4)) != RASS_OK) return rc;
+            if ((rc = dev_alloc(e, &L.w_up, I * H * 2)) != RASS_OK) return rc;
+            if ((rc = dev_alloc(e, reinterpret_cast<void**>(&L.b_up), I * 4)) != RASS_OK) return rc;
+            if ((rc = dev_alloc(e, &L.w_down, H * I * 2)) != RASS_OK) return rc;
+            if ((rc = dev_alloc(e, reinterpret_cast<void**>(&L.b_down), H * 4)) != RASS_OK) return rc;
+            if ((rc = dev_alloc(e, reinterpret_cast<void**>(&L.ln2_g), H * 4)) != RASS_OK) return rc;
+            if ((rc = dev_alloc(e, reinterpret_cast<void**>(&L.ln2_b), H * 4)) != RASS_OK) return rc;
+        }
+        return RASS_OK;
+    };
+    const int rc = init();
+    if (rc != RASS_OK) {  // release the stream, the event and every allocation made so far
+        const std::string why = rass_last_error();
+        rass_encoder_destroy(e);
+        return efail(rc, why);
     }
     *out = e;
     return RASS_OK;
@@ -220,6 +249,7 @@ void rass_encoder_destroy(rass_encoder_t* e) {
     for (void* p : e->allocs) (void)hipFree(p);
     for (void* p : {e->x, e->qkv, e->ctx, e->y, e->h, (void*)e->d_ids, (void*)e->d_cu, (void*)e->d_out})
         if (p) (void)hipFree(p);
+    if (e->done) (void)hipEventDestroy(e->done);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     delete e;
 }

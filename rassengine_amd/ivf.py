@@ -138,6 +138,7 @@ class IvfIndex:
         N.check("rass_ivf_build", N.lib().rass_ivf_build(index._h, c_host.ctypes.data_as(ctypes.c_void_p), int(nlist),
                                                         assign.ctypes.data_as(ctypes.c_void_p), ctypes.byref(h)))
         ivf = cls(h, index.engine, index.dim)
+        ivf.assign = assign                                   # list id of every source row (host int32)
         ivf.list_sizes = np.bincount(assign, minlength=nlist)
         return ivf
 

@@ -75,3 +75,58 @@ def test_oracle_plain_forward_equals_hf(tiny_dir):
     e = bert_ref.pool(a, "mean", normalize=True)
     assert e.shape == (4, 128) and np.allclose(np.linalg.norm(e, axis=1), 1.0, atol=1e-6)
     assert np.array_equal(bert_ref.pool(a, "cls")[1], a[1][0])
+
+
+# ---- committed encoder fixtures (tests/golden/make_encoder_fixtures.py): the oracle must still produce them
+def _unpack(ids, cu):
+    return [ids[cu[i]:cu[i + 1]].tolist() for i in range(len(cu) - 1)]
+
+
+def _probe_sha(model_dir):
+    import hashlib
+    w = load_weights(model_dir)["encoder.layer.0.intermediate.dense.weight"]
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(w).tobytes()).digest(), dtype=np.uint8)
+
+
+def test_oracle_reproduces_tiny_encoder_fixture(tmp_path):
+    import os
+    from oracle import bert_ref
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "encoder_tiny_L2_H128.npz"))
+    v, h, l, a, i, p = (int(x) for x in fx["config"])
+    d = str(tmp_path / "tiny")
+    write_random_model_dir(d, EncoderConfig(vocab_size=v, hidden=h, layers=l, heads=a, intermediate=i, max_positions=p),
+                           seed=int(fx["seed"]))
+    assert np.array_equal(_probe_sha(d), fx["weight_sha256"])      # the seeded weight generator has not drifted
+    hid = bert_ref.forward_plain(d, _unpack(fx["token_ids"], fx["cu_seqlens"]))
+    # fp32 CPU matmuls may block differently between hosts: allow a few ulp of drift, not more
+    assert np.allclose(bert_ref.pool(hid, "cls"), fx["pooled_cls"], rtol=0, atol=2e-5)
+    assert np.allclose(bert_ref.pool(hid, "mean"), fx["pooled_mean"], rtol=0, atol=2e-5)
+    hf = bert_ref.forward_hf(d, _unpack(fx["token_ids"], fx["cu_seqlens"]))
+    assert np.allclose(bert_ref.pool(hf, "mean"), fx["pooled_mean"], rtol=0, atol=5e-5)
+
+
+def test_oracle_reproduces_large_encoder_fixture(tmp_path):
+    """BERT-large-class shape: regenerates the 334 M seeded weights (~15 s) and checks the S=32, B=2 fixture
+    and the first two chunks of the end-to-end corpus fixture."""
+    import os
+    from oracle import bert_ref
+    g = os.path.join(os.path.dirname(__file__), "golden")
+    fx = np.load(os.path.join(g, "encoder_large_S32_B2.npz"))
+    d = str(tmp_path / "large")
+    write_random_model_dir(d, EncoderConfig(pooling="mean"), seed=int(fx["seed"]))
+    assert np.array_equal(_probe_sha(d), fx["weight_sha256"])
+    hid = bert_ref.forward_plain(d, _unpack(fx["token_ids"], fx["cu_seqlens"]))
+    assert np.allclose(bert_ref.pool(hid, "mean"), fx["pooled_mean"], rtol=0, atol=1e-4)
+    assert np.allclose(bert_ref.pool(hid, "cls"), fx["pooled_cls"], rtol=0, atol=1e-4)
+    e2e = np.load(os.path.join(g, "e2e_large_corpus.npz"))
+    assert np.array_equal(e2e["weight_sha256"], fx["weight_sha256"])
+    docs = _unpack(e2e["doc_token_ids"], e2e["doc_cu_seqlens"])
+    got = bert_ref.pool(bert_ref.forward_plain(d, docs[:2]), "mean")
+    assert np.allclose(got, e2e["doc_embeddings"][:2], rtol=0, atol=1e-4)
+    # the stored top-5 is the fp64 ranking of the stored embeddings
+    from oracle import oracle as O
+    xn = O.normalize_ref(e2e["doc_embeddings"]).astype(np.float32)
+    qn = O.normalize_ref(e2e["query_embeddings"]).astype(np.float32)
+    s, i = O.search(xn, qn, 5, kind=O.KIND_F64)
+    assert np.array_equal(i, e2e["top5_ids"]) and np.abs(s - e2e["top5_scores"]).max() < 1e-12
+    assert all(len(set(e2e["doc_family"][row])) == 1 for row in i)  # every query's top-5 is one topic family

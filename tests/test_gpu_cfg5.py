@@ -1,0 +1,120 @@
+"""BASELINE cfg 5 shape on one GPU: IVF with nlist = 4096 over >= 1 M rows (a per-GPU share of the 100 M-row
+config is 12.5 M rows; the semantics do not depend on the row count, the 1 M here keeps the host-side oracle
+within seconds).
+
+What is pinned (exact set semantics, not recall): for a query q and nprobe p, the IVF result must equal the
+oracle's BRUTE FORCE RESTRICTED to the rows assigned to the p lists whose centroids score best for q
+(ids identical, scores within 2e-6 of fp64), and `scanned` must be the number of rows in the union of the
+batch's probed lists.  nprobe = nlist reproduces the flat index bit for bit.  A probe-selection bug (wrong
+lists, lost tiles, a query seeing another query's lists) fails these; a recall curve would not notice.
+
+Near-ties: the engine normalises centroids / queries on the GPU (<= 2 ulp from numpy), so a list whose
+centroid score is within 1e-6 of the nprobe-th best may legitimately fall on either side; such queries are
+checked against both neighbours' sets (and there must be few of them).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N_ROWS = 1_000_000
+NLIST = 4096
+DIM = 1024
+TOL_F64 = 2e-6
+
+
+@pytest.fixture(scope="module")
+def built(gpu):
+    import torch
+    from rassengine_amd.engine import Engine
+    from rassengine_amd.ivf import IvfIndex, train_centroids
+    eng = Engine(0, DIM)
+    flat = eng.open_index("cfg5-flat", capacity_rows=N_ROWS)
+    flat.fill_synthetic(N_ROWS, seed=77)
+    for r in (0, 31, 32, 4097, 999_999):
+        flat.delete(r)
+    cent = train_centroids(flat, NLIST, train_rows=262_144, iters=3, seed=5)
+    ivf = IvfIndex.build(flat, nlist=NLIST, centroids=cent)
+    x = flat.get_rows(0, N_ROWS)                      # the stored (normalised) rows, 4 GB on the host
+    rng = np.random.default_rng(11)
+    # queries near stored rows (so the best lists hold real neighbours) plus pure noise
+    q = np.concatenate([x[rng.integers(0, N_ROWS, size=28)] + 0.02 * rng.standard_normal((28, DIM)).astype(np.float32),
+                        rng.standard_normal((12, DIM)).astype(np.float32)]).astype(np.float32)
+    yield eng, flat, ivf, x, cent.cpu().numpy(), q
+    ivf.close()
+    eng.close()
+
+
+def test_probe_every_list_equals_flat(built):
+    eng, flat, ivf, x, cent, q = built
+    assert ivf.nlist == NLIST and ivf.rows == flat.count == N_ROWS - 5
+    s_f, i_f = flat.search(q, 10)
+    s_i, i_i, scanned = ivf.search(q, 10, nprobe=NLIST)
+    assert np.array_equal(i_i, i_f) and np.array_equal(s_i, s_f)
+    assert scanned == 2 * flat.count                 # 40 queries = 2 batches, every live row once per batch
+
+
+def _restricted_oracle(oracle, x, assign, deleted, lists, qn_row, k):
+    rows = np.nonzero(np.isin(assign, lists) & ~deleted)[0]
+    s, i = oracle.search(x[rows], qn_row[None, :], k, kind=oracle.KIND_F64)
+    ids = np.where(i[0] >= 0, rows[np.clip(i[0], 0, None)], -1)
+    return s[0], ids
+
+
+@pytest.mark.parametrize("nprobe", [1, 8, 32, 33, 64, 128])
+def test_partial_probe_is_restricted_brute_force(built, oracle, nprobe):
+    """nprobe <= 32 goes through the coarse top-k scan, nprobe > 32 through the full centroid score matrix
+    + radix-select threshold: both must implement the same set semantics."""
+    eng, flat, ivf, x, cent, q = built
+    k = 10
+    assign = ivf.assign
+    deleted = np.zeros(N_ROWS, dtype=bool)
+    deleted[[0, 31, 32, 4097, 999_999]] = True
+    live_len = np.bincount(assign[~deleted], minlength=NLIST)
+    cn = oracle.normalize_ref(cent).astype(np.float32)
+    qn = oracle.normalize_ref(q).astype(np.float32)
+    coarse = oracle.scores(cn, qn, kind=oracle.KIND_F64)          # [nq, nlist]
+    order = np.argsort(-coarse, axis=1, kind="stable")
+
+    s_g, i_g, scanned = ivf.search(q, k, nprobe=nprobe)
+
+    ambiguous = 0
+    union_exact = True
+    expect_scanned = 0
+    for b0 in range(0, q.shape[0], 32):
+        union = set()
+        for r in range(b0, min(b0 + 32, q.shape[0])):
+            lists = order[r, :nprobe]
+            gap = coarse[r, order[r, nprobe - 1]] - coarse[r, order[r, nprobe]]
+            candidates = [lists]
+            if gap < 1e-6:                                          # the boundary list may go either way
+                ambiguous += 1
+                union_exact = False
+                candidates.append(np.concatenate([order[r, :nprobe - 1], order[r, nprobe:nprobe + 1]]))
+                candidates.append(order[r, :nprobe + 1])             # threshold path: ties may ADD a list
+            ok = False
+            for cand in candidates:
+                rs, ri = _restricted_oracle(oracle, x, assign, deleted, cand, qn[r], k)
+                if np.array_equal(i_g[r], ri):
+                    valid = ri >= 0
+                    assert np.all(np.abs(s_g[r][valid].astype(np.float64) - rs[valid]) <= TOL_F64)
+                    assert np.all(np.isneginf(s_g[r][~valid]))
+                    ok = True
+                    break
+                # fp32 near-ties inside the restricted set: allow swaps of rows whose fp64 scores are within 2 tol
+                if sorted(i_g[r].tolist()) == sorted(ri.tolist()) and np.all(np.abs(
+                        np.sort(s_g[r].astype(np.float64)) - np.sort(rs)) <= 2 * TOL_F64):
+                    ok = True
+                    break
+            assert ok, (nprobe, r, i_g[r], _restricted_oracle(oracle, x, assign, deleted, lists, qn[r], k)[1])
+            union.update(int(l) for l in lists)
+        expect_scanned += int(live_len[sorted(union)].sum())
+    assert ambiguous <= 2
+    if union_exact:
+        assert scanned == expect_scanned, (scanned, expect_scanned)
+    # every returned row really lives in one of the query's probed lists (no leakage between queries)
+    for r in range(q.shape[0]):
+        allowed = set(order[r, :nprobe + 1].tolist())
+        live = i_g[r][i_g[r] >= 0]
+        assert set(assign[live].tolist()) <= allowed
+        assert not deleted[live].any()

@@ -55,6 +55,13 @@ typedef enum rass_dtype {
 /* Limits of the fused scan kernel. */
 #define RASS_MAX_K 32        /* top-k kept in one half-wave sorted list */
 #define RASS_MAX_QBATCH 32   /* queries per scan launch (two 16-wide MFMA N tiles) */
+#define RASS_MAX_K_MULTIPASS 4096 /* rass_index_search_ex: k > RASS_MAX_K is served in passes of RASS_MAX_K */
+/* Row tag layout used by the Python shim (the engine itself only compares integers): bits 0..23 the
+ * patientId dictionary code (0 = none), bits 24..30 the doc_type code (0 = none).  A masked filter
+ * (rass_index_search_ex) selects on either field or both with one compare. */
+#define RASS_TAG_PATIENT_MASK 0x00ffffff
+#define RASS_TAG_DOCTYPE_SHIFT 24
+#define RASS_TAG_DOCTYPE_MASK 0x7f000000
 #define RASS_ROW_TAG_DELETED (-1)
 #define RASS_QFILTER_NONE (-1)
 
@@ -114,7 +121,8 @@ int rass_index_row_stride(const rass_index_t* idx); /* elements, dim padded to 1
 int rass_index_add(rass_index_t* idx, const float* vecs, const int32_t* tags,
                    int64_t n, int normalize, int64_t* first_row);
 /* Same, from device memory (the encoder's pooled output), async on the
- * engine stream. */
+ * engine stream.  Device tags cannot be validated without a sync: negative values are stored as
+ * 0 (the tombstone code belongs to rass_index_delete). */
 int rass_index_add_device(rass_index_t* idx, const float* d_vecs,
                           const int32_t* d_tags, int64_t n, int normalize,
                           int64_t* first_row);
@@ -141,6 +149,17 @@ int rass_index_get_rows(rass_index_t* idx, int64_t first_row, int64_t n,
 int rass_index_search(rass_index_t* idx, const float* queries, int nq, int k,
                       const int32_t* q_filter, float* out_scores,
                       int64_t* out_ids);
+/* Extended host search.  (1) `q_filter_mask` (may be NULL = exact compare): a row matches query q
+ * when (row_tag & q_filter_mask[q]) == q_filter[q], so one compare serves `term: patientId`
+ * (app/main.py:1549), the `term: doc_type` of hybrid_structured_search (app/main.py:1765) or both.
+ * (2) 1 <= k <= RASS_MAX_K_MULTIPASS: the reference passes the caller's top_k straight through
+ * (app/main.py:2882, 3008); k > RASS_MAX_K is served exactly, in ceil(k/32) passes, pass p ranking only
+ * the rows strictly after pass p-1's last hit under (score desc, id asc).
+ * Thread-safe: concurrent calls (same or different indices) overlap their host round trips; the
+ * engine lock is held while enqueuing only. */
+int rass_index_search_ex(rass_index_t* idx, const float* queries, int nq, int k,
+                         const int32_t* q_filter, const int32_t* q_filter_mask,
+                         float* out_scores, int64_t* out_ids);
 /* Device-resident variant for the multi-GPU path and the benchmark: queries
  * and outputs live in HBM, nothing is synchronised; nq <= RASS_MAX_QBATCH.
  * `id_base` is added to local row ids (row-sharded corpus). */
@@ -295,11 +314,17 @@ int rass_encoder_finalize(rass_encoder_t* enc);
  * out: nseq x hidden fp32, order = input order. */
 int rass_encode(rass_encoder_t* enc, const int32_t* token_ids,
                 const int32_t* cu_seqlens, int nseq, float* out);
-/* Device-resident, asynchronous on `stream` (NULL = the encoder's stream):
- * the output can be handed straight to rass_index_add_device. */
+/* Device-resident, asynchronous on `stream`.  NULL means the encoder's OWN
+ * (non-blocking) stream, rass_encoder_get_stream() — NOT HIP's legacy null
+ * stream, with which it does not synchronise.  The output can be handed
+ * straight to rass_index_add_device when the engine runs on the same stream
+ * (rass_engine_set_stream(eng, rass_encoder_get_stream(enc)), or one caller
+ * stream passed to both); on different streams the caller must order them. */
 int rass_encode_device(rass_encoder_t* enc, const int32_t* d_token_ids,
                        const int32_t* d_cu_seqlens, int nseq, int total_tokens,
                        int max_seqlen, float* d_out, void* stream);
+/* The hipStream_t rass_encode() and rass_encode_device(stream = NULL) run on. */
+void* rass_encoder_get_stream(rass_encoder_t* enc);
 /* The encoder's GEMM on its own: Y[m,n] = epi(X[m,k] W[n,k]^T + bias), bf16
  * operands; epilogue 0 bias, 1 bias+residual, 2 bias+GELU(erf).  m_pad
  * (multiple of 128) rows must be allocated; n % 128 == 0, k % 64 == 0. */

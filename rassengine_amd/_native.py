@@ -20,6 +20,10 @@ LIB_PATH = os.path.join(_HERE, "lib", "librass_hip.so")
 
 RASS_OK = 0
 RASS_MAX_K = 32
+RASS_MAX_K_MULTIPASS = 4096
+RASS_TAG_PATIENT_MASK = 0x00FFFFFF
+RASS_TAG_DOCTYPE_SHIFT = 24
+RASS_TAG_DOCTYPE_MASK = 0x7F000000
 RASS_MAX_QBATCH = 32
 RASS_F32 = 0
 RASS_BF16 = 1
@@ -58,6 +62,8 @@ SIGNATURES = {
     "rass_index_get_rows": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]),
     "rass_index_search": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "rass_index_search_ex": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "rass_index_search_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                                 ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
                                                 ctypes.c_void_p]),
@@ -95,6 +101,7 @@ SIGNATURES = {
     "rass_encoder_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, c_void_pp]),
     "rass_encoder_destroy": (None, [ctypes.c_void_p]),
     "rass_encoder_hidden": (ctypes.c_int, [ctypes.c_void_p]),
+    "rass_encoder_get_stream": (ctypes.c_void_p, [ctypes.c_void_p]),
     "rass_encoder_set_weight": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int64]),
     "rass_encoder_finalize": (ctypes.c_int, [ctypes.c_void_p]),
     "rass_encode": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),

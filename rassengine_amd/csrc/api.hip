@@ -4,8 +4,11 @@
 // Ownership model: the engine singleton of a process owns the corpus slabs
 // for process lifetime; callers own every host buffer they pass in or get filled.
 // Threading: add/delete/grow take the index mutex; searches take the engine mutex only
-// while enqueuing (all GPU work of an engine is ordered on one stream, so the shared
-// scratch is safe by stream order).
+// while ENQUEUING (all GPU work of an engine is ordered on one stream, so the shared device
+// scratch and staging are safe by stream order) and wait for their results on a per-call
+// event outside of it, on a pinned host slot taken from a small pool: searches on different
+// indices (users) overlap their host round trips instead of serialising on a stream sync.
+// rows / deleted / has_tags are atomics: searches read them without the index mutex.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -14,6 +17,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <map>
 #include <mutex>
 #include <new>
@@ -72,6 +77,13 @@ struct IvfPlan {
     int64_t max_tiles;
 };
 
+// Extended per-query filters of a scan (kernels.h ScanArgs): all-null = the plain kernel variant.
+struct ScanExt {
+    const int32_t* d_q_mask = nullptr;
+    const float* d_after_s = nullptr;
+    const int64_t* d_after_i = nullptr;
+};
+
 struct ScratchLayout {
     size_t q_padded, part_scores, part_ids, q_bf16, cand_scores, cand_ids, total;
 };
@@ -100,6 +112,23 @@ ScratchLayout scratch_layout(int nq, int k) {
     return L;
 }
 
+// One host search call in flight: pinned staging for a batch of <= 32 queries and its results, and
+// the event recorded behind the batch's last copy.
+struct HostSlot {
+    float* h_q = nullptr;          // [32][dim]
+    int32_t* h_filter = nullptr;   // [32]
+    int32_t* h_mask = nullptr;     // [32]
+    float* h_after_s = nullptr;    // [32]
+    int64_t* h_after_i = nullptr;  // [32]
+    float* h_out_s = nullptr;      // [32][32]
+    int64_t* h_out_i = nullptr;    // [32][32]
+    int64_t* h_scanned = nullptr;  // [1]
+    void* base = nullptr;          // the one hipHostMalloc behind all of the above
+    hipEvent_t done = nullptr;
+    bool busy = false;
+};
+constexpr int kHostSlots = 8;
+
 }  // namespace
 
 struct rass_engine {
@@ -120,6 +149,13 @@ struct rass_engine {
     int64_t* d_out_ids = nullptr;   // [32][32]
     float* d_stage = nullptr;       // [kStageRows][dim]
     int32_t* d_stage_tags = nullptr;
+    int32_t* d_qmask = nullptr;     // [32] masked-filter masks
+    float* d_after_s = nullptr;     // [32] continuation bound of a multi-pass top-k (k > 32)
+    int64_t* d_after_i = nullptr;   // [32]
+    // pinned host slots of the host search API (one per call in flight)
+    std::vector<HostSlot> slots;
+    std::mutex slot_mu;
+    std::condition_variable slot_cv;
     // optional HIP-event bracket around every scan kernel launch (bench.py's roofline leg)
     std::vector<hipEvent_t> ev_pool;  // pairs: [2i] before, [2i+1] after
     int ev_used = 0;                  // pairs recorded since timing_begin
@@ -132,10 +168,10 @@ struct rass_index {
     rass_dtype dtype = RASS_F32;
     int dim = 0;
     int64_t stride = 0;
-    int64_t rows = 0;
+    std::atomic<int64_t> rows{0};      // published after the rows' pack kernels are enqueued
     int64_t capacity = 0;
-    int64_t deleted = 0;
-    bool has_tags = false;  // any non-zero tag ever stored
+    std::atomic<int64_t> deleted{0};
+    std::atomic<bool> has_tags{false};  // any non-zero tag ever stored
     float* d_rows = nullptr;
     int32_t* d_tags = nullptr;
     unsigned short* d_rows_bf16 = nullptr;  // tile16b copy for the prefilter mode (nullptr = off)
@@ -234,7 +270,7 @@ int scan_launch(const float* d_corpus, int64_t n_rows, int64_t stride, const int
                 const float* d_queries, int q_dim, int64_t q_stride, int nq, const int32_t* d_q_filter, int k,
                 int64_t id_base, float* d_out_scores, int64_t* d_out_ids, unsigned char* ws, size_t ws_bytes,
                 int n_cus, hipStream_t st, rass_engine* timing = nullptr, const IvfPlan* plan = nullptr,
-                const int64_t* id_map = nullptr) {
+                const int64_t* id_map = nullptr, const ScanExt* ext = nullptr) {
     if (nq < 1 || nq > RASS_MAX_QBATCH) return fail(RASS_ERR_INVALID, "nq must be in [1, RASS_MAX_QBATCH]");
     if (k < 1 || k > RASS_MAX_K) return fail(RASS_ERR_INVALID, "k must be in [1, RASS_MAX_K]");
     if (n_rows < 0 || n_rows > 0x7fffffc0LL) return fail(RASS_ERR_INVALID, "n_rows out of range for one scan");
@@ -272,6 +308,11 @@ int scan_launch(const float* d_corpus, int64_t n_rows, int64_t stride, const int
     a.k = k;
     // one workgroup per CU on every XCD: only then does blockIdx parity = XCD parity
     a.xcd_skew = (grid == n_cus && grid % 8 == 0) ? scan_xcd_skew(nq) : 0;
+    if (ext) {
+        a.q_filter_mask = ext->d_q_mask;
+        a.q_after_score = ext->d_after_s;
+        a.q_after_id = ext->d_after_i;
+    }
     if (plan) {
         a.work_tile = plan->work_tile;
         a.work_rows = plan->work_rows;
@@ -397,6 +438,26 @@ int rass_engine_create(int device, int dim, rass_engine_t** out) {
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&eng->d_out_ids), RASS_MAX_QBATCH * RASS_MAX_K * sizeof(int64_t)));
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&eng->d_stage), (size_t)kStageRows * dim * sizeof(float)));
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&eng->d_stage_tags), (size_t)kStageRows * sizeof(int32_t)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&eng->d_qmask), RASS_MAX_QBATCH * sizeof(int32_t)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&eng->d_after_s), RASS_MAX_QBATCH * sizeof(float)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&eng->d_after_i), RASS_MAX_QBATCH * sizeof(int64_t)));
+        eng->slots.resize(kHostSlots);
+        for (HostSlot& sl : eng->slots) {
+            // one pinned block per slot: [out_i 32x32 i64][after_i 32 i64][scanned i64][q 32xdim f32][out_s][after_s][filter][mask]
+            const size_t B = RASS_MAX_QBATCH, K = RASS_MAX_K;
+            const size_t bytes = B * K * 8 + B * 8 + 8 + B * (size_t)dim * 4 + B * K * 4 + B * 4 + B * 4 + B * 4;
+            HIP_TRY(hipHostMalloc(&sl.base, bytes, hipHostMallocDefault));
+            unsigned char* p = static_cast<unsigned char*>(sl.base);
+            sl.h_out_i = reinterpret_cast<int64_t*>(p), p += B * K * 8;
+            sl.h_after_i = reinterpret_cast<int64_t*>(p), p += B * 8;
+            sl.h_scanned = reinterpret_cast<int64_t*>(p), p += 8;
+            sl.h_q = reinterpret_cast<float*>(p), p += B * (size_t)dim * 4;
+            sl.h_out_s = reinterpret_cast<float*>(p), p += B * K * 4;
+            sl.h_after_s = reinterpret_cast<float*>(p), p += B * 4;
+            sl.h_filter = reinterpret_cast<int32_t*>(p), p += B * 4;
+            sl.h_mask = reinterpret_cast<int32_t*>(p), p += B * 4;
+            HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+        }
         return RASS_OK;
     };
     const int rc = init();
@@ -428,6 +489,13 @@ void rass_engine_destroy(rass_engine_t* eng) {
     (void)hipFree(eng->d_out_ids);
     (void)hipFree(eng->d_stage);
     (void)hipFree(eng->d_stage_tags);
+    (void)hipFree(eng->d_qmask);
+    (void)hipFree(eng->d_after_s);
+    (void)hipFree(eng->d_after_i);
+    for (HostSlot& sl : eng->slots) {
+        if (sl.base) (void)hipHostFree(sl.base);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+    }
     for (hipEvent_t e : eng->ev_pool) (void)hipEventDestroy(e);
     if (eng->own_stream) (void)hipStreamDestroy(eng->own_stream);
     delete eng;
@@ -500,17 +568,26 @@ int rass_index_open(rass_engine_t* eng, const char* name, rass_dtype dtype, int6
 
 int rass_index_drop(rass_engine_t* eng, const char* name) {
     if (!eng || !name) return fail(RASS_ERR_INVALID, "NULL argument");
-    std::lock_guard<std::mutex> lk(eng->mu);
+    std::unique_lock<std::mutex> lk(eng->mu);
     auto it = eng->indices.find(name);
     if (it == eng->indices.end()) return fail(RASS_ERR_NOT_FOUND, "no such index");
     HIP_TRY(hipSetDevice(eng->device));
-    HIP_TRY(hipStreamSynchronize(eng->stream));
     rass_index* idx = it->second;
-    if (idx->d_rows) (void)hipFree(idx->d_rows);
-    if (idx->d_tags) (void)hipFree(idx->d_tags);
-    if (idx->d_rows_bf16) (void)hipFree(idx->d_rows_bf16);
-    delete idx;
     eng->indices.erase(it);
+    lk.unlock();
+    {   // an add / delete / get_row / save that already holds the index runs to its end first (lock order
+        // everywhere: index mutex, then engine mutex).  Using the handle AFTER drop returns is the caller's bug.
+        std::lock_guard<std::mutex> ilk(idx->mu);
+        std::lock_guard<std::mutex> elk(eng->mu);
+        (void)hipStreamSynchronize(eng->stream);
+        if (idx->d_rows) (void)hipFree(idx->d_rows);
+        if (idx->d_tags) (void)hipFree(idx->d_tags);
+        if (idx->d_rows_bf16) (void)hipFree(idx->d_rows_bf16);
+        idx->d_rows = nullptr;
+        idx->d_tags = nullptr;
+        idx->d_rows_bf16 = nullptr;
+    }
+    delete idx;
     return RASS_OK;
 }
 
@@ -544,8 +621,8 @@ int rass_index_set_prefilter(rass_index_t* idx, int enable) {
 
 int rass_index_get_prefilter(const rass_index_t* idx) { return (idx && idx->prefilter) ? 1 : 0; }
 
-int64_t rass_index_count(const rass_index_t* idx) { return idx ? idx->rows - idx->deleted : 0; }
-int64_t rass_index_rows(const rass_index_t* idx) { return idx ? idx->rows : 0; }
+int64_t rass_index_count(const rass_index_t* idx) { return idx ? idx->rows.load() - idx->deleted.load() : 0; }
+int64_t rass_index_rows(const rass_index_t* idx) { return idx ? idx->rows.load() : (int64_t)0; }
 int rass_index_dim(const rass_index_t* idx) { return idx ? idx->dim : fail(RASS_ERR_INVALID, "index is NULL"); }
 int rass_index_row_stride(const rass_index_t* idx) {
     return idx ? (int)idx->stride : fail(RASS_ERR_INVALID, "index is NULL");
@@ -587,9 +664,10 @@ static int add_common(rass_index_t* idx, const float* vecs, const int32_t* tags,
         }
         HIP_TRY(rass::launch_pack_rows_tile16(dsrc, dim, idx->d_rows, idx->stride, idx->rows + done, m, dim,
                                               normalize ? 1 : 0, st));
-        if (tags) {
-            HIP_TRY(hipMemcpyAsync(tdst, tags + done, (size_t)m * sizeof(int32_t),
-                                   device_src ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+        if (tags && device_src) {
+            HIP_TRY(rass::launch_copy_tags_clamped(tdst, tags + done, m, st));
+        } else if (tags) {
+            HIP_TRY(hipMemcpyAsync(tdst, tags + done, (size_t)m * sizeof(int32_t), hipMemcpyHostToDevice, st));
         } else {
             HIP_TRY(rass::launch_fill_i32(tdst, m, 0, st));
         }
@@ -674,59 +752,132 @@ int rass_index_search_device(rass_index_t* idx, const float* d_queries, int nq, 
     std::lock_guard<std::mutex> lk(eng->mu);
     int rc = set_device(eng);
     if (rc != RASS_OK) return rc;
-    const bool need_tags = (idx->deleted > 0) || (d_q_filter != nullptr);
-    if (idx->prefilter && idx->rows > 0 && k <= kPrefilterMaxK)
+    const int64_t rows = idx->rows.load(std::memory_order_acquire);
+    const bool need_tags = (idx->deleted.load(std::memory_order_acquire) > 0) || (d_q_filter != nullptr);
+    if (idx->prefilter && rows > 0 && k <= kPrefilterMaxK)
         return prefilter_launch(idx, d_queries, nq, d_q_filter, k, id_base, d_out_scores, d_out_ids,
                                 need_tags ? idx->d_tags : nullptr, eng, eng->stream);
-    return scan_launch(idx->d_rows ? idx->d_rows : reinterpret_cast<const float*>(eng->d_scratch), idx->rows,
+    return scan_launch(idx->d_rows ? idx->d_rows : reinterpret_cast<const float*>(eng->d_scratch), rows,
                        idx->stride, need_tags ? idx->d_tags : nullptr, d_queries, idx->dim, idx->dim, nq,
                        d_q_filter, k, id_base, d_out_scores, d_out_ids, eng->d_scratch, eng->scratch_bytes,
                        eng->n_cus, eng->stream, eng);
 }
 
-int rass_index_search(rass_index_t* idx, const float* queries, int nq, int k, const int32_t* q_filter,
-                      float* out_scores, int64_t* out_ids) {
+namespace {
+
+// A pinned host slot for one search call in flight (blocks while all kHostSlots are taken).
+HostSlot* slot_acquire(rass_engine* eng) {
+    std::unique_lock<std::mutex> lk(eng->slot_mu);
+    for (;;) {
+        for (HostSlot& sl : eng->slots)
+            if (!sl.busy) {
+                sl.busy = true;
+                return &sl;
+            }
+        eng->slot_cv.wait(lk);
+    }
+}
+
+void slot_release(rass_engine* eng, HostSlot* sl) {
+    {
+        std::lock_guard<std::mutex> lk(eng->slot_mu);
+        sl->busy = false;
+    }
+    eng->slot_cv.notify_one();
+}
+
+struct SlotGuard {
+    rass_engine* eng;
+    HostSlot* sl;
+    SlotGuard(rass_engine* e) : eng(e), sl(slot_acquire(e)) {}
+    ~SlotGuard() { slot_release(eng, sl); }
+};
+
+}  // namespace
+
+int rass_index_search_ex(rass_index_t* idx, const float* queries, int nq, int k, const int32_t* q_filter,
+                         const int32_t* q_filter_mask, float* out_scores, int64_t* out_ids) {
     if (!idx || !out_scores || !out_ids) return fail(RASS_ERR_INVALID, "NULL argument");
     if (nq < 0 || (nq > 0 && !queries)) return fail(RASS_ERR_INVALID, "bad queries / nq");
-    if (k < 1 || k > RASS_MAX_K) return fail(RASS_ERR_INVALID, "k must be in [1, RASS_MAX_K]");
+    if (k < 1 || k > RASS_MAX_K_MULTIPASS) return fail(RASS_ERR_INVALID, "k must be in [1, RASS_MAX_K_MULTIPASS]");
+    if (q_filter_mask && !q_filter) return fail(RASS_ERR_INVALID, "q_filter_mask without q_filter");
     rass_engine* eng = idx->eng;
     int rc = set_device(eng);
     if (rc != RASS_OK) return rc;
     const int dim = idx->dim;
+    SlotGuard guard(eng);
+    HostSlot* sl = guard.sl;
     for (int done = 0; done < nq;) {
         const int b = std::min(RASS_MAX_QBATCH, nq - done);
-        hipStream_t st;
-        {
-            // staging buffers are per engine: hold the lock across the whole batch round trip
-            std::lock_guard<std::mutex> lk(eng->mu);
-            st = eng->stream;
-            HIP_TRY(hipMemcpyAsync(eng->d_qraw, queries + (int64_t)done * dim, (size_t)b * dim * sizeof(float),
-                                   hipMemcpyHostToDevice, st));
-            const int32_t* d_filter = nullptr;
-            if (q_filter) {
-                HIP_TRY(hipMemcpyAsync(eng->d_qfilter, q_filter + done, (size_t)b * sizeof(int32_t),
-                                       hipMemcpyHostToDevice, st));
-                d_filter = eng->d_qfilter;
+        memcpy(sl->h_q, queries + (int64_t)done * dim, (size_t)b * dim * sizeof(float));
+        if (q_filter) memcpy(sl->h_filter, q_filter + done, (size_t)b * sizeof(int32_t));
+        if (q_filter_mask) memcpy(sl->h_mask, q_filter_mask + done, (size_t)b * sizeof(int32_t));
+        // k > RASS_MAX_K: passes of <= 32; pass p ranks only the rows strictly AFTER pass p-1's last hit
+        for (int kdone = 0; kdone < k;) {
+            const int kk = std::min(RASS_MAX_K, k - kdone);
+            const bool cont = kdone > 0;
+            {
+                // the engine lock is held while ENQUEUING only: device staging and scratch are shared by
+                // stream order, the wait happens on this call's own event
+                std::lock_guard<std::mutex> lk(eng->mu);
+                hipStream_t st = eng->stream;
+                HIP_TRY(hipMemcpyAsync(eng->d_qraw, sl->h_q, (size_t)b * dim * sizeof(float), hipMemcpyHostToDevice, st));
+                const int32_t* d_filter = nullptr;
+                ScanExt ext;
+                if (q_filter) {
+                    HIP_TRY(hipMemcpyAsync(eng->d_qfilter, sl->h_filter, (size_t)b * sizeof(int32_t),
+                                           hipMemcpyHostToDevice, st));
+                    d_filter = eng->d_qfilter;
+                }
+                if (q_filter_mask) {
+                    HIP_TRY(hipMemcpyAsync(eng->d_qmask, sl->h_mask, (size_t)b * sizeof(int32_t), hipMemcpyHostToDevice, st));
+                    ext.d_q_mask = eng->d_qmask;
+                }
+                if (cont) {
+                    HIP_TRY(hipMemcpyAsync(eng->d_after_s, sl->h_after_s, (size_t)b * sizeof(float), hipMemcpyHostToDevice, st));
+                    HIP_TRY(hipMemcpyAsync(eng->d_after_i, sl->h_after_i, (size_t)b * sizeof(int64_t), hipMemcpyHostToDevice, st));
+                    ext.d_after_s = eng->d_after_s;
+                    ext.d_after_i = eng->d_after_i;
+                }
+                const bool use_ext = q_filter_mask || cont;
+                const int64_t rows = idx->rows.load(std::memory_order_acquire);
+                const bool need_tags = (idx->deleted.load(std::memory_order_acquire) > 0) || (d_filter != nullptr);
+                if (idx->prefilter && rows > 0 && k <= kPrefilterMaxK && !use_ext)
+                    rc = prefilter_launch(idx, eng->d_qraw, b, d_filter, kk, 0, eng->d_out_scores, eng->d_out_ids,
+                                          need_tags ? idx->d_tags : nullptr, eng, st);
+                else
+                    rc = scan_launch(idx->d_rows ? idx->d_rows : reinterpret_cast<const float*>(eng->d_scratch), rows,
+                                     idx->stride, need_tags ? idx->d_tags : nullptr, eng->d_qraw, dim, dim, b, d_filter,
+                                     kk, 0, eng->d_out_scores, eng->d_out_ids, eng->d_scratch, eng->scratch_bytes,
+                                     eng->n_cus, st, eng, nullptr, nullptr, use_ext ? &ext : nullptr);
+                if (rc != RASS_OK) return rc;
+                HIP_TRY(hipMemcpyAsync(sl->h_out_s, eng->d_out_scores, (size_t)b * kk * sizeof(float),
+                                       hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipMemcpyAsync(sl->h_out_i, eng->d_out_ids, (size_t)b * kk * sizeof(int64_t),
+                                       hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipEventRecord(sl->done, st));
             }
-            const bool need_tags = (idx->deleted > 0) || (d_filter != nullptr);
-            if (idx->prefilter && idx->rows > 0 && k <= kPrefilterMaxK)
-                rc = prefilter_launch(idx, eng->d_qraw, b, d_filter, k, 0, eng->d_out_scores, eng->d_out_ids,
-                                      need_tags ? idx->d_tags : nullptr, eng, st);
-            else
-            rc = scan_launch(idx->d_rows ? idx->d_rows : reinterpret_cast<const float*>(eng->d_scratch), idx->rows,
-                             idx->stride, need_tags ? idx->d_tags : nullptr, eng->d_qraw, dim, dim, b, d_filter, k,
-                             0, eng->d_out_scores, eng->d_out_ids, eng->d_scratch, eng->scratch_bytes, eng->n_cus,
-                             st, eng);
-            if (rc != RASS_OK) return rc;
-            HIP_TRY(hipMemcpyAsync(out_scores + (int64_t)done * k, eng->d_out_scores, (size_t)b * k * sizeof(float),
-                                   hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipMemcpyAsync(out_ids + (int64_t)done * k, eng->d_out_ids, (size_t)b * k * sizeof(int64_t),
-                                   hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
+            HIP_TRY(hipEventSynchronize(sl->done));
+            for (int q = 0; q < b; ++q) {
+                memcpy(out_scores + (int64_t)(done + q) * k + kdone, sl->h_out_s + (int64_t)q * kk, (size_t)kk * sizeof(float));
+                memcpy(out_ids + (int64_t)(done + q) * k + kdone, sl->h_out_i + (int64_t)q * kk, (size_t)kk * sizeof(int64_t));
+                // continuation bound for the next pass: this pass's last hit, or "nothing left" (-inf) when the
+                // pass came back short
+                const int64_t last_id = sl->h_out_i[(int64_t)q * kk + kk - 1];
+                sl->h_after_s[q] = last_id >= 0 ? sl->h_out_s[(int64_t)q * kk + kk - 1] : -INFINITY;
+                sl->h_after_i[q] = last_id >= 0 ? last_id : INT64_MAX;
+            }
+            kdone += kk;
         }
         done += b;
     }
     return RASS_OK;
+}
+
+int rass_index_search(rass_index_t* idx, const float* queries, int nq, int k, const int32_t* q_filter,
+                      float* out_scores, int64_t* out_ids) {
+    if (k < 1 || k > RASS_MAX_K) return fail(RASS_ERR_INVALID, "k must be in [1, RASS_MAX_K]");
+    return rass_index_search_ex(idx, queries, nq, k, q_filter, nullptr, out_scores, out_ids);
 }
 
 // ---- persistence: header + unpadded fp32 rows + tags
@@ -1243,25 +1394,30 @@ int rass_ivf_search(rass_ivf_t* v, const float* queries, int nq, int k, int npro
     int rc = set_device(eng);
     if (rc != RASS_OK) return rc;
     int64_t scanned_total = 0;
+    SlotGuard guard(eng);
+    HostSlot* sl = guard.sl;
     for (int done = 0; done < nq;) {
         const int b = std::min(RASS_MAX_QBATCH, nq - done);
-        // staging buffers are per engine: hold the lock across the whole batch round trip
-        std::lock_guard<std::mutex> lk(eng->mu);
-        hipStream_t st = eng->stream;
-        HIP_TRY(hipMemcpyAsync(eng->d_qraw, queries + (int64_t)done * v->dim, (size_t)b * v->dim * 4,
-                               hipMemcpyHostToDevice, st));
-        if (q_filter)
-            HIP_TRY(hipMemcpyAsync(eng->d_qfilter, q_filter + done, (size_t)b * 4, hipMemcpyHostToDevice, st));
-        rc = ivf_search_locked(v, eng->d_qraw, b, k, nprobe, q_filter ? eng->d_qfilter : nullptr, eng->d_out_scores,
-                               eng->d_out_ids);
-        if (rc != RASS_OK) return rc;
-        int64_t scanned = 0;
-        HIP_TRY(hipMemcpyAsync(out_scores + (int64_t)done * k, eng->d_out_scores, (size_t)b * k * 4,
-                               hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(out_ids + (int64_t)done * k, eng->d_out_ids, (size_t)b * k * 8, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(&scanned, v->d_scanned, 8, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        scanned_total += scanned;
+        memcpy(sl->h_q, queries + (int64_t)done * v->dim, (size_t)b * v->dim * 4);
+        if (q_filter) memcpy(sl->h_filter, q_filter + done, (size_t)b * 4);
+        {
+            // engine lock while enqueuing only (shared device staging is safe by stream order)
+            std::lock_guard<std::mutex> lk(eng->mu);
+            hipStream_t st = eng->stream;
+            HIP_TRY(hipMemcpyAsync(eng->d_qraw, sl->h_q, (size_t)b * v->dim * 4, hipMemcpyHostToDevice, st));
+            if (q_filter) HIP_TRY(hipMemcpyAsync(eng->d_qfilter, sl->h_filter, (size_t)b * 4, hipMemcpyHostToDevice, st));
+            rc = ivf_search_locked(v, eng->d_qraw, b, k, nprobe, q_filter ? eng->d_qfilter : nullptr, eng->d_out_scores,
+                                   eng->d_out_ids);
+            if (rc != RASS_OK) return rc;
+            HIP_TRY(hipMemcpyAsync(sl->h_out_s, eng->d_out_scores, (size_t)b * k * 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(sl->h_out_i, eng->d_out_ids, (size_t)b * k * 8, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(sl->h_scanned, v->d_scanned, 8, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipEventRecord(sl->done, st));
+        }
+        HIP_TRY(hipEventSynchronize(sl->done));
+        memcpy(out_scores + (int64_t)done * k, sl->h_out_s, (size_t)b * k * 4);
+        memcpy(out_ids + (int64_t)done * k, sl->h_out_i, (size_t)b * k * 8);
+        scanned_total += *sl->h_scanned;
         done += b;
     }
     if (scanned_rows) *scanned_rows = scanned_total;

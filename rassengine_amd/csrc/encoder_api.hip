@@ -375,6 +375,8 @@ int rass_encode(rass_encoder_t* e, const int32_t* token_ids, const int32_t* cu_s
     return RASS_OK;
 }
 
+void* rass_encoder_get_stream(rass_encoder_t* e) { return e ? reinterpret_cast<void*>(e->own_stream) : nullptr; }
+
 int rass_encoder_hidden(const rass_encoder_t* e) { return e ? e->cfg.hidden : efail(RASS_ERR_INVALID, "encoder is NULL"); }
 
 /* Stand-alone launcher of the encoder GEMM (tests, micro-benchmarks). */

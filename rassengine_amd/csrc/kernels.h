@@ -12,6 +12,14 @@ struct ScanArgs {
     const int32_t* row_tag;   // [n_rows] or nullptr; -1 = tombstone, >= 0 = patientId code
     const float* q_padded;    // [16*NT][row_stride] normalised queries, zero rows past nq
     const int32_t* q_filter;  // [nq] or nullptr; -1 = no filter
+    // Extended per-query filters (all nullptr for the plain scan; any non-null selects the EXT kernel variant):
+    //   q_filter_mask[q]: a row matches when (tag & mask) == q_filter[q] (tag = patient code | doc_type << 24,
+    //                     so one compare serves `term: patientId`, `term: doc_type` or both); nullptr = exact compare
+    //   q_after_score/q_after_id[q]: continuation bound of a multi-pass top-k (k > 32): only rows that rank
+    //                     strictly AFTER (score, global id) under (score desc, id asc) are eligible
+    const int32_t* q_filter_mask = nullptr;
+    const float* q_after_score = nullptr;
+    const int64_t* q_after_id = nullptr;
     float* part_scores;       // [grid][nq][k]
     int64_t* part_ids;        // [grid][nq][k]
     int64_t row_stride;       // elements, multiple of 128
@@ -106,5 +114,7 @@ hipError_t launch_fill_synthetic_f32(float* packed, int64_t stride, int64_t firs
                                      uint64_t seed, int64_t row_id_base, hipStream_t stream);
 
 hipError_t launch_fill_i32(int32_t* dst, int64_t n, int32_t value, hipStream_t stream);
+// dst[i] = max(src[i], 0): device-source row tags (negative = reserved tombstone code -> 0)
+hipError_t launch_copy_tags_clamped(int32_t* dst, const int32_t* src, int64_t n, hipStream_t stream);
 
 }  // namespace rass

@@ -111,6 +111,24 @@ hipError_t launch_fill_i32(int32_t* dst, int64_t n, int32_t value, hipStream_t s
     return hipGetLastError();
 }
 
+// Row tags handed over from device memory cannot be validated on the host without a sync: negative
+// values (the tombstone code is reserved for rass_index_delete, which also keeps the counters) are
+// stored as 0 = "no patient".
+__global__ void copy_tags_clamped_kernel(int32_t* dst, const int32_t* src, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t t = src[i];
+        dst[i] = t < 0 ? 0 : t;
+    }
+}
+
+hipError_t launch_copy_tags_clamped(int32_t* dst, const int32_t* src, int64_t n, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(copy_tags_clamped_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, dst, src, n);
+    return hipGetLastError();
+}
+
 // ---- Philox4x32-10 (Salmon et al., SC'11), counter = (row_lo, row_hi, col/4, 0), key = seed.
 struct U4 {
     uint32_t x, y, z, w;

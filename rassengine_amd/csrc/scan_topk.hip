@@ -238,7 +238,7 @@ __device__ __forceinline__ void insert_candidates(TopList& L, float& tau, float 
     }
 }
 
-template <int CH, int NT, bool IVF>
+template <int CH, int NT, bool IVF, bool EXT>
 __global__ __launch_bounds__(kThreads, 2) void scan_topk_f32_kernel(ScanArgs p) {
     constexpr int NQ = NT * 16;
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [4][kWaves][NQ][kPitch]
@@ -280,6 +280,22 @@ __global__ __launch_bounds__(kThreads, 2) void scan_topk_f32_kernel(ScanArgs p) 
         const int q = pq * 16 + (lane >> 5) * 8 + wid;
         qfilt[pq] = (p.q_filter != nullptr && q < p.nq) ? p.q_filter[q] : -1;
     }
+    // EXT variant only (masked filters, multi-pass continuation); the plain variant's code is unchanged.
+    // The per-query parameters live in LDS (512 B next to the 144 KiB partial images), not in registers:
+    // they are read in the ranking step only and the main loop has no VGPRs to spare at CH = 8, NT = 2.
+    __shared__ int sh_qmask[32];
+    __shared__ float sh_after_s[32];
+    __shared__ int64_t sh_after_i[32];
+    if (EXT) {
+        if (threadIdx.x < 32) {
+            const int q = threadIdx.x;
+            const bool live = q < p.nq;
+            sh_qmask[q] = (p.q_filter_mask != nullptr && live) ? p.q_filter_mask[q] : -1;
+            sh_after_s[q] = (p.q_after_score != nullptr && live) ? p.q_after_score[q] : INFINITY;
+            sh_after_i[q] = (p.q_after_id != nullptr && live) ? p.q_after_id[q] : (int64_t)-1;
+        }
+        __syncthreads();
+    }
 
     const int mt_step = 16 * (int)p.row_stride * 4;
     TileRegs<CH> R0, R1;
@@ -315,7 +331,15 @@ __global__ __launch_bounds__(kThreads, 2) void scan_topk_f32_kernel(ScanArgs p) 
             float s = src[0];
 #pragma unroll
             for (int wv = 1; wv < kWaves; ++wv) s += src[wv * NQ * kPitch];
-            bool ok = row_ok && (qfilt[pq] < 0 || qfilt[pq] == tag);
+            bool ok;
+            if (EXT) {
+                ok = row_ok && (qfilt[pq] < 0 || qfilt[pq] == (tag & sh_qmask[q]));
+                // continuation: strictly after (after_s, after_i) in (score desc, id asc)
+                const float as = sh_after_s[q];
+                ok = ok && (s < as || (s == as && (p.id_base + (int64_t)row) > sh_after_i[q]));
+            } else {
+                ok = row_ok && (qfilt[pq] < 0 || qfilt[pq] == tag);
+            }
             if (IVF) ok = ok && ((w.mask >> q) & 1u);
             s = ok ? s : -INFINITY;
             insert_candidates(L[pq], tau[pq], s, row, p.k);
@@ -364,31 +388,31 @@ __global__ __launch_bounds__(kThreads, 2) void scan_topk_f32_kernel(ScanArgs p) 
     }
 }
 
-template <int CH, int NT, bool IVF>
+template <int CH, int NT, bool IVF, bool EXT>
 static hipError_t launch_variant(const ScanArgs& a, int grid, hipStream_t stream) {
     constexpr size_t lds_bytes = (size_t)4 * kWaves * NT * 16 * kPitch * sizeof(float);  // 144 KiB at NT = 2
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_topk_f32_kernel<CH, NT, IVF>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_topk_f32_kernel<CH, NT, IVF, EXT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((scan_topk_f32_kernel<CH, NT, IVF>), dim3(grid), dim3(kThreads), lds_bytes, stream, a);
+    hipLaunchKernelGGL((scan_topk_f32_kernel<CH, NT, IVF, EXT>), dim3(grid), dim3(kThreads), lds_bytes, stream, a);
     return hipGetLastError();
 }
 
-template <int NT, bool IVF>
+template <int NT, bool IVF, bool EXT = false>
 static hipError_t launch_ch(int ch, const ScanArgs& a, int grid, hipStream_t stream) {
     switch (ch) {
-        case 1: return launch_variant<1, NT, IVF>(a, grid, stream);
-        case 2: return launch_variant<2, NT, IVF>(a, grid, stream);
-        case 3: return launch_variant<3, NT, IVF>(a, grid, stream);
-        case 4: return launch_variant<4, NT, IVF>(a, grid, stream);
-        case 5: return launch_variant<5, NT, IVF>(a, grid, stream);
-        case 6: return launch_variant<6, NT, IVF>(a, grid, stream);
-        case 7: return launch_variant<7, NT, IVF>(a, grid, stream);
-        case 8: return launch_variant<8, NT, IVF>(a, grid, stream);
+        case 1: return launch_variant<1, NT, IVF, EXT>(a, grid, stream);
+        case 2: return launch_variant<2, NT, IVF, EXT>(a, grid, stream);
+        case 3: return launch_variant<3, NT, IVF, EXT>(a, grid, stream);
+        case 4: return launch_variant<4, NT, IVF, EXT>(a, grid, stream);
+        case 5: return launch_variant<5, NT, IVF, EXT>(a, grid, stream);
+        case 6: return launch_variant<6, NT, IVF, EXT>(a, grid, stream);
+        case 7: return launch_variant<7, NT, IVF, EXT>(a, grid, stream);
+        case 8: return launch_variant<8, NT, IVF, EXT>(a, grid, stream);
         default: return hipErrorInvalidValue;
     }
 }
@@ -402,6 +426,14 @@ bool scan_supported_stride(int64_t row_stride) {
 hipError_t launch_scan_topk_f32(const ScanArgs& a, int grid, hipStream_t stream) {
     if (!scan_supported_stride(a.row_stride)) return hipErrorInvalidValue;
     const int ch = (int)(a.row_stride / 128);
+    const bool ext = a.q_filter_mask || a.q_after_score || a.q_after_id;
+    if (ext) {  // masked filters / continuation bound: flat scan only
+        if (a.work_tile != nullptr) return hipErrorInvalidValue;
+        if ((a.q_after_score == nullptr) != (a.q_after_id == nullptr)) return hipErrorInvalidValue;
+        if (a.q_filter_mask != nullptr && a.q_filter == nullptr) return hipErrorInvalidValue;
+        if (a.nq <= 16) return launch_ch<1, false, true>(ch, a, grid, stream);
+        return launch_ch<2, false, true>(ch, a, grid, stream);
+    }
     if (a.work_tile != nullptr) {  // IVF probe: iterate the plan instead of every tile
         if (!a.work_rows || !a.work_mask || !a.n_work) return hipErrorInvalidValue;
         if (a.nq <= 16) return launch_ch<1, true>(ch, a, grid, stream);

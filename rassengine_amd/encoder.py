@@ -353,6 +353,20 @@ class HipSentenceEncoder:
         except Exception:
             pass
 
+    @property
+    def stream(self) -> int:
+        """The encoder's own hipStream_t (as int): what ``rass_encode`` and ``rass_encode_device(stream=NULL)``
+        run on.  Hand it to ``Engine.set_stream`` for the device-resident ingest hand-off."""
+        return int(self._L.rass_encoder_get_stream(self._h) or 0)
+
+    def encode_device(self, d_token_ids_ptr: int, d_cu_seqlens_ptr: int, nseq: int, total_tokens: int,
+                      max_seqlen: int, d_out_ptr: int, stream_ptr: int = 0) -> None:
+        """Device-resident, asynchronous forward (``rass_encode_device``); ``stream_ptr`` 0 = ``self.stream``."""
+        N.check("rass_encode_device",
+                self._L.rass_encode_device(self._h, ctypes.c_void_p(d_token_ids_ptr), ctypes.c_void_p(d_cu_seqlens_ptr),
+                                           int(nseq), int(total_tokens), int(max_seqlen), ctypes.c_void_p(d_out_ptr),
+                                           ctypes.c_void_p(stream_ptr or 0)))
+
     def encode_ids(self, seqs: Sequence[Sequence[int]]) -> np.ndarray:
         """Pooled embeddings of already-tokenised sequences (each ``[CLS] ... [SEP]``)."""
         n = len(seqs)

@@ -199,22 +199,31 @@ class FlatIndex:
         N.check("rass_index_save", self._L.rass_index_save(self._h, path.encode()))
 
     # ---- read path
-    def search(self, queries: np.ndarray, k: int, q_filter: Optional[np.ndarray] = None
-               ) -> Tuple[np.ndarray, np.ndarray]:
+    def search(self, queries: np.ndarray, k: int, q_filter: Optional[np.ndarray] = None,
+               q_filter_mask: Optional[np.ndarray] = None) -> Tuple[np.ndarray, np.ndarray]:
         """Exact cosine top-k.  Returns (scores f32 [nq,k], ids i64 [nq,k]); raw cosine, best
-        first, ties by id ascending, (-inf, -1) padding."""
+        first, ties by id ascending, (-inf, -1) padding.  ``q_filter`` restricts query q to rows whose
+        tag equals it (-1 = no filter); with ``q_filter_mask`` to rows with ``(tag & mask) == filter``.
+        Any k >= 1: k > 32 is served exactly in passes of 32 (``rass_index_search_ex``).  Thread-safe."""
         q = np.ascontiguousarray(queries, dtype=np.float32)
         if q.ndim != 2 or q.shape[1] != self.dim:
             raise ValueError(f"expected [nq, {self.dim}] queries, got {q.shape}")
-        f = None
+        f = m = None
         if q_filter is not None:
             f = np.ascontiguousarray(q_filter, dtype=np.int32)
             if f.shape != (q.shape[0],):
                 raise ValueError("q_filter must be one int32 per query")
+        if q_filter_mask is not None:
+            if f is None:
+                raise ValueError("q_filter_mask needs q_filter")
+            m = np.ascontiguousarray(q_filter_mask, dtype=np.int32)
+            if m.shape != (q.shape[0],):
+                raise ValueError("q_filter_mask must be one int32 per query")
+        k = int(k)
         out_s = np.empty((q.shape[0], k), dtype=np.float32)
         out_i = np.empty((q.shape[0], k), dtype=np.int64)
-        N.check("rass_index_search", self._L.rass_index_search(self._h, _np_ptr(q), q.shape[0], int(k), _np_ptr(f),
-                                                              _np_ptr(out_s), _np_ptr(out_i)))
+        N.check("rass_index_search_ex", self._L.rass_index_search_ex(self._h, _np_ptr(q), q.shape[0], k, _np_ptr(f),
+                                                                    _np_ptr(m), _np_ptr(out_s), _np_ptr(out_i)))
         return out_s, out_i
 
     def search_device(self, d_queries_ptr: int, nq: int, k: int, d_out_scores_ptr: int, d_out_ids_ptr: int,

@@ -51,7 +51,10 @@ if a.from_text:
 enc = HipSentenceEncoder(cfg, w, tok, device=0)
 eng = Engine(0, H)
 idx = eng.open_index("ingest", capacity_rows=a.chunks)
-stream = int(torch.cuda.current_stream().cuda_stream)
+# encoder and index on ONE stream (the encoder's own, non-blocking): the add is ordered behind the forward.
+# torch's default stream is pointer 0, which rass_encode_device reads as "my own stream": passing it to both
+# (as round 1 did) left the forward and the add on two unordered streams.
+stream = enc.stream
 eng.set_stream(stream)
 L = N.lib()
 rng = np.random.default_rng(99)

@@ -39,9 +39,9 @@ class OracleIndex:
     def get_row(self, row):
         return self._rows[row].copy()
 
-    def search(self, queries, k, q_filter=None):
+    def search(self, queries, k, q_filter=None, q_filter_mask=None):
         qn = O.normalize_ref(np.ascontiguousarray(queries, dtype=np.float32)).astype(np.float32)
-        s, i = O.search(self._rows, qn, k, tags=self._tags, qfilter=q_filter)
+        s, i = O.search(self._rows, qn, k, tags=self._tags, qfilter=q_filter, qmask=q_filter_mask)
         return s.astype(np.float32), i
 
 

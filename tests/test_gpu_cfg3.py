@@ -89,18 +89,15 @@ def test_full_window_batch_matches_oracle(large):
 
 
 def _encode_device(enc, seqs, torch):
-    from rassengine_amd import _native as N
     lens = np.array([len(s) for s in seqs], dtype=np.int64)
     cu = np.zeros(len(seqs) + 1, dtype=np.int32)
     np.cumsum(lens, out=cu[1:])
     ids = np.concatenate([np.asarray(s, dtype=np.int32) for s in seqs])
     d_ids = torch.from_numpy(ids).cuda()
     d_cu = torch.from_numpy(cu).cuda()
-    out = torch.empty((len(seqs), enc.dim), dtype=torch.float32, device="cuda")
-    stream = int(torch.cuda.current_stream().cuda_stream)
-    N.check("rass_encode_device", N.lib().rass_encode_device(
-        enc._h, ctypes.c_void_p(d_ids.data_ptr()), ctypes.c_void_p(d_cu.data_ptr()), len(seqs), int(cu[-1]),
-        int(lens.max()), ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(stream)))
+    out = torch.zeros((len(seqs), enc.dim), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()                       # inputs were staged on torch's stream, the encoder has its own
+    enc.encode_device(d_ids.data_ptr(), d_cu.data_ptr(), len(seqs), int(cu[-1]), int(lens.max()), out.data_ptr())
     return out, (d_ids, d_cu)
 
 
@@ -120,7 +117,11 @@ def test_device_handoff_equals_host_path(large):
         dev_idx = eng.open_index("cfg3-dev")
         emb = enc.encode_ids(seqs)                                    # rass_encode: host ids in, host fp32 out
         assert host_idx.add(emb, tags=tags, normalize=True) == 0       # rass_index_add
-        eng.set_stream(int(torch.cuda.current_stream().cuda_stream))   # encoder + index on one stream
+        # encoder + index on ONE stream (the encoder's own): the add is ordered behind the forward with no
+        # host synchronisation in between.  (torch's default stream is HIP's null stream, pointer 0, which
+        # rass_encode_device reads as "my own stream" — the two would NOT be ordered; see the header.)
+        assert enc.stream != 0
+        eng.set_stream(enc.stream)
         out, keep = _encode_device(enc, seqs, torch)
         d_tags = torch.from_numpy(tags).cuda()
         assert dev_idx.add_device(out.data_ptr(), len(seqs), d_tags_ptr=d_tags.data_ptr(), normalize=True) == 0
@@ -135,8 +136,7 @@ def test_device_handoff_equals_host_path(large):
         s_d, i_d = dev_idx.search(q, 10, q_filter=qf)
         assert np.array_equal(i_h, i_d) and np.array_equal(s_h, s_d)
         # a second, differently composed device batch appended behind the first: rows land at the right ids
-        out2, keep2 = None, None
-        eng.set_stream(int(torch.cuda.current_stream().cuda_stream))
+        eng.set_stream(enc.stream)
         out2, keep2 = _encode_device(enc, seqs[:5], torch)
         first = dev_idx.add_device(out2.data_ptr(), 5, normalize=True)
         torch.cuda.synchronize()

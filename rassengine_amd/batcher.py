@@ -34,11 +34,14 @@ class QueryBatcher:
             self._queue = asyncio.Queue()
             self._task = loop.create_task(self._drain())
 
-    async def search(self, query: np.ndarray, k: int, patient_code: int = -1) -> Tuple[np.ndarray, np.ndarray]:
-        """One query vector [dim] -> (scores [k], ids [k]); ``patient_code`` < 0 = no filter."""
+    async def search(self, query: np.ndarray, k: int, filter_value: int = -1, filter_mask: int = -1
+                     ) -> Tuple[np.ndarray, np.ndarray]:
+        """One query vector [dim] -> (scores [k], ids [k]).  ``filter_value`` < 0 = no filter; else rows
+        with ``(tag & filter_mask) == filter_value`` (mask -1 = exact compare)."""
         self._ensure_started()
         fut = asyncio.get_running_loop().create_future()
-        await self._queue.put((np.asarray(query, dtype=np.float32).reshape(-1), int(k), int(patient_code), fut))
+        await self._queue.put((np.asarray(query, dtype=np.float32).reshape(-1), int(k),
+                               (int(filter_value), int(filter_mask)), fut))
         return await fut
 
     async def _drain(self) -> None:
@@ -62,9 +65,15 @@ class QueryBatcher:
         try:
             qs = np.stack([b[0] for b in batch])
             kmax = max(b[1] for b in batch)
-            codes = np.array([b[2] for b in batch], dtype=np.int32)
-            q_filter = codes if bool((codes >= 0).any()) else None
-            scores, ids = await asyncio.to_thread(self.index.search, qs, kmax, q_filter)
+            codes = np.array([b[2][0] for b in batch], dtype=np.int64)
+            masks = np.array([b[2][1] if b[2][0] >= 0 else 0 for b in batch], dtype=np.int64)
+            if not bool((codes >= 0).any()):
+                scores, ids = await asyncio.to_thread(self.index.search, qs, kmax)
+            elif bool((masks[codes >= 0] == -1).all()):          # plain exact filters: the plain kernel variant
+                scores, ids = await asyncio.to_thread(self.index.search, qs, kmax, codes.astype(np.int32))
+            else:
+                scores, ids = await asyncio.to_thread(self.index.search, qs, kmax, codes.astype(np.int32),
+                                                      (masks & 0xFFFFFFFF).astype(np.uint32).view(np.int32))
             self.scans += 1
             self.served += len(batch)
             for i, (_, k, _, fut) in enumerate(batch):

@@ -15,6 +15,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
@@ -34,6 +35,9 @@ thread_local std::string g_err;
 
 int fail(int code, const std::string& msg) {
     g_err = msg;
+    // A failed HIP call (e.g. an out-of-memory hipMalloc) stays behind as the runtime's "last error" and the
+    // NEXT kernel launch's hipGetLastError() would report it as its own: every failure path ends here, clear it.
+    (void)hipGetLastError();
     return code;
 }
 
@@ -933,6 +937,8 @@ int rass_index_save(rass_index_t* idx, const char* path) {
         }
         ok = fwrite(tags.data(), 4, (size_t)idx->rows, f) == (size_t)idx->rows;
     }
+    // durable before the caller renames it into place (docstore.py's manifest scheme)
+    ok = ok && fflush(f) == 0 && fsync(fileno(f)) == 0;
     ok = (fclose(f) == 0) && ok;
     return ok ? RASS_OK : fail(RASS_ERR_IO, std::string("short write: ") + path);
 }

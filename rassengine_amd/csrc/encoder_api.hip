@@ -29,6 +29,9 @@ namespace {
 
 int efail(int code, const std::string& msg) {
     rassint_set_last_error(msg.c_str());
+    // A failed HIP call (e.g. an out-of-memory hipMalloc) stays behind as the runtime's "last error" and the
+    // NEXT kernel launch's hipGetLastError() would report it as its own: every failure path ends here, clear it.
+    (void)hipGetLastError();
     return code;
 }
 

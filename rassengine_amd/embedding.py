@@ -3,6 +3,15 @@
 dtypes, shapes and blank-text behaviour, with the per-text HTTP POST replaced by batched
 calls into the in-process encoder.
 
+Two flavours, because the reference's two modules differ and ``install()`` binds the
+one that belongs to the module it patches:
+
+* ``MAIN_FLAVOUR`` (app/main.py): ``embed_texts_in_batches(texts, batch_size=BATCH_SIZE)``; empty input ->
+  ``np.array([])`` (shape (0,), 246-247); embed errors RAISE (``raise_for_status``, 235);
+* ``GEN_FLAVOUR`` (app/embedding_gen.py): ``embed_texts_in_batches(texts)`` — no ``batch_size`` (173); empty
+  input -> ``np.zeros((0, EMBED_DIM), float32)`` (174-175); an embed error is printed and that text gets a ZERO
+  vector (168-170); no ``embed_query`` in that module.
+
 Contract reproduced:
 
 * ``ollama_embed_text(text)``: blank text -> ``[0.0] * EMBED_DIM`` (227-228), else a list of
@@ -101,3 +110,52 @@ async def embed_query(query: str) -> np.ndarray:
         return np.array([])
     emb_list = await ollama_embed_text(query)
     return np.array([emb_list], dtype=np.float32)
+
+
+# ------------------------------------------------------------------ app/embedding_gen.py:152-192
+async def gen_ollama_embed_text(text: str) -> List[float]:
+    """embedding_gen.py:152-170: as above, but an error is printed and a zero vector returned."""
+    if not text.strip():
+        return [0.0] * EMBED_DIM
+    try:
+        vec = await asyncio.to_thread(_encode_nonblank, [text])
+        return vec[0].tolist()
+    except Exception as ex:
+        print("[ERROR] Ollama embed request:", ex)
+        return [0.0] * EMBED_DIM
+
+
+def _encode_or_zero(texts: List[str]) -> np.ndarray:
+    """One encoder call for the slice; if it fails, every text is retried on its own so that only the
+    texts that really fail become zero rows (the reference's errors are per text, 168-170)."""
+    try:
+        return _encode_nonblank(texts)
+    except Exception as ex:
+        if len(texts) == 1:
+            print("[ERROR] Ollama embed request:", ex)
+            return np.zeros((1, EMBED_DIM), dtype=np.float32)
+    rows = []
+    for t in texts:
+        try:
+            rows.append(_encode_nonblank([t]))
+        except Exception as ex:
+            print("[ERROR] Ollama embed request:", ex)
+            rows.append(np.zeros((1, EMBED_DIM), dtype=np.float32))
+    return np.concatenate(rows, axis=0)
+
+
+async def gen_embed_texts_in_batches(texts: List[str]) -> np.ndarray:
+    """embedding_gen.py:173-192."""
+    if not texts:
+        return np.zeros((0, EMBED_DIM), dtype=np.float32)
+    step = max(int(BATCH_SIZE), 2048)   # see embed_texts_in_batches: a slice is one self-batching encoder call
+    out = []
+    for i in range(0, len(texts), step):
+        out.append(await asyncio.to_thread(_encode_or_zero, texts[i:i + step]))
+    return np.ascontiguousarray(np.concatenate(out, axis=0), dtype=np.float32)
+
+
+MAIN_FLAVOUR = {"ollama_embed_text": ollama_embed_text, "embed_texts_in_batches": embed_texts_in_batches,
+                "embed_query": embed_query}
+GEN_FLAVOUR = {"ollama_embed_text": gen_ollama_embed_text, "embed_texts_in_batches": gen_embed_texts_in_batches,
+               "embed_query": embed_query}

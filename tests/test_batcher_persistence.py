@@ -16,9 +16,9 @@ class CountingIndex(OracleIndex):
         super().__init__(dim)
         self.calls = []
 
-    def search(self, queries, k, q_filter=None):
+    def search(self, queries, k, q_filter=None, q_filter_mask=None):
         self.calls.append((queries.shape[0], k, None if q_filter is None else q_filter.copy()))
-        return super().search(queries, k, q_filter)
+        return super().search(queries, k, q_filter, q_filter_mask)
 
 
 def test_batcher_coalesces_and_matches_individual_searches():
@@ -110,10 +110,11 @@ def test_async_semantic_search_shares_scans():
 def test_metadata_persistence_roundtrip(tmp_path):
     class SavingIndex(OracleIndex):
         def save(self, path):
-            np.savez(path + ".npz", rows=self._rows, tags=self._tags)
+            with open(path, "wb") as f:
+                np.savez(f, rows=self._rows, tags=self._tags)
 
     def loader(name, path):
-        z = np.load(path + ".npz")
+        z = np.load(path)
         i = SavingIndex(z["rows"].shape[1])
         i._rows, i._tags = z["rows"], z["tags"]
         return i
@@ -133,6 +134,44 @@ def test_metadata_persistence_roundtrip(tmp_path):
         st2 = IndexState.load("idx-p", prefix, loader)
         assert st2.doc_row == st.doc_row and st2.structured == st.structured
         assert st2.patients.lookup("p2") == st.patients.lookup("p2") and len(st2.patients) == 3
+        assert st2.doc_types.lookup("unstructured") == st.doc_types.lookup("unstructured") == 1
+
+        # crash safety: a second save writes a NEW generation and only then drops the old one;
+        # a save that dies half-way leaves the previous manifest + vector file intact and loadable
+        import json
+        import os
+        files1 = sorted(os.listdir(tmp_path))
+        assert files1 == ["shard0.g000001.rass", "shard0.meta.json"]
+        asyncio.run(indexer.store_fhir_docs_in_opensearch([], [dict(docs[5], unstructuredText="again")], None, "idx-p"))
+
+        class Dying(SavingIndex):
+            def save(self, path):
+                with open(path, "wb") as f:
+                    f.write(b"partial")
+                raise OSError("disk full")
+        good = st.index
+        dying = Dying(1024)
+        dying._rows, dying._tags = good._rows, good._tags
+        st.index = dying
+        with pytest.raises(OSError):
+            st.save(prefix)
+        st.index = good
+        assert json.load(open(prefix + ".meta.json"))["vectors"] == "shard0.g000001.rass"
+        assert IndexState.load("idx-p", prefix, loader).doc_row == st2.doc_row      # old generation still loads
+        st.save(prefix)
+        assert sorted(f for f in os.listdir(tmp_path) if not f.endswith(".tmp")) == ["shard0.g000002.rass",
+                                                                                      "shard0.meta.json"]
+        st3 = IndexState.load("idx-p", prefix, loader)
+        assert st3.generation == 2 and st3.row_doc[st3.doc_row["d5"]]["unstructuredText"] == "again"
+
+        # a manifest that does not belong to its vector file is rejected, not silently loaded
+        meta = json.load(open(prefix + ".meta.json"))
+        meta["row_doc"] = meta["row_doc"][:-1]
+        json.dump(meta, open(prefix + ".meta.json", "w"))
+        with pytest.raises(ValueError, match="disagree"):
+            IndexState.load("idx-p", prefix, loader)
+        meta["row_doc"] = st.row_doc
+        json.dump(meta, open(prefix + ".meta.json", "w"))
         REGISTRY.clear()
         REGISTRY.put(st2)
         ix = indexer.HipIndexer(None, "idx-p")

@@ -131,8 +131,12 @@ def test_errors_are_reported_not_thrown(engine):
     idx = engine.open_index("t-err")
     idx.add(np.ones((4, 1024), dtype=np.float32))
     with pytest.raises(RassError) as e:
-        idx.search(np.ones((1, 1024), dtype=np.float32), 33)  # k > RASS_MAX_K
+        idx.search(np.ones((1, 1024), dtype=np.float32), 4097)  # k > RASS_MAX_K_MULTIPASS
     assert "k must be" in str(e.value)
+    with pytest.raises(RassError):
+        idx.search(np.ones((1, 1024), dtype=np.float32), 0)
+    s33, i33 = idx.search(np.ones((1, 1024), dtype=np.float32), 33)   # k > RASS_MAX_K is served in passes
+    assert sorted(i33[0][:4].tolist()) == [0, 1, 2, 3] and np.all(i33[0][4:] == -1)
     with pytest.raises(RassError):
         idx.add(np.ones((1, 1024), dtype=np.float32), tags=np.array([-3], dtype=np.int32))
     with pytest.raises(ValueError):

@@ -126,6 +126,18 @@ int rass_index_add(rass_index_t* idx, const float* vecs, const int32_t* tags,
 int rass_index_add_device(rass_index_t* idx, const float* d_vecs,
                           const int32_t* d_tags, int64_t n, int normalize,
                           int64_t* first_row);
+/* Append with CALLER-ASSIGNED ids: row i of the batch is reported by searches as
+ * first_global_id + i instead of its ordinal (first_global_id = -1: ordinals, as rass_index_add).
+ * This is what makes an index one SHARD of a multi-GPU index whose batches are dealt round-robin to
+ * the ranks (rassengine_amd/serving.py; the reference's analogue is OpenSearch routing docs to
+ * SHARD_COUNT shards, app/main.py:89, 357): ids must ascend with the append order, so the per-shard
+ * (score desc, id asc) order is the global one and the cross-shard merge reproduces the single-index
+ * result.  rass_index_delete / get_row(s) keep addressing rows by ORDINAL (*first_row); the caller
+ * maps global ids to (rank, ordinal).  `device_source` != 0: vecs / tags are device pointers.
+ * On such an index id_base is ignored, k <= RASS_MAX_K, and the prefilter mode is not used. */
+int rass_index_add_ex(rass_index_t* idx, const float* vecs, const int32_t* tags,
+                      int64_t n, int normalize, int64_t first_global_id,
+                      int device_source, int64_t* first_row);
 /* Tombstone a row (the overwrite semantics of `_id=doc_id`, app/main.py:1260). */
 int rass_index_delete(rass_index_t* idx, int64_t row);
 /* Copy one stored (normalised) row back to the host as fp32 (dim floats): the
@@ -166,6 +178,13 @@ int rass_index_search_ex(rass_index_t* idx, const float* queries, int nq, int k,
 int rass_index_search_device(rass_index_t* idx, const float* d_queries, int nq,
                              int k, const int32_t* d_q_filter, int64_t id_base,
                              float* d_out_scores, int64_t* d_out_ids);
+
+/* Same with the masked filter of rass_index_search_ex ((tag & mask) == filter); on an index
+ * with caller-assigned ids (rass_index_add_ex) those ids are reported and id_base is ignored. */
+int rass_index_search_device_ex(rass_index_t* idx, const float* d_queries,
+                                int nq, int k, const int32_t* d_q_filter,
+                                const int32_t* d_q_filter_mask, int64_t id_base,
+                                float* d_out_scores, int64_t* d_out_ids);
 
 /* Prefilter mode, OFF by default: keep a bf16 copy of the slab,
  * scan IT (half the HBM bytes per pass, bf16 MFMA) for the 32 best candidates

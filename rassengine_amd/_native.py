@@ -57,6 +57,8 @@ SIGNATURES = {
                                       ctypes.c_int, c_i64_p]),
     "rass_index_add_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                              ctypes.c_int, c_i64_p]),
+    "rass_index_add_ex": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                         ctypes.c_int, ctypes.c_int64, ctypes.c_int, c_i64_p]),
     "rass_index_delete": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64]),
     "rass_index_get_row": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
     "rass_index_get_rows": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]),
@@ -67,6 +69,9 @@ SIGNATURES = {
     "rass_index_search_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                                 ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
                                                 ctypes.c_void_p]),
+    "rass_index_search_device_ex": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                                   ctypes.c_void_p]),
     "rass_index_set_prefilter": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "rass_index_get_prefilter": (ctypes.c_int, [ctypes.c_void_p]),
     "rass_index_save": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p]),

@@ -178,6 +178,9 @@ struct rass_index {
     std::atomic<bool> has_tags{false};  // any non-zero tag ever stored
     float* d_rows = nullptr;
     int32_t* d_tags = nullptr;
+    int64_t* d_gid = nullptr;               // [capacity] id reported for a row: its ordinal, or the caller's
+                                            // GLOBAL id (rass_index_add_ex: a shard of a multi-GPU index)
+    std::atomic<bool> has_gid{false};       // any row carries a caller-assigned id
     unsigned short* d_rows_bf16 = nullptr;  // tile16b copy for the prefilter mode (nullptr = off)
     bool prefilter = false;
     std::vector<uint8_t> host_deleted;  // tombstone bitmap mirror (host)
@@ -205,10 +208,13 @@ int index_reserve(rass_index* idx, int64_t need_rows) {
         e = hipMalloc(reinterpret_cast<void**>(&nrows), (size_t)cap * idx->stride * sizeof(float));
         if (e != hipSuccess) return fail(RASS_ERR_OOM, "index grow: hipMalloc of corpus slab failed");
     }
+    int64_t* ngid = nullptr;
     e = hipMalloc(reinterpret_cast<void**>(&ntags), (size_t)cap * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ngid), (size_t)cap * sizeof(int64_t));
     if (e != hipSuccess) {
         (void)hipFree(nrows);
-        return fail(RASS_ERR_OOM, "index grow: hipMalloc of tag array failed");
+        if (ntags) (void)hipFree(ntags);
+        return fail(RASS_ERR_OOM, "index grow: hipMalloc of tag / id arrays failed");
     }
     // rows of a block past the last appended one must read as finite zeros (they are masked,
     // never ranked): zero the part of the slab the copy below does not overwrite
@@ -222,6 +228,8 @@ int index_reserve(rass_index* idx, int64_t need_rows) {
                                hipMemcpyDeviceToDevice, st);
         if (c == hipSuccess && idx->rows > 0)
             c = hipMemcpyAsync(ntags, idx->d_tags, (size_t)idx->rows * sizeof(int32_t), hipMemcpyDeviceToDevice, st);
+        if (c == hipSuccess && idx->rows > 0)
+            c = hipMemcpyAsync(ngid, idx->d_gid, (size_t)idx->rows * sizeof(int64_t), hipMemcpyDeviceToDevice, st);
         if (c == hipSuccess && idx->prefilter) {
             c = hipMalloc(reinterpret_cast<void**>(&nb16), (size_t)cap * idx->stride * 2);
             if (c == hipSuccess) c = hipMemsetAsync(nb16, 0, (size_t)cap * idx->stride * 2, st);
@@ -237,15 +245,18 @@ int index_reserve(rass_index* idx, int64_t need_rows) {
         (void)hipStreamSynchronize(st);
         (void)hipFree(nrows);
         (void)hipFree(ntags);
+        (void)hipFree(ngid);
         if (nb16) (void)hipFree(nb16);
         return fail(e == hipErrorOutOfMemory ? RASS_ERR_OOM : RASS_ERR_HIP,
                     std::string("index grow failed: ") + hipGetErrorString(e));
     }
     if (idx->d_rows) (void)hipFree(idx->d_rows);
     if (idx->d_tags) (void)hipFree(idx->d_tags);
+    if (idx->d_gid) (void)hipFree(idx->d_gid);
     if (idx->d_rows_bf16) (void)hipFree(idx->d_rows_bf16);
     idx->d_rows = nrows;
     idx->d_tags = ntags;
+    idx->d_gid = ngid;
     idx->d_rows_bf16 = nb16;
     idx->capacity = cap;
     return RASS_OK;
@@ -482,6 +493,7 @@ void rass_engine_destroy(rass_engine_t* eng) {
         rass_index* idx = kv.second;
         if (idx->d_rows) (void)hipFree(idx->d_rows);
         if (idx->d_tags) (void)hipFree(idx->d_tags);
+        if (idx->d_gid) (void)hipFree(idx->d_gid);
         if (idx->d_rows_bf16) (void)hipFree(idx->d_rows_bf16);
         delete idx;
     }
@@ -586,9 +598,11 @@ int rass_index_drop(rass_engine_t* eng, const char* name) {
         (void)hipStreamSynchronize(eng->stream);
         if (idx->d_rows) (void)hipFree(idx->d_rows);
         if (idx->d_tags) (void)hipFree(idx->d_tags);
+        if (idx->d_gid) (void)hipFree(idx->d_gid);
         if (idx->d_rows_bf16) (void)hipFree(idx->d_rows_bf16);
         idx->d_rows = nullptr;
         idx->d_tags = nullptr;
+        idx->d_gid = nullptr;
         idx->d_rows_bf16 = nullptr;
     }
     delete idx;
@@ -633,7 +647,7 @@ int rass_index_row_stride(const rass_index_t* idx) {
 }
 
 static int add_common(rass_index_t* idx, const float* vecs, const int32_t* tags, int64_t n, int normalize,
-                      int64_t* first_row, bool device_src) {
+                      int64_t* first_row, bool device_src, int64_t first_global_id = -1) {
     if (!idx) return fail(RASS_ERR_INVALID, "index is NULL");
     if (n < 0 || (n > 0 && !vecs)) return fail(RASS_ERR_INVALID, "bad vecs / n");
     rass_engine* eng = idx->eng;
@@ -682,6 +696,10 @@ static int add_common(rass_index_t* idx, const float* vecs, const int32_t* tags,
     if (idx->prefilter)
         HIP_TRY(rass::launch_convert_tile16_bf16(idx->d_rows, idx->d_rows_bf16, idx->stride, idx->rows >> 4,
                                                  (idx->rows + n + 15) >> 4, st));
+    // the id a search reports for these rows: their ordinal, or the caller's global ids (ascending with the
+    // ordinal, so the (score desc, id asc) tie order inside the shard is the global one)
+    HIP_TRY(rass::launch_iota_i64(idx->d_gid + idx->rows, n, first_global_id >= 0 ? first_global_id : idx->rows.load(), st));
+    if (first_global_id >= 0 && first_global_id != idx->rows) idx->has_gid = true;
     if (tags) idx->has_tags = true;
     idx->rows += n;
     idx->host_deleted.resize((size_t)((idx->rows + 7) / 8), 0);
@@ -696,6 +714,12 @@ int rass_index_add(rass_index_t* idx, const float* vecs, const int32_t* tags, in
 int rass_index_add_device(rass_index_t* idx, const float* d_vecs, const int32_t* d_tags, int64_t n, int normalize,
                           int64_t* first_row) {
     return add_common(idx, d_vecs, d_tags, n, normalize, first_row, true);
+}
+
+int rass_index_add_ex(rass_index_t* idx, const float* vecs, const int32_t* tags, int64_t n, int normalize,
+                      int64_t first_global_id, int device_source, int64_t* first_row) {
+    if (first_global_id < -1) return fail(RASS_ERR_INVALID, "first_global_id must be >= 0, or -1 for row ordinals");
+    return add_common(idx, vecs, tags, n, normalize, first_row, device_source != 0, first_global_id);
 }
 
 int rass_index_delete(rass_index_t* idx, int64_t row) {
@@ -749,22 +773,33 @@ int rass_index_get_rows(rass_index_t* idx, int64_t first_row, int64_t n, float* 
     return RASS_OK;
 }
 
-int rass_index_search_device(rass_index_t* idx, const float* d_queries, int nq, int k, const int32_t* d_q_filter,
-                             int64_t id_base, float* d_out_scores, int64_t* d_out_ids) {
+int rass_index_search_device_ex(rass_index_t* idx, const float* d_queries, int nq, int k, const int32_t* d_q_filter,
+                                const int32_t* d_q_filter_mask, int64_t id_base, float* d_out_scores,
+                                int64_t* d_out_ids) {
     if (!idx || !d_queries || !d_out_scores || !d_out_ids) return fail(RASS_ERR_INVALID, "NULL argument");
+    if (d_q_filter_mask && !d_q_filter) return fail(RASS_ERR_INVALID, "q_filter_mask without q_filter");
     rass_engine* eng = idx->eng;
     std::lock_guard<std::mutex> lk(eng->mu);
     int rc = set_device(eng);
     if (rc != RASS_OK) return rc;
     const int64_t rows = idx->rows.load(std::memory_order_acquire);
     const bool need_tags = (idx->deleted.load(std::memory_order_acquire) > 0) || (d_q_filter != nullptr);
-    if (idx->prefilter && rows > 0 && k <= kPrefilterMaxK)
+    const bool gid = idx->has_gid.load(std::memory_order_acquire);  // caller-assigned ids: reported instead of
+    if (idx->prefilter && rows > 0 && k <= kPrefilterMaxK && !gid && !d_q_filter_mask)  // id_base + ordinal
         return prefilter_launch(idx, d_queries, nq, d_q_filter, k, id_base, d_out_scores, d_out_ids,
                                 need_tags ? idx->d_tags : nullptr, eng, eng->stream);
+    ScanExt ext;
+    ext.d_q_mask = d_q_filter_mask;
     return scan_launch(idx->d_rows ? idx->d_rows : reinterpret_cast<const float*>(eng->d_scratch), rows,
                        idx->stride, need_tags ? idx->d_tags : nullptr, d_queries, idx->dim, idx->dim, nq,
-                       d_q_filter, k, id_base, d_out_scores, d_out_ids, eng->d_scratch, eng->scratch_bytes,
-                       eng->n_cus, eng->stream, eng);
+                       d_q_filter, k, gid ? 0 : id_base, d_out_scores, d_out_ids, eng->d_scratch, eng->scratch_bytes,
+                       eng->n_cus, eng->stream, eng, nullptr, gid ? idx->d_gid : nullptr,
+                       d_q_filter_mask ? &ext : nullptr);
+}
+
+int rass_index_search_device(rass_index_t* idx, const float* d_queries, int nq, int k, const int32_t* d_q_filter,
+                             int64_t id_base, float* d_out_scores, int64_t* d_out_ids) {
+    return rass_index_search_device_ex(idx, d_queries, nq, k, d_q_filter, nullptr, id_base, d_out_scores, d_out_ids);
 }
 
 namespace {
@@ -846,14 +881,17 @@ int rass_index_search_ex(rass_index_t* idx, const float* queries, int nq, int k,
                 const bool use_ext = q_filter_mask || cont;
                 const int64_t rows = idx->rows.load(std::memory_order_acquire);
                 const bool need_tags = (idx->deleted.load(std::memory_order_acquire) > 0) || (d_filter != nullptr);
-                if (idx->prefilter && rows > 0 && k <= kPrefilterMaxK && !use_ext)
+                const bool gid = idx->has_gid.load(std::memory_order_acquire);
+                if (gid && cont)  // the continuation bound compares row ordinals, the caller would hand back global ids
+                    return fail(RASS_ERR_UNSUPPORTED, "k > RASS_MAX_K on an index with caller-assigned row ids");
+                if (idx->prefilter && rows > 0 && k <= kPrefilterMaxK && !use_ext && !gid)
                     rc = prefilter_launch(idx, eng->d_qraw, b, d_filter, kk, 0, eng->d_out_scores, eng->d_out_ids,
                                           need_tags ? idx->d_tags : nullptr, eng, st);
                 else
                     rc = scan_launch(idx->d_rows ? idx->d_rows : reinterpret_cast<const float*>(eng->d_scratch), rows,
                                      idx->stride, need_tags ? idx->d_tags : nullptr, eng->d_qraw, dim, dim, b, d_filter,
                                      kk, 0, eng->d_out_scores, eng->d_out_ids, eng->d_scratch, eng->scratch_bytes,
-                                     eng->n_cus, st, eng, nullptr, nullptr, use_ext ? &ext : nullptr);
+                                     eng->n_cus, st, eng, nullptr, gid ? idx->d_gid : nullptr, use_ext ? &ext : nullptr);
                 if (rc != RASS_OK) return rc;
                 HIP_TRY(hipMemcpyAsync(sl->h_out_s, eng->d_out_scores, (size_t)b * kk * sizeof(float),
                                        hipMemcpyDeviceToHost, st));
@@ -910,6 +948,8 @@ int rass_index_save(rass_index_t* idx, const char* path) {
     h.dtype = (int32_t)idx->dtype;
     h.rows = idx->rows;
     h.deleted = idx->deleted;
+    const bool save_gid = idx->has_gid.load();
+    h.reserved = save_gid ? 1 : 0;  // 1: rows x int64 caller-assigned ids follow the tags
     bool ok = fwrite(&h, sizeof(h), 1, f) == 1;
     hipStream_t st = idx->eng->stream;
     std::vector<float> buf((size_t)kStageRows * idx->dim);
@@ -937,6 +977,16 @@ int rass_index_save(rass_index_t* idx, const char* path) {
         }
         ok = fwrite(tags.data(), 4, (size_t)idx->rows, f) == (size_t)idx->rows;
     }
+    if (ok && idx->rows > 0 && save_gid) {
+        std::vector<int64_t> gids((size_t)idx->rows);
+        hipError_t e = hipMemcpyAsync(gids.data(), idx->d_gid, (size_t)idx->rows * 8, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) {
+            fclose(f);
+            return fail(RASS_ERR_HIP, std::string("save: id read failed: ") + hipGetErrorString(e));
+        }
+        ok = fwrite(gids.data(), 8, (size_t)idx->rows, f) == (size_t)idx->rows;
+    }
     // durable before the caller renames it into place (docstore.py's manifest scheme)
     ok = ok && fflush(f) == 0 && fsync(fileno(f)) == 0;
     ok = (fclose(f) == 0) && ok;
@@ -961,7 +1011,7 @@ int rass_index_load(rass_engine_t* eng, const char* name, const char* path, rass
         const long body = ftell(f);
         int64_t file_len = -1;
         if (body >= 0 && fseek(f, 0, SEEK_END) == 0) file_len = (int64_t)ftell(f);
-        const int64_t need = (int64_t)sizeof(SaveHeader) + h.rows * ((int64_t)h.dim * 4 + 4);
+        const int64_t need = (int64_t)sizeof(SaveHeader) + h.rows * ((int64_t)h.dim * 4 + 4 + (h.reserved == 1 ? 8 : 0));
         if (body < 0 || h.rows > ((int64_t)1 << 40) || file_len < need || fseek(f, body, SEEK_SET) != 0) {
             fclose(f);
             return fail(RASS_ERR_IO, "truncated index file (shorter than its header says)");
@@ -1023,6 +1073,26 @@ int rass_index_load(rass_engine_t* eng, const char* name, const char* path, rass
             }
         }
     }
+    if (h.rows > 0 && h.reserved == 1) {
+        std::vector<int64_t> gids((size_t)h.rows);
+        hipError_t e = hipSuccess;
+        if (fread(gids.data(), 8, (size_t)h.rows, f) != (size_t)h.rows) {
+            fclose(f);
+            (void)rass_index_drop(eng, name);
+            return fail(RASS_ERR_IO, "truncated index file (ids)");
+        }
+        {
+            std::lock_guard<std::mutex> lk(idx->mu);
+            e = hipMemcpyAsync(idx->d_gid, gids.data(), (size_t)h.rows * 8, hipMemcpyHostToDevice, eng->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(eng->stream);
+            idx->has_gid = true;
+        }
+        if (e != hipSuccess) {
+            fclose(f);
+            (void)rass_index_drop(eng, name);
+            return fail(RASS_ERR_HIP, std::string("load: id upload failed: ") + hipGetErrorString(e));
+        }
+    }
     fclose(f);
     *out = idx;
     return RASS_OK;
@@ -1044,6 +1114,7 @@ int rass_index_fill_synthetic(rass_index_t* idx, int64_t n, uint64_t seed, int64
     hipStream_t st = eng->stream;
     HIP_TRY(rass::launch_fill_synthetic_f32(idx->d_rows, idx->stride, idx->rows, n, idx->dim, seed, row_id_base, st));
     HIP_TRY(rass::launch_fill_i32(idx->d_tags + idx->rows, n, 0, st));
+    HIP_TRY(rass::launch_iota_i64(idx->d_gid + idx->rows, n, idx->rows.load(), st));
     if (idx->prefilter)
         HIP_TRY(rass::launch_convert_tile16_bf16(idx->d_rows, idx->d_rows_bf16, idx->stride, idx->rows >> 4,
                                                  (idx->rows + n + 15) >> 4, st));

@@ -114,6 +114,8 @@ hipError_t launch_fill_synthetic_f32(float* packed, int64_t stride, int64_t firs
                                      uint64_t seed, int64_t row_id_base, hipStream_t stream);
 
 hipError_t launch_fill_i32(int32_t* dst, int64_t n, int32_t value, hipStream_t stream);
+// dst[i] = base + i
+hipError_t launch_iota_i64(int64_t* dst, int64_t n, int64_t base, hipStream_t stream);
 // dst[i] = max(src[i], 0): device-source row tags (negative = reserved tombstone code -> 0)
 hipError_t launch_copy_tags_clamped(int32_t* dst, const int32_t* src, int64_t n, hipStream_t stream);
 

@@ -111,6 +111,19 @@ hipError_t launch_fill_i32(int32_t* dst, int64_t n, int32_t value, hipStream_t s
     return hipGetLastError();
 }
 
+__global__ void iota_i64_kernel(int64_t* dst, int64_t n, int64_t base) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = base + i;
+}
+
+hipError_t launch_iota_i64(int64_t* dst, int64_t n, int64_t base, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(iota_i64_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, dst, n, base);
+    return hipGetLastError();
+}
+
 // Row tags handed over from device memory cannot be validated on the host without a sync: negative
 // values (the tombstone code is reserved for rass_index_delete, which also keeps the counters) are
 // stored as 0 = "no patient".

@@ -147,8 +147,11 @@ class FlatIndex:
         return int(self._L.rass_index_device_tags(self._h) or 0)
 
     # ---- write path
-    def add(self, vecs: np.ndarray, tags: Optional[np.ndarray] = None, normalize: bool = True) -> int:
-        """Append rows (host fp32 [n, dim]); returns the id of the first appended row."""
+    def add(self, vecs: np.ndarray, tags: Optional[np.ndarray] = None, normalize: bool = True,
+            first_global_id: int = -1) -> int:
+        """Append rows (host fp32 [n, dim]); returns the ORDINAL of the first appended row.
+        ``first_global_id`` >= 0: searches report ``first_global_id + i`` for row i of this batch instead
+        of its ordinal (a shard of a multi-GPU index, ``rass_index_add_ex``)."""
         v = np.ascontiguousarray(vecs, dtype=np.float32)
         if v.ndim != 2 or v.shape[1] != self.dim:
             raise ValueError(f"expected [n, {self.dim}] vectors, got {v.shape}")
@@ -158,8 +161,9 @@ class FlatIndex:
             if t.shape != (v.shape[0],):
                 raise ValueError("tags must be one int32 per row")
         first = ctypes.c_int64(-1)
-        N.check("rass_index_add", self._L.rass_index_add(self._h, _np_ptr(v), _np_ptr(t), v.shape[0],
-                                                        1 if normalize else 0, ctypes.byref(first)))
+        N.check("rass_index_add_ex", self._L.rass_index_add_ex(self._h, _np_ptr(v), _np_ptr(t), v.shape[0],
+                                                              1 if normalize else 0, int(first_global_id), 0,
+                                                              ctypes.byref(first)))
         return int(first.value)
 
     def add_device(self, d_vecs_ptr: int, n: int, d_tags_ptr: int = 0, normalize: bool = True) -> int:
@@ -227,12 +231,13 @@ class FlatIndex:
         return out_s, out_i
 
     def search_device(self, d_queries_ptr: int, nq: int, k: int, d_out_scores_ptr: int, d_out_ids_ptr: int,
-                      id_base: int = 0, d_q_filter_ptr: int = 0) -> None:
+                      id_base: int = 0, d_q_filter_ptr: int = 0, d_q_filter_mask_ptr: int = 0) -> None:
         """Async, device-resident variant (multi-GPU path, benchmark); nq <= 32."""
-        N.check("rass_index_search_device",
-                self._L.rass_index_search_device(self._h, ctypes.c_void_p(d_queries_ptr), int(nq), int(k),
-                                                 ctypes.c_void_p(d_q_filter_ptr or 0), int(id_base),
-                                                 ctypes.c_void_p(d_out_scores_ptr), ctypes.c_void_p(d_out_ids_ptr)))
+        N.check("rass_index_search_device_ex",
+                self._L.rass_index_search_device_ex(self._h, ctypes.c_void_p(d_queries_ptr), int(nq), int(k),
+                                                    ctypes.c_void_p(d_q_filter_ptr or 0),
+                                                    ctypes.c_void_p(d_q_filter_mask_ptr or 0), int(id_base),
+                                                    ctypes.c_void_p(d_out_scores_ptr), ctypes.c_void_p(d_out_ids_ptr)))
 
 
 class HipTimer:

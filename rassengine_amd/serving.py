@@ -1,0 +1,425 @@
+"""The multi-GPU index BEHIND the reference boundary.
+
+``dist.ShardedSearch`` is the collective step (broadcast -> local scan -> one all-gather -> merge); this
+module puts it behind ``OpenSearchIndexer``: one process per GPU (``torchrun --nproc-per-node G``), rank 0 runs
+the FastAPI process and serves ``HipIndexer`` over a ``ShardedIndex`` front, ranks 1..G-1 sit in
+``worker_loop`` and follow rank 0's command stream.  The reference's analogue is OpenSearch's
+``number_of_shards = SHARD_COUNT`` (app/main.py:89, 357) with the coordinator merging per-shard top-k; here the
+shards are GPUs, the coordinator is rank 0 and the exchange is ONE RCCL all-gather of packed per-shard top-k.
+
+Command stream: every operation starts with ONE broadcast (src 0) of a fixed-size buffer
+``[16 x int64 header | query / filter / name payload]``; every rank then executes the same operation on its
+shard, so the collectives line up by construction:
+
+    OPEN    every rank opens its local shard of the named index
+    ADD     rows are dealt to the ranks ROUND-ROBIN BY BATCH (batch b -> rank b mod G); the batch travels
+            point-to-point to its owner only; its rows get consecutive GLOBAL row ids (insertion ordinals of the
+            whole index = the single-GPU ids) through rass_index_add_ex, so a shard reports global ids itself
+    SEARCH  local masked scan -> packed (scores | ids) record -> one all-gather -> merge on rank 0
+    DELETE  the owner (global id -> (rank, ordinal) through the extent table) tombstones the row
+    COUNT   all-reduce of the shards' live row counts
+    GETROW  the owner sends the stored row to rank 0
+    SHUTDOWN workers leave the loop; every rank then meets in a barrier (a clean collective exit: the workers
+            are ordinary processes that return, nothing is re-exec'ed or killed)
+
+Because a shard's ids ascend with its append order and ties are broken by (score desc, id asc) both inside a
+shard and in the merge, the sharded result equals the single-index result bit for bit (tests/test_serving_gloo.py;
+tests/test_gpu_dist.py for the HIP shards).
+"""
+from __future__ import annotations
+
+import bisect
+import threading
+from typing import Callable, Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+OP_SHUTDOWN, OP_OPEN, OP_SEARCH, OP_ADD, OP_DELETE, OP_COUNT, OP_GETROW, OP_DROP = range(8)
+HDR_WORDS = 16
+MAX_Q = 32
+MAX_K = 32
+NAME_BYTES = 1024
+ADD_CHUNK_ROWS = 8192
+
+
+class Extents:
+    """Which global row ids a rank holds: sorted (gid_base, ordinal_base, n) runs."""
+
+    def __init__(self):
+        self.gid: List[int] = []
+        self.ordinal: List[int] = []
+        self.n: List[int] = []
+
+    def append(self, gid_base: int, ordinal_base: int, n: int) -> None:
+        if self.gid and self.gid[-1] + self.n[-1] == gid_base and self.ordinal[-1] + self.n[-1] == ordinal_base:
+            self.n[-1] += n
+            return
+        self.gid.append(gid_base)
+        self.ordinal.append(ordinal_base)
+        self.n.append(n)
+
+    def ordinal_of(self, gid: int) -> Optional[int]:
+        e = bisect.bisect_right(self.gid, gid) - 1
+        if e < 0 or gid >= self.gid[e] + self.n[e]:
+            return None
+        return self.ordinal[e] + (gid - self.gid[e])
+
+
+class HipServingShard:
+    """One rank's shard of a served index: a ``FlatIndex`` in HBM (``LocalServingShard`` surface)."""
+
+    def __init__(self, index):
+        from . import ops  # noqa: F401  (fails loudly without the HIP library)
+        self.index = index
+        self.device = torch.device("cuda", index.engine.device)
+        index.engine.set_stream(int(torch.cuda.current_stream(self.device).cuda_stream))
+
+    dim = property(lambda self: self.index.dim)
+    count = property(lambda self: self.index.count)
+    rows = property(lambda self: self.index.rows)
+
+    def add(self, vecs: torch.Tensor, tags: torch.Tensor, normalize: bool, first_global_id: int) -> int:
+        import ctypes
+        from . import _native as N
+        first = ctypes.c_int64(-1)
+        torch.cuda.current_stream(self.device).synchronize()     # the batch arrived through a collective
+        N.check("rass_index_add_ex", N.lib().rass_index_add_ex(
+            self.index._h, ctypes.c_void_p(vecs.data_ptr()), ctypes.c_void_p(tags.data_ptr()), int(vecs.shape[0]),
+            1 if normalize else 0, int(first_global_id), 1, ctypes.byref(first)))
+        return int(first.value)
+
+    def delete(self, ordinal: int) -> None:
+        self.index.delete(ordinal)
+
+    def get_row(self, ordinal: int) -> torch.Tensor:
+        return torch.from_numpy(self.index.get_row(ordinal)).to(self.device)
+
+    @staticmethod
+    def record_bytes(nq: int, k: int) -> Tuple[int, int]:
+        ids_off = (nq * k * 4 + 7) // 8 * 8
+        return ids_off, ids_off + nq * k * 8
+
+    def search_packed(self, queries: torch.Tensor, k: int, filt: Optional[torch.Tensor], mask: Optional[torch.Tensor]
+                      ) -> torch.Tensor:
+        nq = queries.shape[0]
+        ids_off, size = self.record_bytes(nq, k)
+        rec = torch.empty((size,), dtype=torch.uint8, device=self.device)
+        self.index.search_device(queries.data_ptr(), nq, k, rec.data_ptr(), rec.data_ptr() + ids_off, id_base=0,
+                                 d_q_filter_ptr=filt.data_ptr() if filt is not None else 0,
+                                 d_q_filter_mask_ptr=mask.data_ptr() if mask is not None else 0)
+        return rec
+
+    def merge_packed(self, gathered: torch.Tensor, world: int, nq: int, k: int) -> Tuple[np.ndarray, np.ndarray]:
+        import ctypes
+        from . import _native as N
+        ids_off, size = self.record_bytes(nq, k)
+        out_s = torch.empty((nq, k), dtype=torch.float32, device=self.device)
+        out_i = torch.empty((nq, k), dtype=torch.int64, device=self.device)
+        base = gathered.data_ptr()
+        N.check("rass_topk_merge_strided",
+                N.lib().rass_topk_merge_strided(ctypes.c_void_p(base), ctypes.c_void_p(base + ids_off), size // 4,
+                                                size // 8, world, nq, k, ctypes.c_void_p(out_s.data_ptr()),
+                                                ctypes.c_void_p(out_i.data_ptr()),
+                                                ctypes.c_void_p(int(torch.cuda.current_stream(self.device).cuda_stream))))
+        return out_s.cpu().numpy(), out_i.cpu().numpy()
+
+
+class ShardServer:
+    """Runs on EVERY rank: owns the rank's shards and executes the command stream."""
+
+    def __init__(self, shard_factory: Callable[[str], object], dim: int, device: torch.device,
+                 group: Optional[dist.ProcessGroup] = None):
+        self.factory = shard_factory
+        self.dim = dim
+        self.device = device
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.payload_bytes = max(MAX_Q * dim * 4 + 2 * MAX_Q * 4, NAME_BYTES)
+        self.cmd = torch.zeros((HDR_WORDS * 8 + self.payload_bytes,), dtype=torch.uint8, device=device)
+        self.shards: Dict[int, object] = {}
+        self.extents: Dict[int, Extents] = {}
+        # gloo moves device tensors in its collectives by staging, but its point-to-point ops want host memory
+        self._p2p_on_host = dist.get_backend(group) == "gloo" and device.type != "cpu"
+
+    def _send(self, t: torch.Tensor, dst: int) -> None:
+        dist.send(t.cpu() if self._p2p_on_host else t, dst=dst, group=self.group)
+
+    def _recv(self, shape, dtype, src: int) -> torch.Tensor:
+        if self._p2p_on_host:
+            h = torch.empty(shape, dtype=dtype)
+            dist.recv(h, src=src, group=self.group)
+            return h.to(self.device)
+        t = torch.empty(shape, dtype=dtype, device=self.device)
+        dist.recv(t, src=src, group=self.group)
+        return t
+
+    # ---- command transport
+    def post(self, header: List[int], payload: Optional[np.ndarray] = None) -> np.ndarray:
+        """Rank 0: fill and broadcast the command buffer.  Returns the header."""
+        host = np.zeros(self.cmd.numel(), dtype=np.uint8)
+        hdr = np.zeros(HDR_WORDS, dtype=np.int64)
+        hdr[:len(header)] = header
+        host[:HDR_WORDS * 8] = hdr.view(np.uint8)
+        if payload is not None:
+            raw = np.ascontiguousarray(payload).view(np.uint8).reshape(-1)
+            host[HDR_WORDS * 8:HDR_WORDS * 8 + raw.size] = raw
+        self.cmd.copy_(torch.from_numpy(host))
+        dist.broadcast(self.cmd, src=0, group=self.group)
+        return hdr
+
+    def recv(self) -> np.ndarray:
+        """Ranks > 0: wait for rank 0's next command.  Returns the header."""
+        dist.broadcast(self.cmd, src=0, group=self.group)
+        return self.cmd[:HDR_WORDS * 8].cpu().numpy().view(np.int64).copy()
+
+    def _payload(self, nbytes: int, offset: int = 0) -> torch.Tensor:
+        a = HDR_WORDS * 8 + offset
+        return self.cmd[a:a + nbytes]
+
+    # ---- the operations (identical code on every rank)
+    def execute(self, hdr: np.ndarray, vecs: Optional[torch.Tensor] = None, tags: Optional[torch.Tensor] = None):
+        op, code = int(hdr[0]), int(hdr[1])
+        if op == OP_OPEN:
+            name = bytes(self._payload(int(hdr[2])).cpu().numpy()).decode("utf-8")
+            self.shards[code] = self.factory(name)
+            self.extents[code] = Extents()
+            return None
+        if op == OP_DROP:
+            self.shards.pop(code, None)
+            self.extents.pop(code, None)
+            return None
+        shard = self.shards[code]
+        if op == OP_SEARCH:
+            nq, k, flags = int(hdr[2]), int(hdr[3]), int(hdr[4])
+            q = self._payload(nq * self.dim * 4).view(torch.float32).view(nq, self.dim)
+            off = MAX_Q * self.dim * 4
+            filt = self._payload(nq * 4, off).view(torch.int32) if flags & 1 else None
+            mask = self._payload(nq * 4, off + MAX_Q * 4).view(torch.int32) if flags & 2 else None
+            rec = shard.search_packed(q, k, filt, mask)
+            if self.world == 1:
+                return shard.merge_packed(rec, 1, nq, k)
+            gathered = torch.empty((self.world * rec.numel(),), dtype=torch.uint8, device=rec.device)
+            dist.all_gather_into_tensor(gathered, rec, group=self.group)
+            return shard.merge_packed(gathered, self.world, nq, k) if self.rank == 0 else None
+        if op == OP_ADD:
+            n, owner, gid_base, normalize = int(hdr[2]), int(hdr[3]), int(hdr[4]), bool(hdr[5])
+            if owner != 0:   # the batch travels to its owner only
+                if self.rank == 0:
+                    self._send(vecs, owner)
+                    self._send(tags, owner)
+                elif self.rank == owner:
+                    vecs = self._recv((n, self.dim), torch.float32, 0)
+                    tags = self._recv((n,), torch.int32, 0)
+            if self.rank == owner:
+                first = shard.add(vecs, tags, normalize, gid_base)
+                self.extents[code].append(gid_base, first, n)
+            return None
+        if op == OP_DELETE:
+            ordinal = self.extents[code].ordinal_of(int(hdr[2]))
+            if ordinal is not None:
+                shard.delete(ordinal)
+            return None
+        if op == OP_COUNT:
+            t = torch.tensor([shard.count, shard.rows], dtype=torch.int64, device=self.device)
+            if self.world > 1:
+                dist.all_reduce(t, group=self.group)
+            return [int(v) for v in t.cpu()]
+        if op == OP_GETROW:
+            gid, owner = int(hdr[2]), int(hdr[3])
+            row = None
+            if self.rank == owner:
+                row = shard.get_row(self.extents[code].ordinal_of(gid))
+                if owner != 0:
+                    self._send(row, 0)
+            elif self.rank == 0:
+                row = self._recv((self.dim,), torch.float32, owner)
+            return row.cpu().numpy() if (self.rank == 0 and row is not None) else None
+        raise RuntimeError(f"unknown serving op {op}")
+
+
+def worker_loop(server: ShardServer) -> None:
+    """Ranks 1..G-1: follow rank 0 until it shuts the service down."""
+    while True:
+        hdr = server.recv()
+        if int(hdr[0]) == OP_SHUTDOWN:
+            break
+        server.execute(hdr)
+    dist.barrier(group=server.group)
+
+
+class ShardedFront:
+    """Rank 0: hands out ``ShardedIndex`` objects (the ``REGISTRY`` index factory) and owns the command stream.
+    Every operation is serialised by one lock: the ranks must see one agreed order of collectives."""
+
+    def __init__(self, server: ShardServer):
+        assert server.rank == 0
+        self.server = server
+        self.lock = threading.RLock()
+        self.indices: Dict[str, "ShardedIndex"] = {}
+        self._closed = False
+
+    def open_index(self, name: str) -> "ShardedIndex":
+        with self.lock:
+            idx = self.indices.get(name)
+            if idx is None:
+                code = len(self.indices)
+                raw = np.frombuffer(name.encode("utf-8"), dtype=np.uint8)
+                if raw.size > NAME_BYTES:
+                    raise ValueError("index name too long")
+                hdr = self.server.post([OP_OPEN, code, raw.size], raw)
+                self.server.execute(hdr)
+                idx = self.indices[name] = ShardedIndex(self, name, code)
+            return idx
+
+    def shutdown(self) -> None:
+        """Clean collective exit: workers leave their loop, every rank meets in a barrier."""
+        with self.lock:
+            if self._closed:
+                return
+            self._closed = True
+            self.server.post([OP_SHUTDOWN])
+            dist.barrier(group=self.server.group)
+
+
+class ShardedIndex:
+    """``FlatIndex`` surface over all ranks' shards (what ``IndexState.index`` / ``HipIndexer`` talk to).
+    Row ids are GLOBAL insertion ordinals, as on a single GPU."""
+
+    def __init__(self, front: ShardedFront, name: str, code: int):
+        self.front = front
+        self.name = name
+        self.code = code
+        self.dim = front.server.dim
+        self._rows = 0                      # global rows ever appended = next global id
+        self._batches = 0                   # round-robin cursor
+        self._owner_gid: List[int] = []     # extent table of the WHOLE index: sorted gid bases ...
+        self._owner_rank: List[int] = []    # ... and the rank that holds each run
+        self._deleted = set()
+
+    # ---- bookkeeping
+    @property
+    def rows(self) -> int:
+        return self._rows
+
+    @property
+    def count(self) -> int:
+        """Live rows, reduced over the ranks (OpenSearchIndexer.has_any_data's count, app/main.py:1475)."""
+        with self.front.lock:
+            s = self.front.server
+            live, _rows = s.execute(s.post([OP_COUNT, self.code]))
+            return live
+
+    def _owner(self, gid: int) -> int:
+        e = bisect.bisect_right(self._owner_gid, gid) - 1
+        if e < 0 or not 0 <= gid < self._rows:
+            raise IndexError(f"row {gid} out of range")
+        return self._owner_rank[e]
+
+    # ---- write path
+    def add(self, vecs: np.ndarray, tags: Optional[np.ndarray] = None, normalize: bool = True) -> int:
+        """Append a batch; it goes to ONE rank (round-robin by batch, in chunks of <= 8192 rows).  Returns the
+        global id of its first row."""
+        v = np.ascontiguousarray(vecs, dtype=np.float32)
+        if v.ndim != 2 or v.shape[1] != self.dim:
+            raise ValueError(f"expected [n, {self.dim}] vectors, got {v.shape}")
+        n = v.shape[0]
+        t = np.zeros(n, dtype=np.int32) if tags is None else np.ascontiguousarray(tags, dtype=np.int32)
+        if t.shape != (n,) or (n and t.min() < 0):
+            raise ValueError("tags must be one non-negative int32 per row")
+        with self.front.lock:
+            s = self.front.server
+            first = self._rows
+            if n == 0:
+                return first
+            owner = self._batches % s.world
+            self._batches += 1
+            for a in range(0, n, ADD_CHUNK_ROWS):
+                m = min(ADD_CHUNK_ROWS, n - a)
+                dv = torch.from_numpy(v[a:a + m]).to(s.device)
+                dt = torch.from_numpy(t[a:a + m]).to(s.device)
+                hdr = s.post([OP_ADD, self.code, m, owner, self._rows, 1 if normalize else 0])
+                s.execute(hdr, dv, dt)
+                if not self._owner_rank or self._owner_rank[-1] != owner:
+                    self._owner_gid.append(self._rows)
+                    self._owner_rank.append(owner)
+                self._rows += m
+            return first
+
+    def delete(self, row: int) -> None:
+        with self.front.lock:
+            self._owner(row)                 # range check
+            if row in self._deleted:
+                return
+            s = self.front.server
+            s.execute(s.post([OP_DELETE, self.code, int(row)]))
+            self._deleted.add(row)
+
+    def get_row(self, row: int) -> np.ndarray:
+        with self.front.lock:
+            s = self.front.server
+            return s.execute(s.post([OP_GETROW, self.code, int(row), self._owner(row)]))
+
+    # ---- read path
+    def search(self, queries: np.ndarray, k: int, q_filter: Optional[np.ndarray] = None,
+               q_filter_mask: Optional[np.ndarray] = None) -> Tuple[np.ndarray, np.ndarray]:
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        if q.ndim != 2 or q.shape[1] != self.dim:
+            raise ValueError(f"expected [nq, {self.dim}] queries, got {q.shape}")
+        k = int(k)
+        if not 1 <= k <= MAX_K:
+            raise ValueError(f"k must be in [1, {MAX_K}] on a sharded index (got {k})")
+        if q_filter_mask is not None and q_filter is None:
+            raise ValueError("q_filter_mask needs q_filter")
+        nq = q.shape[0]
+        out_s = np.empty((nq, k), dtype=np.float32)
+        out_i = np.empty((nq, k), dtype=np.int64)
+        s = self.front.server
+        for a in range(0, nq, MAX_Q):
+            b = min(MAX_Q, nq - a)
+            payload = np.zeros(MAX_Q * self.dim * 4 + 2 * MAX_Q * 4, dtype=np.uint8)
+            payload[:b * self.dim * 4] = q[a:a + b].view(np.uint8).reshape(-1)
+            flags = 0
+            off = MAX_Q * self.dim * 4
+            if q_filter is not None:
+                flags |= 1
+                payload[off:off + b * 4] = np.ascontiguousarray(q_filter[a:a + b], dtype=np.int32).view(np.uint8)
+            if q_filter_mask is not None:
+                flags |= 2
+                payload[off + MAX_Q * 4:off + MAX_Q * 4 + b * 4] = \
+                    np.ascontiguousarray(q_filter_mask[a:a + b], dtype=np.int32).view(np.uint8)
+            with self.front.lock:
+                sc, ids = s.execute(s.post([OP_SEARCH, self.code, b, k, flags], payload))
+            out_s[a:a + b] = sc
+            out_i[a:a + b] = ids
+        return out_s, out_i
+
+
+def start(shard_factory: Callable[[str], object], dim: int, device: Optional[torch.device] = None,
+          group: Optional[dist.ProcessGroup] = None, install_registry: bool = True) -> Optional[ShardedFront]:
+    """Call on EVERY rank after ``init_process_group``.  Rank 0 gets the front back at once (and, with
+    ``install_registry``, ``docstore.REGISTRY`` now opens sharded indices, so ``HipIndexer`` /
+    ``store_fhir_docs_in_opensearch`` serve the multi-GPU index unchanged); the other ranks stay inside
+    this call, following rank 0, until it calls ``front.shutdown()``, and then return ``None``."""
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+    server = ShardServer(shard_factory, dim, device, group)
+    if server.rank != 0:
+        worker_loop(server)
+        return None
+    front = ShardedFront(server)
+    if install_registry:
+        from .docstore import REGISTRY
+        REGISTRY.set_index_factory(front.open_index)
+    return front
+
+
+def hip_shard_factory(device_index: int, dim: int) -> Callable[[str], HipServingShard]:
+    """The production shard factory: one engine per process per GPU."""
+    from .engine import Engine
+
+    def make(name: str) -> HipServingShard:
+        return HipServingShard(Engine.get(device_index, dim).open_index(name))
+    return make

@@ -150,3 +150,64 @@ def test_two_rank_ivf_shards_share_centroids_and_match_flat(gpu, tmp_path):
                 assert truth[(qq, int(a))] == float(b)
                 hits += 1
     assert hits > 0
+
+
+def _serving_worker(rank, world, port, out_dir, backend):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    device = rank if backend == "nccl" else 0
+    torch.cuda.set_device(device)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from rassengine_amd import config, embedding, indexer, serving
+        from rassengine_amd.docstore import REGISTRY
+        from rassengine_amd.engine import Engine
+        from tests.helpers import HashEmbedder
+        from tests.test_serving_gloo import _scenario
+        front = serving.start(serving.hip_shard_factory(device, 1024), 1024, torch.device("cuda", device))
+        if rank != 0:
+            assert front is None
+            open(os.path.join(out_dir, f"worker{rank}.done"), "w").write("ok")
+            return
+        embedding.set_embedder(HashEmbedder(1024))
+        sharded = _scenario(indexer, embedding, REGISTRY, config, "rass-idx-user1")
+        idx = REGISTRY.get("rass-idx-user1").index
+        assert isinstance(idx, serving.ShardedIndex) and sorted(set(idx._owner_rank)) == [0, 1]
+        front.shutdown()
+        # the same scenario on ONE HIP index in this process
+        REGISTRY.clear()
+        eng = Engine.get(device, 1024)
+        REGISTRY.set_index_factory(lambda name: eng.open_index("single-" + name))
+        single = _scenario(indexer, embedding, REGISTRY, config, "rass-idx-user1")
+        np.savez(os.path.join(out_dir, "serving.npz"), **{"sharded_" + k: np.asarray(v) for k, v in sharded.items()},
+                 **{"single_" + k: np.asarray(v) for k, v in single.items()})
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_shim_over_sharded_hip_index_equals_single_hip_index(gpu, tmp_path, backend):
+    """rassengine_amd.serving on real HIP shards: rank 0 serves HipIndexer / store_fhir_docs_in_opensearch over
+    a ShardedIndex (rows dealt round-robin by batch, global ids assigned through rass_index_add_ex), rank 1
+    follows in worker_loop; everything the shim returns must equal the single-index run bit for bit."""
+    import torch.multiprocessing as mp
+    if backend == "nccl" and gpu.cuda.device_count() < 2:
+        pytest.skip("RCCL leg needs >= 2 GPUs; 1 visible here")
+    mp.spawn(_serving_worker, args=(2, _free_port(), str(tmp_path), backend), nprocs=2, join=True)
+    assert os.path.exists(os.path.join(str(tmp_path), "worker1.done"))       # clean collective shutdown
+    z = np.load(os.path.join(str(tmp_path), "serving.npz"))
+    keys = sorted(k[len("single_"):] for k in z.files if k.startswith("single_"))
+    for k in keys:
+        a, b = z["sharded_" + k], z["single_" + k]
+        if a.dtype.kind == "f":
+            assert a.shape == b.shape and np.array_equal(a, b), k
+        else:
+            assert a.tolist() == b.tolist(), (k, a, b)
+    assert int(z["single_count"]) == 90 and int(z["single_rows"]) == 92 and len(z["single_sem_ids"]) == 10

@@ -1,0 +1,179 @@
+"""The multi-GPU index behind the boundary on CPU: world-size 2 and 3 ``gloo`` runs of
+rassengine_amd.serving — rank 0 serves ``HipIndexer`` / ``store_fhir_docs_in_opensearch`` over a
+``ShardedIndex``, the other ranks sit in ``worker_loop`` — with oracle-backed shards (test doubles).
+store -> semantic_search through the reference-shaped shim must equal the single-index result: same doc ids in
+the same order, same scores; overwrite (tombstone on the owning rank), patient / doc_type filters, count
+reduced over ranks, the embedding quirk (row fetched from its owner) and a clean collective shutdown."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+class OracleServingShard:
+    """serving.HipServingShard's surface on CPU tensors; arithmetic = the CPU oracle."""
+
+    def __init__(self, dim):
+        self.dim = dim
+        self.device = torch.device("cpu")
+        self._x = np.zeros((0, dim), dtype=np.float32)
+        self._tags = np.zeros((0,), dtype=np.int32)
+        self._gid = np.zeros((0,), dtype=np.int64)
+
+    rows = property(lambda self: self._x.shape[0])
+    count = property(lambda self: int((self._tags != -1).sum()))
+
+    def add(self, vecs, tags, normalize, first_global_id):
+        from oracle import oracle as O
+        v = vecs.numpy().astype(np.float32)
+        if normalize:
+            v = O.normalize_ref(v).astype(np.float32)
+        first = self.rows
+        self._x = np.concatenate([self._x, v])
+        self._tags = np.concatenate([self._tags, tags.numpy().astype(np.int32)])
+        self._gid = np.concatenate([self._gid, first_global_id + np.arange(v.shape[0], dtype=np.int64)])
+        return first
+
+    def delete(self, ordinal):
+        self._tags[ordinal] = -1
+
+    def get_row(self, ordinal):
+        return torch.from_numpy(self._x[ordinal].copy())
+
+    def search_packed(self, queries, k, filt, mask):
+        from oracle import oracle as O
+        from rassengine_amd.serving import HipServingShard
+        nq = queries.shape[0]
+        qn = O.normalize_ref(queries.numpy().copy()).astype(np.float32)
+        s, i = O.search(self._x, qn, k, tags=self._tags, qfilter=None if filt is None else filt.numpy().copy(),
+                        qmask=None if mask is None else mask.numpy().copy())
+        gids = np.full(i.shape, -1, dtype=np.int64)
+        if self.rows:
+            gids = np.where(i >= 0, self._gid[np.clip(i, 0, None)], -1).astype(np.int64)
+        ids_off, size = HipServingShard.record_bytes(nq, k)
+        rec = np.zeros(size, dtype=np.uint8)
+        rec[:nq * k * 4] = s.astype(np.float32).view(np.uint8).reshape(-1)
+        rec[ids_off:] = gids.view(np.uint8).reshape(-1)
+        return torch.from_numpy(rec)
+
+    def merge_packed(self, gathered, world, nq, k):
+        from oracle import oracle as O
+        from rassengine_amd.serving import HipServingShard
+        ids_off, size = HipServingShard.record_bytes(nq, k)
+        g = gathered.numpy().reshape(world, size)
+        ls = np.stack([g[r, :nq * k * 4].copy().view(np.float32).reshape(nq, k) for r in range(world)])
+        li = np.stack([g[r, ids_off:].copy().view(np.int64).reshape(nq, k) for r in range(world)])
+        s, i = O.merge(ls.astype(np.float64), li)
+        return s.astype(np.float32), i
+
+
+def _docs(n):
+    return [{"doc_id": f"text-note-{i}", "doc_type": "unstructured" if i % 5 else "structured",
+             "patientId": f"p{i % 3}", "unstructuredText": f"chunk number {i} about topic{i % 7} and drug{i % 4}"}
+            for i in range(n)]
+
+
+def _scenario(indexer, embedding, REGISTRY, config, name):
+    """What a FastAPI process does through the reference-shaped shim; returns comparable plain data."""
+    import asyncio
+    docs = _docs(90)
+    out = {}
+    # three uploads (three batches: dealt to different ranks), then an overwrite of two docs
+    for a in range(0, 90, 30):
+        asyncio.run(indexer.store_fhir_docs_in_opensearch([], docs[a:a + 30], None, name))
+    asyncio.run(indexer.store_fhir_docs_in_opensearch(
+        [], [dict(docs[7], unstructuredText="entirely new words here"), dict(docs[40], unstructuredText="other text")],
+        None, name))
+    ix = indexer.HipIndexer(None, name)
+    q = asyncio.run(embedding.embed_query("chunk number 12 about topic5 and drug0"))
+    out["has"] = ix.has_any_data()
+    hits = {"sem": ix.semantic_search(q, k=10), "pat": ix.semantic_search(q, k=10, patient_id="p1"),
+            "hyb": ix.hybrid_search("x", q, k=7), "hs": ix.hybrid_structured_search("x", q, k=5, patient_id="p0"),
+            "new": ix.semantic_search(asyncio.run(embedding.embed_query("entirely new words here")), k=3),
+            "none": ix.semantic_search(q, k=5, patient_id="nobody")}
+    for key, h in hits.items():
+        out[key + "_ids"] = [d["doc_id"] for d, _ in h]
+        out[key + "_scores"] = [float(s) for _, s in h]
+    st = REGISTRY.get(name)
+    out["count"] = int(st.index.count)
+    out["rows"] = int(st.index.rows)
+    config.RASS_RETURN_EMBEDDING = True
+    out["emb"] = np.asarray(ix.semantic_search(q, k=2)[1][0]["embedding"], dtype=np.float32)
+    config.RASS_RETURN_EMBEDDING = False
+    return out
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from rassengine_amd import config, embedding, indexer, serving
+        from rassengine_amd.docstore import REGISTRY
+        from tests.helpers import HashEmbedder, OracleIndex
+        front = serving.start(lambda name: OracleServingShard(1024), 1024, torch.device("cpu"))
+        if rank != 0:
+            assert front is None                       # the worker left its loop through the collective shutdown
+            open(os.path.join(out_dir, f"worker{rank}.done"), "w").write("ok")
+            return
+        embedding.set_embedder(HashEmbedder(1024))
+        sharded = _scenario(indexer, embedding, REGISTRY, config, "rass-idx-user1")
+        # round-robin by batch really spread the rows: every rank holds some
+        idx = REGISTRY.get("rass-idx-user1").index
+        assert isinstance(idx, serving.ShardedIndex)
+        assert sorted(set(idx._owner_rank)) == list(range(min(world, 4)))
+        front.shutdown()
+        front.shutdown()                               # idempotent
+        # the same scenario on ONE index in this very process (same HashEmbedder hash seed)
+        REGISTRY.clear()
+        REGISTRY.set_index_factory(lambda name: OracleIndex(1024))
+        single = _scenario(indexer, embedding, REGISTRY, config, "rass-idx-user1")
+        np.savez(os.path.join(out_dir, "rank0.npz"), **{"sharded_" + k: np.asarray(v) for k, v in sharded.items()},
+                 **{"single_" + k: np.asarray(v) for k, v in single.items()})
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_store_and_search_through_the_shim_equal_the_single_index(world, tmp_path):
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(1, world):
+        assert os.path.exists(os.path.join(str(tmp_path), f"worker{r}.done"))
+    z = np.load(os.path.join(str(tmp_path), "rank0.npz"))
+    keys = sorted(k[len("single_"):] for k in z.files if k.startswith("single_"))
+    assert "sem_ids" in keys and "emb" in keys
+    for k in keys:
+        a, b = z["sharded_" + k], z["single_" + k]
+        if a.dtype.kind == "f":
+            assert a.shape == b.shape and np.array_equal(a, b), k       # bit-identical scores / stored row
+        else:
+            assert a.tolist() == b.tolist(), (k, a, b)
+    assert bool(z["single_has"]) and int(z["single_count"]) == 90 and int(z["single_rows"]) == 92
+    assert len(z["single_sem_ids"]) == 10 and len(z["single_none_ids"]) == 0
+    assert z["single_new_ids"][0] == "text-note-7"
+    assert len(z["single_hs_ids"]) > 0                                  # structured rows of patient p0 exist
+
+
+def test_extent_table():
+    from rassengine_amd.serving import Extents
+    e = Extents()
+    e.append(0, 0, 30)
+    e.append(60, 30, 30)       # the batch in between went to another rank
+    e.append(90, 60, 5)        # contiguous in both spaces: merged into the previous run
+    assert len(e.gid) == 2
+    assert e.ordinal_of(0) == 0 and e.ordinal_of(29) == 29 and e.ordinal_of(30) is None and e.ordinal_of(59) is None
+    assert e.ordinal_of(60) == 30 and e.ordinal_of(94) == 64 and e.ordinal_of(95) is None and e.ordinal_of(-1) is None

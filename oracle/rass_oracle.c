@@ -18,6 +18,7 @@
  * The normalise restatement IS pinned: tests/test_oracle.py checks it bit-for-bit against
  * the verbatim numpy expression.
  */
+#include <immintrin.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -149,27 +150,34 @@ static float score_f32_fast(const float* x, const float* q, int dim) {
  * brute-force scan a CPU does well; the unblocked KIND_F32_FAST ran at ~2 GFLOP/s per thread. */
 #define QBLK 8
 static void dots_blocked(const float* x, const float* Q, int64_t q_stride, int nqb, int dim, float* out) {
-    float acc[QBLK][8];
-    for (int q = 0; q < QBLK; ++q)
-        for (int l = 0; l < 8; ++l) acc[q][l] = 0.f;
+    __m256 acc[QBLK];
+    for (int q = 0; q < QBLK; ++q) acc[q] = _mm256_setzero_ps();
     int c = 0;
     if (nqb == QBLK) {
-        for (; c + 8 <= dim; c += 8)
-            for (int q = 0; q < QBLK; ++q) {
-                const float* qv = Q + (int64_t)q * q_stride + c;
-#pragma omp simd
-                for (int l = 0; l < 8; ++l) acc[q][l] += x[c + l] * qv[l];
-            }
+        const float *q0 = Q, *q1 = Q + q_stride, *q2 = Q + 2 * q_stride, *q3 = Q + 3 * q_stride,
+                    *q4 = Q + 4 * q_stride, *q5 = Q + 5 * q_stride, *q6 = Q + 6 * q_stride, *q7 = Q + 7 * q_stride;
+        for (; c + 8 <= dim; c += 8) {
+            const __m256 xv = _mm256_loadu_ps(x + c);
+            acc[0] = _mm256_fmadd_ps(xv, _mm256_loadu_ps(q0 + c), acc[0]);
+            acc[1] = _mm256_fmadd_ps(xv, _mm256_loadu_ps(q1 + c), acc[1]);
+            acc[2] = _mm256_fmadd_ps(xv, _mm256_loadu_ps(q2 + c), acc[2]);
+            acc[3] = _mm256_fmadd_ps(xv, _mm256_loadu_ps(q3 + c), acc[3]);
+            acc[4] = _mm256_fmadd_ps(xv, _mm256_loadu_ps(q4 + c), acc[4]);
+            acc[5] = _mm256_fmadd_ps(xv, _mm256_loadu_ps(q5 + c), acc[5]);
+            acc[6] = _mm256_fmadd_ps(xv, _mm256_loadu_ps(q6 + c), acc[6]);
+            acc[7] = _mm256_fmadd_ps(xv, _mm256_loadu_ps(q7 + c), acc[7]);
+        }
     } else {
-        for (; c + 8 <= dim; c += 8)
-            for (int q = 0; q < nqb; ++q) {
-                const float* qv = Q + (int64_t)q * q_stride + c;
-#pragma omp simd
-                for (int l = 0; l < 8; ++l) acc[q][l] += x[c + l] * qv[l];
-            }
+        for (; c + 8 <= dim; c += 8) {
+            const __m256 xv = _mm256_loadu_ps(x + c);
+            for (int q = 0; q < nqb; ++q)
+                acc[q] = _mm256_fmadd_ps(xv, _mm256_loadu_ps(Q + (int64_t)q * q_stride + c), acc[q]);
+        }
     }
     for (int q = 0; q < nqb; ++q) {
-        float s = ((acc[q][0] + acc[q][4]) + (acc[q][1] + acc[q][5])) + ((acc[q][2] + acc[q][6]) + (acc[q][3] + acc[q][7]));
+        float l[8];
+        _mm256_storeu_ps(l, acc[q]);
+        float s = ((l[0] + l[4]) + (l[1] + l[5])) + ((l[2] + l[6]) + (l[3] + l[7]));
         for (int t = c; t < dim; ++t) s += x[t] * Q[(int64_t)q * q_stride + t];
         out[q] = s;
     }

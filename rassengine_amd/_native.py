@@ -16,7 +16,8 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "librass_hip.so")
+# RASS_HIP_LIB: A/B another build of the same ABI (kernel experiments); the default is the in-tree library
+LIB_PATH = os.environ.get("RASS_HIP_LIB") or os.path.join(_HERE, "lib", "librass_hip.so")
 
 RASS_OK = 0
 RASS_MAX_K = 32

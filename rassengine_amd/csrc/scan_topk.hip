@@ -145,8 +145,11 @@ __device__ __forceinline__ TileDesc make_tile_desc(const float* __restrict__ X, 
     return d;
 }
 
-__device__ __forceinline__ f32x4 load_chunk(const TileDesc& d, int voff) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(d.rows, voff, 0, /*aux: nt*/ 2));
+// voff: this lane's byte offset inside a chunk (ONE VGPR for every load of the kernel); soff: the wave-uniform
+// part (M-tile and chunk), which goes into the instruction's SGPR / immediate offset fields.  Folding it into
+// per-load VGPR offsets, as the first version did, cost ~10 VGPRs the main loop does not have.
+__device__ __forceinline__ f32x4 load_chunk(const TileDesc& d, int voff, int soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(d.rows, voff, soff, /*aux: nt*/ 2));
 }
 
 __device__ __forceinline__ int load_tag(const TileDesc& d) {
@@ -160,7 +163,7 @@ __device__ __forceinline__ void issue_tile_loads(TileRegs<CH>& r, const TileDesc
 #pragma unroll
     for (int j = 0; j < CH; ++j)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) r.a[mt][j] = load_chunk(d, voff_lane + mt * mt_step + j * 1024);
+        for (int mt = 0; mt < 2; ++mt) r.a[mt][j] = load_chunk(d, voff_lane, mt * mt_step + j * 1024);
 }
 
 // Multiply the resident tile and, chunk by chunk, re-issue each consumed register's load
@@ -168,10 +171,16 @@ __device__ __forceinline__ void issue_tile_loads(TileRegs<CH>& r, const TileDesc
 // stay in flight at all times instead of one tile requested in a burst after the previous
 // one has fully arrived.  sched_barrier(0) per chunk pins the load placement (hipcc would
 // otherwise sink the loads behind the whole MFMA block).
-template <int CH, int NT>
+//
+// `between(j)` runs after chunk j's MFMAs were issued: the ranking of the PREVIOUS tile pair is cut into
+// parts and placed there, so its VALU / LDS / scalar work issues while this wave's (and its SIMD partner's)
+// MFMAs execute on the matrix pipe (a v_mfma_f32_16x16x4_f32 occupies the pipe for 32 cycles but takes only a
+// few to issue).  Ranked in a phase of its own behind the barrier — as the first version did — it left the
+// matrix pipe idle while all 8 waves ranked in lockstep: 72 us of a 690 us launch at B = 32.
+template <int CH, int NT, typename Between>
 __device__ __forceinline__ void multiply_and_refill(TileRegs<CH>& r, const f32x4 (&qf)[NT][CH],
                                                     f32x4 (&acc)[2][NT], const TileDesc& next, int voff_lane,
-                                                    int mt_step) {
+                                                    int mt_step, Between&& between) {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -179,20 +188,26 @@ __device__ __forceinline__ void multiply_and_refill(TileRegs<CH>& r, const f32x4
     r.tag = load_tag(next);
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const f32x4 a = r.a[mt][j];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                f32x4 c = acc[mt][nt];
-                c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, qf[nt][j].x, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, qf[nt][j].y, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, qf[nt][j].z, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, qf[nt][j].w, c, 0, 0, 0);
-                acc[mt][nt] = c;
-            }
-            r.a[mt][j] = load_chunk(next, voff_lane + mt * mt_step + j * 1024);
-        }
+        // The 2 x NT accumulators are advanced ROUND-ROBIN, one k-step at a time: a dependent
+        // v_mfma_f32_16x16x4_f32 can issue 40 cycles after its producer but the pipe takes a new one every 32, so
+        // back-to-back MFMAs on one accumulator (what hipcc emitted for the second M-tile when left to itself:
+        // two chains of four) leave the pipe idle 20 % of the time whenever the SIMD's other wave is not in its
+        // MFMA phase.  With >= 2 independent accumulators between a producer and its consumer there is no bubble.
+        const f32x4 a0 = r.a[0][j], a1 = r.a[1][j];
+#define RASS_KSTEP(comp)                                                                                              \
+    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                                               \
+        acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.comp, qf[nt][j].comp, acc[0][nt], 0, 0, 0);              \
+        acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.comp, qf[nt][j].comp, acc[1][nt], 0, 0, 0);              \
+    }
+        RASS_KSTEP(x)
+        RASS_KSTEP(y)
+        RASS_KSTEP(z)
+        RASS_KSTEP(w)
+#undef RASS_KSTEP
+        r.a[0][j] = load_chunk(next, voff_lane, j * 1024);
+        r.a[1][j] = load_chunk(next, voff_lane, mt_step + j * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+        between(j);
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -203,11 +218,23 @@ struct TopList {
     int i;
 };
 
+// The k-th best score of my half (lanes 0..31 / 32..63): two readlanes + a select, no LDS permute.
 __device__ __forceinline__ float bcast_kth(float v, int k) {
-    return __shfl(v, (lane_id() & 32) + k - 1, 64);
+    const int a = __builtin_amdgcn_readlane(__float_as_int(v), k - 1);
+    const int b = __builtin_amdgcn_readlane(__float_as_int(v), 32 + k - 1);
+    return __int_as_float((lane_id() & 32) ? b : a);
 }
 
+// Lane i <- lane i-1 across the whole wave (lane 0 keeps its value): one DPP move (wave_shr:1).
+__device__ __forceinline__ int wave_shr1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false); }
+
 // Insert every lane's candidate (cs valid where cs > tau of its half) into the half-wave lists.
+// Everything stays in registers / the scalar unit: the first version used __shfl_up / __shfl here, which
+// hipcc lowers to ds_bpermute_b32 — three LDS round trips (~400 cycles) per inserted candidate.  A per-workgroup
+// list takes ~k ln(n/k) (60 at k = 10, 3 900 rows) insertions per launch and the 8 waves meet at a barrier every
+// two tiles, so the slowest wave's insertions were on every workgroup's critical path: with the ranking
+// removed the B = 32 kernel ran 72 us (10 %) faster, with only the insertion removed 57 us
+// (profiles/r02_scan_phase_experiments.txt).
 __device__ __forceinline__ void insert_candidates(TopList& L, float& tau, float s, int row, int k) {
     unsigned long long mask = __ballot(s > tau);
     const int lane = lane_id();
@@ -217,24 +244,19 @@ __device__ __forceinline__ void insert_candidates(TopList& L, float& tau, float 
         mask &= mask - 1;
         const float cs = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), c));
         const int ci = __builtin_amdgcn_readlane(row, c);
+        // straight-line body (bitwise predicates, selects): the short-circuit / nested-if form compiled to five
+        // exec-mask branches per candidate
         const bool mine = ((lane ^ c) & 32) == 0;
-        const bool better = (L.s > cs) || (L.s == cs && L.i < ci);
-        const unsigned long long bm = __ballot(better && mine);
-        const int pos = __builtin_popcountll(bm);
-        if (pos < k) {
-            const float us = __shfl_up(L.s, 1, 64);
-            const int ui = __shfl_up(L.i, 1, 64);
-            if (mine) {
-                if (lpos == pos) {
-                    L.s = cs;
-                    L.i = ci;
-                } else if (lpos > pos) {
-                    L.s = us;
-                    L.i = ui;
-                }
-            }
-            tau = bcast_kth(L.s, k);
-        }
+        const bool better = (L.s > cs) | ((L.s == cs) & (L.i < ci));
+        const int pos = __builtin_popcountll(__ballot(better & mine));
+        const float us = __int_as_float(wave_shr1(__float_as_int(L.s)));
+        const int ui = wave_shr1(L.i);
+        const bool live = mine & (pos < k);          // a candidate that ranks behind the k kept changes nothing
+        const bool take = live & (lpos == pos);
+        const bool shift = live & (lpos > pos);
+        L.s = take ? cs : (shift ? us : L.s);
+        L.i = take ? ci : (shift ? ui : L.i);
+        tau = bcast_kth(L.s, k);
     }
 }
 
@@ -271,31 +293,31 @@ __global__ __launch_bounds__(kThreads, 2) void scan_topk_f32_kernel(ScanArgs p) 
     // Top-k state: pass pq handles query pq*16 + (lane>>5)*8 + wid for row lane&31.
     TopList L[NT];
     float tau[NT];
-    int qfilt[NT];
 #pragma unroll
     for (int pq = 0; pq < NT; ++pq) {
         L[pq].s = -INFINITY;
         L[pq].i = 0x7fffffff;
         tau[pq] = -INFINITY;
-        const int q = pq * 16 + (lane >> 5) * 8 + wid;
-        qfilt[pq] = (p.q_filter != nullptr && q < p.nq) ? p.q_filter[q] : -1;
     }
-    // EXT variant only (masked filters, multi-pass continuation); the plain variant's code is unchanged.
-    // The per-query parameters live in LDS (512 B next to the 144 KiB partial images), not in registers:
-    // they are read in the ranking step only and the main loop has no VGPRs to spare at CH = 8, NT = 2.
+    // Per-query filter parameters and the dumped tiles' row tags live in LDS (1.5 KiB next to the 144 KiB of
+    // partial images), not in registers: they are read in the ranking step only, and the main loop has no VGPRs
+    // to spare at CH = 8, NT = 2 (the ranking runs between the MFMA chunks, so its operands are live there).
+    __shared__ int sh_qfilt[32];
+    __shared__ int sh_tags[4][32];
     __shared__ int sh_qmask[32];
     __shared__ float sh_after_s[32];
     __shared__ int64_t sh_after_i[32];
-    if (EXT) {
-        if (threadIdx.x < 32) {
-            const int q = threadIdx.x;
-            const bool live = q < p.nq;
+    if (threadIdx.x < 32) {
+        const int q = threadIdx.x;
+        const bool live = q < p.nq;
+        sh_qfilt[q] = (p.q_filter != nullptr && live) ? p.q_filter[q] : -1;
+        if (EXT) {
             sh_qmask[q] = (p.q_filter_mask != nullptr && live) ? p.q_filter_mask[q] : -1;
             sh_after_s[q] = (p.q_after_score != nullptr && live) ? p.q_after_score[q] : INFINITY;
             sh_after_i[q] = (p.q_after_id != nullptr && live) ? p.q_after_id[q] : (int64_t)-1;
         }
-        __syncthreads();
     }
+    __syncthreads();
 
     const int mt_step = 16 * (int)p.row_stride * 4;
     TileRegs<CH> R0, R1;
@@ -319,56 +341,83 @@ __global__ __launch_bounds__(kThreads, 2) void scan_topk_f32_kernel(ScanArgs p) 
             for (int nt = 0; nt < NT; ++nt)
                 *reinterpret_cast<f32x4*>(P + (wid * NQ + nt * 16 + m) * kPitch + mt * 16 + 4 * g) = acc[mt][nt];
     };
-    auto rank_tile = [&](const WorkItem& w, int tag, int buf) {
+    // Rank one (tile, query group pq) of a dumped tile: sum the 8 K-partials in fixed order, filter, insert.
+    auto rank_part = [&](const WorkItem& w, int buf, int pq) {
         const float* P = lds + buf * (kWaves * NQ * kPitch);
         const int r = lane & 31;
         const int row = w.tile * kTileRows + r;
+        const int tag = sh_tags[buf][r];
         const bool row_ok = (r < w.rows) && (tag != -1);
+        const int q = pq * 16 + (lane >> 5) * 8 + wid;
+        const int qf1 = sh_qfilt[q];
+        const float* src = P + q * kPitch + r;
+        float s = src[0];
 #pragma unroll
-        for (int pq = 0; pq < NT; ++pq) {
-            const int q = pq * 16 + (lane >> 5) * 8 + wid;
-            const float* src = P + q * kPitch + r;
-            float s = src[0];
-#pragma unroll
-            for (int wv = 1; wv < kWaves; ++wv) s += src[wv * NQ * kPitch];
-            bool ok;
-            if (EXT) {
-                ok = row_ok && (qfilt[pq] < 0 || qfilt[pq] == (tag & sh_qmask[q]));
-                // continuation: strictly after (after_s, after_i) in (score desc, id asc)
-                const float as = sh_after_s[q];
-                ok = ok && (s < as || (s == as && (p.id_base + (int64_t)row) > sh_after_i[q]));
-            } else {
-                ok = row_ok && (qfilt[pq] < 0 || qfilt[pq] == tag);
-            }
-            if (IVF) ok = ok && ((w.mask >> q) & 1u);
-            s = ok ? s : -INFINITY;
-            insert_candidates(L[pq], tau[pq], s, row, p.k);
+        for (int wv = 1; wv < kWaves; ++wv) s += src[wv * NQ * kPitch];
+        bool ok;
+        if (EXT) {
+            ok = row_ok && (qf1 < 0 || qf1 == (tag & sh_qmask[q]));
+            // continuation: strictly after (after_s, after_i) in (score desc, id asc)
+            const float as = sh_after_s[q];
+            ok = ok && (s < as || (s == as && (p.id_base + (int64_t)row) > sh_after_i[q]));
+        } else {
+            ok = row_ok && (qf1 < 0 || qf1 == tag);
         }
+        if (IVF) ok = ok && ((w.mask >> q) & 1u);
+        s = ok ? s : -INFINITY;
+        insert_candidates(L[pq], tau[pq], s, row, p.k);
     };
 
-    int pair = 0;  // 0 / 2: which two LDS images this iteration uses
+    // Main loop.  Iteration i multiplies the tile pair (A_i, B_i) and, between the MFMA chunks, ranks the pair
+    // of iteration i-1 out of the LDS images that iteration dumped (2 x NT parts spread over the 2 x CH chunk
+    // slots; rows are still ranked in ascending order, which the strict `>` tie rule needs).  One barrier per
+    // iteration: it orders this iteration's dumps before the next iteration's reads, and the next iteration's
+    // dumps (into the images read now) behind this iteration's reads.
+    constexpr int kParts = 2 * NT;
+    auto slot_of = [](int part) { return ((part + 1) * 2 * CH) / kParts - 1; };
+    WorkItem Pa{0, 0, 0u}, Pb{0, 0, 0u};  // the previous pair (rows = 0: nothing ranks in the first iteration)
+    int pair = 0;  // 0 / 2: which two LDS images this iteration dumps into
     while (t < n_tiles) {
         f32x4 acc[2][NT];
-        const int tag0 = R0.tag;
+        // the pair's row tags go to LDS now (every wave loaded the same 32 per tile): the refill below reuses
+        // R.tag for the tile two steps ahead, and the ranking reads them an iteration later
+        if (wid == 0 && lane < 32) {
+            sh_tags[pair][lane] = R0.tag;
+            sh_tags[pair + 1][lane] = R1.tag;
+        }
         const WorkItem Wa = W0;
         t = seq.next();
         WorkItem Wn = get_work<IVF>(p, t, n_tiles);
+        auto rank_prev = [&](int slot) {
+#pragma unroll
+            for (int part = 0; part < kParts; ++part)
+                if (slot_of(part) == slot) {
+                    if (part < NT)
+                        rank_part(Pa, pair ^ 2, part);
+                    else
+                        rank_part(Pb, (pair ^ 2) + 1, part - NT);
+                }
+        };
         multiply_and_refill<CH, NT>(R0, qf, acc, make_tile_desc(p.corpus, p.row_stride, p.row_tag, Wn), voff_lane,
-                                    mt_step);
+                                    mt_step, [&](int j) { rank_prev(j); });
         dump_tile(acc, pair);
         W0 = Wn;
-        const int tag1 = R1.tag;
         const WorkItem Wb = W1;
         Wn = get_work<IVF>(p, seq.next(), n_tiles);
         multiply_and_refill<CH, NT>(R1, qf, acc, make_tile_desc(p.corpus, p.row_stride, p.row_tag, Wn), voff_lane,
-                                    mt_step);
+                                    mt_step, [&](int j) { rank_prev(CH + j); });
         dump_tile(acc, pair + 1);
         W1 = Wn;
+        Pa = Wa;
+        Pb = Wb;
         __syncthreads();
-        rank_tile(Wa, tag0, pair);
-        rank_tile(Wb, tag1, pair + 1);
         pair ^= 2;
     }
+    // the last pair
+#pragma unroll
+    for (int pq = 0; pq < NT; ++pq) rank_part(Pa, pair ^ 2, pq);
+#pragma unroll
+    for (int pq = 0; pq < NT; ++pq) rank_part(Pb, (pair ^ 2) + 1, pq);
 
 #ifdef RASS_SCAN_CLOCKS
     if (threadIdx.x == 0) g_scan_clocks[2 * blockIdx.x + 1] = wall_clock64();

@@ -7,11 +7,16 @@ in HBM (BASELINE.json metric; N=1 workload = configs[1], "1M x 1024-d flat cosin
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A step = one pass of the hot path over one batch of B synthetic queries: query normalise,
-fused scan + top-k over the rank's shard, merge; for N > 1 also the query broadcast, the
-RCCL all-gather of per-shard top-k and the cross-shard merge (weak scaling: every GPU holds
-ROWS_PER_GPU rows, the global corpus is N x ROWS_PER_GPU rows, each query is answered over
-all of it).  Inputs are in HBM when the timed region starts.  Rank 0 prints ONE JSON line.
+A step = one pass of the hot path over one batch of 1 024 synthetic queries.  The scan kernel
+answers <= 32 queries per launch (two 16-wide MFMA N tiles), so a step is 32 LAUNCH GROUPS of
+32 queries, each: query normalise, fused scan + top-k over the rank's shard, merge; for N > 1
+also the query broadcast, the RCCL all-gather of per-shard top-k and the cross-shard merge
+(weak scaling: every GPU holds ROWS_PER_GPU rows, the global corpus is N x ROWS_PER_GPU rows,
+each query is answered over all of it).  (Round 1 called ONE launch group a step: 0.7 ms, so
+a driver run of --warmup 5 --steps 20 timed 14 ms of GPU work that began 3.5 ms after the GPU
+left idle — inside the ~20 ms the clocks take to settle — and hid 40 extra scans in front to
+compensate.  A 1 024-query step is 22 ms: --warmup is exactly what runs, and it is enough.)
+Inputs are in HBM when the timed region starts.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import ctypes
@@ -30,17 +35,21 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--rows-per-gpu", type=int, default=1_000_000)
     ap.add_argument("--rows-global", type=int, default=0,
                     help="STRONG scaling instead: a fixed global corpus (BASELINE configs[3]: 10000000) split "
                          "into contiguous row ranges over the ranks; overrides --rows-per-gpu")
     ap.add_argument("--dim", type=int, default=1024)
-    ap.add_argument("--batch", type=int, default=32, help="queries per scan (<= 32)")
+    ap.add_argument("--batch", type=int, default=32, help="queries per scan launch (<= 32)")
+    ap.add_argument("--launches-per-step", type=int, default=32,
+                    help="scan launch groups per step: a step answers batch x this many queries (default 1024)")
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--query-pool", type=int, default=4096)
     ap.add_argument("--cpu-sample-rows", type=int, default=200_000)
+    ap.add_argument("--cpu-hnsw-rows", type=int, default=8_000,
+                    help="rows of the HNSW restatement's sample (cpu_baseline.hnsw); 0 disables it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prefilter", action="store_true",
                     help="flagged mode (not the parity default): bf16 candidate scan + exact fp32 re-rank")
@@ -92,23 +101,25 @@ def main():
     n_batches = args.query_pool // B
     q_buf = torch.empty((B, dim), device=dev)
 
-    def step(i: int):
-        if rank == 0:
-            q_buf.copy_(pool[(i % n_batches) * B:(i % n_batches + 1) * B])
-        return search.search(q_buf, k)  # broadcast (N>1) + scan + all-gather + merge
+    LPS = args.launches_per_step
 
-    # Initialisation, not a step: the first ~30 scans after the Philox fill kernel run 5-40 % slow while
-    # the clocks settle (profiles/r01_bench_1M_B32_kernel_stats.csv: 703 .. 989 .. 680 us); a caller's small
-    # --warmup would leave that transient inside the timed region.
-    for i in range(40):
-        step(i)
+    def step(i: int):
+        out = None
+        for j in range(LPS):   # one step = LPS launch groups of B queries each
+            g = (i * LPS + j) % n_batches
+            if rank == 0:
+                q_buf.copy_(pool[g * B:(g + 1) * B])
+            out = search.search(q_buf, k)  # broadcast (N>1) + scan + all-gather + merge
+        return out
+
+    # EXACTLY --warmup untimed steps, nothing else.
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    eng.kernel_timing_begin(args.steps)
+    eng.kernel_timing_begin(args.steps * LPS)
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = step(args.warmup + i)
@@ -124,7 +135,7 @@ def main():
         elapsed = float(t.item())
 
     ms_per_step = elapsed / args.steps * 1e3
-    qps = B * args.steps / elapsed
+    qps = B * LPS * args.steps / elapsed
     # algorithmic bytes of the dominant kernel: N_loc * D * 4 (fp32 scan); the bf16
     # candidate scan of the prefilter mode reads N_loc * D * 2
     bytes_per_launch = n_local * idx.row_stride * (2 if args.prefilter else 4)
@@ -152,10 +163,11 @@ def main():
                         + ("(BASELINE configs[3] corpus, fixed, row-sharded)" if strong else
                            "(BASELINE configs[1] shard per GPU)"),
             "rows_per_gpu": n_local, "rows_global": rows_global, "dim": dim, "k": k, "query_batch": B,
+            "queries_per_step": B * LPS, "launch_groups_per_step": LPS,
             "corpus_dtype": "f32" if not args.prefilter else "f32 + bf16 candidate copy (exact fp32 re-rank)",
             "layout": "tile16", "mode": "prefilter" if args.prefilter else "flat", "sharding": f"row-sharded x{world}, RCCL all-gather merge"
             if world > 1 else "single shard",
-            "aggregate_scan_GBps": round(bytes_per_launch * world * args.steps / elapsed / 1e9, 1),
+            "aggregate_scan_GBps": round(bytes_per_launch * world * args.steps * LPS / elapsed / 1e9, 1),
         },
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -166,7 +178,11 @@ def main():
         },
     }
 
-    result["roofline"]["traffic"] = pmc_traffic(result["roofline"]["kernel"], bytes_per_launch)
+    # `traffic` = HBM bytes per launch from PMC counters.  They cannot be read from inside this process, so the
+    # field stays null in an ordinary run; a run under `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` is summarised
+    # by scripts/pmc_traffic.py into profiles/*pmc_traffic*.json, and the newest committed figure for THIS kernel
+    # at THIS byte count is quoted under a key of its own (it was not measured by this run).
+    result["roofline"]["traffic_committed_pmc"] = pmc_traffic(result["roofline"]["kernel"], bytes_per_launch)
 
     # Outside the timed region, single GPU only: the same scan at the other batch sizes SURVEY §8d
     # asks for (B <= 16 runs the NT=1 kernel variant, purely HBM-bound; B = 32 sits at the HBM / fp32-
@@ -216,10 +232,9 @@ def main():
 
 
 def pmc_traffic(kernel: str, bytes_per_launch: int):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC pass
-    (`--pmc FETCH_SIZE` in its own run, gfx950 x2 correction; scripts/pmc_traffic.py).
-    PMC counters cannot be read from inside this process, so the figure comes from the newest
-    profiles/*pmc_traffic*.json that holds THIS kernel at THIS byte count (+-10%); else null."""
+    """HBM bytes per launch of the dominant kernel from the newest COMMITTED rocprofv3 PMC pass
+    (`--pmc FETCH_SIZE` / `WRITE_SIZE` in runs of their own, gfx950 x2 correction; scripts/pmc_traffic.py)
+    that holds THIS kernel at THIS byte count (+-10%); else null.  {"bytes": ..., "source": file}."""
     import glob
     best = None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json"))):
@@ -230,7 +245,8 @@ def pmc_traffic(kernel: str, bytes_per_launch: int):
         for name, e in data.items():
             b = e.get("hbm_read_bytes_per_launch")
             if kernel in name and b and abs(b - bytes_per_launch) <= 0.1 * bytes_per_launch:
-                best = round(b + e.get("hbm_write_bytes_per_launch", 0.0))
+                best = {"bytes": round(b + e.get("hbm_write_bytes_per_launch", 0.0)),
+                        "source": os.path.relpath(path, ROOT)}
     return best
 
 
@@ -265,27 +281,59 @@ def cpu_baseline_and_recall(np, torch, eng, idx, pool, args, n_local, dim, B, k)
     recall = float(np.mean([len(set(ids_gpu[q]) & set(i64[q])) / k for q in range(B)]))
     max_dcos = float(np.abs(out_s.cpu().numpy().astype(np.float64) - s64).max())
 
-    cores = O.num_threads()
-    O.search(x[:20000], qn, k, kind=O.KIND_F32_FAST)  # warm the thread pool
+    cores = O.usable_cpus()   # affinity mask capped by the cgroup quota, not the host's logical CPU count
+    O.search(x[:20000], qn, k, kind=O.KIND_F32_BLOCKED, threads=cores)  # warm the thread pool
     t0 = time.perf_counter()
     reps = 0
     while True:
-        O.search(x, qn, k, kind=O.KIND_F32_FAST)
+        O.search(x, qn, k, kind=O.KIND_F32_BLOCKED, threads=cores)
         reps += 1
         el = time.perf_counter() - t0
         if el >= 10.0 or reps >= 5000:
             break
     qps_sample = B * reps / el
     qps_full = qps_sample * sample / n_local  # brute force is linear in rows
+    gflops = 2.0 * sample * dim * B * reps / el / 1e9
+
+    # The reference's ALGORITHM on the same cores: HNSW with its parameters (m 48, ef_construction 400,
+    # app/main.py:563-572; ef_search = the k-NN plugin's default 512), restated in oracle/hnsw.c.  Built on a
+    # bounded prefix of the same corpus (the build is single-threaded, ~1 ms per row); its queries/s are those
+    # of THAT sample — graph search is ~log N per query, so nothing is extrapolated — and its recall@k is
+    # measured against the exact top-k of the same sample.
+    hs = min(args.cpu_hnsw_rows, sample)
+    hnsw = None
+    if hs >= 1000:
+        t0 = time.perf_counter()
+        h = O.Hnsw(x[:hs])
+        build_s = time.perf_counter() - t0
+        nqh = 8 * B
+        qh = O.normalize_ref(pool[:nqh].cpu().numpy()).astype(np.float32)
+        h.search(qh[:B], k, O.Hnsw.EF_SEARCH, threads=cores)
+        t0 = time.perf_counter()
+        _, ids_h, evals = h.search(qh, k, O.Hnsw.EF_SEARCH, threads=cores)
+        t_h = time.perf_counter() - t0
+        _, truth = O.search(x[:hs], qh, k, kind=O.KIND_F64, threads=cores)
+        hnsw = {"value": round(nqh / t_h, 1), "unit": "queries/s", "cores": cores, "kind": "port",
+                "recall_at_k": round(float(np.mean([len(set(ids_h[r]) & set(truth[r])) / k for r in range(nqh)])), 4),
+                "m": O.Hnsw.M, "ef_construction": O.Hnsw.EF_CONSTRUCTION, "ef_search": O.Hnsw.EF_SEARCH,
+                "sample_rows": hs, "build_s": round(build_s, 1),
+                "distance_evals_per_query": round(evals / nqh, 1),
+                "sample": f"oracle/hnsw.c (HNSW restatement with the reference's parameters), built on the first {hs} "
+                          f"rows of the same corpus in {build_s:.1f} s (1 thread), {nqh} queries on {cores} threads; "
+                          "queries/s and recall are of that sample, not extrapolated"}
+        h.close()
     return {
         "recall_at_k": recall,
         "max_abs_cosine_err": max_dcos,
         "cpu_baseline": {
             "value": round(qps_full, 2), "unit": "queries/s", "cores": cores, "kind": "port",
-            "sample": f"oracle exact fp32 cosine top-{k} (OpenMP, {cores} threads), batch {B}, timed on the first "
-                      f"{sample} rows of the same corpus for {el:.1f} s ({reps} passes), scaled x{sample}/{n_local} "
-                      f"to {n_local} rows; stand-in for OpenSearch k-NN (reference stack absent, BASELINE.md s2)",
-            "measured_qps_on_sample": round(qps_sample, 2), "sample_rows": sample,
+            "sample": f"oracle exact fp32 cosine top-{k}, register-blocked over 8 queries (AVX2, OpenMP, {cores} threads "
+                      f"= the CPUs this job may use of {os.cpu_count()} logical), batch {B}, timed on the first "
+                      f"{sample} rows of the same corpus for {el:.1f} s ({reps} passes, {gflops:.0f} GFLOP/s), scaled "
+                      f"x{sample}/{n_local} to {n_local} rows; stand-in for OpenSearch k-NN (reference stack absent, "
+                      "BASELINE.md s2)",
+            "measured_qps_on_sample": round(qps_sample, 2), "sample_rows": sample, "gflops": round(gflops, 1),
+            "hnsw": hnsw,
         },
     }
 

@@ -1506,7 +1506,7 @@ const char* rass_scan_kernel_name(int dim, int nq) {
     const int64_t stride = pad128(dim);
     if (dim < 1 || !rass::scan_supported_stride(stride) || stride > kMaxStride || nq < 1 || nq > RASS_MAX_QBATCH)
         return "";
-    snprintf(buf, sizeof(buf), "scan_topk_f32_kernel<%d, %d, false>", (int)(stride / 128), nq <= 16 ? 1 : 2);
+    snprintf(buf, sizeof(buf), "scan_topk_f32_kernel<%d, %d, false, false>", (int)(stride / 128), nq <= 16 ? 1 : 2);
     return buf;
 }
 

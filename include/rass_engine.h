@@ -276,6 +276,25 @@ int rass_normalize_rows_f32(const float* d_in, int64_t in_stride, float* d_out,
  * nprobe and is measured, never assumed (nprobe = nlist is exact). */
 typedef struct rass_ivf rass_ivf_t;
 
+/* K9(i): the two O(rows) steps of spherical k-means, over rows already resident in `idx`'s slab, asynchronous
+ * on the engine stream.  The processed rows are 32-row blocks first_block, first_block + block_step, ...
+ * (n_blocks of them: a strided training sample, or every block with block_step = 1).
+ *   rass_kmeans_assign: d_assign[b*32 + r] = arg max over the nlist centroids of the cosine with row r of the
+ *     b-th processed block (exact fp32 MFMA, ties -> lowest list); d_best (may be NULL) the winning cosine.
+ *     `d_centroids_tile16`: nlist normalised centroids as a tile16 slab (rass_pack_rows_f32, normalize = 1),
+ *     row_stride = rass_index_row_stride(idx), whole 16-row blocks.  Entries of rows past rass_index_rows() or
+ *     tombstoned are computed like any other and must be ignored by the caller.
+ *   rass_kmeans_accumulate: d_sums[list][0..dim) += row, d_counts[list] += 1 for every processed row below
+ *     rass_index_rows() (fp32 atomics; d_sums is nlist x dim row-major, caller-zeroed).
+ * The all-reduce over ranks, the normalisation of the sums and the re-seeding of empty lists are O(nlist x dim)
+ * and stay with the caller (rassengine_amd/ivf.py). */
+int rass_kmeans_assign(rass_index_t* idx, int64_t first_block, int64_t block_step,
+                       int64_t n_blocks, const float* d_centroids_tile16, int nlist,
+                       int32_t* d_assign, float* d_best);
+int rass_kmeans_accumulate(rass_index_t* idx, int64_t first_block, int64_t block_step,
+                           int64_t n_blocks, const int32_t* d_assign, float* d_sums,
+                           float* d_counts, int nlist);
+
 /* Build from a flat index: `centroids` nlist x dim fp32 (host; normalised
  * here), `assign[r]` = list of source row r (host, one per appended row;
  * tombstoned rows are skipped).  Training / assignment are offline and live in

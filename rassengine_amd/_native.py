@@ -96,6 +96,10 @@ SIGNATURES = {
                                                ctypes.c_void_p, ctypes.c_void_p]),
     "rass_normalize_rows_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
                                                ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
+    "rass_kmeans_assign": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                          ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
+    "rass_kmeans_accumulate": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                              ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
     "rass_ivf_build": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, c_void_pp]),
     "rass_ivf_destroy": (None, [ctypes.c_void_p]),
     "rass_ivf_rows": (ctypes.c_int64, [ctypes.c_void_p]),

@@ -1501,6 +1501,56 @@ int rass_ivf_search(rass_ivf_t* v, const float* queries, int nq, int k, int npro
     return RASS_OK;
 }
 
+// ---- K9(i): k-means over rows resident in an index's slab
+static int kmeans_range_ok(const rass_index* idx, int64_t first_block, int64_t block_step, int64_t n_blocks) {
+    if (first_block < 0 || block_step < 1 || n_blocks < 0) return 0;
+    if (n_blocks == 0) return 1;
+    const int64_t last = first_block + (n_blocks - 1) * block_step;
+    return last * 32 < idx->rows.load();  // the last processed block must hold at least one appended row
+}
+
+int rass_kmeans_assign(rass_index_t* idx, int64_t first_block, int64_t block_step, int64_t n_blocks,
+                       const float* d_centroids_tile16, int nlist, int32_t* d_assign, float* d_best) {
+    if (!idx || !d_centroids_tile16 || !d_assign) return fail(RASS_ERR_INVALID, "NULL argument");
+    if (nlist < 1 || nlist > 65536) return fail(RASS_ERR_INVALID, "nlist must be in [1, 65536]");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    if (!kmeans_range_ok(idx, first_block, block_step, n_blocks) || n_blocks > 0x7fffffff)
+        return fail(RASS_ERR_INVALID, "block range outside the index");
+    rass_engine* eng = idx->eng;
+    int rc = set_device(eng);
+    if (rc != RASS_OK) return rc;
+    std::lock_guard<std::mutex> elk(eng->mu);
+    rass::AssignArgs a;
+    a.rows = idx->d_rows;
+    a.centroids = d_centroids_tile16;
+    a.assign = d_assign;
+    a.best = d_best;
+    a.row_stride = idx->stride;
+    a.slab_rows = idx->capacity;
+    a.first_block = first_block;
+    a.block_step = block_step;
+    a.n_blocks = (int)n_blocks;
+    a.nlist = nlist;
+    HIP_TRY(rass::launch_kmeans_assign_f32(a, eng->n_cus, eng->stream));
+    return RASS_OK;
+}
+
+int rass_kmeans_accumulate(rass_index_t* idx, int64_t first_block, int64_t block_step, int64_t n_blocks,
+                           const int32_t* d_assign, float* d_sums, float* d_counts, int nlist) {
+    if (!idx || !d_assign || !d_sums || !d_counts) return fail(RASS_ERR_INVALID, "NULL argument");
+    if (nlist < 1) return fail(RASS_ERR_INVALID, "nlist < 1");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    if (!kmeans_range_ok(idx, first_block, block_step, n_blocks) || n_blocks > 0x7fffffff)
+        return fail(RASS_ERR_INVALID, "block range outside the index");
+    rass_engine* eng = idx->eng;
+    int rc = set_device(eng);
+    if (rc != RASS_OK) return rc;
+    std::lock_guard<std::mutex> elk(eng->mu);
+    HIP_TRY(rass::launch_kmeans_accumulate(idx->d_rows, idx->stride, first_block, block_step, (int)n_blocks,
+                                           idx->rows.load(), d_assign, d_sums, d_counts, idx->dim, nlist, eng->stream));
+    return RASS_OK;
+}
+
 const char* rass_scan_kernel_name(int dim, int nq) {
     static thread_local char buf[64];
     const int64_t stride = pad128(dim);

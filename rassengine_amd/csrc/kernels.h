@@ -71,6 +71,25 @@ hipError_t launch_rerank_f32(const float* slab, int64_t stride, const float* q_p
                              int n_cand, int k, int64_t id_base, float* out_scores, int64_t* out_ids,
                              hipStream_t stream);
 
+// ---- k-means of the IVF build (kmeans.hip)
+struct AssignArgs {
+    const float* rows;       // tile16 slab holding the rows to assign (normalised)
+    const float* centroids;  // tile16 slab of nlist normalised centroids (whole 16-row blocks)
+    int32_t* assign;         // [n_blocks * 32] list of row (b, r) at b*32 + r (compact over the processed blocks)
+    float* best;             // optional [n_blocks * 32]: the winning cosine
+    int64_t row_stride;      // elements, 128 * {1..8}
+    int64_t slab_rows;       // rows ALLOCATED in `rows` (multiple of 16): halves past it read as zero
+    int64_t first_block;     // first 32-row block processed ...
+    int64_t block_step;      // ... and the stride between processed blocks (a strided training sample)
+    int n_blocks;
+    int nlist;
+};
+hipError_t launch_kmeans_assign_f32(const AssignArgs& a, int n_cus, hipStream_t stream);
+// sums[assign][0..dim) += row, counts[assign] += 1 over the processed blocks; rows >= n_valid are skipped
+hipError_t launch_kmeans_accumulate(const float* rows, int64_t stride, int64_t first_block, int64_t block_step,
+                                    int n_blocks, int64_t n_valid, const int32_t* assign, float* sums, float* counts,
+                                    int dim, int nlist, hipStream_t stream);
+
 // ---- IVF (ivf.hip)
 hipError_t launch_plan_probe(const int64_t* probe_ids, int nq, int nprobe, int nlist, const int32_t* list_tile0,
                              const int32_t* list_len, int32_t* work_tile, int32_t* work_rows, uint32_t* work_mask,

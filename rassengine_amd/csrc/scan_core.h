@@ -1,0 +1,138 @@
+// scan_core.h — device-side building blocks shared by the kernels that stream a tile16 fp32 slab through
+// v_mfma_f32_16x16x4_f32 with the K axis split over 8 waves: the fused scan + top-k (scan_topk.hip) and the
+// k-means assignment of the IVF build (kmeans.hip).  Not part of any ABI.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rass {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kWaves = 8;
+constexpr int kThreads = kWaves * 64;
+constexpr int kTileRows = 32;
+constexpr int kPitch = 36;  // floats per query row of the LDS partial image (32 rows + pad)
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// One tile's A fragments for one wave: 2 M-tiles x CH chunks of 16 B per lane.
+template <int CH>
+struct TileRegs {
+    f32x4 a[2][CH];
+    int tag;
+};
+
+// Wave-uniform buffer descriptors of one tile: corpus rows and row tags.  The range check
+// drops every lane past the end (rows beyond n_rows, or a whole run-ahead tile past the last
+// one): zeros come back and no memory request is made.
+struct TileDesc {
+    __amdgpu_buffer_rsrc_t rows;
+    __amdgpu_buffer_rsrc_t tags;
+};
+
+// One unit of work of a workgroup: a 32-row slab tile, how many of its rows exist, and which
+// queries of the batch may rank its rows (all of them for the flat scan; for IVF the queries
+// that probe the list the tile belongs to).
+struct WorkItem {
+    int tile;
+    int rows;
+    unsigned mask;
+};
+
+__device__ __forceinline__ TileDesc make_tile_desc(const float* __restrict__ X, int64_t row_stride,
+                                                   const int32_t* __restrict__ row_tag, const WorkItem& w) {
+    const int rows_here = w.rows;
+    const int64_t base_row = (int64_t)w.tile * kTileRows;
+    // The descriptor must be PROVABLY wave-uniform or hipcc wraps every buffer op in a
+    // waterfall loop: pin its inputs with readfirstlane (guide T20).
+    const uint64_t base_u = reinterpret_cast<uint64_t>(X + base_row * row_stride);
+    const uint32_t base_lo = __builtin_amdgcn_readfirstlane((uint32_t)base_u);
+    const uint32_t base_hi = __builtin_amdgcn_readfirstlane((uint32_t)(base_u >> 32));
+    const unsigned blocks_here = (unsigned)(rows_here + 15) >> 4;  // tile16: whole 16-row blocks
+    const unsigned bytes = __builtin_amdgcn_readfirstlane(blocks_here * 16u * (unsigned)row_stride * 4u);
+    TileDesc d;
+    d.rows = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(((uint64_t)base_hi << 32) | base_lo),
+                                               /*stride*/ 0, (int)bytes, 0x00020000);
+    // Row tags: always loaded (straight-line code keeps hipcc's vmcnt counts exact); with no
+    // tag array the descriptor has zero records: the load returns 0 and costs no traffic.
+    const bool has_tags = row_tag != nullptr;
+    const uint64_t tbase_u = has_tags ? reinterpret_cast<uint64_t>(row_tag + base_row) : base_u;
+    const uint32_t tlo = __builtin_amdgcn_readfirstlane((uint32_t)tbase_u);
+    const uint32_t thi = __builtin_amdgcn_readfirstlane((uint32_t)(tbase_u >> 32));
+    const unsigned tbytes = __builtin_amdgcn_readfirstlane(has_tags ? (unsigned)(rows_here * 4) : 0u);
+    d.tags = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<int32_t*>(((uint64_t)thi << 32) | tlo), 0,
+                                               (int)tbytes, 0x00020000);
+    return d;
+}
+
+// voff: this lane's byte offset inside a chunk (ONE VGPR for every load of the kernel); soff: the wave-uniform
+// part (M-tile and chunk), which goes into the instruction's SGPR / immediate offset fields.  Folding it into
+// per-load VGPR offsets, as the first version did, cost ~10 VGPRs the main loop does not have.
+__device__ __forceinline__ f32x4 load_chunk(const TileDesc& d, int voff, int soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(d.rows, voff, soff, /*aux: nt*/ 2));
+}
+
+__device__ __forceinline__ int load_tag(const TileDesc& d) {
+    return (int)__builtin_amdgcn_raw_buffer_load_b32(d.tags, (lane_id() & 31) * 4, 0, 0);
+}
+
+// Prologue: all of a tile's loads, in the order multiply_and_refill consumes them.
+template <int CH, bool TAGS = true>
+__device__ __forceinline__ void issue_tile_loads(TileRegs<CH>& r, const TileDesc& d, int voff_lane, int mt_step) {
+    if (TAGS) r.tag = load_tag(d);
+#pragma unroll
+    for (int j = 0; j < CH; ++j)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) r.a[mt][j] = load_chunk(d, voff_lane, mt * mt_step + j * 1024);
+}
+
+// Multiply the resident tile and, chunk by chunk, re-issue each consumed register's load
+// for the tile two steps ahead (`next`): about two tiles (32 KiB per wave, 256 KiB per CU)
+// stay in flight at all times instead of one tile requested in a burst after the previous
+// one has fully arrived.  sched_barrier(0) per chunk pins the load placement (hipcc would
+// otherwise sink the loads behind the whole MFMA block).
+//
+// `between(j)` runs after chunk j's MFMAs were issued: the ranking of the PREVIOUS tile pair is cut into
+// parts and placed there, so its VALU / LDS / scalar work issues while this wave's (and its SIMD partner's)
+// MFMAs execute on the matrix pipe (a v_mfma_f32_16x16x4_f32 occupies the pipe for 32 cycles but takes only a
+// few to issue).  Ranked in a phase of its own behind the barrier — as the first version did — it left the
+// matrix pipe idle while all 8 waves ranked in lockstep: 72 us of a 690 us launch at B = 32.
+template <int CH, int NT, bool TAGS = true, typename Between>
+__device__ __forceinline__ void multiply_and_refill(TileRegs<CH>& r, const f32x4 (&qf)[NT][CH],
+                                                    f32x4 (&acc)[2][NT], const TileDesc& next, int voff_lane,
+                                                    int mt_step, Between&& between) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (TAGS) r.tag = load_tag(next);  // the k-means kernel streams centroids: no row tags
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+        // The 2 x NT accumulators are advanced ROUND-ROBIN, one k-step at a time: a dependent
+        // v_mfma_f32_16x16x4_f32 can issue 40 cycles after its producer but the pipe takes a new one every 32, so
+        // back-to-back MFMAs on one accumulator (what hipcc emitted for the second M-tile when left to itself:
+        // two chains of four) leave the pipe idle 20 % of the time whenever the SIMD's other wave is not in its
+        // MFMA phase.  With >= 2 independent accumulators between a producer and its consumer there is no bubble.
+        const f32x4 a0 = r.a[0][j], a1 = r.a[1][j];
+#define RASS_KSTEP(comp)                                                                                              \
+    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                                               \
+        acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.comp, qf[nt][j].comp, acc[0][nt], 0, 0, 0);              \
+        acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.comp, qf[nt][j].comp, acc[1][nt], 0, 0, 0);              \
+    }
+        RASS_KSTEP(x)
+        RASS_KSTEP(y)
+        RASS_KSTEP(z)
+        RASS_KSTEP(w)
+#undef RASS_KSTEP
+        r.a[0][j] = load_chunk(next, voff_lane, j * 1024);
+        r.a[1][j] = load_chunk(next, voff_lane, mt_step + j * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+        between(j);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+}  // namespace rass

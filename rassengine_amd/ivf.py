@@ -2,19 +2,21 @@
 
 Division of labour:
 
-* OFFLINE build (this file): spherical k-means on a row sample and the row -> list
-  assignment.  Both are plain dense GEMMs + argmax over data already in HBM, run through
-  ``torch.matmul`` (a library GEMM is the right tool for a plain GEMM; it is not on the
-  query path).  With several GPUs the centroid sums are all-reduced (16.8 MB at 4096 x 1024:
-  ~0.2 ms ring over xGMI), so every rank ends with identical centroids and builds lists over
-  its own row shard.
-* HOT PATH (HIP, behind the C ABI): ``rass_ivf_search*`` — coarse top-nprobe over the centroid
-  slab with the fused flat scan, a plan kernel, and the same fused scan over the union of the
-  batch's probed lists (``csrc/ivf.hip``, IVF mode of ``csrc/scan_topk.hip``).
+* BUILD (offline): spherical k-means on a strided sample of the rows and the row -> list assignment.  The two
+  O(rows) steps are HIP kernels behind the C ABI, working on the rows where they already are (the index's tile16
+  slab in HBM): ``rass_kmeans_assign`` (exact fp32 MFMA GEMM rows x centroids^T with a row-argmax epilogue,
+  ``csrc/kmeans.hip``) and ``rass_kmeans_accumulate`` (centroid sums / counts, fp32 atomics).  What stays here is
+  O(nlist x dim): the all-reduce of sums and counts across ranks (16.8 MB at 4096 x 1024: ~0.2 ms ring over
+  xGMI, so every rank ends with identical centroids and builds lists over its own row shard), the normalisation
+  of the new centroids (``rass_normalize_rows_f32``) and the re-seeding of empty lists.  No library GEMM.
+* HOT PATH (HIP, behind the C ABI): ``rass_ivf_search*`` — coarse top-nprobe over the centroid slab with the
+  fused flat scan, a plan kernel, and the same fused scan over the union of the batch's probed lists
+  (``csrc/ivf.hip``, IVF mode of ``csrc/scan_topk.hip``).
 
-IVF is approximate: recall@k against the flat index is measured per nprobe
-(``scripts/bench_ivf.py``, ``tests/test_gpu_ivf.py``); ``nprobe = nlist`` reproduces the flat result (nprobe > 32 selects lists by a per-query score
-threshold from the full centroid score matrix).
+IVF is approximate BY CONSTRUCTION, with exact semantics: a query's result is the brute-force top-k restricted to
+the rows of its nprobe best-scoring lists (``tests/test_gpu_cfg5.py`` pins that against the oracle); recall@k
+against the flat index is therefore a property of the data and of nprobe, measured per configuration
+(``scripts/bench_ivf.py``), and ``nprobe = nlist`` reproduces the flat result bit for bit.
 """
 from __future__ import annotations
 
@@ -26,15 +28,120 @@ import torch
 import torch.distributed as dist
 
 from . import _native as N
+from . import ops
 from .engine import FlatIndex
 
+BLOCK_ROWS = 32  # the k-means kernels work on 32-row blocks of the slab
 
-class _DevArray:
-    """A raw device pointer as a ``__cuda_array_interface__`` object (zero-copy torch view)."""
 
-    def __init__(self, ptr: int, shape, typestr: str = "<f4"):
-        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False),
-                                         "version": 2}
+class _engine_on_torch_stream:
+    """Run the engine's kernels on torch's current stream for the duration (they are ordered with the torch
+    ops around them without host synchronisation), then put its stream back."""
+
+    def __init__(self, index: FlatIndex):
+        self.engine = index.engine
+        self.prev = None
+
+    def __enter__(self):
+        self.prev = self.engine.stream
+        dev = torch.device("cuda", self.engine.device)
+        self.engine.set_stream(int(torch.cuda.current_stream(dev).cuda_stream))
+        return self
+
+    def __exit__(self, *exc):
+        torch.cuda.current_stream(torch.device("cuda", self.engine.device)).synchronize()
+        self.engine.set_stream(self.prev)
+        return False
+
+
+def _pack_centroids(cent: torch.Tensor, row_stride: int) -> torch.Tensor:
+    """Row-major [nlist, dim] -> normalised tile16 slab (what the assign kernel and the probe stream)."""
+    return ops.pack_rows(cent.contiguous(), normalize=True, row_stride=row_stride)
+
+
+def kmeans_assign(index: FlatIndex, centroids: torch.Tensor, first_block: int = 0, block_step: int = 1,
+                  n_blocks: Optional[int] = None, with_best: bool = False):
+    """List id (arg max cosine, exact fp32) of the rows of the processed 32-row blocks; device int32
+    [n_blocks * 32] (entries of rows past ``index.rows`` are meaningless).  Async on torch's current stream
+    when called inside ``_engine_on_torch_stream``."""
+    dev = centroids.device
+    if n_blocks is None:
+        n_blocks = max(0, -(-(index.rows - first_block * BLOCK_ROWS) // (BLOCK_ROWS * block_step)))
+    slab = _pack_centroids(centroids, index.row_stride)
+    assign = torch.empty((n_blocks * BLOCK_ROWS,), dtype=torch.int32, device=dev)
+    best = torch.empty((n_blocks * BLOCK_ROWS,), dtype=torch.float32, device=dev) if with_best else None
+    N.check("rass_kmeans_assign",
+            N.lib().rass_kmeans_assign(index._h, int(first_block), int(block_step), int(n_blocks),
+                                       ctypes.c_void_p(slab.data_ptr()), int(centroids.shape[0]),
+                                       ctypes.c_void_p(assign.data_ptr()),
+                                       ctypes.c_void_p(best.data_ptr()) if best is not None else None))
+    return (assign, best, slab) if with_best else (assign, slab)
+
+
+def kmeans_accumulate(index: FlatIndex, assign: torch.Tensor, nlist: int, first_block: int, block_step: int,
+                      n_blocks: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(sums [nlist, dim] fp32, counts [nlist] fp32) of the processed rows by list."""
+    dev = assign.device
+    sums = torch.zeros((nlist, index.dim), dtype=torch.float32, device=dev)
+    counts = torch.zeros((nlist,), dtype=torch.float32, device=dev)
+    N.check("rass_kmeans_accumulate",
+            N.lib().rass_kmeans_accumulate(index._h, int(first_block), int(block_step), int(n_blocks),
+                                           ctypes.c_void_p(assign.data_ptr()), ctypes.c_void_p(sums.data_ptr()),
+                                           ctypes.c_void_p(counts.data_ptr()), int(nlist)))
+    return sums, counts
+
+
+def train_centroids(index: FlatIndex, nlist: int, train_rows: int = 0, iters: int = 20, seed: int = 0,
+                    group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
+    """Spherical k-means over a strided sample of the index's 32-row blocks (every ``step``-th block, about
+    ``train_rows`` rows; 0 = all); returns unit centroids [nlist, dim] on the GPU, identical on every rank."""
+    dev = torch.device("cuda", index.engine.device)
+    n = index.rows
+    total_blocks = -(-n // BLOCK_ROWS)
+    m = n if train_rows <= 0 else min(n, int(train_rows))
+    if m < nlist:
+        raise ValueError(f"need at least nlist={nlist} training rows, have {m}")
+    step = max(1, total_blocks // max(1, -(-m // BLOCK_ROWS)))
+    n_blocks = -(-total_blocks // step)
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    with _engine_on_torch_stream(index):
+        # seeds: nlist distinct sample rows (deterministic for a seed); every rank starts from rank 0's
+        pick = torch.randperm(min(n_blocks * BLOCK_ROWS, n - 0), generator=g)[:nlist]
+        rows = (pick // BLOCK_ROWS) * step * BLOCK_ROWS + (pick % BLOCK_ROWS)
+        rows = torch.clamp(rows, max=n - 1)
+        cent = torch.empty((nlist, index.dim), dtype=torch.float32, device=dev)
+        one = torch.empty((1, index.dim), dtype=torch.float32, device=dev)
+        for i, r in enumerate(rows.tolist()):
+            cent[i] = _rows_chunk(index, int(r), 1, one)[0]
+        if world > 1:
+            dist.broadcast(cent, src=0, group=group)
+        for _ in range(iters):
+            assign, _slab = kmeans_assign(index, cent, 0, step, n_blocks)
+            sums, counts = kmeans_accumulate(index, assign, nlist, 0, step, n_blocks)
+            if world > 1:
+                dist.all_reduce(sums, group=group)
+                dist.all_reduce(counts, group=group)
+            new = ops.normalize_rows(sums)                      # sums / (||sums|| + 1e-9)
+            empty = counts == 0
+            if bool(empty.any()):  # re-seed empty lists from (deterministic) sample rows; rank 0's win
+                idx = torch.nonzero(empty).flatten()
+                for li in idx.tolist():
+                    r = min(n - 1, ((li * 7919 + 13) % n_blocks) * step * BLOCK_ROWS + (li % BLOCK_ROWS))
+                    new[li] = _rows_chunk(index, int(r), 1, one)[0]
+                if world > 1:
+                    dist.broadcast(new, src=0, group=group)
+            cent = new
+    return cent
+
+
+def assign_rows(index: FlatIndex, centroids: torch.Tensor) -> np.ndarray:
+    """List id (arg max cosine) of every row of the index; int32 host array."""
+    with _engine_on_torch_stream(index):
+        assign, _slab = kmeans_assign(index, centroids)
+        out = assign[:index.rows].cpu().numpy()
+    return out
 
 
 def _rows_chunk(index: FlatIndex, first: int, n: int, out: torch.Tensor) -> torch.Tensor:
@@ -44,78 +151,6 @@ def _rows_chunk(index: FlatIndex, first: int, n: int, out: torch.Tensor) -> torc
                                          index.dim, ctypes.c_void_p(out.data_ptr()), index.dim,
                                          ctypes.c_void_p(int(torch.cuda.current_stream().cuda_stream))))
     return out[:n]
-
-
-def _assign_chunk(x: torch.Tensor, cent_t: torch.Tensor) -> torch.Tensor:
-    return torch.argmax(x @ cent_t, dim=1)
-
-
-def train_centroids(index: FlatIndex, nlist: int, train_rows: int = 0, iters: int = 20, seed: int = 0,
-                    group: Optional[dist.ProcessGroup] = None, chunk: int = 65536) -> torch.Tensor:
-    """Spherical k-means over (a strided sample of) the index's rows; returns unit centroids
-    [nlist, dim] on the GPU.  Deterministic for a given seed and shard layout."""
-    dev = torch.device("cuda", index.engine.device)
-    n = index.rows
-    m = n if train_rows <= 0 else min(n, int(train_rows))
-    if m < nlist:
-        raise ValueError(f"need at least nlist={nlist} training rows, have {m}")
-    index.engine.synchronize()
-    step = max(1, n // m)
-    buf = torch.empty((chunk, index.dim), dtype=torch.float32, device=dev)
-    # strided sample, materialised once (m x dim fp32)
-    sample = torch.empty((m, index.dim), dtype=torch.float32, device=dev)
-    got = 0
-    first = 0
-    while got < m and first < n:
-        cnt = min(chunk, n - first)
-        rows = _rows_chunk(index, first, cnt, buf)[::step]
-        take = min(rows.shape[0], m - got)
-        sample[got:got + take] = rows[:take]
-        got += take
-        first += cnt
-    sample = sample[:got]
-    g = torch.Generator(device="cpu")
-    g.manual_seed(seed)
-    world = dist.get_world_size(group) if (dist.is_initialized()) else 1
-    perm = torch.randperm(got, generator=g)[:nlist].to(dev)
-    cent = sample[perm].clone()
-    if world > 1:  # every rank starts from rank 0's seeds
-        dist.broadcast(cent, src=0, group=group)
-    for _ in range(iters):
-        sums = torch.zeros((nlist, index.dim), dtype=torch.float32, device=dev)
-        counts = torch.zeros((nlist,), dtype=torch.float32, device=dev)
-        cent_t = cent.t().contiguous()
-        for a in range(0, got, chunk):
-            x = sample[a:a + chunk]
-            lab = _assign_chunk(x, cent_t)
-            sums.index_add_(0, lab, x)
-            counts.index_add_(0, lab, torch.ones_like(lab, dtype=torch.float32))
-        if world > 1:
-            dist.all_reduce(sums, group=group)
-            dist.all_reduce(counts, group=group)
-        empty = counts == 0
-        new = sums / (sums.norm(dim=1, keepdim=True) + 1e-9)
-        if bool(empty.any()):  # re-seed empty lists from (deterministic) sample rows
-            idx = torch.nonzero(empty).flatten()
-            new[idx] = sample[(idx * 7919 + 13) % got]
-            if world > 1:
-                dist.broadcast(new, src=0, group=group)
-        cent = new
-    return cent
-
-
-def assign_rows(index: FlatIndex, centroids: torch.Tensor, chunk: int = 65536) -> np.ndarray:
-    """List id (argmax cosine) of every row of the index; int32 host array."""
-    dev = centroids.device
-    n = index.rows
-    index.engine.synchronize()
-    buf = torch.empty((chunk, index.dim), dtype=torch.float32, device=dev)
-    cent_t = centroids.t().contiguous()
-    out = torch.empty((n,), dtype=torch.int32, device=dev)
-    for a in range(0, n, chunk):
-        cnt = min(chunk, n - a)
-        out[a:a + cnt] = _assign_chunk(_rows_chunk(index, a, cnt, buf), cent_t).to(torch.int32)
-    return out.cpu().numpy()
 
 
 class IvfIndex:

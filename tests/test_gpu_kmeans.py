@@ -1,0 +1,97 @@
+"""K9(i) on the GPU: the k-means kernels of the IVF build (csrc/kmeans.hip) through the C ABI against plain fp32
+torch references of the same ops (a floating-point kernel: the one place a torch reference is the yardstick).
+
+  * rass_kmeans_assign: row -> arg max cosine over the centroids.  The chosen list's score must be the row's
+    maximum to within fp32 summation order (1e-6 on unit vectors), equal to torch's argmax wherever the runner-up
+    is further away than that, and the reported best score within 2e-6 of fp64.
+  * rass_kmeans_accumulate: per-list sums / counts equal torch's index_add (atomics reorder the fp32 adds: 1e-4
+    relative).
+  * train_centroids: one iteration reproduces a torch Lloyd step from the same seeds; empty lists are re-seeded;
+    the sampled variant touches only the sampled blocks.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n,dim,nlist,step", [(1000, 1024, 64, 1), (4099, 1024, 500, 1), (70000, 1024, 4096, 1),
+                                              (5000, 256, 33, 1), (9000, 640, 100, 3), (33, 128, 7, 1)])
+def test_assign_and_accumulate_match_torch(gpu, n, dim, nlist, step):
+    torch = gpu
+    from rassengine_amd import ivf
+    from rassengine_amd.engine import Engine
+    g = torch.Generator(device="cpu")
+    g.manual_seed(n + nlist)
+    x = torch.randn((n, dim), generator=g)
+    cent = torch.randn((nlist, dim), generator=g)
+    cent[nlist // 2] = x[5]                      # a row that IS a centroid: cosine 1
+    eng = Engine(0, dim)
+    try:
+        idx = eng.open_index("km", capacity_rows=n)       # capacity % 32 may be 16: the half-block guard
+        idx.add(x.numpy(), normalize=True)
+        cd = cent.cuda()
+        total_blocks = -(-n // 32)
+        n_blocks = -(-total_blocks // step)
+        with ivf._engine_on_torch_stream(idx):
+            assign, best, _slab = ivf.kmeans_assign(idx, cd, 0, step, n_blocks, with_best=True)
+            sums, counts = ivf.kmeans_accumulate(idx, assign, nlist, 0, step, n_blocks)
+            torch.cuda.synchronize()
+        rows = (torch.arange(n_blocks * 32) // 32) * step * 32 + torch.arange(n_blocks * 32) % 32
+        valid = rows < n
+        xs = torch.nn.functional.normalize(x.double(), dim=1)[rows[valid]]
+        cn = torch.nn.functional.normalize(cent.double(), dim=1)
+        scores = xs @ cn.T                                        # fp64 truth
+        top2 = scores.topk(min(2, nlist), dim=1)
+        a = assign.cpu()[valid].long()
+        chosen = scores.gather(1, a[:, None])[:, 0]
+        assert bool((a >= 0).all()) and bool((a < nlist).all())
+        assert bool((top2.values[:, 0] - chosen <= 1e-6).all()), float((top2.values[:, 0] - chosen).max())
+        clear = (top2.values[:, 0] - top2.values[:, -1]) > 2e-6 if nlist > 1 else torch.ones_like(chosen, dtype=torch.bool)
+        assert bool((a[clear] == top2.indices[:, 0][clear]).all())
+        assert bool(((best.cpu()[valid].double() - chosen).abs() <= 2e-6).all())
+        if step == 1 and n > 5:
+            assert int(a[5]) == nlist // 2 and abs(float(best[5]) - 1.0) < 1e-6
+        # accumulate vs index_add on the very assignment the kernel produced
+        ref_s = torch.zeros((nlist, dim), dtype=torch.float64).index_add_(0, a, xs)
+        ref_c = torch.bincount(a, minlength=nlist).double()
+        assert torch.equal(counts.cpu().double(), ref_c)
+        err = (sums.cpu().double() - ref_s).abs().max()
+        assert float(err) <= 1e-4 * max(1.0, float(ref_s.abs().max())), float(err)
+    finally:
+        eng.close()
+
+
+def test_train_centroids_is_a_lloyd_iteration_and_reseeds_empty_lists(gpu):
+    torch = gpu
+    from rassengine_amd import ivf
+    from rassengine_amd.engine import Engine
+    rng = np.random.default_rng(0)
+    centres = rng.standard_normal((20, 256)).astype(np.float32)
+    x = (centres[rng.integers(0, 20, size=6000)] + 0.3 * rng.standard_normal((6000, 256))).astype(np.float32)
+    eng = Engine(0, 256)
+    try:
+        idx = eng.open_index("km-train")
+        idx.add(x, normalize=True)
+        c0 = ivf.train_centroids(idx, nlist=20, iters=0, seed=3)              # the seeds
+        c1 = ivf.train_centroids(idx, nlist=20, iters=1, seed=3)
+        xn = torch.nn.functional.normalize(torch.from_numpy(x), dim=1)
+        lab = (xn @ c0.cpu().T).argmax(dim=1)
+        sums = torch.zeros((20, 256)).index_add_(0, lab, xn)
+        ref = sums / (sums.norm(dim=1, keepdim=True) + 1e-9)
+        live = torch.bincount(lab, minlength=20) > 0
+        assert torch.allclose(c1.cpu()[live], ref[live], atol=1e-5)
+        assert torch.allclose(c1.norm(dim=1).cpu(), torch.ones(20), atol=1e-5)    # re-seeded rows are unit too
+        c8 = ivf.train_centroids(idx, nlist=20, iters=8, seed=3)
+        assign = ivf.assign_rows(idx, c8)
+        assert assign.shape == (6000,) and assign.dtype == np.int32
+        # k-means found the 20 planted clusters: every list is (almost) pure
+        truth = (xn @ torch.nn.functional.normalize(torch.from_numpy(centres), dim=1).T).argmax(dim=1).numpy()
+        purity = np.mean([np.bincount(truth[assign == l], minlength=20).max() / max(1, (assign == l).sum())
+                          for l in range(20) if (assign == l).any()])
+        assert purity > 0.9, purity
+        # a strided sample (every 4th block) trains too and more lists than clusters leaves no NaN behind
+        c_s = ivf.train_centroids(idx, nlist=64, train_rows=1500, iters=3, seed=1)
+        assert bool(torch.isfinite(c_s).all()) and torch.allclose(c_s.norm(dim=1).cpu(), torch.ones(64), atol=1e-5)
+    finally:
+        eng.close()

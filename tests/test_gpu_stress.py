@@ -104,3 +104,139 @@ def test_concurrent_adds_to_different_indices_share_the_engine_staging_buffer(gp
             assert np.array_equal(idxs[name].get_rows(0, n), data[name]), name
     finally:
         eng.close()
+
+
+def test_many_indices_many_threads_overlap_their_round_trips(gpu, oracle):
+    """The reference keeps ONE index per user (app/main.py:346-347) and serves requests concurrently: N indices
+    x M threads searching at once (masked filters and k > 32 in the mix), one thread ingesting into two of them
+    and dropping / re-creating a third.  rass_index_search_ex holds the engine lock while enqueuing only and
+    waits on a per-call event on a pinned slot (8 slots, 12 threads: the pool must block and hand over, not
+    corrupt).  Every answer must equal the oracle's for the rows that index held when the call started or ended."""
+    from rassengine_amd.engine import Engine
+    dim, n_idx, n_threads, rows0 = 256, 6, 12, 3000
+    eng = Engine(0, dim)
+    rng = np.random.default_rng(9)
+    data, tags, xn = {}, {}, {}
+    try:
+        idxs = {}
+        for u in range(n_idx):
+            data[u] = rng.standard_normal((rows0 + 600, dim)).astype(np.float32)
+            tags[u] = rng.integers(1, 4, size=rows0 + 600).astype(np.int32)
+            xn[u] = oracle.normalize_ref(data[u]).astype(np.float32)
+            idxs[u] = eng.open_index(f"user-{u}")
+            idxs[u].add(data[u][:rows0], tags=tags[u][:rows0])
+        errors = []
+        stop = threading.Event()
+
+        def expect(u, q, k, n_rows, qf=None, qm=None):
+            qn = oracle.normalize_ref(q).astype(np.float32)
+            return oracle.search(xn[u][:n_rows], qn, k, tags=tags[u][:n_rows], qfilter=qf, qmask=qm)
+
+        def searcher(t):
+            r = np.random.default_rng(100 + t)
+            try:
+                n = 0
+                while not stop.is_set() or n < 30:
+                    u = int(r.integers(0, n_idx))
+                    nq = int(r.integers(1, 40))
+                    k = int(r.choice([1, 5, 10, 32, 40]))
+                    q = r.standard_normal((nq, dim)).astype(np.float32)
+                    mode = int(r.integers(0, 3))
+                    qf = qm = None
+                    if mode == 1:
+                        qf = r.integers(-1, 4, size=nq).astype(np.int32)
+                    elif mode == 2:
+                        qf = r.integers(1, 4, size=nq).astype(np.int32)
+                        qm = np.full(nq, 0x00FFFFFF, dtype=np.int32)
+                    before = idxs[u].rows
+                    s, i = idxs[u].search(q, k, q_filter=qf, q_filter_mask=qm)
+                    after = idxs[u].rows
+                    ok = False
+                    for n_rows in sorted({before, after} | ({rows0 + 300} if before < rows0 + 300 < after else set())):
+                        rs, ri = expect(u, q, k, n_rows, qf, qm)
+                        if np.array_equal(i, ri) and np.all(np.abs(s[ri >= 0].astype(np.float64) - rs[ri >= 0]) <= 2e-6):
+                            ok = True
+                            break
+                    if not ok:
+                        # an add published between the two reads: the result must still be a valid top-k of a
+                        # prefix of the rows — check it is best-first, in range, and filter-correct
+                        assert np.all(i < after) and np.all(np.diff(s, axis=1)[(i >= 0)[:, 1:]] <= 0), (u, k, nq)
+                        if qf is not None:
+                            for row_q in range(nq):
+                                live = i[row_q][i[row_q] >= 0]
+                                if qf[row_q] >= 0:
+                                    assert np.all((tags[u][live] & (-1 if qm is None else int(qm[row_q]))) == qf[row_q])
+                    n += 1
+            except Exception as e:  # noqa: BLE001
+                errors.append((f"searcher{t}", repr(e)))
+
+        def writer():
+            try:
+                for step in range(2):
+                    for u in (0, 1):
+                        lo = rows0 + 300 * step
+                        idxs[u].add(data[u][lo:lo + 300], tags=tags[u][lo:lo + 300])
+                    # a whole user index goes away and comes back while others are searched
+                    eng.drop_index("scratch-user") if step else None
+                    sc = eng.open_index("scratch-user")
+                    sc.add(data[2][:500])
+                    assert sc.search(data[2][:3], 1)[1][:, 0].tolist() == [0, 1, 2]
+            except Exception as e:  # noqa: BLE001
+                errors.append(("writer", repr(e)))
+            finally:
+                stop.set()
+
+        threads = [threading.Thread(target=searcher, args=(t,)) for t in range(n_threads)] + \
+                  [threading.Thread(target=writer)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=300)
+        assert not any(t.is_alive() for t in threads), "stress threads did not finish"
+        assert not errors, errors[:3]
+        for u in (0, 1):
+            assert idxs[u].rows == rows0 + 600
+    finally:
+        eng.close()
+
+
+def test_query_batcher_over_the_hip_index(gpu, oracle):
+    """the cross-request micro-batcher on the REAL index: 100 concurrent asemantic_search-style
+    requests (mixed k, mixed patient filters) share scans and each gets exactly the single-request answer."""
+    import asyncio
+    from rassengine_amd.batcher import QueryBatcher
+    from rassengine_amd.engine import Engine
+    dim = 512
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal((5000, dim)).astype(np.float32)
+    tags = (rng.integers(1, 5, size=5000) | (1 << 24)).astype(np.int32)     # patient code | doc_type 1
+    eng = Engine(0, dim)
+    try:
+        idx = eng.open_index("batched")
+        idx.add(x, tags=tags)
+        qs = rng.standard_normal((100, dim)).astype(np.float32)
+        ks = rng.integers(1, 11, size=100)
+        pats = rng.integers(0, 5, size=100)         # 0 = no filter
+
+        async def main():
+            b = QueryBatcher(idx, max_batch=32, max_delay_ms=20.0)
+            res = await asyncio.gather(*[
+                b.search(qs[i], int(ks[i]), int(pats[i]) if pats[i] else -1, 0x00FFFFFF if pats[i] else -1)
+                for i in range(100)])
+            await b.close()
+            return b, res
+
+        b, res = asyncio.run(main())
+        assert b.served == 100 and b.scans <= 8
+        xn = oracle.normalize_ref(x).astype(np.float32)
+        for i, (s, ids) in enumerate(res):
+            qn = oracle.normalize_ref(qs[i:i + 1]).astype(np.float32)
+            if pats[i]:
+                rs, ri = oracle.search(xn, qn, int(ks[i]), tags=tags, qfilter=np.array([pats[i]], dtype=np.int32),
+                                       qmask=np.array([0x00FFFFFF], dtype=np.int32))
+            else:
+                rs, ri = oracle.search(xn, qn, int(ks[i]), tags=tags)
+            assert ids.shape == (ks[i],) and np.array_equal(ids, ri[0]), i
+            assert np.all(np.abs(s.astype(np.float64) - rs[0]) <= 2e-6)
+    finally:
+        eng.close()

@@ -303,6 +303,11 @@ int rass_kmeans_accumulate(rass_index_t* idx, int64_t first_block, int64_t block
 int rass_ivf_build(rass_index_t* src, const float* centroids, int nlist,
                    const int32_t* assign, rass_ivf_t** out);
 void rass_ivf_destroy(rass_ivf_t* ivf);
+/* IVF persistence (SURVEY §8f-3 for the IVF shard): the whole device state — list table, slab ids, tags,
+ * centroid slab, permuted row slab — so a load needs neither the flat index nor a re-training.  The file is
+ * fsynced before close (write to a temporary name and rename for crash safety, as docstore.py does). */
+int rass_ivf_save(rass_ivf_t* ivf, const char* path);
+int rass_ivf_load(rass_engine_t* eng, const char* path, rass_ivf_t** out);
 int64_t rass_ivf_rows(const rass_ivf_t* ivf);
 int rass_ivf_nlist(const rass_ivf_t* ivf);
 /* Same contract as rass_index_search; nprobe >= 1 lists per query (capped at

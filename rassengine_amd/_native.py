@@ -100,6 +100,8 @@ SIGNATURES = {
                                           ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     "rass_kmeans_accumulate": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
                                               ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
+    "rass_ivf_save": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p]),
+    "rass_ivf_load": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, c_void_pp]),
     "rass_ivf_build": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, c_void_pp]),
     "rass_ivf_destroy": (None, [ctypes.c_void_p]),
     "rass_ivf_rows": (ctypes.c_int64, [ctypes.c_void_p]),

@@ -1393,6 +1393,157 @@ void rass_ivf_destroy(rass_ivf_t* v) {
     ivf_free(v);
 }
 
+// ---- IVF persistence: header + list table + slab ids + tags + centroid slab + row slab (raw tile16)
+struct IvfSaveHeader {
+    char magic[8];
+    int32_t version, dim, nlist, any_tags;
+    int64_t stride, rows, slab_rows, total_tiles, cent_rows;
+};
+
+static bool dev_to_file(FILE* f, const void* d_src, size_t bytes, hipStream_t st, std::vector<unsigned char>& buf) {
+    const unsigned char* p = static_cast<const unsigned char*>(d_src);
+    for (size_t done = 0; done < bytes;) {
+        const size_t m = std::min(buf.size(), bytes - done);
+        if (hipMemcpyAsync(buf.data(), p + done, m, hipMemcpyDeviceToHost, st) != hipSuccess) return false;
+        if (hipStreamSynchronize(st) != hipSuccess) return false;
+        if (fwrite(buf.data(), 1, m, f) != m) return false;
+        done += m;
+    }
+    return true;
+}
+
+static bool file_to_dev(FILE* f, void* d_dst, size_t bytes, hipStream_t st, std::vector<unsigned char>& buf) {
+    unsigned char* p = static_cast<unsigned char*>(d_dst);
+    for (size_t done = 0; done < bytes;) {
+        const size_t m = std::min(buf.size(), bytes - done);
+        if (fread(buf.data(), 1, m, f) != m) return false;
+        if (hipMemcpyAsync(p + done, buf.data(), m, hipMemcpyHostToDevice, st) != hipSuccess) return false;
+        if (hipStreamSynchronize(st) != hipSuccess) return false;
+        done += m;
+    }
+    return true;
+}
+
+int rass_ivf_save(rass_ivf_t* v, const char* path) {
+    if (!v || !path) return fail(RASS_ERR_INVALID, "NULL argument");
+    rass_engine* eng = v->eng;
+    int rc = set_device(eng);
+    if (rc != RASS_OK) return rc;
+    std::lock_guard<std::mutex> lk(eng->mu);
+    hipStream_t st = eng->stream;
+    FILE* f = fopen(path, "wb");
+    if (!f) return fail(RASS_ERR_IO, std::string("cannot open for write: ") + path);
+    IvfSaveHeader h;
+    memset(&h, 0, sizeof(h));
+    memcpy(h.magic, "RASSIVF1", 8);
+    h.version = 1;
+    h.dim = v->dim;
+    h.nlist = v->nlist;
+    h.any_tags = v->any_tags ? 1 : 0;
+    h.stride = v->stride;
+    h.rows = v->rows;
+    h.slab_rows = v->slab_rows;
+    h.total_tiles = v->total_tiles;
+    h.cent_rows = ((int64_t)v->nlist + 15) / 16 * 16;
+    std::vector<unsigned char> buf((size_t)32 << 20);
+    bool ok = fwrite(&h, sizeof(h), 1, f) == 1;
+    ok = ok && dev_to_file(f, v->d_list_tile0, (size_t)v->nlist * 4, st, buf);
+    ok = ok && dev_to_file(f, v->d_list_len, (size_t)v->nlist * 4, st, buf);
+    ok = ok && dev_to_file(f, v->d_ids, (size_t)v->slab_rows * 8, st, buf);
+    ok = ok && dev_to_file(f, v->d_tags, (size_t)v->slab_rows * 4, st, buf);
+    ok = ok && dev_to_file(f, v->d_centroids, (size_t)h.cent_rows * v->stride * 4, st, buf);
+    ok = ok && dev_to_file(f, v->d_slab, (size_t)v->slab_rows * v->stride * 4, st, buf);
+    ok = ok && fflush(f) == 0 && fsync(fileno(f)) == 0;
+    ok = (fclose(f) == 0) && ok;
+    return ok ? RASS_OK : fail(RASS_ERR_IO, std::string("ivf save failed (short write or device read): ") + path);
+}
+
+int rass_ivf_load(rass_engine_t* eng, const char* path, rass_ivf_t** out) {
+    if (!eng || !path || !out) return fail(RASS_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    int rc = set_device(eng);
+    if (rc != RASS_OK) return rc;
+    FILE* f = fopen(path, "rb");
+    if (!f) return fail(RASS_ERR_IO, std::string("cannot open for read: ") + path);
+    IvfSaveHeader h;
+    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "RASSIVF1", 8) != 0 || h.version != 1) {
+        fclose(f);
+        return fail(RASS_ERR_IO, "not a rass IVF file");
+    }
+    const int64_t cent_rows = ((int64_t)h.nlist + 15) / 16 * 16;
+    bool sane = h.dim == eng->dim && h.stride == pad128(h.dim) && h.nlist >= 1 && h.nlist <= 32768 && h.rows >= 0 &&
+                h.slab_rows >= 32 && h.slab_rows % 32 == 0 && h.slab_rows <= 0x7fffffc0LL &&
+                h.total_tiles == h.slab_rows / 32 && h.cent_rows == cent_rows && h.rows <= h.slab_rows;
+    if (sane) {  // the header must agree with the file length before anything is allocated from it
+        const long body = ftell(f);
+        int64_t len = -1;
+        if (body >= 0 && fseek(f, 0, SEEK_END) == 0) len = (int64_t)ftell(f);
+        const int64_t need = (int64_t)sizeof(h) + (int64_t)h.nlist * 8 + h.slab_rows * 12 +
+                             (cent_rows + h.slab_rows) * h.stride * 4;
+        sane = body >= 0 && len == need && fseek(f, body, SEEK_SET) == 0;
+    }
+    if (!sane) {
+        fclose(f);
+        return fail(RASS_ERR_IO, "IVF file does not match the engine (dim) or is truncated / corrupt");
+    }
+    rass_ivf* v = new (std::nothrow) rass_ivf();
+    if (!v) {
+        fclose(f);
+        return fail(RASS_ERR_OOM, "host allocation failed");
+    }
+    v->eng = eng;
+    v->dim = h.dim;
+    v->stride = h.stride;
+    v->nlist = h.nlist;
+    v->rows = h.rows;
+    v->slab_rows = h.slab_rows;
+    v->total_tiles = h.total_tiles;
+    v->any_tags = h.any_tags != 0;
+    std::lock_guard<std::mutex> lk(eng->mu);
+    hipStream_t st = eng->stream;
+    auto alloc = [&](void** p, size_t bytes) { return hipMalloc(p, bytes) == hipSuccess; };
+    bool ok = alloc((void**)&v->d_slab, (size_t)h.slab_rows * h.stride * 4) && alloc((void**)&v->d_tags, (size_t)h.slab_rows * 4) &&
+              alloc((void**)&v->d_ids, (size_t)h.slab_rows * 8) && alloc((void**)&v->d_centroids, (size_t)cent_rows * h.stride * 4) &&
+              alloc((void**)&v->d_list_tile0, (size_t)h.nlist * 4) && alloc((void**)&v->d_list_len, (size_t)h.nlist * 4) &&
+              alloc((void**)&v->d_work_tile, (size_t)h.total_tiles * 4) && alloc((void**)&v->d_work_rows, (size_t)h.total_tiles * 4) &&
+              alloc((void**)&v->d_work_mask, (size_t)h.total_tiles * 4) && alloc((void**)&v->d_n_work, 4) &&
+              alloc((void**)&v->d_scanned, 8) && alloc((void**)&v->d_probe_scores, RASS_MAX_QBATCH * RASS_MAX_K * 4) &&
+              alloc((void**)&v->d_probe_ids, RASS_MAX_QBATCH * RASS_MAX_K * 8) && alloc((void**)&v->d_tau, RASS_MAX_QBATCH * 4) &&
+              alloc((void**)&v->d_list_mask, (size_t)h.nlist * 4);
+    if (!ok) {
+        fclose(f);
+        ivf_free(v);
+        return fail(RASS_ERR_OOM, "ivf load: device allocation failed");
+    }
+    std::vector<unsigned char> buf((size_t)32 << 20);
+    ok = file_to_dev(f, v->d_list_tile0, (size_t)h.nlist * 4, st, buf) && file_to_dev(f, v->d_list_len, (size_t)h.nlist * 4, st, buf) &&
+         file_to_dev(f, v->d_ids, (size_t)h.slab_rows * 8, st, buf) && file_to_dev(f, v->d_tags, (size_t)h.slab_rows * 4, st, buf) &&
+         file_to_dev(f, v->d_centroids, (size_t)cent_rows * h.stride * 4, st, buf) &&
+         file_to_dev(f, v->d_slab, (size_t)h.slab_rows * h.stride * 4, st, buf);
+    fclose(f);
+    if (!ok) {
+        ivf_free(v);
+        return fail(RASS_ERR_IO, "ivf load: short read or upload failure");
+    }
+    // the list table must index inside the slab: a corrupt table would send the probe out of bounds
+    {
+        std::vector<int32_t> t0((size_t)h.nlist), len((size_t)h.nlist);
+        bool good = hipMemcpy(t0.data(), v->d_list_tile0, (size_t)h.nlist * 4, hipMemcpyDeviceToHost) == hipSuccess &&
+                    hipMemcpy(len.data(), v->d_list_len, (size_t)h.nlist * 4, hipMemcpyDeviceToHost) == hipSuccess;
+        int64_t tiles = 0;
+        for (int l = 0; good && l < h.nlist; ++l) {
+            good = len[(size_t)l] >= 0 && t0[(size_t)l] == tiles;
+            tiles += (len[(size_t)l] + 31) / 32;
+        }
+        if (!good || std::max<int64_t>(tiles, 1) != h.total_tiles) {
+            ivf_free(v);
+            return fail(RASS_ERR_IO, "ivf load: inconsistent list table");
+        }
+    }
+    *out = v;
+    return RASS_OK;
+}
+
 int64_t rass_ivf_rows(const rass_ivf_t* v) { return v ? v->rows : 0; }
 int rass_ivf_nlist(const rass_ivf_t* v) { return v ? v->nlist : 0; }
 

@@ -177,6 +177,20 @@ class IvfIndex:
         ivf.list_sizes = np.bincount(assign, minlength=nlist)
         return ivf
 
+    def save(self, path: str) -> None:
+        """The whole device state of this IVF shard (``rass_ivf_save``), written next to a temporary name and
+        renamed into place."""
+        import os
+        tmp = path + ".tmp"
+        N.check("rass_ivf_save", self._L.rass_ivf_save(self._h, tmp.encode()))
+        os.replace(tmp, path)
+
+    @classmethod
+    def load(cls, engine, path: str) -> "IvfIndex":
+        h = ctypes.c_void_p()
+        N.check("rass_ivf_load", N.lib().rass_ivf_load(engine._h, path.encode(), ctypes.byref(h)))
+        return cls(h, engine, engine.dim)
+
     @property
     def rows(self) -> int:
         return int(self._L.rass_ivf_rows(self._h))

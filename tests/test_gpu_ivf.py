@@ -72,8 +72,14 @@ def test_recall_grows_with_nprobe(built):
     assert recalls[-1] >= 0.95, recalls
     assert recalls[0] >= 0.3, recalls
     assert all(b >= a for a, b in zip(scanned, scanned[1:]))
-    # one list per query: at most 32 of the 128 lists per batch are touched
-    assert scanned[0] < 0.3 * 2 * flat.count
+    # one list per query: a batch of b queries touches at most b lists, so the rows scanned by the two batches
+    # (32 + 18 queries) cannot exceed the 32 + 18 longest lists.  (Round 1 had `< 0.2 * 2 * count` here, which
+    # failed — queries fall into LONG lists more often than into short ones, size-biased sampling — and was
+    # loosened to 0.3; the exact equality `scanned == rows of the union of the probed lists` is pinned in
+    # tests/test_gpu_cfg5.py against the oracle's coarse ranking.)
+    longest = np.sort(ivf.list_sizes)[::-1]
+    assert scanned[0] <= int(longest[:32].sum() + longest[:18].sum())
+    assert scanned[0] >= int(np.sort(ivf.list_sizes)[:1].sum())
 
 
 def test_wide_probe_threshold_path(built):
@@ -129,3 +135,43 @@ def test_ivf_empty_lists_and_small_index(gpu):
         ivf.close()
     finally:
         eng.close()
+
+
+def test_ivf_save_load_roundtrip(built, tmp_path):
+    """rass_ivf_save / rass_ivf_load: the whole device state travels (no flat index, no re-training needed);
+    the loaded shard answers bit for bit like the one that was saved; corrupt files are refused."""
+    from rassengine_amd.ivf import IvfIndex
+    from rassengine_amd._native import RassError
+    eng, flat, ivf, q, tags = built
+    path = str(tmp_path / "shard0.ivf")
+    ivf.save(path)
+    import os
+    assert os.path.exists(path) and not os.path.exists(path + ".tmp")
+    back = IvfIndex.load(eng, path)
+    try:
+        assert back.nlist == ivf.nlist and back.rows == ivf.rows
+        qf = np.array([(r % 4) + 1 for r in range(q.shape[0])], dtype=np.int32)
+        for nprobe, f in ((1, None), (8, None), (128, None), (32, qf)):
+            s0, i0, sc0 = ivf.search(q, 10, nprobe, q_filter=f)
+            s1, i1, sc1 = back.search(q, 10, nprobe, q_filter=f)
+            assert np.array_equal(i0, i1) and np.array_equal(s0, s1) and sc0 == sc1
+    finally:
+        back.close()
+    raw = open(path, "rb").read()
+    bad = str(tmp_path / "truncated.ivf")
+    open(bad, "wb").write(raw[: len(raw) // 2])
+    with pytest.raises(RassError):
+        IvfIndex.load(eng, bad)
+    bad2 = str(tmp_path / "garbage.ivf")
+    open(bad2, "wb").write(b"not an ivf file" * 100)
+    with pytest.raises(RassError):
+        IvfIndex.load(eng, bad2)
+    # a list table that points outside the slab is refused too (it would send the probe out of bounds)
+    import struct
+    hdr = 8 + 4 * 4 + 8 * 5
+    tampered = bytearray(raw)
+    tampered[hdr:hdr + 4] = struct.pack("<i", 5)            # list 0 no longer starts at tile 0
+    bad3 = str(tmp_path / "tampered.ivf")
+    open(bad3, "wb").write(bytes(tampered))
+    with pytest.raises(RassError):
+        IvfIndex.load(eng, bad3)

@@ -42,11 +42,13 @@ typedef enum rass_status {
     RASS_ERR_IO = -6           /* save/load failure */
 } rass_status;
 
-/* Corpus storage dtype (fp32 is the parity path and the only one
- * rass_index_open accepts in ABI version 1).  RASS_BF16 is reserved for a bf16-only
- * corpus (half the HBM per row): today it is refused with RASS_ERR_UNSUPPORTED; the
- * bf16 scan exists as the candidate copy of an fp32 index (rass_index_set_prefilter),
- * whose results are re-ranked in fp32 and stay exact. */
+/* Corpus storage dtype.  RASS_F32 is the parity path (exact fp32 MFMA, bit-equal to the
+ * oracle's fmaf-order emulation).  RASS_BF16 is a first-class bf16-ONLY corpus: rows are normalised in fp32, rounded
+ * to bf16 and stored in the "tile16b" layout (half the HBM per row, half the bytes per scan); a search rounds the
+ * normalised queries to bf16 and runs v_mfma_f32_16x16x32_bf16 with fp32 accumulation, so a returned score is the
+ * fp32-accumulated dot product of the two bf16-rounded unit vectors (|error| vs the fp32 cosine ~1e-3, the
+ * north_star tolerance; recall@k vs the fp32 index is measured, bench.py --corpus-dtype bf16).  Needs dim padded to
+ * a multiple of 256; masked filters, k > RASS_MAX_K, the prefilter mode and the IVF build are fp32-only. */
 typedef enum rass_dtype {
     RASS_F32 = 0,
     RASS_BF16 = 1

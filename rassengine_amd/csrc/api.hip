@@ -153,6 +153,7 @@ struct rass_engine {
     int64_t* d_out_ids = nullptr;   // [32][32]
     float* d_stage = nullptr;       // [kStageRows][dim]
     int32_t* d_stage_tags = nullptr;
+    float* d_stage_t16 = nullptr;   // bf16 indices: (kStageRows + 32) x kMaxStride fp32 tile16 staging, lazily allocated
     int32_t* d_qmask = nullptr;     // [32] masked-filter masks
     float* d_after_s = nullptr;     // [32] continuation bound of a multi-pass top-k (k > 32)
     int64_t* d_after_i = nullptr;   // [32]
@@ -201,37 +202,44 @@ int index_reserve(rass_index* idx, int64_t need_rows) {
     float* nrows = nullptr;
     int32_t* ntags = nullptr;
     hipStream_t st = idx->eng->stream;
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&nrows), (size_t)cap * idx->stride * sizeof(float));
+    const bool want_f32 = idx->dtype == RASS_F32;                  // a bf16 index holds the bf16 slab ONLY
+    const bool want_b16 = idx->dtype == RASS_BF16 || idx->prefilter;
+    const size_t elem = want_f32 ? sizeof(float) : 2;
+    void* nmain = nullptr;  // the dtype's own slab
+    hipError_t e = hipMalloc(&nmain, (size_t)cap * idx->stride * elem);
     if (e != hipSuccess) {
         // retry with the exact size before giving up
         cap = (need_rows + 15) / 16 * 16;
-        e = hipMalloc(reinterpret_cast<void**>(&nrows), (size_t)cap * idx->stride * sizeof(float));
+        e = hipMalloc(&nmain, (size_t)cap * idx->stride * elem);
         if (e != hipSuccess) return fail(RASS_ERR_OOM, "index grow: hipMalloc of corpus slab failed");
     }
+    if (want_f32) nrows = static_cast<float*>(nmain);
     int64_t* ngid = nullptr;
     e = hipMalloc(reinterpret_cast<void**>(&ntags), (size_t)cap * sizeof(int32_t));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ngid), (size_t)cap * sizeof(int64_t));
     if (e != hipSuccess) {
-        (void)hipFree(nrows);
+        (void)hipFree(nmain);
         if (ntags) (void)hipFree(ntags);
         return fail(RASS_ERR_OOM, "index grow: hipMalloc of tag / id arrays failed");
     }
     // rows of a block past the last appended one must read as finite zeros (they are masked,
     // never ranked): zero the part of the slab the copy below does not overwrite
     const int64_t used_rows = (idx->rows + 15) / 16 * 16;
-    unsigned short* nb16 = nullptr;
+    unsigned short* nb16 = want_f32 ? nullptr : static_cast<unsigned short*>(nmain);
     auto copy_over = [&]() -> hipError_t {
-        hipError_t c = hipMemsetAsync(nrows + used_rows * idx->stride, 0,
-                                      (size_t)(cap - used_rows) * idx->stride * sizeof(float), st);
-        if (c == hipSuccess && idx->rows > 0)
-            c = hipMemcpyAsync(nrows, idx->d_rows, (size_t)used_rows * idx->stride * sizeof(float),
-                               hipMemcpyDeviceToDevice, st);
+        hipError_t c = hipSuccess;
+        if (want_f32) {
+            c = hipMemsetAsync(nrows + used_rows * idx->stride, 0, (size_t)(cap - used_rows) * idx->stride * sizeof(float), st);
+            if (c == hipSuccess && idx->rows > 0)
+                c = hipMemcpyAsync(nrows, idx->d_rows, (size_t)used_rows * idx->stride * sizeof(float),
+                                   hipMemcpyDeviceToDevice, st);
+        }
         if (c == hipSuccess && idx->rows > 0)
             c = hipMemcpyAsync(ntags, idx->d_tags, (size_t)idx->rows * sizeof(int32_t), hipMemcpyDeviceToDevice, st);
         if (c == hipSuccess && idx->rows > 0)
             c = hipMemcpyAsync(ngid, idx->d_gid, (size_t)idx->rows * sizeof(int64_t), hipMemcpyDeviceToDevice, st);
-        if (c == hipSuccess && idx->prefilter) {
-            c = hipMalloc(reinterpret_cast<void**>(&nb16), (size_t)cap * idx->stride * 2);
+        if (c == hipSuccess && want_b16) {
+            if (want_f32) c = hipMalloc(reinterpret_cast<void**>(&nb16), (size_t)cap * idx->stride * 2);
             if (c == hipSuccess) c = hipMemsetAsync(nb16, 0, (size_t)cap * idx->stride * 2, st);
             if (c == hipSuccess && idx->rows > 0)
                 c = hipMemcpyAsync(nb16, idx->d_rows_bf16, (size_t)used_rows * idx->stride * 2,
@@ -243,10 +251,10 @@ int index_reserve(rass_index* idx, int64_t need_rows) {
     e = copy_over();
     if (e != hipSuccess) {  // nothing of the old index was touched: release the new allocations and report
         (void)hipStreamSynchronize(st);
-        (void)hipFree(nrows);
+        (void)hipFree(nmain);
         (void)hipFree(ntags);
         (void)hipFree(ngid);
-        if (nb16) (void)hipFree(nb16);
+        if (nb16 && want_f32) (void)hipFree(nb16);
         return fail(e == hipErrorOutOfMemory ? RASS_ERR_OOM : RASS_ERR_HIP,
                     std::string("index grow failed: ") + hipGetErrorString(e));
     }
@@ -340,6 +348,50 @@ int scan_launch(const float* d_corpus, int64_t n_rows, int64_t stride, const int
     if (timed) {
         HIP_TRY(hipEventRecord(timing->ev_pool[2 * timing->ev_used + 1], st));
         timing->ev_used += 1;
+    }
+    HIP_TRY(rass::launch_merge_topk(part_scores, part_ids, grid, nq, k, d_out_scores, d_out_ids, st, id_map));
+    return RASS_OK;
+}
+
+// A bf16 corpus (RASS_BF16): the bf16 scan IS the search — normalise the queries, round them to bf16,
+// v_mfma_f32_16x16x32_bf16 with fp32 accumulation over the bf16 slab, per-workgroup top-k, merge.
+int bf16_scan_launch(rass_index* idx, const float* d_queries, int nq, const int32_t* d_q_filter, int k, int64_t id_base,
+                     float* d_out_scores, int64_t* d_out_ids, const int32_t* d_row_tag, rass_engine* eng, hipStream_t st,
+                     const int64_t* id_map) {
+    if (nq < 1 || nq > RASS_MAX_QBATCH) return fail(RASS_ERR_INVALID, "nq must be in [1, RASS_MAX_QBATCH]");
+    if (k < 1 || k > RASS_MAX_K) return fail(RASS_ERR_INVALID, "k must be in [1, RASS_MAX_K]");
+    const int64_t stride = idx->stride;
+    const int64_t rows = idx->rows.load(std::memory_order_acquire);
+    const ScratchLayout L = scratch_layout(RASS_MAX_QBATCH, RASS_MAX_K);
+    unsigned char* ws = eng->d_scratch;
+    float* q_padded = reinterpret_cast<float*>(ws + L.q_padded);
+    float* part_scores = reinterpret_cast<float*>(ws + L.part_scores);
+    int64_t* part_ids = reinterpret_cast<int64_t*>(ws + L.part_ids);
+    unsigned short* q_bf16 = reinterpret_cast<unsigned short*>(ws + L.q_bf16);
+    const int nq_pad = nq <= 16 ? 16 : 32;
+    HIP_TRY(rass::launch_normalize_rows_f32(d_queries, idx->dim, q_padded, stride, nq, idx->dim, st, nq_pad));
+    HIP_TRY(rass::launch_queries_to_bf16(q_padded, q_bf16, (int64_t)nq_pad * stride, st));
+    const int64_t n_tiles = (rows + 63) / 64;
+    int grid = (int)std::min<int64_t>(std::max<int64_t>(n_tiles, 1), std::min(eng->n_cus, kMaxGrid));
+    if ((int64_t)grid * k > rass::kMergeMaxCandidates) grid = rass::kMergeMaxCandidates / k;
+    rass::ScanBf16Args a;
+    a.corpus = idx->d_rows_bf16 ? idx->d_rows_bf16 : reinterpret_cast<const unsigned short*>(eng->d_scratch);
+    a.row_tag = d_row_tag;
+    a.q_bf16 = q_bf16;
+    a.q_filter = d_q_filter;
+    a.part_scores = part_scores;
+    a.part_ids = part_ids;
+    a.row_stride = stride;
+    a.n_rows = (int)rows;
+    a.nq = nq;
+    a.k = k;
+    a.id_base = id_map ? 0 : id_base;
+    const bool timed = eng->ev_on && (size_t)(2 * eng->ev_used + 1) < eng->ev_pool.size();
+    if (timed) HIP_TRY(hipEventRecord(eng->ev_pool[2 * eng->ev_used], st));
+    HIP_TRY(rass::launch_scan_bf16_topk(a, grid, st));
+    if (timed) {
+        HIP_TRY(hipEventRecord(eng->ev_pool[2 * eng->ev_used + 1], st));
+        eng->ev_used += 1;
     }
     HIP_TRY(rass::launch_merge_topk(part_scores, part_ids, grid, nq, k, d_out_scores, d_out_ids, st, id_map));
     return RASS_OK;
@@ -505,6 +557,7 @@ void rass_engine_destroy(rass_engine_t* eng) {
     (void)hipFree(eng->d_out_ids);
     (void)hipFree(eng->d_stage);
     (void)hipFree(eng->d_stage_tags);
+    if (eng->d_stage_t16) (void)hipFree(eng->d_stage_t16);
     (void)hipFree(eng->d_qmask);
     (void)hipFree(eng->d_after_s);
     (void)hipFree(eng->d_after_i);
@@ -553,7 +606,9 @@ int rass_index_open(rass_engine_t* eng, const char* name, rass_dtype dtype, int6
                     rass_index_t** out) {
     if (!eng || !name || !out) return fail(RASS_ERR_INVALID, "NULL argument");
     *out = nullptr;
-    if (dtype != RASS_F32) return fail(RASS_ERR_UNSUPPORTED, "only the fp32 corpus is implemented");
+    if (dtype != RASS_F32 && dtype != RASS_BF16) return fail(RASS_ERR_INVALID, "unknown corpus dtype");
+    if (dtype == RASS_BF16 && pad128(eng->dim) % 256 != 0)
+        return fail(RASS_ERR_UNSUPPORTED, "a bf16 corpus needs dim padded to a multiple of 256 (the bf16 scan's K split)");
     std::lock_guard<std::mutex> lk(eng->mu);
     auto it = eng->indices.find(name);
     if (it != eng->indices.end()) {
@@ -624,6 +679,7 @@ int rass_index_set_prefilter(rass_index_t* idx, int enable) {
         idx->prefilter = false;
         return RASS_OK;
     }
+    if (idx->dtype == RASS_BF16) return fail(RASS_ERR_UNSUPPORTED, "a bf16 corpus IS the bf16 scan: no prefilter mode");
     if (idx->prefilter) return RASS_OK;
     if (idx->stride % 256 != 0) return fail(RASS_ERR_UNSUPPORTED, "prefilter needs dim padded to a multiple of 256");
     if (idx->capacity > 0) {
@@ -680,6 +736,18 @@ static int add_common(rass_index_t* idx, const float* vecs, const int32_t* tags,
             HIP_TRY(hipMemcpyAsync(eng->d_stage, src, (size_t)m * dim * sizeof(float), hipMemcpyHostToDevice, st));
             dsrc = eng->d_stage;
         }
+        if (idx->dtype == RASS_BF16) {
+            // normalise + pack into the fp32 staging slab at the destination's phase inside a 16-row block, then round
+            // the chunk's rows (and only them) into the bf16 slab
+            if (!elk.owns_lock()) elk.lock();
+            if (!eng->d_stage_t16)
+                HIP_TRY(hipMalloc(reinterpret_cast<void**>(&eng->d_stage_t16), (size_t)(kStageRows + 32) * kMaxStride * sizeof(float)));
+            const int64_t at = idx->rows + done, phase = at & 15;
+            HIP_TRY(rass::launch_pack_rows_tile16(dsrc, dim, eng->d_stage_t16, idx->stride, phase, m, dim,
+                                                  normalize ? 1 : 0, st));
+            HIP_TRY(rass::launch_convert_tile16_bf16(eng->d_stage_t16, idx->d_rows_bf16, idx->stride, at >> 4,
+                                                     (at + m + 15) >> 4, st, 0, at, at + m));
+        } else
         HIP_TRY(rass::launch_pack_rows_tile16(dsrc, dim, idx->d_rows, idx->stride, idx->rows + done, m, dim,
                                               normalize ? 1 : 0, st));
         if (tags && device_src) {
@@ -690,10 +758,10 @@ static int add_common(rass_index_t* idx, const float* vecs, const int32_t* tags,
             HIP_TRY(rass::launch_fill_i32(tdst, m, 0, st));
         }
         // the staging buffer is reused by the next chunk
-        if (!device_src) HIP_TRY(hipStreamSynchronize(st));
+        if (!device_src || idx->dtype == RASS_BF16) HIP_TRY(hipStreamSynchronize(st));
         done += m;
     }
-    if (idx->prefilter)
+    if (idx->prefilter && idx->dtype == RASS_F32)
         HIP_TRY(rass::launch_convert_tile16_bf16(idx->d_rows, idx->d_rows_bf16, idx->stride, idx->rows >> 4,
                                                  (idx->rows + n + 15) >> 4, st));
     // the id a search reports for these rows: their ordinal, or the caller's global ids (ascending with the
@@ -746,6 +814,10 @@ int rass_index_get_row(rass_index_t* idx, int64_t row, float* out) {
     hipStream_t st = idx->eng->stream;
     {
         std::lock_guard<std::mutex> elk(idx->eng->mu);  // d_stage is shared engine scratch
+        if (idx->dtype == RASS_BF16)
+            HIP_TRY(rass::launch_unpack_rows_tile16b(idx->d_rows_bf16, idx->stride, row, 1, idx->dim, idx->eng->d_stage,
+                                                     idx->dim, st));
+        else
         HIP_TRY(rass::launch_unpack_rows_tile16(idx->d_rows, idx->stride, row, 1, idx->dim, idx->eng->d_stage,
                                                 idx->dim, st));
         HIP_TRY(hipMemcpyAsync(out, idx->eng->d_stage, (size_t)idx->dim * sizeof(float), hipMemcpyDeviceToHost, st));
@@ -764,6 +836,10 @@ int rass_index_get_rows(rass_index_t* idx, int64_t first_row, int64_t n, float* 
     std::lock_guard<std::mutex> elk(idx->eng->mu);  // d_stage is shared engine scratch
     for (int64_t done = 0; done < n; done += kStageRows) {
         const int64_t m = std::min<int64_t>(kStageRows, n - done);
+        if (idx->dtype == RASS_BF16)
+            HIP_TRY(rass::launch_unpack_rows_tile16b(idx->d_rows_bf16, idx->stride, first_row + done, m, idx->dim,
+                                                     idx->eng->d_stage, idx->dim, st));
+        else
         HIP_TRY(rass::launch_unpack_rows_tile16(idx->d_rows, idx->stride, first_row + done, m, idx->dim,
                                                 idx->eng->d_stage, idx->dim, st));
         HIP_TRY(hipMemcpyAsync(out + done * idx->dim, idx->eng->d_stage, (size_t)m * idx->dim * sizeof(float),
@@ -785,6 +861,11 @@ int rass_index_search_device_ex(rass_index_t* idx, const float* d_queries, int n
     const int64_t rows = idx->rows.load(std::memory_order_acquire);
     const bool need_tags = (idx->deleted.load(std::memory_order_acquire) > 0) || (d_q_filter != nullptr);
     const bool gid = idx->has_gid.load(std::memory_order_acquire);  // caller-assigned ids: reported instead of
+    if (idx->dtype == RASS_BF16) {
+        if (d_q_filter_mask) return fail(RASS_ERR_UNSUPPORTED, "masked filters are not implemented for a bf16 corpus");
+        return bf16_scan_launch(idx, d_queries, nq, d_q_filter, k, id_base, d_out_scores, d_out_ids,
+                                need_tags ? idx->d_tags : nullptr, eng, eng->stream, gid ? idx->d_gid : nullptr);
+    }
     if (idx->prefilter && rows > 0 && k <= kPrefilterMaxK && !gid && !d_q_filter_mask)  // id_base + ordinal
         return prefilter_launch(idx, d_queries, nq, d_q_filter, k, id_base, d_out_scores, d_out_ids,
                                 need_tags ? idx->d_tags : nullptr, eng, eng->stream);
@@ -884,7 +965,12 @@ int rass_index_search_ex(rass_index_t* idx, const float* queries, int nq, int k,
                 const bool gid = idx->has_gid.load(std::memory_order_acquire);
                 if (gid && cont)  // the continuation bound compares row ordinals, the caller would hand back global ids
                     return fail(RASS_ERR_UNSUPPORTED, "k > RASS_MAX_K on an index with caller-assigned row ids");
-                if (idx->prefilter && rows > 0 && k <= kPrefilterMaxK && !use_ext && !gid)
+                if (idx->dtype == RASS_BF16 && use_ext)
+                    return fail(RASS_ERR_UNSUPPORTED, "masked filters / k > RASS_MAX_K are not implemented for a bf16 corpus");
+                if (idx->dtype == RASS_BF16)
+                    rc = bf16_scan_launch(idx, eng->d_qraw, b, d_filter, kk, 0, eng->d_out_scores, eng->d_out_ids,
+                                          need_tags ? idx->d_tags : nullptr, eng, st, gid ? idx->d_gid : nullptr);
+                else if (idx->prefilter && rows > 0 && k <= kPrefilterMaxK && !use_ext && !gid)
                     rc = prefilter_launch(idx, eng->d_qraw, b, d_filter, kk, 0, eng->d_out_scores, eng->d_out_ids,
                                           need_tags ? idx->d_tags : nullptr, eng, st);
                 else
@@ -956,8 +1042,11 @@ int rass_index_save(rass_index_t* idx, const char* path) {
     for (int64_t r = 0; ok && r < idx->rows; r += kStageRows) {
         const int64_t m = std::min<int64_t>(kStageRows, idx->rows - r);
         std::lock_guard<std::mutex> elk(idx->eng->mu);  // d_stage is shared engine scratch
-        hipError_t e = rass::launch_unpack_rows_tile16(idx->d_rows, idx->stride, r, m, idx->dim, idx->eng->d_stage,
-                                                       idx->dim, st);
+        hipError_t e = idx->dtype == RASS_BF16
+                           ? rass::launch_unpack_rows_tile16b(idx->d_rows_bf16, idx->stride, r, m, idx->dim,
+                                                              idx->eng->d_stage, idx->dim, st)
+                           : rass::launch_unpack_rows_tile16(idx->d_rows, idx->stride, r, m, idx->dim, idx->eng->d_stage,
+                                                             idx->dim, st);
         if (e == hipSuccess)
             e = hipMemcpyAsync(buf.data(), idx->eng->d_stage, (size_t)m * idx->dim * 4, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -1003,7 +1092,7 @@ int rass_index_load(rass_engine_t* eng, const char* name, const char* path, rass
         fclose(f);
         return fail(RASS_ERR_IO, "not a rass index file");
     }
-    if (h.dim != eng->dim || h.dtype != RASS_F32 || h.rows < 0) {
+    if (h.dim != eng->dim || (h.dtype != RASS_F32 && h.dtype != RASS_BF16) || h.rows < 0) {
         fclose(f);
         return fail(RASS_ERR_INVALID, "index file does not match the engine (dim / dtype)");
     }
@@ -1025,7 +1114,8 @@ int rass_index_load(rass_engine_t* eng, const char* name, const char* path, rass
         }
     }
     rass_index_t* idx = nullptr;
-    int rc = rass_index_open(eng, name, RASS_F32, h.rows, &idx);
+    int rc = rass_index_open(eng, name, (rass_dtype)h.dtype, h.rows, &idx);  // a bf16 corpus was saved as its exact
+                                                                              // fp32 upcast: re-rounding is lossless
     if (rc != RASS_OK) {
         fclose(f);
         return rc;
@@ -1112,10 +1202,25 @@ int rass_index_fill_synthetic(rass_index_t* idx, int64_t n, uint64_t seed, int64
         if (rc != RASS_OK) return rc;
     }
     hipStream_t st = eng->stream;
+    if (idx->dtype == RASS_BF16) {
+        std::lock_guard<std::mutex> elk(eng->mu);
+        if (!eng->d_stage_t16)
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&eng->d_stage_t16), (size_t)(kStageRows + 32) * kMaxStride * sizeof(float)));
+        for (int64_t done = 0; done < n; done += kStageRows) {
+            const int64_t m = std::min<int64_t>(kStageRows, n - done);
+            const int64_t at = idx->rows + done, phase = at & 15;
+            // the generator keys a row by row_id_base + its slab row: shift the base so staging row `phase` is row `at`
+            HIP_TRY(rass::launch_fill_synthetic_f32(eng->d_stage_t16, idx->stride, phase, m, idx->dim, seed,
+                                                    row_id_base + at - phase, st));
+            HIP_TRY(rass::launch_convert_tile16_bf16(eng->d_stage_t16, idx->d_rows_bf16, idx->stride, at >> 4,
+                                                     (at + m + 15) >> 4, st, 0, at, at + m));
+        }
+        HIP_TRY(hipStreamSynchronize(st));
+    } else
     HIP_TRY(rass::launch_fill_synthetic_f32(idx->d_rows, idx->stride, idx->rows, n, idx->dim, seed, row_id_base, st));
     HIP_TRY(rass::launch_fill_i32(idx->d_tags + idx->rows, n, 0, st));
     HIP_TRY(rass::launch_iota_i64(idx->d_gid + idx->rows, n, idx->rows.load(), st));
-    if (idx->prefilter)
+    if (idx->prefilter && idx->dtype == RASS_F32)
         HIP_TRY(rass::launch_convert_tile16_bf16(idx->d_rows, idx->d_rows_bf16, idx->stride, idx->rows >> 4,
                                                  (idx->rows + n + 15) >> 4, st));
     idx->rows += n;
@@ -1290,6 +1395,7 @@ int rass_ivf_build(rass_index_t* src, const float* centroids, int nlist, const i
     if (!src || !centroids || !assign || !out) return fail(RASS_ERR_INVALID, "NULL argument");
     *out = nullptr;
     if (nlist < 1 || nlist > 32768) return fail(RASS_ERR_INVALID, "nlist must be in [1, 32768]");
+    if (src->dtype != RASS_F32) return fail(RASS_ERR_UNSUPPORTED, "the IVF build needs an fp32 source index");
     rass_engine* eng = src->eng;
     std::lock_guard<std::mutex> lk(src->mu);
     int rc = set_device(eng);
@@ -1664,6 +1770,7 @@ int rass_kmeans_assign(rass_index_t* idx, int64_t first_block, int64_t block_ste
                        const float* d_centroids_tile16, int nlist, int32_t* d_assign, float* d_best) {
     if (!idx || !d_centroids_tile16 || !d_assign) return fail(RASS_ERR_INVALID, "NULL argument");
     if (nlist < 1 || nlist > 65536) return fail(RASS_ERR_INVALID, "nlist must be in [1, 65536]");
+    if (idx->dtype != RASS_F32) return fail(RASS_ERR_UNSUPPORTED, "k-means needs an fp32 index");
     std::lock_guard<std::mutex> lk(idx->mu);
     if (!kmeans_range_ok(idx, first_block, block_step, n_blocks) || n_blocks > 0x7fffffff)
         return fail(RASS_ERR_INVALID, "block range outside the index");
@@ -1690,6 +1797,7 @@ int rass_kmeans_accumulate(rass_index_t* idx, int64_t first_block, int64_t block
                            const int32_t* d_assign, float* d_sums, float* d_counts, int nlist) {
     if (!idx || !d_assign || !d_sums || !d_counts) return fail(RASS_ERR_INVALID, "NULL argument");
     if (nlist < 1) return fail(RASS_ERR_INVALID, "nlist < 1");
+    if (idx->dtype != RASS_F32) return fail(RASS_ERR_UNSUPPORTED, "k-means needs an fp32 index");
     std::lock_guard<std::mutex> lk(idx->mu);
     if (!kmeans_range_ok(idx, first_block, block_step, n_blocks) || n_blocks > 0x7fffffff)
         return fail(RASS_ERR_INVALID, "block range outside the index");

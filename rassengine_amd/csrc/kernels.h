@@ -62,10 +62,16 @@ struct ScanBf16Args {
     int n_rows;
     int nq;
     int k;                          // candidates kept per query (<= 32)
+    int64_t id_base = 0;            // added to the reported rows (0 for the prefilter's candidate scan)
 };
 hipError_t launch_scan_bf16_topk(const ScanBf16Args& a, int grid, hipStream_t stream);
+// fp32 tile16 blocks -> bf16 tile16b blocks [block0, block1) of dst.  src_block0 (default = block0): the source
+// block that lands in block0 (a staging slab); only destination rows in [row_lo, row_hi) are written.
 hipError_t launch_convert_tile16_bf16(const float* src, void* dst, int64_t stride, int64_t block0, int64_t block1,
-                                      hipStream_t stream);
+                                      hipStream_t stream, int64_t src_block0 = -1, int64_t row_lo = 0,
+                                      int64_t row_hi = -1);
+hipError_t launch_unpack_rows_tile16b(const void* slab, int64_t stride, int64_t first_row, int64_t n, int dim,
+                                      float* out, int64_t out_stride, hipStream_t stream);
 hipError_t launch_queries_to_bf16(const float* src, void* dst, int64_t n, hipStream_t stream);
 hipError_t launch_rerank_f32(const float* slab, int64_t stride, const float* q_padded, const int64_t* cand_rows, int nq,
                              int n_cand, int k, int64_t id_base, float* out_scores, int64_t* out_ids,

@@ -22,12 +22,11 @@
 #include <stdint.h>
 
 #include "kernels.h"
+#include "scan_core.h"
 
 namespace rass {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16;
 
 constexpr int kBWaves = 8;
@@ -38,40 +37,6 @@ constexpr int kBPitch = 68;     // floats per query row of the LDS partial image
 __device__ __forceinline__ u16 f2bf_s(float f) {
     __hip_bfloat16 h = __float2bfloat16(f);
     return *reinterpret_cast<u16*>(&h);
-}
-
-struct BList {
-    float s;
-    int i;
-};
-
-__device__ __forceinline__ void binsert(BList& L, float& tau, float s, int row, int k) {
-    unsigned long long mask = __ballot(s > tau);
-    const int lane = threadIdx.x & 63;
-    const int lpos = lane & 31;
-    while (mask) {
-        const int c = __builtin_ctzll(mask);
-        mask &= mask - 1;
-        const float cs = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), c));
-        const int ci = __builtin_amdgcn_readlane(row, c);
-        const bool mine = ((lane ^ c) & 32) == 0;
-        const bool better = (L.s > cs) || (L.s == cs && L.i < ci);
-        const int pos = __builtin_popcountll(__ballot(better && mine));
-        if (pos < k) {
-            const float us = __shfl_up(L.s, 1, 64);
-            const int ui = __shfl_up(L.i, 1, 64);
-            if (mine) {
-                if (lpos == pos) {
-                    L.s = cs;
-                    L.i = ci;
-                } else if (lpos > pos) {
-                    L.s = us;
-                    L.i = ui;
-                }
-            }
-            tau = __shfl(L.s, (lane & 32) + k - 1, 64);
-        }
-    }
 }
 
 struct BDesc {
@@ -127,7 +92,7 @@ __global__ __launch_bounds__(kBThreads, 2) void scan_bf16_topk_kernel(ScanBf16Ar
     const int voff_lane = wid * CHB * 1024 + lane * 16;
     const int blk_step = 16 * (int)p.row_stride * 2;
 
-    BList L[NT];
+    TopList L[NT];
     float tau[NT];
     int qfilt[NT];
 #pragma unroll
@@ -190,7 +155,7 @@ __global__ __launch_bounds__(kBThreads, 2) void scan_bf16_topk_kernel(ScanBf16Ar
 #pragma unroll
                 for (int w = 1; w < kBWaves; ++w) s += src[w * NQ * kBPitch];
                 const bool ok = row_ok && (qfilt[pq] < 0 || qfilt[pq] == rtag);
-                binsert(L[pq], tau[pq], ok ? s : -INFINITY, row, p.k);
+                insert_candidates(L[pq], tau[pq], ok ? s : -INFINITY, row, p.k);
             }
         }
     };
@@ -217,7 +182,8 @@ __global__ __launch_bounds__(kBThreads, 2) void scan_bf16_topk_kernel(ScanBf16Ar
             const int64_t o = ((int64_t)blockIdx.x * p.nq + q) * p.k + lpos;
             const bool filled = L[pq].i != 0x7fffffff;
             p.part_scores[o] = filled ? L[pq].s : -INFINITY;
-            p.part_ids[o] = filled ? (int64_t)L[pq].i : (int64_t)-1;  // LOCAL rows: the re-rank needs them
+            // id_base = 0 for the candidate scan of the prefilter mode (the re-rank needs LOCAL rows)
+            p.part_ids[o] = filled ? (p.id_base + (int64_t)L[pq].i) : (int64_t)-1;
         }
     }
 }
@@ -251,14 +217,19 @@ hipError_t launch_scan_bf16_topk(const ScanBf16Args& a, int grid, hipStream_t st
 
 // fp32 tile16 slab -> bf16 tile16b slab, blocks [b0, b1).  bf16 lane (m, g) of chunk jb holds
 // columns 32jb + 8g .. +7 = fp32 chunk 2jb + (g>>1), lane groups 2(g&1) and 2(g&1)+1.
+// `src_b0`: the source block that lands in destination block b0 (a staging slab starts at block 0); only rows in
+// [row_lo, row_hi) of the DESTINATION are written, so a partially filled block keeps its earlier rows.
 __global__ __launch_bounds__(256) void convert_tile16_bf16_kernel(const float* __restrict__ src, u16* __restrict__ dst,
-                                                                  int64_t stride, int64_t b0, int64_t b1) {
+                                                                  int64_t stride, int64_t b0, int64_t b1, int64_t src_b0,
+                                                                  int64_t row_lo, int64_t row_hi) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m = lane & 15, g = lane >> 4;
     const int nchb = (int)(stride >> 5);
     for (int64_t b = b0 + (int64_t)blockIdx.x * 4 + wave; b < b1; b += (int64_t)gridDim.x * 4) {
-        const float* sb = src + b * 16 * stride;
+        const float* sb = src + (b - b0 + src_b0) * 16 * stride;
         u16* db = dst + b * 16 * stride;
+        const int64_t r = b * 16 + m;
+        if (r < row_lo || r >= row_hi) continue;
         for (int jb = 0; jb < nchb; ++jb) {
             const float* sc = sb + (int64_t)(2 * jb + (g >> 1)) * 256;
             const f32x4 v0 = *reinterpret_cast<const f32x4*>(sc + ((2 * (g & 1)) * 16 + m) * 4);
@@ -274,13 +245,38 @@ __global__ __launch_bounds__(256) void convert_tile16_bf16_kernel(const float* _
 }
 
 hipError_t launch_convert_tile16_bf16(const float* src, void* dst, int64_t stride, int64_t block0, int64_t block1,
-                                      hipStream_t stream) {
+                                      hipStream_t stream, int64_t src_block0, int64_t row_lo, int64_t row_hi) {
+    if (src_block0 < 0) src_block0 = block0;
+    if (row_hi < 0) row_hi = block1 * 16;
     if (block1 <= block0) return hipSuccess;
     if (stride % 32 != 0) return hipErrorInvalidValue;
     int64_t blocks = (block1 - block0 + 3) / 4;
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(convert_tile16_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, src,
-                       static_cast<u16*>(dst), stride, block0, block1);
+                       static_cast<u16*>(dst), stride, block0, block1, src_block0, row_lo, row_hi);
+    return hipGetLastError();
+}
+
+// bf16 tile16b slab rows [first_row, first_row + n) -> row-major fp32 (exact upcast), dim columns at out_stride
+__global__ void unpack_rows_tile16b_kernel(const u16* __restrict__ slab, int64_t stride, int64_t first_row, int64_t n,
+                                           int dim, float* __restrict__ out, int64_t out_stride) {
+    const int64_t total = n * dim;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = e / dim;
+        const int c = (int)(e - i * dim);
+        const int64_t r = first_row + i;
+        const int64_t off = (r >> 4) * 16 * stride + (int64_t)(c >> 5) * 512 + ((((c >> 3) & 3) * 16 + (r & 15)) * 8) + (c & 7);
+        out[i * out_stride + c] = __uint_as_float((unsigned)slab[off] << 16);
+    }
+}
+
+hipError_t launch_unpack_rows_tile16b(const void* slab, int64_t stride, int64_t first_row, int64_t n, int dim,
+                                      float* out, int64_t out_stride, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    int64_t blocks = (n * dim + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(unpack_rows_tile16b_kernel, dim3((unsigned)blocks), dim3(256), 0, stream,
+                       static_cast<const u16*>(slab), stride, first_row, n, dim, out, out_stride);
     return hipGetLastError();
 }
 

@@ -135,4 +135,52 @@ __device__ __forceinline__ void multiply_and_refill(TileRegs<CH>& r, const f32x4
     }
 }
 
+// Half-wave sorted list: lanes 0..31 hold query A's best-first top-32, lanes 32..63 query B's.
+struct TopList {
+    float s;
+    int i;
+};
+
+// The k-th best score of my half (lanes 0..31 / 32..63): two readlanes + a select, no LDS permute.
+__device__ __forceinline__ float bcast_kth(float v, int k) {
+    const int a = __builtin_amdgcn_readlane(__float_as_int(v), k - 1);
+    const int b = __builtin_amdgcn_readlane(__float_as_int(v), 32 + k - 1);
+    return __int_as_float((lane_id() & 32) ? b : a);
+}
+
+// Lane i <- lane i-1 across the whole wave (lane 0 keeps its value): one DPP move (wave_shr:1).
+__device__ __forceinline__ int wave_shr1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false); }
+
+// Insert every lane's candidate (cs valid where cs > tau of its half) into the half-wave lists.
+// Everything stays in registers / the scalar unit: the first version used __shfl_up / __shfl here, which
+// hipcc lowers to ds_bpermute_b32 — three LDS round trips (~400 cycles) per inserted candidate.  A per-workgroup
+// list takes ~k ln(n/k) (60 at k = 10, 3 900 rows) insertions per launch and the 8 waves meet at a barrier every
+// two tiles, so the slowest wave's insertions were on every workgroup's critical path: with the ranking
+// removed the B = 32 kernel ran 72 us (10 %) faster, with only the insertion removed 57 us
+// (profiles/r02_scan_phase_experiments.txt).
+__device__ __forceinline__ void insert_candidates(TopList& L, float& tau, float s, int row, int k) {
+    unsigned long long mask = __ballot(s > tau);
+    const int lane = lane_id();
+    const int lpos = lane & 31;
+    while (mask) {
+        const int c = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        const float cs = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), c));
+        const int ci = __builtin_amdgcn_readlane(row, c);
+        // straight-line body (bitwise predicates, selects): the short-circuit / nested-if form compiled to five
+        // exec-mask branches per candidate
+        const bool mine = ((lane ^ c) & 32) == 0;
+        const bool better = (L.s > cs) | ((L.s == cs) & (L.i < ci));
+        const int pos = __builtin_popcountll(__ballot(better & mine));
+        const float us = __int_as_float(wave_shr1(__float_as_int(L.s)));
+        const int ui = wave_shr1(L.i);
+        const bool live = mine & (pos < k);          // a candidate that ranks behind the k kept changes nothing
+        const bool take = live & (lpos == pos);
+        const bool shift = live & (lpos > pos);
+        L.s = take ? cs : (shift ? us : L.s);
+        L.i = take ? ci : (shift ? ui : L.i);
+        tau = bcast_kth(L.s, k);
+    }
+}
+
 }  // namespace rass

@@ -86,14 +86,16 @@ class Engine:
                 self._L.rass_engine_kernel_timing_end(self._h, ctypes.byref(ms), ctypes.byref(n)))
         return float(ms.value), int(n.value)
 
-    def open_index(self, name: str, capacity_rows: int = 0) -> "FlatIndex":
-        """Look up or create the named cosine index (ensure_index_exists, app/main.py:350)."""
+    def open_index(self, name: str, capacity_rows: int = 0, dtype: str = "f32") -> "FlatIndex":
+        """Look up or create the named cosine index (ensure_index_exists, app/main.py:350).  ``dtype``:
+        "f32" (the parity path) or "bf16" (a bf16-only corpus: half the HBM, scores within ~1e-3)."""
         idx = self._indices.get(name)
         if idx is not None:
             return idx
+        code = {"f32": N.RASS_F32, "bf16": N.RASS_BF16}[dtype]
         h = ctypes.c_void_p()
         N.check("rass_index_open",
-                self._L.rass_index_open(self._h, name.encode(), N.RASS_F32, int(capacity_rows), ctypes.byref(h)))
+                self._L.rass_index_open(self._h, name.encode(), code, int(capacity_rows), ctypes.byref(h)))
         idx = FlatIndex(self, name, h)
         self._indices[name] = idx
         return idx

@@ -51,6 +51,9 @@ def main():
     ap.add_argument("--cpu-hnsw-rows", type=int, default=8_000,
                     help="rows of the HNSW restatement's sample (cpu_baseline.hnsw); 0 disables it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--corpus-dtype", choices=["f32", "bf16"], default="f32",
+                    help="bf16: FLAGGED mode, never the headline: a bf16-only corpus (RASS_BF16), half the bytes per "
+                         "scan, scores within ~1e-3 of the fp32 cosine; recall@k vs the fp32 index is reported")
     ap.add_argument("--prefilter", action="store_true",
                     help="flagged mode (not the parity default): bf16 candidate scan + exact fp32 re-rank")
     args = ap.parse_args()
@@ -86,7 +89,10 @@ def main():
     row_lo, row_hi = shard_bounds(rows_global, world)[rank]
     n_local = row_hi - row_lo
     eng = Engine(device=local_rank, dim=dim)
-    idx = eng.open_index("bench", capacity_rows=n_local)
+    bf16 = args.corpus_dtype == "bf16"
+    if bf16 and args.prefilter:
+        raise SystemExit("--prefilter is a mode of the fp32 corpus")
+    idx = eng.open_index("bench", capacity_rows=n_local, dtype=args.corpus_dtype)
     # Philox rows keyed by the GLOBAL row id: shard r regenerates exactly rows [row_lo, row_hi)
     idx.fill_synthetic(n_local, seed=1234, row_id_base=row_lo)
     if args.prefilter:
@@ -138,11 +144,12 @@ def main():
     qps = B * LPS * args.steps / elapsed
     # algorithmic bytes of the dominant kernel: N_loc * D * 4 (fp32 scan); the bf16
     # candidate scan of the prefilter mode reads N_loc * D * 2
-    bytes_per_launch = n_local * idx.row_stride * (2 if args.prefilter else 4)
+    bytes_per_launch = n_local * idx.row_stride * (2 if (args.prefilter or bf16) else 4)
     achieved = bytes_per_launch * scan_launches / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
 
     result = {
-        "metric": "queries/sec, exact cosine top-10 over N x 1024-d fp32 corpus in HBM",
+        "metric": "queries/sec, exact cosine top-10 over N x 1024-d fp32 corpus in HBM" if not bf16 else
+                  "queries/sec, cosine top-10 over N x 1024-d bf16 corpus in HBM (FLAGGED mode, not the headline)",
         "value": round(qps, 1),
         "unit": "queries/s",
         "n_gpus": world,
@@ -156,7 +163,7 @@ def main():
         # N x is row_queries_per_s = value * rows_global (and config.aggregate_scan_GBps)
         "row_queries_per_s": round(qps * rows_global, 1),
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "bf16" if bf16 else "f32",
         "data": "synthetic",
         "config": {
             "workload": f"{rows_global} x {dim}-d flat cosine top-{k}, {world} x MI355X, precomputed embeddings "
@@ -164,15 +171,16 @@ def main():
                            "(BASELINE configs[1] shard per GPU)"),
             "rows_per_gpu": n_local, "rows_global": rows_global, "dim": dim, "k": k, "query_batch": B,
             "queries_per_step": B * LPS, "launch_groups_per_step": LPS,
-            "corpus_dtype": "f32" if not args.prefilter else "f32 + bf16 candidate copy (exact fp32 re-rank)",
-            "layout": "tile16", "mode": "prefilter" if args.prefilter else "flat", "sharding": f"row-sharded x{world}, RCCL all-gather merge"
+            "corpus_dtype": "bf16 only (fp32-accumulated bf16 MFMA)" if bf16 else
+                            "f32" if not args.prefilter else "f32 + bf16 candidate copy (exact fp32 re-rank)",
+            "layout": "tile16b" if bf16 else "tile16", "mode": "prefilter" if args.prefilter else "flat", "sharding": f"row-sharded x{world}, RCCL all-gather merge"
             if world > 1 else "single shard",
             "aggregate_scan_GBps": round(bytes_per_launch * world * args.steps * LPS / elapsed / 1e9, 1),
         },
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
-            "kernel": scan_kernel_name(dim, B) if not args.prefilter else
+            "kernel": scan_kernel_name(dim, B) if not (args.prefilter or bf16) else
             f"scan_bf16_topk_kernel<{idx.row_stride // 256}, {1 if B <= 16 else 2}>", "bytes_per_launch": bytes_per_launch,
             "avg_launch_us": round(scan_ms / max(scan_launches, 1) * 1e3, 2), "launches": scan_launches,
         },
@@ -187,7 +195,7 @@ def main():
     # Outside the timed region, single GPU only: the same scan at the other batch sizes SURVEY §8d
     # asks for (B <= 16 runs the NT=1 kernel variant, purely HBM-bound; B = 32 sits at the HBM / fp32-
     # MFMA corner).  Reported next to the headline, never as `value`.
-    if world == 1 and not args.prefilter and rank == 0:
+    if world == 1 and not args.prefilter and not bf16 and rank == 0:
         others = []
         for Bo in (16, 1):
             if Bo == B:
@@ -220,7 +228,25 @@ def main():
         result["prefilter_recall_vs_flat"] = float(np.mean([len(set(i_p[r]) & set(i_f[r])) / k for r in range(B)]))
         result["prefilter_scores_bit_identical"] = bool(np.array_equal(s_p[i_p == i_f], s_f[i_p == i_f]))
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and bf16:
+        # the flagged mode against the parity path: the same first rows as an fp32 index and as a bf16 index
+        sample = min(args.cpu_sample_rows, n_local)
+        ref = eng.open_index("bench-f32-sample", capacity_rows=sample)
+        ref.fill_synthetic(sample, seed=1234, row_id_base=row_lo)
+        sb = eng.open_index("bench-bf16-sample", capacity_rows=sample, dtype="bf16")
+        sb.fill_synthetic(sample, seed=1234, row_id_base=row_lo)
+        qh = pool[:4 * B].cpu().numpy()
+        s_f, i_f = ref.search(qh, k)
+        s_b, i_b = sb.search(qh, k)
+        same = i_f == i_b
+        result["bf16_vs_f32"] = {
+            "sample_rows": sample, "queries": int(qh.shape[0]),
+            "recall_at_k": float(np.mean([len(set(i_b[r]) & set(i_f[r])) / k for r in range(qh.shape[0])])),
+            "max_abs_score_diff_on_common_ranks": float(np.abs(s_f[same] - s_b[same]).max()) if same.any() else None}
+        if not args.no_cpu_baseline:
+            result.update(cpu_baseline_and_recall(np, torch, eng, ref, pool, args, n_local, dim, B, k))
+            result["recall_at_k_note"] = "recall_at_k / max_abs_cosine_err above are the fp32 parity path's on the sample"
+    elif rank == 0 and world == 1 and not args.no_cpu_baseline:
         result.update(cpu_baseline_and_recall(np, torch, eng, idx, pool, args, n_local, dim, B, k))
 
     if rank == 0:
@@ -243,6 +269,8 @@ def pmc_traffic(kernel: str, bytes_per_launch: int):
         except Exception:
             continue
         for name, e in data.items():
+            if not isinstance(e, dict):
+                continue
             b = e.get("hbm_read_bytes_per_launch")
             if kernel in name and b and abs(b - bytes_per_launch) <= 0.1 * bytes_per_launch:
                 best = {"bytes": round(b + e.get("hbm_write_bytes_per_launch", 0.0)),

@@ -21,12 +21,21 @@
 //     the run-ahead prefetch of a tile past the end cost no HBM traffic (range check)
 //   * two register tile buffers per wave; each 16 B register is re-loaded for the tile two
 //     steps ahead right after the MFMAs that consumed it, so ~32 KiB per wave (256 KiB per
-//     CU) stay in flight continuously
-//   * per tile, each wave dumps its 32x(16*NT) partial scores to LDS (one barrier per
-//     tile, two LDS buffers), then wave w sums the 8 K-partials of "its" queries in a
-//     fixed order and runs the half-wave sorted-list insert (threshold filter by ballot)
+//     CU) stay in flight continuously; ONE VGPR carries the lane's load offset, the M-tile /
+//     chunk part goes into the instruction's SGPR and immediate offset fields
+//   * per tile, each wave dumps its 32x(16*NT) partial scores to LDS; two tiles share one barrier
+//     (four LDS images).  The RANKING of a tile pair — wave w sums the 8 K-partials of "its" queries
+//     in a fixed order, filters by threshold (ballot) and inserts into the half-wave sorted lists —
+//     runs one iteration later, cut into 2*NT parts placed BETWEEN the MFMA chunks of the next pair,
+//     so its LDS reads and VALU work issue while the matrix pipe executes (round 1 ranked in a phase
+//     of its own behind the barrier: the pipe idled while all 8 waves ranked, 72 us of 690 at B = 32;
+//     profiles/r02_scan_phase_experiments.txt).  Row tags and per-query filters live in LDS
+//   * the insertion itself is register / scalar only: DPP wave_shr for the shift, readlane for the
+//     broadcasts, bitwise predicates + selects instead of exec-mask branches (scan_core.h)
 //   * at the end each workgroup writes a sorted top-k list per query; merge_topk.hip
 //     reduces [n_workgroups][nq][k] -> [nq][k]
+//   * EXT variant (template flag, same main loop): masked tag filters and the continuation bound of
+//     a multi-pass top-k (k > 32), parameters in LDS
 //
 // Numerics: v_mfma_f32_16x16x4_f32 is an exact f32 fmaf chain in k order, so a score is
 // a fixed sequence of fmaf's per K-slice followed by 7 f32 adds: independent of the grid,

@@ -1,4 +1,6 @@
-"""BASELINE.json configs[0] — the reference's own CPU-runnable case: one user's index of
+"""(Lives under tests/: it times the CPU oracle, which only tests/, smoke() and bench.py's cpu_baseline leg may touch.)
+
+BASELINE.json configs[0] — the reference's own CPU-runnable case: one user's index of
 10 000 x 1024 unit vectors, top_k = 5, one query per request (app/main.py:1093-1107, 1552).
 
 GPU side: the HIP flat index through the C ABI (host query in, host top-5 out: what one /ask
@@ -7,7 +9,7 @@ reference's parameters (oracle/hnsw.c: m 48, ef_construction 400, ef_search 512)
 flat scan, on this box's host cores.  Recall@5 of HNSW vs the exact top-5 is reported next to
 the HIP path's (1.0 by construction, ids compared with the f64 oracle)."""
 import argparse, json, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 from rassengine_amd.engine import Engine, HipTimer

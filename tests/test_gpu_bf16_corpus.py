@@ -49,9 +49,12 @@ def test_bf16_index_matches_oracle_on_rounded_operands(gpu, oracle, tmp_path):
         t_live = tags.copy()
         t_live[dead] = -1
         assert ix.rows == n and ix.count == n - len(dead)
-        xn = oracle.normalize_ref(x).astype(np.float32)
         stored = ix.get_rows(0, n)
-        assert np.array_equal(stored, _bf16_round(xn))                 # rows = bf16(normalised fp32 row), exactly
+        # rows = bf16(the fp32 index's normalised row), exactly (the GPU normalise is within 2 ulp of numpy's, which
+        # can move a value across a bf16 rounding boundary: compare with the fp32 index, not with numpy)
+        assert np.array_equal(stored, _bf16_round(f32.get_rows(0, n)))
+        xn = oracle.normalize_ref(x).astype(np.float32)
+        assert np.abs(stored - xn).max() <= 2.0 ** -8 * np.abs(xn).max()
         q = rng.standard_normal((40, dim)).astype(np.float32)
         from rassengine_amd import ops
         import torch
@@ -103,7 +106,7 @@ def test_bf16_index_synthetic_fill_and_device_path(gpu):
         b = eng.open_index("syn-b16", dtype="bf16")
         a.fill_synthetic(5000, seed=9, row_id_base=100)
         b.fill_synthetic(3001, seed=9, row_id_base=100)                 # two calls: phase inside a block
-        b.fill_synthetic(1999, seed=9, row_id_base=100 + 3001)
+        b.fill_synthetic(1999, seed=9, row_id_base=100)                 # the key is row_id_base + the row ORDINAL
         assert np.array_equal(b.get_rows(0, 5000), _bf16_round(a.get_rows(0, 5000)))
         q = torch.randn((32, 1024), device="cuda")
         s = torch.empty((32, 10), device="cuda")

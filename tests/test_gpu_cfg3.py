@@ -158,11 +158,11 @@ def test_end_to_end_embed_index_search(large, oracle):
       * end to end: every query's top-5 is the oracle's topic family (6 members; ranks INSIDE a family are
         separated by 1e-4..1e-3 in cosine, below the bf16 encoder's resolution) so id overlap >= 4/5, and the
         returned score of a chunk differs from the oracle's score for the SAME chunk by <= E2E_DCOS.
-    E2E_DCOS = 5e-3 is the bound of the bf16 (weights + activations) encoder, not of the search: the measured
+    E2E_DCOS = 2e-3 is the bound of the bf16 (weights + activations) encoder, not of the search: the measured
     maximum is printed; the fp32 search on top of it contributes < 2e-6.
     """
     from rassengine_amd.engine import Engine
-    E2E_DCOS = 5e-3
+    E2E_DCOS = 2e-3
     _, enc = large
     fx = np.load(os.path.join(GOLDEN, "e2e_large_corpus.npz"))
     docs = _unpack(fx["doc_token_ids"], fx["doc_cu_seqlens"])

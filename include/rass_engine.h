@@ -174,6 +174,14 @@ int rass_index_search(rass_index_t* idx, const float* queries, int nq, int k,
 int rass_index_search_ex(rass_index_t* idx, const float* queries, int nq, int k,
                          const int32_t* q_filter, const int32_t* q_filter_mask,
                          float* out_scores, int64_t* out_ids);
+/* CROSS-INDEX batch: query i is answered over index idxs[i] (the reference keeps one index per user,
+ * app/main.py:346-347, and serves users concurrently: their queries then share ONE scan launch instead of one
+ * launch per user).  All indices must live on one engine, be fp32 and carry plain row ids; any nq (groups of 32).
+ * Each distinct index of a group is streamed once, whatever the number of its queries; out_ids are rows of the
+ * query's own index.  A group may cover at most 65 536 32-row tiles (2 M rows) over its distinct indices. */
+int rass_index_search_multi(rass_index_t* const* idxs, const float* queries, int nq, int k,
+                            const int32_t* q_filter, const int32_t* q_filter_mask,
+                            float* out_scores, int64_t* out_ids);
 /* Device-resident variant for the multi-GPU path and the benchmark: queries
  * and outputs live in HBM, nothing is synchronised; nq <= RASS_MAX_QBATCH.
  * `id_base` is added to local row ids (row-sharded corpus). */

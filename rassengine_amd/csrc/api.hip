@@ -128,10 +128,12 @@ struct HostSlot {
     int64_t* h_out_i = nullptr;    // [32][32]
     int64_t* h_scanned = nullptr;  // [1]
     void* base = nullptr;          // the one hipHostMalloc behind all of the above
+    void* h_items = nullptr;       // pinned work list of a cross-index batch (lazily allocated, kMultiMaxItems)
     hipEvent_t done = nullptr;
     bool busy = false;
 };
 constexpr int kHostSlots = 8;
+constexpr int kMultiMaxItems = 65536;  // 32-row tiles per cross-index batch (2 M rows over all its indices)
 
 }  // namespace
 
@@ -153,6 +155,11 @@ struct rass_engine {
     int64_t* d_out_ids = nullptr;   // [32][32]
     float* d_stage = nullptr;       // [kStageRows][dim]
     int32_t* d_stage_tags = nullptr;
+    // cross-index batches (rass_index_search_multi): device work list, lazily allocated
+    int32_t *d_mw_tile = nullptr, *d_mw_rows = nullptr, *d_mw_n = nullptr;
+    uint32_t* d_mw_mask = nullptr;
+    const float** d_mw_base = nullptr;
+    const int32_t** d_mw_tags = nullptr;
     float* d_stage_t16 = nullptr;   // bf16 indices: (kStageRows + 32) x kMaxStride fp32 tile16 staging, lazily allocated
     int32_t* d_qmask = nullptr;     // [32] masked-filter masks
     float* d_after_s = nullptr;     // [32] continuation bound of a multi-pass top-k (k > 32)
@@ -558,11 +565,15 @@ void rass_engine_destroy(rass_engine_t* eng) {
     (void)hipFree(eng->d_stage);
     (void)hipFree(eng->d_stage_tags);
     if (eng->d_stage_t16) (void)hipFree(eng->d_stage_t16);
+    for (void* p : {(void*)eng->d_mw_tile, (void*)eng->d_mw_rows, (void*)eng->d_mw_n, (void*)eng->d_mw_mask,
+                    (void*)eng->d_mw_base, (void*)eng->d_mw_tags})
+        if (p) (void)hipFree(p);
     (void)hipFree(eng->d_qmask);
     (void)hipFree(eng->d_after_s);
     (void)hipFree(eng->d_after_i);
     for (HostSlot& sl : eng->slots) {
         if (sl.base) (void)hipHostFree(sl.base);
+        if (sl.h_items) (void)hipHostFree(sl.h_items);
         if (sl.done) (void)hipEventDestroy(sl.done);
     }
     for (hipEvent_t e : eng->ev_pool) (void)hipEventDestroy(e);
@@ -997,6 +1008,133 @@ int rass_index_search_ex(rass_index_t* idx, const float* queries, int nq, int k,
             }
             kdone += kk;
         }
+        done += b;
+    }
+    return RASS_OK;
+}
+
+int rass_index_search_multi(rass_index_t* const* idxs, const float* queries, int nq, int k, const int32_t* q_filter,
+                            const int32_t* q_filter_mask, float* out_scores, int64_t* out_ids) {
+    if (!idxs || !out_scores || !out_ids) return fail(RASS_ERR_INVALID, "NULL argument");
+    if (nq < 0 || (nq > 0 && !queries)) return fail(RASS_ERR_INVALID, "bad queries / nq");
+    if (k < 1 || k > RASS_MAX_K) return fail(RASS_ERR_INVALID, "k must be in [1, RASS_MAX_K]");
+    if (q_filter_mask && !q_filter) return fail(RASS_ERR_INVALID, "q_filter_mask without q_filter");
+    if (nq == 0) return RASS_OK;
+    rass_engine* eng = idxs[0] ? idxs[0]->eng : nullptr;
+    for (int q = 0; q < nq; ++q) {
+        if (!idxs[q]) return fail(RASS_ERR_INVALID, "NULL index");
+        if (idxs[q]->eng != eng) return fail(RASS_ERR_INVALID, "the indices of one batch must share an engine (one GPU)");
+        if (idxs[q]->dtype != RASS_F32) return fail(RASS_ERR_UNSUPPORTED, "cross-index batches are fp32-only");
+        if (idxs[q]->has_gid.load()) return fail(RASS_ERR_UNSUPPORTED, "cross-index batches need plain row ids");
+    }
+    int rc = set_device(eng);
+    if (rc != RASS_OK) return rc;
+    const int dim = eng->dim;
+    SlotGuard guard(eng);
+    HostSlot* sl = guard.sl;
+    const size_t item_bytes = 4 + 4 + 4 + 8 + 8;
+    if (!sl->h_items) HIP_TRY(hipHostMalloc(&sl->h_items, (size_t)kMultiMaxItems * item_bytes, hipHostMallocDefault));
+    int32_t* h_tile = static_cast<int32_t*>(sl->h_items);
+    int32_t* h_rows = h_tile + kMultiMaxItems;
+    uint32_t* h_mask = reinterpret_cast<uint32_t*>(h_rows + kMultiMaxItems);
+    const float** h_base = reinterpret_cast<const float**>(h_mask + kMultiMaxItems);
+    const int32_t** h_tags = reinterpret_cast<const int32_t**>(h_base + kMultiMaxItems);
+    for (int done = 0; done < nq;) {
+        const int b = std::min(RASS_MAX_QBATCH, nq - done);
+        memcpy(sl->h_q, queries + (int64_t)done * dim, (size_t)b * dim * sizeof(float));
+        if (q_filter) memcpy(sl->h_filter, q_filter + done, (size_t)b * sizeof(int32_t));
+        if (q_filter_mask) memcpy(sl->h_mask, q_filter_mask + done, (size_t)b * sizeof(int32_t));
+        {
+            std::lock_guard<std::mutex> lk(eng->mu);  // slab pointers and row counts are stable under it
+            hipStream_t st = eng->stream;
+            if (!eng->d_mw_tile) {
+                HIP_TRY(hipMalloc(reinterpret_cast<void**>(&eng->d_mw_tile), (size_t)kMultiMaxItems * 4));
+                HIP_TRY(hipMalloc(reinterpret_cast<void**>(&eng->d_mw_rows), (size_t)kMultiMaxItems * 4));
+                HIP_TRY(hipMalloc(reinterpret_cast<void**>(&eng->d_mw_mask), (size_t)kMultiMaxItems * 4));
+                HIP_TRY(hipMalloc(reinterpret_cast<void**>(&eng->d_mw_base), (size_t)kMultiMaxItems * 8));
+                HIP_TRY(hipMalloc(reinterpret_cast<void**>(&eng->d_mw_tags), (size_t)kMultiMaxItems * 8));
+                HIP_TRY(hipMalloc(reinterpret_cast<void**>(&eng->d_mw_n), 4));
+            }
+            // the work list: for every DISTINCT index of the batch its tiles, each with the mask of the batch's
+            // queries that belong to that index (a tile is fetched once however many of them there are)
+            int n_items = 0;
+            for (int q = 0; q < b; ++q) {
+                rass_index* idx = idxs[done + q];
+                bool seen = false;
+                for (int p = 0; p < q && !seen; ++p) seen = idxs[done + p] == idx;
+                if (seen) continue;
+                uint32_t mask = 0;
+                for (int p = q; p < b; ++p)
+                    if (idxs[done + p] == idx) mask |= 1u << p;
+                const int64_t rows = idx->rows.load(std::memory_order_acquire);
+                const bool need_tags = idx->deleted.load(std::memory_order_acquire) > 0 || q_filter != nullptr;
+                const int64_t tiles = (rows + 31) / 32;
+                if (n_items + tiles > kMultiMaxItems)
+                    return fail(RASS_ERR_UNSUPPORTED, "cross-index batch exceeds 65536 tiles (2 M rows): search the large index on its own");
+                for (int64_t t = 0; t < tiles; ++t) {
+                    h_tile[n_items] = (int32_t)t;
+                    h_rows[n_items] = (int32_t)std::min<int64_t>(32, rows - 32 * t);
+                    h_mask[n_items] = mask;
+                    h_base[n_items] = idx->d_rows;
+                    h_tags[n_items] = need_tags ? idx->d_tags : nullptr;
+                    ++n_items;
+                }
+            }
+            sl->h_scanned[0] = n_items;  // reused as the pinned source of the item count
+            if (n_items > 0) {
+                HIP_TRY(hipMemcpyAsync(eng->d_mw_tile, h_tile, (size_t)n_items * 4, hipMemcpyHostToDevice, st));
+                HIP_TRY(hipMemcpyAsync(eng->d_mw_rows, h_rows, (size_t)n_items * 4, hipMemcpyHostToDevice, st));
+                HIP_TRY(hipMemcpyAsync(eng->d_mw_mask, h_mask, (size_t)n_items * 4, hipMemcpyHostToDevice, st));
+                HIP_TRY(hipMemcpyAsync(eng->d_mw_base, h_base, (size_t)n_items * 8, hipMemcpyHostToDevice, st));
+                HIP_TRY(hipMemcpyAsync(eng->d_mw_tags, h_tags, (size_t)n_items * 8, hipMemcpyHostToDevice, st));
+            }
+            HIP_TRY(hipMemcpyAsync(eng->d_mw_n, sl->h_scanned, 4, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(eng->d_qraw, sl->h_q, (size_t)b * dim * sizeof(float), hipMemcpyHostToDevice, st));
+            const int32_t* d_filter = nullptr;
+            if (q_filter) {
+                HIP_TRY(hipMemcpyAsync(eng->d_qfilter, sl->h_filter, (size_t)b * 4, hipMemcpyHostToDevice, st));
+                d_filter = eng->d_qfilter;
+            }
+            if (q_filter_mask) HIP_TRY(hipMemcpyAsync(eng->d_qmask, sl->h_mask, (size_t)b * 4, hipMemcpyHostToDevice, st));
+            // launch: normalise -> MULTI scan over the work list -> merge (ids are rows of each query's own index)
+            const int64_t stride = pad128(dim);
+            const ScratchLayout L = scratch_layout(b, k);
+            unsigned char* ws = eng->d_scratch;
+            float* q_padded = reinterpret_cast<float*>(ws + L.q_padded);
+            float* part_scores = reinterpret_cast<float*>(ws + L.part_scores);
+            int64_t* part_ids = reinterpret_cast<int64_t*>(ws + L.part_ids);
+            const int nq_pad = b <= 16 ? 16 : 32;
+            HIP_TRY(rass::launch_normalize_rows_f32(eng->d_qraw, dim, q_padded, stride, b, dim, st, nq_pad));
+            int grid = std::min(std::max(n_items, 1), std::min(eng->n_cus, kMaxGrid));
+            if ((int64_t)grid * k > rass::kMergeMaxCandidates) grid = rass::kMergeMaxCandidates / k;
+            rass::ScanArgs a;
+            a.corpus = reinterpret_cast<const float*>(eng->d_scratch);
+            a.row_tag = nullptr;
+            a.q_padded = q_padded;
+            a.q_filter = d_filter;
+            a.q_filter_mask = q_filter_mask ? eng->d_qmask : nullptr;
+            a.part_scores = part_scores;
+            a.part_ids = part_ids;
+            a.row_stride = stride;
+            a.id_base = 0;
+            a.n_rows = 0;
+            a.nq = b;
+            a.k = k;
+            a.work_tile = eng->d_mw_tile;
+            a.work_rows = eng->d_mw_rows;
+            a.work_mask = eng->d_mw_mask;
+            a.n_work = eng->d_mw_n;
+            a.work_base = eng->d_mw_base;
+            a.work_tags = eng->d_mw_tags;
+            HIP_TRY(rass::launch_scan_topk_f32(a, grid, st));
+            HIP_TRY(rass::launch_merge_topk(part_scores, part_ids, grid, b, k, eng->d_out_scores, eng->d_out_ids, st));
+            HIP_TRY(hipMemcpyAsync(sl->h_out_s, eng->d_out_scores, (size_t)b * k * sizeof(float), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(sl->h_out_i, eng->d_out_ids, (size_t)b * k * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipEventRecord(sl->done, st));
+        }
+        HIP_TRY(hipEventSynchronize(sl->done));
+        memcpy(out_scores + (int64_t)done * k, sl->h_out_s, (size_t)b * k * sizeof(float));
+        memcpy(out_ids + (int64_t)done * k, sl->h_out_i, (size_t)b * k * sizeof(int64_t));
         done += b;
     }
     return RASS_OK;
@@ -1815,7 +1953,7 @@ const char* rass_scan_kernel_name(int dim, int nq) {
     const int64_t stride = pad128(dim);
     if (dim < 1 || !rass::scan_supported_stride(stride) || stride > kMaxStride || nq < 1 || nq > RASS_MAX_QBATCH)
         return "";
-    snprintf(buf, sizeof(buf), "scan_topk_f32_kernel<%d, %d, false, false>", (int)(stride / 128), nq <= 16 ? 1 : 2);
+    snprintf(buf, sizeof(buf), "scan_topk_f32_kernel<%d, %d, 0, false>", (int)(stride / 128), nq <= 16 ? 1 : 2);
     return buf;
 }
 

@@ -33,6 +33,10 @@ struct ScanArgs {
     const int32_t* work_rows = nullptr;
     const uint32_t* work_mask = nullptr;
     const int32_t* n_work = nullptr;  // device scalar: number of work items
+    // cross-index batch (all nullptr otherwise): item i scans tile work_tile[i] of the slab work_base[i] with the
+    // row tags work_tags[i] (may be null per item); ids are rows of THAT slab
+    const float* const* work_base = nullptr;
+    const int32_t* const* work_tags = nullptr;
     // XCD skew (0 = plain round-robin).  Workgroups land on XCD blockIdx % 8; measured on MI355X
     // (scripts/microbench/scan_tail.hip) the odd XCDs stream ~14 % slower than the even ones when
     // the scan is purely HBM-bound (B <= 16).  With skew s > 0 the even workgroups take s+1 items

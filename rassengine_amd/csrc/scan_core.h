@@ -42,6 +42,11 @@ struct WorkItem {
     unsigned mask;
 };
 
+// Which work a workgroup iterates over: every tile of one slab (flat), the tiles of a device-built probe plan
+// over one slab (IVF), or the tiles of SEVERAL slabs — one per index of a cross-index query batch — each item
+// naming its own slab and tag array (MULTI: concurrent users' per-user indices share one launch).
+enum ScanMode { kFlat = 0, kIvf = 1, kMulti = 2 };
+
 __device__ __forceinline__ TileDesc make_tile_desc(const float* __restrict__ X, int64_t row_stride,
                                                    const int32_t* __restrict__ row_tag, const WorkItem& w) {
     const int rows_here = w.rows;

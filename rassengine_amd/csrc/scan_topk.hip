@@ -77,10 +77,10 @@ struct ItemSeq {
     }
 };
 
-template <bool IVF>
+template <int MODE>
 __device__ __forceinline__ WorkItem get_work(const ScanArgs& p, int i, int n_items) {
     WorkItem w;
-    if (IVF) {
+    if (MODE != kFlat) {
         const bool ok = i < n_items;
         w.tile = ok ? p.work_tile[i] : 0;
         w.rows = ok ? p.work_rows[i] : 0;
@@ -95,8 +95,20 @@ __device__ __forceinline__ WorkItem get_work(const ScanArgs& p, int i, int n_ite
     return w;
 }
 
-template <int CH, int NT, bool IVF, bool EXT>
+// The slab / tag array a work item streams: the launch's one slab, or (MULTI) the item's own.  `i` past the end
+// reads item 0's pointers (rows = 0 there, so the descriptor has zero records and nothing is fetched).
+template <int MODE>
+__device__ __forceinline__ const float* slab_of(const ScanArgs& p, int i, int n_items) {
+    return MODE == kMulti ? p.work_base[i < n_items ? i : 0] : p.corpus;
+}
+template <int MODE>
+__device__ __forceinline__ const int32_t* tags_of(const ScanArgs& p, int i, int n_items) {
+    return MODE == kMulti ? p.work_tags[i < n_items ? i : 0] : p.row_tag;
+}
+
+template <int CH, int NT, int MODE, bool EXT>
 __global__ __launch_bounds__(kThreads, 2) void scan_topk_f32_kernel(ScanArgs p) {
+    constexpr bool IVF = MODE != kFlat;  // a work list with per-item query masks
     constexpr int NQ = NT * 16;
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [4][kWaves][NQ][kPitch]
 
@@ -158,9 +170,12 @@ __global__ __launch_bounds__(kThreads, 2) void scan_topk_f32_kernel(ScanArgs p) 
     TileRegs<CH> R0, R1;
     ItemSeq seq((int)blockIdx.x, G, (G & 1) ? 0 : p.xcd_skew);
     int t = seq.next();  // the item R0 holds; R1 holds the one after it
-    WorkItem W0 = get_work<IVF>(p, t, n_tiles), W1 = get_work<IVF>(p, seq.next(), n_tiles);
-    issue_tile_loads<CH>(R0, make_tile_desc(p.corpus, p.row_stride, p.row_tag, W0), voff_lane, mt_step);
-    issue_tile_loads<CH>(R1, make_tile_desc(p.corpus, p.row_stride, p.row_tag, W1), voff_lane, mt_step);
+    const int t1 = seq.next();
+    WorkItem W0 = get_work<MODE>(p, t, n_tiles), W1 = get_work<MODE>(p, t1, n_tiles);
+    issue_tile_loads<CH>(R0, make_tile_desc(slab_of<MODE>(p, t, n_tiles), p.row_stride, tags_of<MODE>(p, t, n_tiles), W0),
+                         voff_lane, mt_step);
+    issue_tile_loads<CH>(R1, make_tile_desc(slab_of<MODE>(p, t1, n_tiles), p.row_stride, tags_of<MODE>(p, t1, n_tiles), W1),
+                         voff_lane, mt_step);
     __builtin_amdgcn_sched_barrier(0);
 
     // A tile's 8 K-partials meet in LDS.  Two tiles share ONE barrier: both are dumped (four LDS
@@ -222,7 +237,7 @@ __global__ __launch_bounds__(kThreads, 2) void scan_topk_f32_kernel(ScanArgs p) 
         }
         const WorkItem Wa = W0;
         t = seq.next();
-        WorkItem Wn = get_work<IVF>(p, t, n_tiles);
+        WorkItem Wn = get_work<MODE>(p, t, n_tiles);
         auto rank_prev = [&](int slot) {
 #pragma unroll
             for (int part = 0; part < kParts; ++part)
@@ -233,14 +248,17 @@ __global__ __launch_bounds__(kThreads, 2) void scan_topk_f32_kernel(ScanArgs p) 
                         rank_part(Pb, (pair ^ 2) + 1, part - NT);
                 }
         };
-        multiply_and_refill<CH, NT>(R0, qf, acc, make_tile_desc(p.corpus, p.row_stride, p.row_tag, Wn), voff_lane,
-                                    mt_step, [&](int j) { rank_prev(j); });
+        multiply_and_refill<CH, NT>(R0, qf, acc,
+                                    make_tile_desc(slab_of<MODE>(p, t, n_tiles), p.row_stride, tags_of<MODE>(p, t, n_tiles), Wn),
+                                    voff_lane, mt_step, [&](int j) { rank_prev(j); });
         dump_tile(acc, pair);
         W0 = Wn;
         const WorkItem Wb = W1;
-        Wn = get_work<IVF>(p, seq.next(), n_tiles);
-        multiply_and_refill<CH, NT>(R1, qf, acc, make_tile_desc(p.corpus, p.row_stride, p.row_tag, Wn), voff_lane,
-                                    mt_step, [&](int j) { rank_prev(CH + j); });
+        const int tn = seq.next();
+        Wn = get_work<MODE>(p, tn, n_tiles);
+        multiply_and_refill<CH, NT>(R1, qf, acc,
+                                    make_tile_desc(slab_of<MODE>(p, tn, n_tiles), p.row_stride, tags_of<MODE>(p, tn, n_tiles), Wn),
+                                    voff_lane, mt_step, [&](int j) { rank_prev(CH + j); });
         dump_tile(acc, pair + 1);
         W1 = Wn;
         Pa = Wa;
@@ -272,31 +290,31 @@ __global__ __launch_bounds__(kThreads, 2) void scan_topk_f32_kernel(ScanArgs p) 
     }
 }
 
-template <int CH, int NT, bool IVF, bool EXT>
+template <int CH, int NT, int MODE, bool EXT>
 static hipError_t launch_variant(const ScanArgs& a, int grid, hipStream_t stream) {
     constexpr size_t lds_bytes = (size_t)4 * kWaves * NT * 16 * kPitch * sizeof(float);  // 144 KiB at NT = 2
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_topk_f32_kernel<CH, NT, IVF, EXT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_topk_f32_kernel<CH, NT, MODE, EXT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((scan_topk_f32_kernel<CH, NT, IVF, EXT>), dim3(grid), dim3(kThreads), lds_bytes, stream, a);
+    hipLaunchKernelGGL((scan_topk_f32_kernel<CH, NT, MODE, EXT>), dim3(grid), dim3(kThreads), lds_bytes, stream, a);
     return hipGetLastError();
 }
 
-template <int NT, bool IVF, bool EXT = false>
+template <int NT, int MODE, bool EXT = false>
 static hipError_t launch_ch(int ch, const ScanArgs& a, int grid, hipStream_t stream) {
     switch (ch) {
-        case 1: return launch_variant<1, NT, IVF, EXT>(a, grid, stream);
-        case 2: return launch_variant<2, NT, IVF, EXT>(a, grid, stream);
-        case 3: return launch_variant<3, NT, IVF, EXT>(a, grid, stream);
-        case 4: return launch_variant<4, NT, IVF, EXT>(a, grid, stream);
-        case 5: return launch_variant<5, NT, IVF, EXT>(a, grid, stream);
-        case 6: return launch_variant<6, NT, IVF, EXT>(a, grid, stream);
-        case 7: return launch_variant<7, NT, IVF, EXT>(a, grid, stream);
-        case 8: return launch_variant<8, NT, IVF, EXT>(a, grid, stream);
+        case 1: return launch_variant<1, NT, MODE, EXT>(a, grid, stream);
+        case 2: return launch_variant<2, NT, MODE, EXT>(a, grid, stream);
+        case 3: return launch_variant<3, NT, MODE, EXT>(a, grid, stream);
+        case 4: return launch_variant<4, NT, MODE, EXT>(a, grid, stream);
+        case 5: return launch_variant<5, NT, MODE, EXT>(a, grid, stream);
+        case 6: return launch_variant<6, NT, MODE, EXT>(a, grid, stream);
+        case 7: return launch_variant<7, NT, MODE, EXT>(a, grid, stream);
+        case 8: return launch_variant<8, NT, MODE, EXT>(a, grid, stream);
         default: return hipErrorInvalidValue;
     }
 }
@@ -311,20 +329,32 @@ hipError_t launch_scan_topk_f32(const ScanArgs& a, int grid, hipStream_t stream)
     if (!scan_supported_stride(a.row_stride)) return hipErrorInvalidValue;
     const int ch = (int)(a.row_stride / 128);
     const bool ext = a.q_filter_mask || a.q_after_score || a.q_after_id;
+    if (ext && a.work_base != nullptr) {  // cross-index batch with masked filters
+        if (!a.work_tile || !a.work_rows || !a.work_mask || !a.n_work || !a.work_tags) return hipErrorInvalidValue;
+        if (a.q_after_score || a.q_after_id) return hipErrorInvalidValue;
+        if (a.q_filter_mask != nullptr && a.q_filter == nullptr) return hipErrorInvalidValue;
+        if (a.nq <= 16) return launch_ch<1, kMulti, true>(ch, a, grid, stream);
+        return launch_ch<2, kMulti, true>(ch, a, grid, stream);
+    }
     if (ext) {  // masked filters / continuation bound: flat scan only
         if (a.work_tile != nullptr) return hipErrorInvalidValue;
         if ((a.q_after_score == nullptr) != (a.q_after_id == nullptr)) return hipErrorInvalidValue;
         if (a.q_filter_mask != nullptr && a.q_filter == nullptr) return hipErrorInvalidValue;
-        if (a.nq <= 16) return launch_ch<1, false, true>(ch, a, grid, stream);
-        return launch_ch<2, false, true>(ch, a, grid, stream);
+        if (a.nq <= 16) return launch_ch<1, kFlat, true>(ch, a, grid, stream);
+        return launch_ch<2, kFlat, true>(ch, a, grid, stream);
+    }
+    if (a.work_base != nullptr) {  // cross-index batch: every item names its slab
+        if (!a.work_tile || !a.work_rows || !a.work_mask || !a.n_work || !a.work_tags) return hipErrorInvalidValue;
+        if (a.nq <= 16) return launch_ch<1, kMulti>(ch, a, grid, stream);
+        return launch_ch<2, kMulti>(ch, a, grid, stream);
     }
     if (a.work_tile != nullptr) {  // IVF probe: iterate the plan instead of every tile
         if (!a.work_rows || !a.work_mask || !a.n_work) return hipErrorInvalidValue;
-        if (a.nq <= 16) return launch_ch<1, true>(ch, a, grid, stream);
-        return launch_ch<2, true>(ch, a, grid, stream);
+        if (a.nq <= 16) return launch_ch<1, kIvf>(ch, a, grid, stream);
+        return launch_ch<2, kIvf>(ch, a, grid, stream);
     }
-    if (a.nq <= 16) return launch_ch<1, false>(ch, a, grid, stream);
-    return launch_ch<2, false>(ch, a, grid, stream);
+    if (a.nq <= 16) return launch_ch<1, kFlat>(ch, a, grid, stream);
+    return launch_ch<2, kFlat>(ch, a, grid, stream);
 }
 
 }  // namespace rass

@@ -100,6 +100,27 @@ class Engine:
         self._indices[name] = idx
         return idx
 
+    def search_multi(self, indices, queries: np.ndarray, k: int, q_filter: Optional[np.ndarray] = None,
+                     q_filter_mask: Optional[np.ndarray] = None) -> Tuple[np.ndarray, np.ndarray]:
+        """CROSS-INDEX batch (``rass_index_search_multi``): query i is answered over ``indices[i]``; queries of
+        different per-user indices share scan launches.  Returns (scores f32 [nq,k], ids i64 [nq,k]), ids being
+        rows of each query's own index."""
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        if q.ndim != 2 or q.shape[1] != self.dim or q.shape[0] != len(indices):
+            raise ValueError(f"expected one [{self.dim}] query per index, got {q.shape} for {len(indices)} indices")
+        nq = q.shape[0]
+        f = None if q_filter is None else np.ascontiguousarray(q_filter, dtype=np.int32)
+        m = None if q_filter_mask is None else np.ascontiguousarray(q_filter_mask, dtype=np.int32)
+        if (f is not None and f.shape != (nq,)) or (m is not None and (f is None or m.shape != (nq,))):
+            raise ValueError("q_filter / q_filter_mask must be one int32 per query (mask needs filter)")
+        handles = (ctypes.c_void_p * nq)(*[ix._h for ix in indices])
+        out_s = np.empty((nq, int(k)), dtype=np.float32)
+        out_i = np.empty((nq, int(k)), dtype=np.int64)
+        N.check("rass_index_search_multi",
+                self._L.rass_index_search_multi(handles, _np_ptr(q), nq, int(k), _np_ptr(f), _np_ptr(m), _np_ptr(out_s),
+                                                _np_ptr(out_i)))
+        return out_s, out_i
+
     def drop_index(self, name: str) -> None:
         N.check("rass_index_drop", self._L.rass_index_drop(self._h, name.encode()))
         self._indices.pop(name, None)

@@ -193,6 +193,14 @@ class HipIndexer:
             if prep is None:
                 return []
             q, k_eff, (fval, fmask) = prep
+            eng = getattr(st.index, "engine", None)
+            if eng is not None and hasattr(eng, "search_multi") and k_eff <= 32:
+                # one batcher per ENGINE: concurrent users' per-user indices share scan launches
+                if getattr(eng, "_cross_batcher", None) is None:
+                    from .batcher import CrossIndexBatcher
+                    eng._cross_batcher = CrossIndexBatcher(eng)
+                scores, ids = await eng._cross_batcher.search(st.index, q[0], k_eff, fval, fmask)
+                return self._hits(st, scores, ids, 1.0, None)
             if st.batcher is None:
                 from .batcher import QueryBatcher
                 st.batcher = QueryBatcher(st.index)

@@ -54,8 +54,8 @@ def test_library_loads_without_gpu_and_reports_errors(built_lib):
     # pure host-side queries only: no kernels, no device memory
     assert L.rass_scan_workspace_bytes(32, 32) > 0
     assert L.rass_scan_workspace_bytes(33, 10) == 0
-    assert L.rass_scan_kernel_name(1024, 32) == b"scan_topk_f32_kernel<8, 2, false, false>"
-    assert L.rass_scan_kernel_name(1024, 7) == b"scan_topk_f32_kernel<8, 1, false, false>"
+    assert L.rass_scan_kernel_name(1024, 32) == b"scan_topk_f32_kernel<8, 2, 0, false>"
+    assert L.rass_scan_kernel_name(1024, 7) == b"scan_topk_f32_kernel<8, 1, 0, false>"
     assert L.rass_scan_kernel_name(5000, 1) == b""
 
 

@@ -240,3 +240,61 @@ def test_query_batcher_over_the_hip_index(gpu, oracle):
             assert np.all(np.abs(s.astype(np.float64) - rs[0]) <= 2e-6)
     finally:
         eng.close()
+
+
+def test_cross_index_batch_equals_per_index_search(gpu, oracle):
+    """rass_index_search_multi: 70 queries over 9 per-user indices of very different sizes (0 .. 40 000 rows, one
+    with tombstones), patient filters (plain and masked) in the mix, answered by 3 scan launches instead of 70 —
+    every row must be bit-identical to that index's own rass_index_search_ex answer; and the engine-wide
+    CrossIndexBatcher behind HipIndexer.asemantic_search coalesces requests of DIFFERENT users."""
+    import asyncio
+    from rassengine_amd.batcher import CrossIndexBatcher
+    from rassengine_amd.engine import Engine
+    dim = 512
+    rng = np.random.default_rng(21)
+    sizes = [0, 1, 31, 33, 500, 4000, 9000, 40000, 2500]
+    eng = Engine(0, dim)
+    try:
+        idxs, tags = [], []
+        for u, n in enumerate(sizes):
+            ix = eng.open_index(f"user-{u}")
+            t = (rng.integers(1, 4, size=n) | (1 << 24)).astype(np.int32)
+            if n:
+                ix.add(rng.standard_normal((n, dim)).astype(np.float32), tags=t)
+            idxs.append(ix)
+            tags.append(t)
+        for r in (3, 777, 3999):
+            idxs[5].delete(r)
+        nq = 70
+        who = rng.integers(0, len(sizes), size=nq)
+        who[:4] = [7, 7, 0, 7]                                   # several queries on one index, one on the empty one
+        q = rng.standard_normal((nq, dim)).astype(np.float32)
+        for k, qf, qm in ((10, None, None), (32, None, None),
+                          (5, rng.integers(-1, 4, size=nq).astype(np.int32) | np.int32(0), None),
+                          (7, rng.integers(1, 4, size=nq).astype(np.int32), np.full(nq, 0x00FFFFFF, dtype=np.int32))):
+            if qf is not None and qm is None:
+                qf = np.where(qf >= 0, qf | (1 << 24), -1).astype(np.int32)     # exact compare needs the full tag
+            s, i = eng.search_multi([idxs[w] for w in who], q, k, qf, qm)
+            for r in range(nq):
+                s1, i1 = idxs[who[r]].search(q[r:r + 1], k, None if qf is None else qf[r:r + 1],
+                                             None if qm is None else qm[r:r + 1])
+                assert np.array_equal(i[r], i1[0]) and np.array_equal(s[r], s1[0]), (k, r, who[r])
+            assert np.all(i[2] == -1)                            # the empty index answers with padding
+            if qf is not None:
+                for r in range(nq):
+                    live = i[r][i[r] >= 0]
+                    if qf[r] >= 0:
+                        assert np.all((tags[who[r]][live] & (-1 if qm is None else int(qm[r]))) == qf[r])
+
+        async def main():
+            b = CrossIndexBatcher(eng, max_batch=32, max_delay_ms=20.0)
+            res = await asyncio.gather(*[b.search(idxs[who[r]], q[r], 10) for r in range(nq)])
+            await b.close()
+            return b, res
+        b, res = asyncio.run(main())
+        assert b.served == nq and b.scans <= 4                    # 70 users' requests in <= 4 launches
+        s10, i10 = eng.search_multi([idxs[w] for w in who], q, 10)
+        for r, (sr, ir) in enumerate(res):
+            assert np.array_equal(ir, i10[r]) and np.array_equal(sr, s10[r])
+    finally:
+        eng.close()

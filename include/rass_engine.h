@@ -268,6 +268,22 @@ int rass_topk_merge_strided(const float* d_scores, const int64_t* d_ids,
                             int n_lists, int nq, int k, float* d_out_scores,
                             int64_t* d_out_ids, void* stream);
 
+/* the cross-shard exchange without a collective.  Rank 0 creates a buffer in its HBM and hands
+ * the 64-byte HIP IPC handle to the other ranks' processes (one process per GPU); every rank then STORES its
+ * packed per-shard top-k record into its slot (over xGMI between GPUs) and releases a per-rank sequence flag at
+ * system scope (rass_peer_post: copy, fence, flag); rank 0 enqueues rass_peer_wait (one workgroup acquiring the
+ * n flags, BOUNDED: after max_spins polls it gives up and stores 1 + the missing rank in *d_status instead of
+ * hanging the GPU) in front of its rass_topk_merge_strided.  Replaces the OpenSearch shard -> coordinator
+ * response (SHARD_COUNT, app/main.py:89, 357).  Layout and step protocol: rassengine_amd/dist.py
+ * (PeerMergeSearch).  The processes need HSA_ENABLE_IPC_MODE_LEGACY=0 on this platform. */
+int rass_peer_buffer_create(int device, size_t bytes, void** d_ptr, unsigned char* handle64);
+int rass_peer_buffer_open(int device, const unsigned char* handle64, void** d_ptr);
+int rass_peer_buffer_close(void* d_ptr, int opened_from_handle);
+int rass_peer_post(const void* d_record, size_t bytes, void* d_remote_slot, void* d_remote_flag,
+                   uint64_t seq, void* stream);
+int rass_peer_wait(const void* d_flags, int n, int flag_stride_bytes, uint64_t seq, int* d_status,
+                   int64_t max_spins, void* stream);
+
 /* a4 (app/main.py:1249-1251, 1536-1537): out = in / (||in||_2 + 1e-9), rows
  * of `dim` floats read at in_stride, written at out_stride (elements); the
  * out_stride - dim tail of each output row is zero-filled. */

@@ -98,6 +98,13 @@ SIGNATURES = {
                                                ctypes.c_void_p, ctypes.c_void_p]),
     "rass_normalize_rows_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
                                                ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
+    "rass_peer_buffer_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_size_t, c_void_pp, ctypes.c_char_p]),
+    "rass_peer_buffer_open": (ctypes.c_int, [ctypes.c_int, ctypes.c_char_p, c_void_pp]),
+    "rass_peer_buffer_close": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "rass_peer_post": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p,
+                                      ctypes.c_uint64, ctypes.c_void_p]),
+    "rass_peer_wait": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_uint64, ctypes.c_void_p,
+                                      ctypes.c_int64, ctypes.c_void_p]),
     "rass_kmeans_assign": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
                                           ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     "rass_kmeans_accumulate": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,

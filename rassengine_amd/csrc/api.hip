@@ -1948,6 +1948,61 @@ int rass_kmeans_accumulate(rass_index_t* idx, int64_t first_block, int64_t block
     return RASS_OK;
 }
 
+// ---- §8f-4: peer-store exchange (no collective on the search path)
+int rass_peer_buffer_create(int device, size_t bytes, void** d_ptr, unsigned char* handle64) {
+    if (!d_ptr || !handle64 || bytes == 0) return fail(RASS_ERR_INVALID, "bad argument");
+    *d_ptr = nullptr;
+    HIP_TRY(hipSetDevice(device));
+    void* p = nullptr;
+    HIP_TRY(hipMalloc(&p, bytes));
+    hipError_t e = hipMemset(p, 0, bytes);
+    hipIpcMemHandle_t h;
+    if (e == hipSuccess) e = hipIpcGetMemHandle(&h, p);
+    if (e != hipSuccess) {
+        (void)hipFree(p);
+        return fail(RASS_ERR_HIP, std::string("peer buffer: ") + hipGetErrorString(e) +
+                                      " (multi-process GPU memory sharing needs HSA_ENABLE_IPC_MODE_LEGACY=0 here)");
+    }
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "the ABI carries the IPC handle as 64 bytes");
+    memcpy(handle64, &h, 64);
+    *d_ptr = p;
+    return RASS_OK;
+}
+
+int rass_peer_buffer_open(int device, const unsigned char* handle64, void** d_ptr) {
+    if (!d_ptr || !handle64) return fail(RASS_ERR_INVALID, "NULL argument");
+    *d_ptr = nullptr;
+    HIP_TRY(hipSetDevice(device));
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle64, 64);
+    HIP_TRY(hipIpcOpenMemHandle(d_ptr, h, hipIpcMemLazyEnablePeerAccess));
+    return RASS_OK;
+}
+
+int rass_peer_buffer_close(void* d_ptr, int opened_from_handle) {
+    if (!d_ptr) return RASS_OK;
+    if (opened_from_handle)
+        HIP_TRY(hipIpcCloseMemHandle(d_ptr));
+    else
+        HIP_TRY(hipFree(d_ptr));
+    return RASS_OK;
+}
+
+int rass_peer_post(const void* d_record, size_t bytes, void* d_remote_slot, void* d_remote_flag, uint64_t seq,
+                   void* stream) {
+    if (!d_record || !d_remote_slot || !d_remote_flag) return fail(RASS_ERR_INVALID, "NULL argument");
+    HIP_TRY(rass::launch_peer_post(d_record, bytes, d_remote_slot, d_remote_flag, seq, reinterpret_cast<hipStream_t>(stream)));
+    return RASS_OK;
+}
+
+int rass_peer_wait(const void* d_flags, int n, int flag_stride_bytes, uint64_t seq, int* d_status, int64_t max_spins,
+                   void* stream) {
+    if (!d_flags || !d_status || max_spins < 1) return fail(RASS_ERR_INVALID, "bad argument");
+    HIP_TRY(rass::launch_peer_wait(d_flags, n, flag_stride_bytes, seq, d_status, max_spins,
+                                   reinterpret_cast<hipStream_t>(stream)));
+    return RASS_OK;
+}
+
 const char* rass_scan_kernel_name(int dim, int nq) {
     static thread_local char buf[64];
     const int64_t stride = pad128(dim);

@@ -81,6 +81,12 @@ hipError_t launch_rerank_f32(const float* slab, int64_t stride, const float* q_p
                              int n_cand, int k, int64_t id_base, float* out_scores, int64_t* out_ids,
                              hipStream_t stream);
 
+// ---- peer-store exchange of per-shard top-k (peer.hip)
+hipError_t launch_peer_post(const void* local, size_t bytes, void* remote_slot, void* remote_flag, uint64_t seq,
+                            hipStream_t stream);
+hipError_t launch_peer_wait(const void* flags, int n, int flag_stride_bytes, uint64_t seq, int* status,
+                            int64_t max_spins, hipStream_t stream);
+
 // ---- k-means of the IVF build (kmeans.hip)
 struct AssignArgs {
     const float* rows;       // tile16 slab holding the rows to assign (normalised)

@@ -125,3 +125,98 @@ class ShardedSearch:
         dist.all_gather_into_tensor(gath_s.view(self.world * nq, k), loc_s.contiguous(), group=self.group)
         dist.all_gather_into_tensor(gath_i.view(self.world * nq, k), loc_i.contiguous(), group=self.group)
         return self.shard.merge(gath_s, gath_i)
+
+
+class PeerMergeSearch:
+    """``ShardedSearch`` with the all-gather replaced by peer stores (``csrc/peer.hip``).
+
+    Rank 0 owns a buffer ``[G flags, 64 B apart][2 parities][G record slots]`` in its HBM; the other ranks map
+    it through a HIP IPC handle (exchanged once, at construction).  A step: broadcast(queries) -> every rank scans
+    its shard into a packed record and STORES it into its slot of parity ``step & 1`` (over xGMI between GPUs),
+    then releases its flag = step -> rank 0 enqueues the bounded flag wait and the strided merge.  Only rank 0
+    gets the result (the coordinator; ``search`` returns ``None`` elsewhere).  Results are identical to
+    ``ShardedSearch`` (same records, same merge kernel).  Validated with 2 ranks sharing one GPU
+    (tests/test_gpu_dist.py); between GPUs it has not run yet (no multi-GPU box in this build)."""
+
+    FLAG_STRIDE = 64
+    MAX_SPINS = 1 << 22          # x s_sleep(8): gives up after ~1 s instead of hanging the GPU
+
+    def __init__(self, shard: "HipShard", nq_max: int = 32, k_max: int = 32, group: Optional[dist.ProcessGroup] = None):
+        import ctypes
+        from . import _native as N
+        self.shard = shard
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.device = shard.device
+        _, self.slot_bytes = HipShard.record_bytes(nq_max, k_max)
+        self.slot_bytes = (self.slot_bytes + 255) // 256 * 256
+        self.flags_bytes = (self.world * self.FLAG_STRIDE + 255) // 256 * 256
+        total = self.flags_bytes + 2 * self.world * self.slot_bytes
+        L = N.lib()
+        ptr = ctypes.c_void_p()
+        handle = ctypes.create_string_buffer(64)
+        self._opened = False
+        if self.rank == 0:
+            N.check("rass_peer_buffer_create", L.rass_peer_buffer_create(self.device.index, total, ctypes.byref(ptr), handle))
+        box = [bytes(handle.raw) if self.rank == 0 else None]
+        if self.world > 1:
+            dist.broadcast_object_list(box, src=0, group=group)
+        if self.rank != 0:
+            N.check("rass_peer_buffer_open", L.rass_peer_buffer_open(self.device.index, box[0], ctypes.byref(ptr)))
+            self._opened = True
+        self._base = int(ptr.value)
+        self._L = L
+        self._N = N
+        self.step = 0
+        self._status = torch.zeros((1,), dtype=torch.int32, device=self.device) if self.rank == 0 else None
+
+    def close(self) -> None:
+        if getattr(self, "_base", 0):
+            torch.cuda.synchronize(self.device)
+            if self.world > 1:
+                dist.barrier(group=self.group)       # nobody unmaps / frees while a peer may still store
+            import ctypes
+            if self._opened:
+                self._N.check("rass_peer_buffer_close", self._L.rass_peer_buffer_close(ctypes.c_void_p(self._base), 1))
+            if self.world > 1:
+                dist.barrier(group=self.group)       # rank 0 frees after every peer has unmapped
+            if not self._opened:
+                self._N.check("rass_peer_buffer_close", self._L.rass_peer_buffer_close(ctypes.c_void_p(self._base), 0))
+            self._base = 0
+
+    def search(self, queries: torch.Tensor, k: int, src: int = 0):
+        import ctypes
+        if self.world > 1:
+            dist.broadcast(queries, src=src, group=self.group)
+        nq = queries.shape[0]
+        self.step += 1
+        seq = self.step
+        rec = self.shard.search_local_packed(queries, k)
+        ids_off, size = HipShard.record_bytes(nq, k)
+        size16 = (size + 15) // 16 * 16
+        if rec.numel() < size16:                    # the copy kernel moves whole 16-byte pieces
+            rec = torch.cat([rec, torch.zeros((size16 - rec.numel(),), dtype=torch.uint8, device=rec.device)])
+        slots = self._base + self.flags_bytes + (seq & 1) * self.world * self.slot_bytes
+        stream = ctypes.c_void_p(int(torch.cuda.current_stream(self.device).cuda_stream))
+        self._N.check("rass_peer_post", self._L.rass_peer_post(
+            ctypes.c_void_p(rec.data_ptr()), size16, ctypes.c_void_p(slots + self.rank * self.slot_bytes),
+            ctypes.c_void_p(self._base + self.rank * self.FLAG_STRIDE), seq, stream))
+        if self.rank != 0:
+            return None
+        self._N.check("rass_peer_wait", self._L.rass_peer_wait(
+            ctypes.c_void_p(self._base), self.world, self.FLAG_STRIDE, seq, ctypes.c_void_p(self._status.data_ptr()),
+            self.MAX_SPINS, stream))
+        out_s = torch.empty((nq, k), dtype=torch.float32, device=self.device)
+        out_i = torch.empty((nq, k), dtype=torch.int64, device=self.device)
+        self._N.check("rass_topk_merge_strided", self._L.rass_topk_merge_strided(
+            ctypes.c_void_p(slots), ctypes.c_void_p(slots + ids_off), self.slot_bytes // 4, self.slot_bytes // 8,
+            self.world, nq, k, ctypes.c_void_p(out_s.data_ptr()), ctypes.c_void_p(out_i.data_ptr()), stream))
+        return out_s, out_i
+
+    def check(self) -> None:
+        """Rank 0: raise if a wait gave up (a peer never posted)."""
+        if self.rank == 0:
+            st = int(self._status.item())
+            if st:
+                raise RuntimeError(f"peer-store exchange: rank {st - 1} never posted its record")

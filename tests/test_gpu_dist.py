@@ -211,3 +211,57 @@ def test_shim_over_sharded_hip_index_equals_single_hip_index(gpu, tmp_path, back
         else:
             assert a.tolist() == b.tolist(), (k, a, b)
     assert int(z["single_count"]) == 90 and int(z["single_rows"]) == 92 and len(z["single_sem_ids"]) == 10
+
+
+def _peer_worker(rank, world, port, n_local, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from rassengine_amd.dist import HipShard, PeerMergeSearch, ShardedSearch
+        from rassengine_amd.engine import Engine
+        eng = Engine(0, 1024)
+        idx = eng.open_index("shard", capacity_rows=n_local)
+        idx.fill_synthetic(n_local, seed=91, row_id_base=rank * n_local)
+        eng.synchronize()
+        shard = HipShard(idx, id_base=rank * n_local)
+        peer = PeerMergeSearch(shard)
+        gather = ShardedSearch(shard)
+        g = torch.Generator(device="cpu")
+        g.manual_seed(8)
+        out = {}
+        for step, (nq, k) in enumerate([(32, 10), (5, 32), (17, 3), (32, 10), (1, 1)] * 6):   # 30 steps: both parities
+            q_all = torch.randn((nq, 1024), generator=g).cuda()
+            q = q_all.clone() if rank == 0 else torch.zeros_like(q_all)
+            res = peer.search(q, k)
+            s2, i2 = gather.search(q.clone(), k, broadcast=False)        # q already holds the broadcast queries
+            if rank == 0:
+                s1, i1 = res
+                peer.check()
+                out[f"ok{step}"] = np.array(bool(torch.equal(i1, i2) and torch.equal(s1, s2)))
+                out[f"both{step}"] = np.array(bool((i1 >= n_local).any() and (i1 < n_local).any()) or nq * k < 4)
+            else:
+                assert res is None
+        torch.cuda.synchronize()
+        peer.close()
+        if rank == 0:
+            np.savez(os.path.join(out_dir, "peer.npz"), **out)
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_peer_store_merge_equals_all_gather_merge(gpu, tmp_path):
+    """per-shard top-k records stored straight into rank 0's buffer (HIP IPC mapping) + system-scope
+    flags + bounded wait, instead of the all-gather: 30 steps of varying (nq, k) on 2 ranks sharing the test GPU must
+    give rank 0 exactly the all-gather path's result, hits from both shards included."""
+    import torch.multiprocessing as mp
+    mp.spawn(_peer_worker, args=(2, _free_port(), 20000, str(tmp_path)), nprocs=2, join=True)
+    z = np.load(os.path.join(str(tmp_path), "peer.npz"))
+    assert len(z.files) == 60
+    assert all(bool(z[k]) for k in z.files), [k for k in z.files if not bool(z[k])]

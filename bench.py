@@ -51,6 +51,9 @@ def main():
     ap.add_argument("--cpu-hnsw-rows", type=int, default=8_000,
                     help="rows of the HNSW restatement's sample (cpu_baseline.hnsw); 0 disables it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--merge", choices=["allgather", "peer"], default="allgather",
+                    help="cross-shard exchange for N > 1: one RCCL all-gather (default) or peer stores into rank 0's "
+                         "buffer + flags (SURVEY 8f-4; validated on 2 ranks sharing a GPU only)")
     ap.add_argument("--corpus-dtype", choices=["f32", "bf16"], default="f32",
                     help="bf16: FLAGGED mode, never the headline: a bf16-only corpus (RASS_BF16), half the bytes per "
                          "scan, scores within ~1e-3 of the fp32 cosine; recall@k vs the fp32 index is reported")
@@ -80,7 +83,7 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    from rassengine_amd.dist import HipShard, ShardedSearch, shard_bounds
+    from rassengine_amd.dist import HipShard, PeerMergeSearch, ShardedSearch, shard_bounds
     from rassengine_amd.engine import Engine, scan_kernel_name
 
     dim, B, k = args.dim, args.batch, args.k
@@ -100,7 +103,7 @@ def main():
     eng.synchronize()
 
     shard = HipShard(idx, id_base=row_lo)  # switches the engine to torch's current stream
-    search = ShardedSearch(shard)
+    search = PeerMergeSearch(shard) if (args.merge == "peer" and world > 1) else ShardedSearch(shard)
     gen = torch.Generator(device=dev)
     gen.manual_seed(4321)
     pool = torch.randn((args.query_pool, dim), generator=gen, device=dev)  # same on every rank (same seed)
@@ -109,13 +112,24 @@ def main():
 
     LPS = args.launches_per_step
 
+    step_q = torch.empty((LPS * B, dim), device=dev)
+    batched = world > 1 and isinstance(search, ShardedSearch)
+
     def step(i: int):
+        if batched:
+            # N > 1: the step's 1 024 queries travel in ONE broadcast, the per-shard top-k of its 32 launch groups
+            # in ONE all-gather (2 collectives per step instead of 64), then one strided merge per group
+            if rank == 0:
+                for j in range(LPS):
+                    g = (i * LPS + j) % n_batches
+                    step_q[j * B:(j + 1) * B].copy_(pool[g * B:(g + 1) * B])
+            return search.search_batch(step_q, k, B)
         out = None
         for j in range(LPS):   # one step = LPS launch groups of B queries each
             g = (i * LPS + j) % n_batches
             if rank == 0:
                 q_buf.copy_(pool[g * B:(g + 1) * B])
-            out = search.search(q_buf, k)  # broadcast (N>1) + scan + all-gather + merge
+            out = search.search(q_buf, k)  # scan + merge (N = 1), or the peer-store exchange per group
         return out
 
     # EXACTLY --warmup untimed steps, nothing else.
@@ -173,7 +187,8 @@ def main():
             "queries_per_step": B * LPS, "launch_groups_per_step": LPS,
             "corpus_dtype": "bf16 only (fp32-accumulated bf16 MFMA)" if bf16 else
                             "f32" if not args.prefilter else "f32 + bf16 candidate copy (exact fp32 re-rank)",
-            "layout": "tile16b" if bf16 else "tile16", "mode": "prefilter" if args.prefilter else "flat", "sharding": f"row-sharded x{world}, RCCL all-gather merge"
+            "layout": "tile16b" if bf16 else "tile16", "mode": "prefilter" if args.prefilter else "flat",
+            "cross_shard_exchange": ("peer stores + flags" if args.merge == "peer" else "RCCL all-gather") if world > 1 else None, "sharding": f"row-sharded x{world}, RCCL all-gather merge"
             if world > 1 else "single shard",
             "aggregate_scan_GBps": round(bytes_per_launch * world * args.steps * LPS / elapsed / 1e9, 1),
         },
@@ -251,6 +266,9 @@ def main():
 
     if rank == 0:
         print(json.dumps(result), flush=True)
+    if isinstance(search, PeerMergeSearch):
+        search.check()
+        search.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

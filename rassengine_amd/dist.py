@@ -82,6 +82,27 @@ class HipShard:
                                                 ctypes.c_void_p(int(torch.cuda.current_stream(self.device).cuda_stream))))
         return out_s, out_i
 
+    def search_local_packed_into(self, queries: torch.Tensor, k: int, rec: torch.Tensor) -> None:
+        """Same, into a caller-owned record (a slice of a batch's record buffer)."""
+        nq = queries.shape[0]
+        ids_off, size = self.record_bytes(nq, k)
+        assert rec.numel() >= size and rec.data_ptr() % 8 == 0
+        self.index.search_device(queries.data_ptr(), nq, k, rec.data_ptr(), rec.data_ptr() + ids_off,
+                                 id_base=self.id_base)
+
+    def merge_packed_group(self, gathered: torch.Tensor, world: int, group: int, groups: int, nq: int, k: int,
+                           out_s: torch.Tensor, out_i: torch.Tensor) -> None:
+        """Merge launch group ``group`` of a gathered [world][groups][record] buffer into out_s / out_i."""
+        import ctypes
+        from . import _native as N
+        ids_off, size = self.record_bytes(nq, k)
+        base = gathered.data_ptr() + group * size
+        N.check("rass_topk_merge_strided",
+                N.lib().rass_topk_merge_strided(ctypes.c_void_p(base), ctypes.c_void_p(base + ids_off), groups * size // 4,
+                                                groups * size // 8, world, nq, k, ctypes.c_void_p(out_s.data_ptr()),
+                                                ctypes.c_void_p(out_i.data_ptr()),
+                                                ctypes.c_void_p(int(torch.cuda.current_stream(self.device).cuda_stream))))
+
     def search_local(self, queries: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
         nq = queries.shape[0]
         out_s = torch.empty((nq, k), dtype=torch.float32, device=self.device)
@@ -125,6 +146,39 @@ class ShardedSearch:
         dist.all_gather_into_tensor(gath_s.view(self.world * nq, k), loc_s.contiguous(), group=self.group)
         dist.all_gather_into_tensor(gath_i.view(self.world * nq, k), loc_i.contiguous(), group=self.group)
         return self.shard.merge(gath_s, gath_i)
+
+
+def search_batch(self: "ShardedSearch", queries: torch.Tensor, k: int, group_size: int = 32, src: int = 0
+                 ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """A whole batch of queries [n, dim] (n a multiple of ``group_size`` <= 32, the kernel's queries per launch)
+    with TWO collectives however many launch groups it takes: one broadcast of the batch, the groups' local
+    scans into one record buffer, ONE all-gather of [groups][record], one strided merge per group.  Returns
+    (scores [n, k], global ids [n, k]) on every rank.  (Per-group ``search`` costs a broadcast + an all-gather
+    per 32 queries: 64 collectives for a 1 024-query batch.)"""
+    n = queries.shape[0]
+    assert n % group_size == 0 and getattr(self.shard, "packed", False)
+    groups = n // group_size
+    if self.world > 1:
+        dist.broadcast(queries, src=src, group=self.group)
+    dev = queries.device
+    _, size = HipShard.record_bytes(group_size, k)
+    recs = torch.empty((groups * size,), dtype=torch.uint8, device=dev)
+    for g in range(groups):
+        self.shard.search_local_packed_into(queries[g * group_size:(g + 1) * group_size], k, recs[g * size:(g + 1) * size])
+    if self.world > 1:
+        gathered = torch.empty((self.world * recs.numel(),), dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(gathered, recs, group=self.group)
+    else:
+        gathered = recs
+    out_s = torch.empty((n, k), dtype=torch.float32, device=dev)
+    out_i = torch.empty((n, k), dtype=torch.int64, device=dev)
+    for g in range(groups):
+        self.shard.merge_packed_group(gathered, self.world, g, groups, group_size, k,
+                                      out_s[g * group_size:(g + 1) * group_size], out_i[g * group_size:(g + 1) * group_size])
+    return out_s, out_i
+
+
+ShardedSearch.search_batch = search_batch
 
 
 class PeerMergeSearch:

@@ -47,6 +47,14 @@ def _worker(rank, world, port, n_local, out_dir, backend="gloo"):
         q = q_all.clone() if rank == 0 else torch.zeros_like(q_all)   # only rank 0 holds the batch
         s, i = search.search(q, 10)
         torch.cuda.synchronize()
+        # a 96-query batch in 3 launch groups: 2 collectives in all, same answers as group-by-group
+        qb_all = torch.randn((96, 1024), generator=g).cuda()
+        qb = qb_all.clone() if rank == 0 else torch.zeros_like(qb_all)
+        sb, ib = search.search_batch(qb, 10, 32)
+        for j in range(3):
+            sj, ij = search.search(qb[32 * j:32 * j + 32].clone(), 10, broadcast=False)
+            assert torch.equal(ij, ib[32 * j:32 * j + 32]) and torch.equal(sj, sb[32 * j:32 * j + 32])
+        torch.cuda.synchronize()
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), s=s.cpu().numpy(), i=i.cpu().numpy(), q=q.cpu().numpy())
         eng.close()
     finally:

@@ -89,7 +89,7 @@ struct ScanExt {
 };
 
 struct ScratchLayout {
-    size_t q_padded, part_scores, part_ids, q_bf16, cand_scores, cand_ids, total;
+    size_t q_padded, part_scores, part_ids, q_bf16, cand_scores, cand_ids, sample_best, total;
 };
 
 ScratchLayout scratch_layout(int nq, int k) {
@@ -112,6 +112,8 @@ ScratchLayout scratch_layout(int nq, int k) {
     L.cand_ids = off;
     off += (size_t)RASS_MAX_QBATCH * RASS_MAX_K * sizeof(int64_t);
     off = (off + 255) / 256 * 256;
+    L.sample_best = off;  // the sample pass's per-workgroup best scores [32][kMaxSampleGroups]
+    off += (size_t)rass::kMaxSampleGroups * 32 * sizeof(float);
     L.total = off;
     return L;
 }
@@ -296,6 +298,22 @@ int scan_xcd_skew(int nq) {
     return nq <= 16 ? skew.b16 : skew.b32;
 }
 
+// The sample floor (ScanArgs::sample_best): before a large flat scan with more than 16 queries, the first tile pair of
+// every workgroup (64 * grid rows, 16,384 on MI355X) is scanned on its own, keeping only each workgroup's best score
+// per query, and the k-th largest of those becomes the big scan's floor: k different rows reach it, so the final
+// k-th best does too.  A row of the slab ranks above that floor with probability ~k / 16,384, so a 1M-row scan feeds
+// ~600 candidates per query to the sorted insertion instead of ~18,000 (256 lists x ~70), for one short extra launch
+// (the sample scan, which does no sorted insertion; the selection runs in the big scan's prologue).  Only worth it where the insertion is on the critical path: with <= 16 queries the scan
+// is HBM-bound and the ranking hides under the loads.  RASS_SCAN_SAMPLE_FLOOR=0 switches it off and =force lowers
+// the size threshold to twice the sample (A/B and tests; results are identical either way; read at every launch so
+// that one process can compare the settings).
+int64_t scan_sample_floor_min_share() {  // the slab must hold at least this many samples; 0 = never sample
+    const char* e = getenv("RASS_SCAN_SAMPLE_FLOOR");
+    if (e && e[0] == '0') return 0;
+    if (e && e[0] == 'f') return 2;
+    return 32;
+}
+
 int scan_launch(const float* d_corpus, int64_t n_rows, int64_t stride, const int32_t* d_row_tag,
                 const float* d_queries, int q_dim, int64_t q_stride, int nq, const int32_t* d_q_filter, int k,
                 int64_t id_base, float* d_out_scores, int64_t* d_out_ids, unsigned char* ws, size_t ws_bytes,
@@ -348,6 +366,20 @@ int scan_launch(const float* d_corpus, int64_t n_rows, int64_t stride, const int
         a.work_rows = plan->work_rows;
         a.work_mask = plan->work_mask;
         a.n_work = plan->n_work;
+    }
+    const int64_t sample_rows = (int64_t)64 * grid;
+    const int64_t min_share = scan_sample_floor_min_share();
+    if (min_share > 0 && !plan && nq > 16 && grid <= rass::kMaxSampleGroups && n_rows >= min_share * sample_rows) {
+        // same filters, same continuation bound, same id space: only the row count differs
+        rass::ScanArgs s = a;
+        s.n_rows = (int)sample_rows;
+        s.xcd_skew = 0;
+        s.sample_pass = true;
+        s.part_scores = reinterpret_cast<float*>(ws + L.sample_best);
+        s.part_ids = nullptr;
+        HIP_TRY(rass::launch_scan_topk_f32(s, grid, st));
+        a.sample_best = s.part_scores;
+        a.sample_groups = grid;
     }
     const bool timed = timing && timing->ev_on && (size_t)(2 * timing->ev_used + 1) < timing->ev_pool.size();
     if (timed) HIP_TRY(hipEventRecord(timing->ev_pool[2 * timing->ev_used], st));

@@ -7,6 +7,8 @@
 
 namespace rass {
 
+constexpr int kMaxSampleGroups = 256;  // workgroups of a sample pass (ScanArgs::sample_best)
+
 struct ScanArgs {
     const float* corpus;      // tile16-packed fp32 slab (see below), rows L2-normalised, zero padded past dim
     const int32_t* row_tag;   // [n_rows] or nullptr; -1 = tombstone, >= 0 = patientId code
@@ -37,6 +39,17 @@ struct ScanArgs {
     // row tags work_tags[i] (may be null per item); ids are rows of THAT slab
     const float* const* work_base = nullptr;
     const int32_t* const* work_tags = nullptr;
+    // The sample floor (nullptr = none).  sample_best[32][kMaxSampleGroups] holds, for g < sample_groups, the best
+    // score per query that workgroup g of a SAMPLE PASS found (the same scan over a small prefix of the slab, run
+    // first with sample_pass = true, which writes exactly this array through part_scores).  Each wave of the big
+    // scan takes, per query, the k-th largest of those as a floor: k different rows reach it, hence so does the
+    // final k-th best, and rows scoring below it are dropped before the sorted insertion.  That insertion is where
+    // the 32-query scan spends its non-MFMA time: every workgroup list otherwise takes ~k(1 + ln(rows/k))
+    // insertions, ~70 at k = 10 over 3,900 rows, most of them in the first iterations.  Results do not depend on
+    // the floor (rows tying with it are kept).
+    const float* sample_best = nullptr;
+    int sample_groups = 0;
+    bool sample_pass = false;  // this launch IS the sample pass (flat, > 16 queries): same code, its own kernel name
     // XCD skew (0 = plain round-robin).  Workgroups land on XCD blockIdx % 8; measured on MI355X
     // (scripts/microbench/scan_tail.hip) the odd XCDs stream ~14 % slower than the even ones when
     // the scan is purely HBM-bound (B <= 16).  With skew s > 0 the even workgroups take s+1 items

@@ -45,7 +45,10 @@ struct WorkItem {
 // Which work a workgroup iterates over: every tile of one slab (flat), the tiles of a device-built probe plan
 // over one slab (IVF), or the tiles of SEVERAL slabs — one per index of a cross-index query batch — each item
 // naming its own slab and tag array (MULTI: concurrent users' per-user indices share one launch).
-enum ScanMode { kFlat = 0, kIvf = 1, kMulti = 2 };
+// kFlatSample is kFlat under its own kernel name: the sample pass that finds the score floors (ScanArgs::floors),
+// kept apart so that per-kernel profiles do not average the short sample launches into the scan's.
+enum ScanMode { kFlat = 0, kIvf = 1, kMulti = 2, kFlatSample = 3 };
+constexpr bool mode_is_flat(int mode) { return mode == kFlat || mode == kFlatSample; }
 
 __device__ __forceinline__ TileDesc make_tile_desc(const float* __restrict__ X, int64_t row_stride,
                                                    const int32_t* __restrict__ row_tag, const WorkItem& w) {
@@ -138,6 +141,16 @@ __device__ __forceinline__ void multiply_and_refill(TileRegs<CH>& r, const f32x4
         between(j);
         __builtin_amdgcn_sched_barrier(0);
     }
+}
+
+// Order-preserving u32 key of a finite float score (larger score <-> larger key; every finite score's key is
+// >= 0x00800000, so 0 can stand for "no score"): the sample floor's selection counts keys by ballot.
+__device__ __forceinline__ unsigned score_key(float s) {
+    const unsigned u = __float_as_uint(s);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_score(unsigned k) {
+    return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k);
 }
 
 // Half-wave sorted list: lanes 0..31 hold query A's best-first top-32, lanes 32..63 query B's.

@@ -53,6 +53,11 @@
 
 namespace rass {
 
+#ifdef RASS_SCAN_DIAG  // diagnostic builds only (scripts/probe_scan_diag.py): launch-wide event counters
+// [0] ranking calls, [1] calls with >= 1 candidate, [2] candidates, [4] candidates the sample floor rejected
+__device__ unsigned long long g_scan_diag[8];
+#endif
+
 #ifdef RASS_SCAN_CLOCKS  // scripts/microbench/scan_tail.hip only: per-workgroup start / end wall clocks
 __device__ unsigned long long g_scan_clocks[2 * 1024];
 __device__ unsigned long long g_scan_core[2];
@@ -80,7 +85,7 @@ struct ItemSeq {
 template <int MODE>
 __device__ __forceinline__ WorkItem get_work(const ScanArgs& p, int i, int n_items) {
     WorkItem w;
-    if (MODE != kFlat) {
+    if (!mode_is_flat(MODE)) {
         const bool ok = i < n_items;
         w.tile = ok ? p.work_tile[i] : 0;
         w.rows = ok ? p.work_rows[i] : 0;
@@ -108,7 +113,7 @@ __device__ __forceinline__ const int32_t* tags_of(const ScanArgs& p, int i, int 
 
 template <int CH, int NT, int MODE, bool EXT>
 __global__ __launch_bounds__(kThreads, 2) void scan_topk_f32_kernel(ScanArgs p) {
-    constexpr bool IVF = MODE != kFlat;  // a work list with per-item query masks
+    constexpr bool IVF = !mode_is_flat(MODE);  // a work list with per-item query masks
     constexpr int NQ = NT * 16;
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [4][kWaves][NQ][kPitch]
 
@@ -150,6 +155,7 @@ __global__ __launch_bounds__(kThreads, 2) void scan_topk_f32_kernel(ScanArgs p) 
     // partial images), not in registers: they are read in the ranking step only, and the main loop has no VGPRs
     // to spare at CH = 8, NT = 2 (the ranking runs between the MFMA chunks, so its operands are live there).
     __shared__ int sh_qfilt[32];
+    __shared__ float sh_floor[32];  // the launch's per-query score floors (ScanArgs::sample_best), -inf without
     __shared__ int sh_tags[4][32];
     __shared__ int sh_qmask[32];
     __shared__ float sh_after_s[32];
@@ -158,6 +164,7 @@ __global__ __launch_bounds__(kThreads, 2) void scan_topk_f32_kernel(ScanArgs p) 
         const int q = threadIdx.x;
         const bool live = q < p.nq;
         sh_qfilt[q] = (p.q_filter != nullptr && live) ? p.q_filter[q] : -1;
+        sh_floor[q] = -INFINITY;
         if (EXT) {
             sh_qmask[q] = (p.q_filter_mask != nullptr && live) ? p.q_filter_mask[q] : -1;
             sh_after_s[q] = (p.q_after_score != nullptr && live) ? p.q_after_score[q] : INFINITY;
@@ -165,6 +172,22 @@ __global__ __launch_bounds__(kThreads, 2) void scan_topk_f32_kernel(ScanArgs p) 
         }
     }
     __syncthreads();
+
+    // The sample pass's per-workgroup best scores of this wave's 2 x NT queries, as order-preserving keys (0 = none):
+    // loaded BEFORE the first tiles so that the selection below runs while those are in flight.
+    unsigned best_key[NT][2][kMaxSampleGroups / 64];
+    if (MODE == kFlat && p.sample_best != nullptr) {
+#pragma unroll
+        for (int pq = 0; pq < NT; ++pq)
+#pragma unroll
+            for (int half = 0; half < 2; ++half)
+#pragma unroll
+                for (int j = 0; j < kMaxSampleGroups / 64; ++j) {
+                    const int grp = lane + 64 * j;
+                    const float v = grp < p.sample_groups ? p.sample_best[(pq * 16 + half * 8 + wid) * kMaxSampleGroups + grp] : -INFINITY;
+                    best_key[pq][half][j] = v == -INFINITY ? 0u : score_key(v);
+                }
+    }
 
     const int mt_step = 16 * (int)p.row_stride * 4;
     TileRegs<CH> R0, R1;
@@ -177,6 +200,34 @@ __global__ __launch_bounds__(kThreads, 2) void scan_topk_f32_kernel(ScanArgs p) 
     issue_tile_loads<CH>(R1, make_tile_desc(slab_of<MODE>(p, t1, n_tiles), p.row_stride, tags_of<MODE>(p, t1, n_tiles), W1),
                          voff_lane, mt_step);
     __builtin_amdgcn_sched_barrier(0);
+
+    // The sample floor of each of this wave's queries: the k-th largest of the sample pass's per-workgroup bests
+    // (those workgroups scanned disjoint rows, so k rows of the slab reach it under the query's filters, and so
+    // does the final k-th best; fewer than k finite entries: no floor).  Radix selection over the keys' top
+    // kFloorBits bits by ballot counts — the truncation only lowers the floor by < 2^-11 of its value.
+    if (MODE == kFlat && p.sample_best != nullptr) {
+        constexpr int kFloorBits = 20;
+        unsigned T[NT][2] = {};
+        // bit by bit, the wave's 2 x NT selections side by side (each is a chain of dependent scalar steps)
+#pragma unroll 1
+        for (int b = 31; b >= 32 - kFloorBits; --b) {
+#pragma unroll
+            for (int pq = 0; pq < NT; ++pq)
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const unsigned cand = T[pq][half] | (1u << b);
+                    int c = 0;
+#pragma unroll
+                    for (int j = 0; j < kMaxSampleGroups / 64; ++j) c += __popcll(__ballot(best_key[pq][half][j] >= cand));
+                    T[pq][half] = c >= p.k ? cand : T[pq][half];
+                }
+        }
+#pragma unroll
+        for (int pq = 0; pq < NT; ++pq)
+#pragma unroll
+            for (int half = 0; half < 2; ++half)
+                if (lane == 0) sh_floor[pq * 16 + half * 8 + wid] = T[pq][half] ? key_score(T[pq][half]) : -INFINITY;
+    }
 
     // A tile's 8 K-partials meet in LDS.  Two tiles share ONE barrier: both are dumped (four LDS
     // images: two per loop iteration, alternating between iterations so a fast wave's next dump never
@@ -191,6 +242,9 @@ __global__ __launch_bounds__(kThreads, 2) void scan_topk_f32_kernel(ScanArgs p) 
             for (int nt = 0; nt < NT; ++nt)
                 *reinterpret_cast<f32x4*>(P + (wid * NQ + nt * 16 + m) * kPitch + mt * 16 + 4 * g) = acc[mt][nt];
     };
+#ifdef RASS_SCAN_DIAG
+    unsigned d_calls = 0, d_any = 0, d_cand = 0, d_rej = 0;
+#endif
     // Rank one (tile, query group pq) of a dumped tile: sum the 8 K-partials in fixed order, filter, insert.
     auto rank_part = [&](const WorkItem& w, int buf, int pq) {
         const float* P = lds + buf * (kWaves * NQ * kPitch);
@@ -214,8 +268,24 @@ __global__ __launch_bounds__(kThreads, 2) void scan_topk_f32_kernel(ScanArgs p) 
             ok = row_ok && (qf1 < 0 || qf1 == tag);
         }
         if (IVF) ok = ok && ((w.mask >> q) & 1u);
+        // the sample floor: k rows of the corpus already score >= floor_q, so a row below it cannot be in the
+        // query's top-k (ties are kept: the id order decides them in the merge)
+        const float floor_q = MODE == kFlat ? sh_floor[q] : -INFINITY;
+#ifdef RASS_SCAN_DIAG
+        d_rej += __popcll(__ballot(ok && s > tau[pq] && s < floor_q));
+#endif
+        if (MODE == kFlat) ok = ok && (s >= floor_q);
         s = ok ? s : -INFINITY;
-        insert_candidates(L[pq], tau[pq], s, row, p.k);
+#ifdef RASS_SCAN_DIAG
+        {
+            const int c = __popcll(__ballot(s > tau[pq]));
+            d_calls += 1; d_any += c != 0; d_cand += c;
+        }
+#endif
+        if (MODE == kFlatSample)
+            L[pq].s = fmaxf(L[pq].s, s);  // the sample pass keeps each row slot's best score, nothing else
+        else
+            insert_candidates(L[pq], tau[pq], s, row, p.k);
     };
 
     // Main loop.  Iteration i multiplies the tile pair (A_i, B_i) and, between the MFMA chunks, ranks the pair
@@ -272,10 +342,31 @@ __global__ __launch_bounds__(kThreads, 2) void scan_topk_f32_kernel(ScanArgs p) 
 #pragma unroll
     for (int pq = 0; pq < NT; ++pq) rank_part(Pb, (pair ^ 2) + 1, pq);
 
+#ifdef RASS_SCAN_DIAG
+    if (lane == 0) {
+        atomicAdd(&g_scan_diag[0], (unsigned long long)d_calls);
+        atomicAdd(&g_scan_diag[1], (unsigned long long)d_any);
+        atomicAdd(&g_scan_diag[2], (unsigned long long)d_cand);
+        atomicAdd(&g_scan_diag[4], (unsigned long long)d_rej);
+    }
+#endif
 #ifdef RASS_SCAN_CLOCKS
     if (threadIdx.x == 0) g_scan_clocks[2 * blockIdx.x + 1] = wall_clock64();
     if (threadIdx.x == 0 && blockIdx.x == 0) g_scan_core[1] = clock64();
 #endif
+    if (MODE == kFlatSample) {
+        // The sample pass: this workgroup's best score per query -> part_scores[32][kMaxSampleGroups] (-inf: no row of the
+        // sample passed the query's filters); the big scan's waves take the k-th largest over the workgroups.
+#pragma unroll
+        for (int pq = 0; pq < NT; ++pq) {
+            float v = L[pq].s;
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 32));
+            const int q = pq * 16 + (lane >> 5) * 8 + wid;
+            if ((lane & 31) == 0) p.part_scores[q * kMaxSampleGroups + (int)blockIdx.x] = q < p.nq ? v : -INFINITY;
+        }
+        return;
+    }
     // Per-workgroup sorted lists -> [gridDim.x][nq][k]
     const int lpos = lane & 31;
 #pragma unroll
@@ -329,6 +420,12 @@ hipError_t launch_scan_topk_f32(const ScanArgs& a, int grid, hipStream_t stream)
     if (!scan_supported_stride(a.row_stride)) return hipErrorInvalidValue;
     const int ch = (int)(a.row_stride / 128);
     const bool ext = a.q_filter_mask || a.q_after_score || a.q_after_id;
+    if (a.sample_pass) {  // the score-floor sample of a flat scan with > 16 queries
+        if (a.work_base != nullptr || a.work_tile != nullptr || a.nq <= 16) return hipErrorInvalidValue;
+        if ((a.q_after_score == nullptr) != (a.q_after_id == nullptr)) return hipErrorInvalidValue;
+        if (a.q_filter_mask != nullptr && a.q_filter == nullptr) return hipErrorInvalidValue;
+        return ext ? launch_ch<2, kFlatSample, true>(ch, a, grid, stream) : launch_ch<2, kFlatSample>(ch, a, grid, stream);
+    }
     if (ext && a.work_base != nullptr) {  // cross-index batch with masked filters
         if (!a.work_tile || !a.work_rows || !a.work_mask || !a.n_work || !a.work_tags) return hipErrorInvalidValue;
         if (a.q_after_score || a.q_after_id) return hipErrorInvalidValue;
@@ -358,3 +455,16 @@ hipError_t launch_scan_topk_f32(const ScanArgs& a, int grid, hipStream_t stream)
 }
 
 }  // namespace rass
+
+#ifdef RASS_SCAN_DIAG
+// read-and-clear the launch counters (diagnostic builds only)
+extern "C" int rassdiag_read(unsigned long long* out, int n) {
+    unsigned long long h[8] = {0};
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(rass::g_scan_diag), sizeof(h)) != hipSuccess) return -2;
+    for (int i = 0; i < n && i < 8; ++i) out[i] = h[i];
+    unsigned long long z[8] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(rass::g_scan_diag), z, sizeof(z)) != hipSuccess) return -3;
+    return 0;
+}
+#endif

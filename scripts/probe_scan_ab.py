@@ -1,5 +1,5 @@
 """A/B timing of the flat scan step across builds of librass_hip (RASS_HIP_LIB) — kernel experiments."""
-import os, sys
+import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from rassengine_amd.engine import Engine, HipTimer
@@ -16,9 +16,11 @@ for b in (32, 16):
         idx.search_device(q.data_ptr(), b, k, os_.data_ptr(), oi.data_ptr())
     eng.synchronize()
     eng.kernel_timing_begin(200)
+    t0 = time.perf_counter()
     for _ in range(200):
         idx.search_device(q.data_ptr(), b, k, os_.data_ptr(), oi.data_ptr())
     eng.synchronize()
+    wall = (time.perf_counter() - t0) / 200
     ms, launches = eng.kernel_timing_end()
-    out.append(f"B={b}: {ms / launches * 1e3:7.1f} us")
-print(os.path.basename(os.environ.get("RASS_HIP_LIB", "default")), "  ".join(out), flush=True)
+    out.append(f"B={b}: scan kernel {ms / launches * 1e3:7.1f} us, whole search {wall * 1e6:7.1f} us")
+print(os.path.basename(os.environ.get("RASS_HIP_LIB", "default")), "sample_floor=" + os.environ.get("RASS_SCAN_SAMPLE_FLOOR", "1"), "  ".join(out), flush=True)

@@ -51,6 +51,10 @@ def main():
     ap.add_argument("--cpu-hnsw-rows", type=int, default=8_000,
                     help="rows of the HNSW restatement's sample (cpu_baseline.hnsw); 0 disables it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--per-group", action="store_true",
+                    help="one engine call per launch group of 32 queries (the N = 1 default) also for N > 1")
+    ap.add_argument("--batched", action="store_true",
+                    help="N = 1: one engine call per 1 024-query step (rass_index_search_device_batch; the N > 1 default)")
     ap.add_argument("--merge", choices=["allgather", "peer"], default="allgather",
                     help="cross-shard exchange for N > 1: one RCCL all-gather (default) or peer stores into rank 0's "
                          "buffer + flags (SURVEY 8f-4; validated on 2 ranks sharing a GPU only)")
@@ -113,12 +117,18 @@ def main():
     LPS = args.launches_per_step
 
     step_q = torch.empty((LPS * B, dim), device=dev)
-    batched = world > 1 and isinstance(search, ShardedSearch)
+    # N > 1: one engine call per step (rass_index_search_device_batch: one normalise + one merge launch for the
+    # step's 32 launch groups), ONE broadcast and ONE all-gather.  N = 1 keeps one engine call per launch group —
+    # the unit a caller of the reference's semantic_search issues — unless --batched: measured on MI355X the two
+    # give the same queries/s (21.09 vs 21.10 ms per step): the chip is power-limited in this kernel, and what the
+    # batch saves in launches and idle gaps (-0.5 ms) comes back as a lower clock in the back-to-back scans
+    # (628 vs 611 us per launch).
+    batched = isinstance(search, ShardedSearch) and B == 32 and not args.per_group and (world > 1 or args.batched)
 
     def step(i: int):
         if batched:
-            # N > 1: the step's 1 024 queries travel in ONE broadcast, the per-shard top-k of its 32 launch groups
-            # in ONE all-gather (2 collectives per step instead of 64), then one strided merge per group
+            # the step's 1 024 queries travel in ONE broadcast, the per-shard top-k of its 32 launch groups in ONE
+            # all-gather (2 collectives per step instead of 64), then one grouped merge launch
             if rank == 0:
                 for j in range(LPS):
                     g = (i * LPS + j) % n_batches
@@ -185,6 +195,7 @@ def main():
                            "(BASELINE configs[1] shard per GPU)"),
             "rows_per_gpu": n_local, "rows_global": rows_global, "dim": dim, "k": k, "query_batch": B,
             "queries_per_step": B * LPS, "launch_groups_per_step": LPS,
+            "engine_calls_per_step": 1 if batched else LPS,
             "corpus_dtype": "bf16 only (fp32-accumulated bf16 MFMA)" if bf16 else
                             "f32" if not args.prefilter else "f32 + bf16 candidate copy (exact fp32 re-rank)",
             "layout": "tile16b" if bf16 else "tile16", "mode": "prefilter" if args.prefilter else "flat",

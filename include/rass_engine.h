@@ -58,6 +58,7 @@ typedef enum rass_dtype {
 #define RASS_MAX_K 32        /* top-k kept in one half-wave sorted list */
 #define RASS_MAX_QBATCH 32   /* queries per scan launch (two 16-wide MFMA N tiles) */
 #define RASS_MAX_K_MULTIPASS 4096 /* rass_index_search_ex: k > RASS_MAX_K is served in passes of RASS_MAX_K */
+#define RASS_MAX_DEVICE_BATCH 4096 /* queries per rass_index_search_device_batch call */
 /* Row tag layout used by the Python shim (the engine itself only compares integers): bits 0..23 the
  * patientId dictionary code (0 = none), bits 24..30 the doc_type code (0 = none).  A masked filter
  * (rass_index_search_ex) selects on either field or both with one compare. */
@@ -196,6 +197,19 @@ int rass_index_search_device_ex(rass_index_t* idx, const float* d_queries,
                                 const int32_t* d_q_filter_mask, int64_t id_base,
                                 float* d_out_scores, int64_t* d_out_ids);
 
+/* Many launch groups in one call (nq <= RASS_MAX_DEVICE_BATCH, k <= RASS_MAX_K): the result is, bit for bit,
+ * that of rass_index_search_device on consecutive groups of RASS_MAX_QBATCH queries, but on an fp32 index the
+ * batch shares ONE normalise launch and ONE merge launch and runs the groups' score-floor sample passes back to
+ * back ahead of the big scans, so the serial tail a lone group pays after its scan is paid once.
+ * This is the shape of the reference's load: embed_texts_in_batches / ask() under concurrent users hand the
+ * engine many queries at once (app/main.py:1536-1560 is called per request; the micro-batcher coalesces them).
+ * Group g's results go to d_out_scores + g * out_scores_group_stride (floats) and d_out_ids + g *
+ * out_ids_group_stride (int64s); 0 = contiguous [nq][k].  d_q_filter: nq tags or NULL. */
+int rass_index_search_device_batch(rass_index_t* idx, const float* d_queries, int nq, int k,
+                                   const int32_t* d_q_filter, int64_t id_base,
+                                   float* d_out_scores, int64_t* d_out_ids,
+                                   int64_t out_scores_group_stride, int64_t out_ids_group_stride);
+
 /* Prefilter mode, OFF by default: keep a bf16 copy of the slab,
  * scan IT (half the HBM bytes per pass, bf16 MFMA) for the 32 best candidates
  * per query, then recompute those candidates' scores exactly from the fp32
@@ -267,6 +281,15 @@ int rass_topk_merge_strided(const float* d_scores, const int64_t* d_ids,
                             int64_t score_list_stride, int64_t id_list_stride,
                             int n_lists, int nq, int k, float* d_out_scores,
                             int64_t* d_out_ids, void* stream);
+
+/* The same merge for several launch groups in ONE launch: query q of nq_total belongs to group q / group_size,
+ * whose lists start g * score_group_stride / id_group_stride elements after group 0's (the gathered
+ * [rank][group][record] buffer of dist.ShardedSearch.search_batch); output contiguous [nq_total][k]. */
+int rass_topk_merge_strided_batch(const float* d_scores, const int64_t* d_ids,
+                                  int64_t score_list_stride, int64_t id_list_stride,
+                                  int n_lists, int nq_total, int group_size,
+                                  int64_t score_group_stride, int64_t id_group_stride, int k,
+                                  float* d_out_scores, int64_t* d_out_ids, void* stream);
 
 /* the cross-shard exchange without a collective.  Rank 0 creates a buffer in its HBM and hands
  * the 64-byte HIP IPC handle to the other ranks' processes (one process per GPU); every rank then STORES its

@@ -75,6 +75,9 @@ SIGNATURES = {
     "rass_index_search_device_ex": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
                                                    ctypes.c_void_p]),
+    "rass_index_search_device_batch": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                                      ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                                                      ctypes.c_int64, ctypes.c_int64]),
     "rass_index_set_prefilter": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "rass_index_get_prefilter": (ctypes.c_int, [ctypes.c_void_p]),
     "rass_index_save": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p]),
@@ -96,6 +99,10 @@ SIGNATURES = {
     "rass_topk_merge_strided": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
                                                ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                                                ctypes.c_void_p, ctypes.c_void_p]),
+    "rass_topk_merge_strided_batch": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+                                                     ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64,
+                                                     ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                                     ctypes.c_void_p]),
     "rass_normalize_rows_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
                                                ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
     "rass_peer_buffer_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_size_t, c_void_pp, ctypes.c_char_p]),

@@ -62,10 +62,20 @@ hipError_t launch_scan_topk_f32(const ScanArgs& a, int grid, hipStream_t stream)
 
 // [n_lists][nq][k] sorted candidate lists -> [nq][k]; n_lists * k <= kMergeMaxCandidates.
 constexpr int kMergeMaxCandidates = 8192;
+// `groups` (optional): ONE launch merges the lists of several launch groups of <= size queries each; nq is then
+// the total query count, blockIdx / size the group, and every pointer advances by its *_stride per group (in
+// elements).  lists_are_dense: a group's lists are [n_lists][nq_g][k] with nq_g its own query count (the scan's
+// per-workgroup lists); otherwise the caller's list strides hold for every group (gathered packed records).
+struct MergeGroups {
+    int size = 0;  // 0 = ungrouped
+    int nq_total = 0;
+    bool lists_are_dense = false;
+    int64_t score_stride = 0, id_stride = 0, out_score_stride = 0, out_id_stride = 0;
+};
 hipError_t launch_merge_topk(const float* scores, const int64_t* ids, int n_lists, int nq, int k,
                              float* out_scores, int64_t* out_ids, hipStream_t stream,
                              const int64_t* id_map = nullptr, int64_t score_list_stride = 0,
-                             int64_t id_list_stride = 0);
+                             int64_t id_list_stride = 0, const MergeGroups* groups = nullptr);
 
 // ---- bf16 candidate scan + exact re-rank (scan_bf16.hip)
 struct ScanBf16Args {

@@ -91,10 +91,25 @@ __global__ __launch_bounds__(kMergeThreads) void merge_topk_kernel(const float* 
                                                                    int /*nq = gridDim.x*/, int k, float* __restrict__ out_scores,
                                                                    int64_t* __restrict__ out_ids,
                                                                    const int64_t* __restrict__ id_map,
-                                                                   int64_t score_list_stride, int64_t id_list_stride) {
+                                                                   int64_t score_list_stride, int64_t id_list_stride,
+                                                                   MergeGroups grp) {
     __shared__ float sh_s[kMergeWaves * 32];
     __shared__ int64_t sh_i[kMergeWaves * 32];
-    const int q = blockIdx.x;
+    // Grouped form (grp.size > 0): blockIdx.x counts the queries of SEVERAL launch groups; group g's lists start
+    // grp.*_stride elements after group g-1's and hold min(grp.size, nq_total - g*size) queries each.
+    int q = blockIdx.x;
+    if (grp.size > 0) {
+        const int g = q / grp.size;
+        q -= g * grp.size;
+        scores += (int64_t)g * grp.score_stride;
+        ids += (int64_t)g * grp.id_stride;
+        out_scores += (int64_t)g * grp.out_score_stride;
+        out_ids += (int64_t)g * grp.out_id_stride;
+        if (grp.lists_are_dense) {  // [n_lists][nq_g][k] per group: the list stride follows the group's query count
+            const int nq_g = min(grp.size, grp.nq_total - g * grp.size);
+            score_list_stride = id_list_stride = (int64_t)nq_g * k;
+        }
+    }
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int n = n_lists * k;
@@ -157,13 +172,18 @@ __global__ __launch_bounds__(kMergeThreads) void merge_topk_kernel(const float* 
 
 hipError_t launch_merge_topk(const float* scores, const int64_t* ids, int n_lists, int nq, int k,
                              float* out_scores, int64_t* out_ids, hipStream_t stream, const int64_t* id_map,
-                             int64_t score_list_stride, int64_t id_list_stride) {
+                             int64_t score_list_stride, int64_t id_list_stride, const MergeGroups* groups) {
     const int64_t n = (int64_t)n_lists * k;
     if (n_lists < 1 || nq < 1 || k < 1 || k > 32 || n > kMergeMaxCandidates) return hipErrorInvalidValue;
     if (score_list_stride <= 0) score_list_stride = (int64_t)nq * k;
     if (id_list_stride <= 0) id_list_stride = (int64_t)nq * k;
+    MergeGroups grp;
+    if (groups) {
+        grp = *groups;
+        if (grp.size < 1 || grp.nq_total != nq) return hipErrorInvalidValue;
+    }
     hipLaunchKernelGGL(merge_topk_kernel, dim3(nq), dim3(kMergeThreads), 0, stream, scores, ids, n_lists, nq, k,
-                       out_scores, out_ids, id_map, score_list_stride, id_list_stride);
+                       out_scores, out_ids, id_map, score_list_stride, id_list_stride, grp);
     return hipGetLastError();
 }
 

@@ -103,6 +103,39 @@ class HipShard:
                                                 ctypes.c_void_p(out_i.data_ptr()),
                                                 ctypes.c_void_p(int(torch.cuda.current_stream(self.device).cuda_stream))))
 
+    def search_local_packed_batch_into(self, queries: torch.Tensor, k: int, group_size: int, recs: torch.Tensor) -> None:
+        """All launch groups of a batch in ONE engine call (``rass_index_search_device_batch``): group g's packed
+        record lands at recs[g * record_size:].  Needs group_size = 32, the engine's launch group."""
+        n = queries.shape[0]
+        ids_off, size = self.record_bytes(group_size, k)
+        assert group_size == 32 and n % group_size == 0 and recs.numel() >= (n // group_size) * size
+        assert recs.data_ptr() % 8 == 0 and queries.is_contiguous()
+        self.index.search_device_batch(queries.data_ptr(), n, k, recs.data_ptr(), recs.data_ptr() + ids_off,
+                                       id_base=self.id_base, out_scores_group_stride=size // 4,
+                                       out_ids_group_stride=size // 8)
+
+    def merge_packed_batch(self, gathered: torch.Tensor, world: int, groups: int, group_size: int, k: int,
+                           out_s: torch.Tensor, out_i: torch.Tensor) -> None:
+        """ONE merge launch over a gathered [world][groups][record] buffer -> out_s / out_i [groups * group_size, k]."""
+        import ctypes
+        from . import _native as N
+        ids_off, size = self.record_bytes(group_size, k)
+        base = gathered.data_ptr()
+        N.check("rass_topk_merge_strided_batch",
+                N.lib().rass_topk_merge_strided_batch(
+                    ctypes.c_void_p(base), ctypes.c_void_p(base + ids_off), groups * size // 4, groups * size // 8, world,
+                    groups * group_size, group_size, size // 4, size // 8, k, ctypes.c_void_p(out_s.data_ptr()),
+                    ctypes.c_void_p(out_i.data_ptr()),
+                    ctypes.c_void_p(int(torch.cuda.current_stream(self.device).cuda_stream))))
+
+    def search_local_batch(self, queries: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Single shard: a whole batch [n, dim] -> (scores [n, k], ids [n, k]) in one engine call."""
+        n = queries.shape[0]
+        out_s = torch.empty((n, k), dtype=torch.float32, device=self.device)
+        out_i = torch.empty((n, k), dtype=torch.int64, device=self.device)
+        self.index.search_device_batch(queries.data_ptr(), n, k, out_s.data_ptr(), out_i.data_ptr(), id_base=self.id_base)
+        return out_s, out_i
+
     def search_local(self, queries: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
         nq = queries.shape[0]
         out_s = torch.empty((nq, k), dtype=torch.float32, device=self.device)
@@ -160,11 +193,17 @@ def search_batch(self: "ShardedSearch", queries: torch.Tensor, k: int, group_siz
     groups = n // group_size
     if self.world > 1:
         dist.broadcast(queries, src=src, group=self.group)
+    elif group_size == 32 and hasattr(self.shard, "search_local_batch"):
+        return self.shard.search_local_batch(queries, k)   # one shard: nothing to exchange or merge again
     dev = queries.device
     _, size = HipShard.record_bytes(group_size, k)
     recs = torch.empty((groups * size,), dtype=torch.uint8, device=dev)
-    for g in range(groups):
-        self.shard.search_local_packed_into(queries[g * group_size:(g + 1) * group_size], k, recs[g * size:(g + 1) * size])
+    one_call = group_size == 32 and hasattr(self.shard, "search_local_packed_batch_into")
+    if one_call:    # every group's scan in one engine call: one normalise + one merge launch for the batch
+        self.shard.search_local_packed_batch_into(queries, k, group_size, recs)
+    else:
+        for g in range(groups):
+            self.shard.search_local_packed_into(queries[g * group_size:(g + 1) * group_size], k, recs[g * size:(g + 1) * size])
     if self.world > 1:
         gathered = torch.empty((self.world * recs.numel(),), dtype=torch.uint8, device=dev)
         dist.all_gather_into_tensor(gathered, recs, group=self.group)
@@ -172,9 +211,12 @@ def search_batch(self: "ShardedSearch", queries: torch.Tensor, k: int, group_siz
         gathered = recs
     out_s = torch.empty((n, k), dtype=torch.float32, device=dev)
     out_i = torch.empty((n, k), dtype=torch.int64, device=dev)
-    for g in range(groups):
-        self.shard.merge_packed_group(gathered, self.world, g, groups, group_size, k,
-                                      out_s[g * group_size:(g + 1) * group_size], out_i[g * group_size:(g + 1) * group_size])
+    if one_call:
+        self.shard.merge_packed_batch(gathered, self.world, groups, group_size, k, out_s, out_i)
+    else:
+        for g in range(groups):
+            self.shard.merge_packed_group(gathered, self.world, g, groups, group_size, k,
+                                          out_s[g * group_size:(g + 1) * group_size], out_i[g * group_size:(g + 1) * group_size])
     return out_s, out_i
 
 

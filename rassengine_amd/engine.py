@@ -262,6 +262,18 @@ class FlatIndex:
                                                     ctypes.c_void_p(d_q_filter_mask_ptr or 0), int(id_base),
                                                     ctypes.c_void_p(d_out_scores_ptr), ctypes.c_void_p(d_out_ids_ptr)))
 
+    def search_device_batch(self, d_queries_ptr: int, nq: int, k: int, d_out_scores_ptr: int, d_out_ids_ptr: int,
+                            id_base: int = 0, d_q_filter_ptr: int = 0, out_scores_group_stride: int = 0,
+                            out_ids_group_stride: int = 0) -> None:
+        """Async, device-resident, MANY launch groups per call (nq <= 4096, k <= 32): bit-identical to
+        ``search_device`` on consecutive groups of 32 queries, with one normalise and one merge launch for the whole
+        batch.  Group g's results go to out + g * group_stride (elements; 0 = contiguous [nq][k])."""
+        N.check("rass_index_search_device_batch",
+                self._L.rass_index_search_device_batch(self._h, ctypes.c_void_p(d_queries_ptr), int(nq), int(k),
+                                                       ctypes.c_void_p(d_q_filter_ptr or 0), int(id_base),
+                                                       ctypes.c_void_p(d_out_scores_ptr), ctypes.c_void_p(d_out_ids_ptr),
+                                                       int(out_scores_group_stride), int(out_ids_group_stride)))
+
 
 class HipTimer:
     """hipEvent pair on an explicit stream (rass_timer_*)."""

@@ -26,6 +26,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
+
 #include "encoder_kernels.h"
 
 namespace rass {
@@ -33,6 +35,7 @@ namespace rass {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int GBM = 128, GBN = 128, GBK = 64;
 constexpr int kGemmThreads = 256;
@@ -738,6 +741,314 @@ static hipError_t launch_pring(const u16* X, const u16* W, const float* bias, co
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------
+// 4-wave form: one workgroup of FOUR waves per CU, every wave a 128 x 128 tile (64 MFMAs per K step of 32 against
+// 16 fragment reads: two thirds of the 8-wave kernel's LDS reads per MFMA, one barrier per K step instead of two,
+// no second wave competing for the SIMD's issue slots).  What makes it possible:
+//   * the 256 fp32 accumulators live in AGPRs: the MFMA is issued as inline asm with "a" constraints (the builtin
+//     form made hipcc spill 115 registers and shuffle accumulators through v_accvgpr_mov, DESIGN round 1);
+//   * with one wave per SIMD nothing hides a wave's own LDS latency, so the fragments are double-buffered in
+//     registers: the 16 ds_read_b128 of step t+1 are issued between the MFMA rows of step t;
+//   * a 4-slot ring, DMA three steps ahead: a step has two full K steps to land;
+//   * no LDS transpose in the epilogue.  The W rows are staged PERMUTED: MFMA row rho of M-tile i holds output
+//     feature 32*(rho>>2) + 4*i + (rho&3) of the wave's 128, so the 4 accumulator rows a lane owns in the 8 tiles
+//     of a token column are 32 CONSECUTIVE features — bias, residual, GELU and the bf16 pack happen in registers
+//     and a lane writes its 64 contiguous bytes with four 16-B stores (the permutation costs nothing: a DMA
+//     lane computes its own source row either way).
+constexpr int kW4Threads = 256;
+constexpr int kW4Slots = 4;
+constexpr int kW4Ahead = 3;
+constexpr int kW4LdsBytes = kW4Slots * kRingSlotBytes;  // 128 KiB
+
+#define RASS_MFMA_BF16_ACC(acc, a, b) \
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b))
+#define RASS_MFMA_BF16_NEW(acc, a, b) \
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(acc) : "v"(a), "v"(b))
+
+template <int EPI>
+__global__ __launch_bounds__(kW4Threads) void gemm_bf16_w4_kernel(const u16* __restrict__ X, const u16* __restrict__ W,
+                                                                  const float* __restrict__ bias,
+                                                                  const u16* __restrict__ residual, u16* __restrict__ Y,
+                                                                  int M, int N, int K, int tiles_total) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wn = wave >> 1, wm = wave & 1;
+    const int G = gridDim.x, orig = blockIdx.x;
+    const int pos = (G % 8 == 0) ? (orig % 8) * (G / 8) + orig / 8 : orig;
+    int tile = pos;
+    if (tile >= tiles_total) return;
+    const int tiles_n = N / RBN;
+    const int nk = K / RBK;  // >= kW4Ahead (launcher)
+
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    unsigned offA0, offB0;
+    {
+        const int rowA = wn * 128 + (lane & 15), rowB = wm * 128 + (lane & 15);
+        offA0 = rowA * 64 + (((lane >> 4) ^ (((rowA >> 3) & 1) * 3)) * 16);
+        offB0 = kRingTileBytes + rowB * 64 + (((lane >> 4) ^ (((rowB >> 3) & 1) * 3)) * 16);
+    }
+    // DMA: an operand tile is 16 pieces of 16 rows x 64 B; this wave moves pieces wave, wave+4, wave+8, wave+12
+    const u16* srcW[4];
+    const u16* srcX[4];
+    auto point_at = [&](int t) {
+        const int tn0 = (t % tiles_n) * RBN, tm0 = (t / tiles_n) * RBM;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int r = (wave + 4 * p) * 16 + (lane >> 2);  // row of the LDS image
+            const int c_src = (lane & 3) ^ (((r >> 3) & 1) * 3);
+            // W: image row (half h, M-tile i, MFMA row rho) <- feature h*128 + 32*(rho>>2) + 4*i + (rho&3)
+            const int rho = r & 15, i = (r >> 4) & 7, h = r >> 7;
+            const int feat = h * 128 + 32 * (rho >> 2) + 4 * i + (rho & 3);
+            srcW[p] = W + (int64_t)(tn0 + feat) * K + c_src * 8;
+            srcX[p] = X + (int64_t)(tm0 + r) * K + c_src * 8;
+        }
+    };
+    auto stage_step = [&](int slot) {
+        unsigned char* slot_base = lds + slot * kRingSlotBytes;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)srcW[p],
+                                             (__attribute__((address_space(3))) void*)(slot_base + (wave + 4 * p) * 1024),
+                                             16, 0, 0);
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)srcX[p],
+                (__attribute__((address_space(3))) void*)(slot_base + kRingTileBytes + (wave + 4 * p) * 1024), 16, 0, 0);
+            srcW[p] += RBK;
+            srcX[p] += RBK;
+        }
+    };
+
+    f32x4 acc[8][8];
+    bf16x8 fa[2][8], fb[2][8];
+    // fragments of a step: a[i] = W image rows wn*128 + 16i.., b[j] = X image rows wm*128 + 16j.. (1 KiB apart)
+#define RASS_W4_READ_A(set, i, slot) RASS_DS_READ_B128(fa[set][i], lds_base + (slot) * kRingSlotBytes + offA0, 0 + 1024 * (i))
+#define RASS_W4_READ_B(set, j, slot) RASS_DS_READ_B128(fb[set][j], lds_base + (slot) * kRingSlotBytes + offB0, 0 + 1024 * (j))
+    auto read_frags = [&fa, &fb, lds_base, offA0, offB0](auto set_c, int slot) {
+        constexpr int set = decltype(set_c)::value;
+        const unsigned ab = lds_base + slot * kRingSlotBytes + offA0;
+        const unsigned bb = lds_base + slot * kRingSlotBytes + offB0;
+        RASS_DS_READ_B128(fa[set][0], ab, 0);    RASS_DS_READ_B128(fb[set][0], bb, 0);
+        RASS_DS_READ_B128(fa[set][1], ab, 1024); RASS_DS_READ_B128(fb[set][1], bb, 1024);
+        RASS_DS_READ_B128(fa[set][2], ab, 2048); RASS_DS_READ_B128(fb[set][2], bb, 2048);
+        RASS_DS_READ_B128(fa[set][3], ab, 3072); RASS_DS_READ_B128(fb[set][3], bb, 3072);
+        RASS_DS_READ_B128(fa[set][4], ab, 4096); RASS_DS_READ_B128(fb[set][4], bb, 4096);
+        RASS_DS_READ_B128(fa[set][5], ab, 5120); RASS_DS_READ_B128(fb[set][5], bb, 5120);
+        RASS_DS_READ_B128(fa[set][6], ab, 6144); RASS_DS_READ_B128(fb[set][6], bb, 6144);
+        RASS_DS_READ_B128(fa[set][7], ab, 7168); RASS_DS_READ_B128(fb[set][7], bb, 7168);
+    };
+
+    // One K step.  FIRST: the tile's first step writes the accumulators instead of adding to them.
+    // PREFETCHED: steps 1 and 2 of a tile were in flight before the previous tile's epilogue, whose own global
+    // reads (issued after them, consumed there) retired them: no DMA wait, which would also wait for that
+    // epilogue's stores.
+    // One K step, everything about its place in the tile known at compile time (no branch in the MFMA stream):
+    //   FIRST  the tile's first step writes the accumulators instead of adding to them
+    //   WAIT   own DMA pieces of step t+1: 8 = vmcnt(8) (step t+2 stays in flight), 0 = vmcnt(0), -1 = none (steps
+    //          1, 2 of a tile were prefetched and retired before the previous epilogue ended; the last step has no
+    //          successor) — a wait there would also wait for that epilogue's stores
+    //   STAGE  step t+3 exists and goes out after the barrier;  READS  step t+1 exists: its fragments are requested
+    auto kstep = [&fa, &fb, &acc, &stage_step, lds_base, offA0, offB0](auto set_c, auto first_c, auto wait_c, auto stage_c,
+                                                                    auto reads_c, int slot) {
+        constexpr int set = decltype(set_c)::value;
+        constexpr bool first = decltype(first_c)::value;
+        constexpr int wait = decltype(wait_c)::value;
+        constexpr bool stage = decltype(stage_c)::value;
+        constexpr bool reads = decltype(reads_c)::value;
+        const int slot1 = (slot + 1) & 3, slot3 = (slot + 3) & 3;
+        const unsigned ab = lds_base + slot1 * kRingSlotBytes + offA0;
+        const unsigned bb = lds_base + slot1 * kRingSlotBytes + offB0;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this step's fragments
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (first) RASS_MFMA_BF16_NEW(acc[0][j], fa[set][0], fb[set][j]);
+            else RASS_MFMA_BF16_ACC(acc[0][j], fa[set][0], fb[set][j]);
+        }
+        // step t+1 has landed in every wave's pieces (own pieces: counted wait; the others': the barrier), and
+        // every wave is done reading the slot step t+3 goes into (it held step t-1)
+        if (wait == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if (wait == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (stage) stage_step(slot3);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 1; i < 8; ++i) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (first) RASS_MFMA_BF16_NEW(acc[i][j], fa[set][i], fb[set][j]);
+                else RASS_MFMA_BF16_ACC(acc[i][j], fa[set][i], fb[set][j]);
+            }
+            if (reads) {  // next step's fragments into the other register set, spread over the MFMA rows
+                if (i == 1) { RASS_DS_READ_B128(fa[set ^ 1][0], ab, 0);    RASS_DS_READ_B128(fb[set ^ 1][0], bb, 0);
+                              RASS_DS_READ_B128(fb[set ^ 1][1], bb, 1024); }
+                if (i == 2) { RASS_DS_READ_B128(fb[set ^ 1][2], bb, 2048); RASS_DS_READ_B128(fb[set ^ 1][3], bb, 3072);
+                              RASS_DS_READ_B128(fb[set ^ 1][4], bb, 4096); }
+                if (i == 3) { RASS_DS_READ_B128(fb[set ^ 1][5], bb, 5120); RASS_DS_READ_B128(fb[set ^ 1][6], bb, 6144);
+                              RASS_DS_READ_B128(fb[set ^ 1][7], bb, 7168); }
+                if (i == 4) { RASS_DS_READ_B128(fa[set ^ 1][1], ab, 1024); RASS_DS_READ_B128(fa[set ^ 1][2], ab, 2048); }
+                if (i == 5) { RASS_DS_READ_B128(fa[set ^ 1][3], ab, 3072); RASS_DS_READ_B128(fa[set ^ 1][4], ab, 4096); }
+                if (i == 6) { RASS_DS_READ_B128(fa[set ^ 1][5], ab, 5120); RASS_DS_READ_B128(fa[set ^ 1][6], ab, 6144); }
+                if (i == 7) { RASS_DS_READ_B128(fa[set ^ 1][7], ab, 7168); }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using C0 = std::integral_constant<int, 0>;
+    using C1 = std::integral_constant<int, 1>;
+    using BT = std::integral_constant<bool, true>;
+    using BF = std::integral_constant<bool, false>;
+    using W8 = std::integral_constant<int, 8>;
+    using W0 = std::integral_constant<int, 0>;
+    using WN = std::integral_constant<int, -1>;
+
+    // pipeline prologue of the first tile: steps 0, 1, 2 out, all landed, step 0's fragments requested
+    point_at(tile);
+    for (int s0 = 0; s0 < kW4Ahead; ++s0) stage_step(s0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    read_frags(C0{}, 0);
+
+    for (;;) {
+        const int n0 = (tile % tiles_n) * RBN, m0 = (tile / tiles_n) * RBM;
+        // ---- K loop (nk even, >= 6: launcher): steps 0, 1 without a DMA wait, the steady state two steps per trip
+        // (the fragment register sets alternate), the last three steps draining the ring
+        //    set  first  wait  stage reads
+        kstep(C0{}, BT{}, WN{}, BT{}, BT{}, 0);
+        kstep(C1{}, BF{}, WN{}, BT{}, BT{}, 1);
+        int slot = 2;
+        for (int t = 2; t + kW4Ahead + 1 < nk; t += 2) {
+            kstep(C0{}, BF{}, W8{}, BT{}, BT{}, slot);
+            kstep(C1{}, BF{}, W8{}, BT{}, BT{}, (slot + 1) & 3);
+            slot = (slot + 2) & 3;
+        }
+        kstep(C0{}, BF{}, W8{}, BT{}, BT{}, slot);             // t = nk - 4: the last step that stages (nk - 1)
+        kstep(C1{}, BF{}, W8{}, BF{}, BT{}, (slot + 1) & 3);   // t = nk - 3: nk - 1 may still be in flight
+        kstep(C0{}, BF{}, W0{}, BF{}, BT{}, (slot + 2) & 3);   // t = nk - 2
+        kstep(C1{}, BF{}, WN{}, BF{}, BF{}, (slot + 3) & 3);   // t = nk - 1: its barrier = every wave's reads are done
+        // every wave passed the last step's barrier with all its fragment reads done: the ring is free
+        const int next = tile + G;
+        const bool has_next = next < tiles_total;
+        // ---- epilogue in registers: lane (g = lane>>4, c = lane&15) owns features 32g .. 32g+31 of token 16j + c.
+        // Order of this wave's memory operations (vmcnt retires in order): the epilogue's READS (bias, the whole
+        // residual tile: 128 registers the fragments no longer need), then the next tile's first three K steps
+        // (24 DMAs, which land under the epilogue), then the 32 stores.  So one counted wait covers the reads
+        // without waiting for the DMAs, and the DMAs are known to have landed once at most the stores are left.
+        {
+            const int g = lane >> 4, c = lane & 15;
+            const int fbase = n0 + wn * 128 + 32 * g;
+            // bias through opaque asm loads: a load hipcc can see stays "possibly pending" on its destination
+            // registers across the tile loop and costs a vmcnt(0) in front of the K loop's first MFMA
+            f32x4 bv[8];
+            {
+                const float* bp = bias + fbase;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bv[0]) : "v"(bp));
+                asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(bv[1]) : "v"(bp));
+                asm volatile("global_load_dwordx4 %0, %1, off offset:32" : "=v"(bv[2]) : "v"(bp));
+                asm volatile("global_load_dwordx4 %0, %1, off offset:48" : "=v"(bv[3]) : "v"(bp));
+                asm volatile("global_load_dwordx4 %0, %1, off offset:64" : "=v"(bv[4]) : "v"(bp));
+                asm volatile("global_load_dwordx4 %0, %1, off offset:80" : "=v"(bv[5]) : "v"(bp));
+                asm volatile("global_load_dwordx4 %0, %1, off offset:96" : "=v"(bv[6]) : "v"(bp));
+                asm volatile("global_load_dwordx4 %0, %1, off offset:112" : "=v"(bv[7]) : "v"(bp));
+            }
+            u32x4 res[8][4];
+            if (EPI == 1) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    int m = m0 + wm * 128 + j * 16 + c;
+                    m = m < M ? m : M - 1;  // rows past M are never stored: read a valid row instead of branching
+                    const u16* rp = residual + (int64_t)m * N + fbase;
+                    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(res[j][0]) : "v"(rp));
+                    asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(res[j][1]) : "v"(rp));
+                    asm volatile("global_load_dwordx4 %0, %1, off offset:32" : "=v"(res[j][2]) : "v"(rp));
+                    asm volatile("global_load_dwordx4 %0, %1, off offset:48" : "=v"(res[j][3]) : "v"(rp));
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (has_next) {
+                point_at(next);
+                for (int s0 = 0; s0 < kW4Ahead; ++s0) stage_step(s0);
+                asm volatile("s_waitcnt vmcnt(24)" ::: "memory");  // the reads; the 24 DMAs stay in flight
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs' results (inline asm: no hazard tracking)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int m = m0 + wm * 128 + j * 16 + c;
+                u16* yp = Y + (int64_t)m * N + fbase;
+#pragma unroll
+                for (int ip = 0; ip < 4; ++ip) {
+                    __builtin_amdgcn_sched_barrier(0);  // accumulators leave the AGPRs 8 at a time, not all 256 up front
+                    f32x4 v0 = acc[2 * ip][j] + bv[2 * ip];
+                    f32x4 v1 = acc[2 * ip + 1][j] + bv[2 * ip + 1];
+                    if (EPI == 1) {
+                        const u32x4 r = res[j][ip];
+                        v0.x += bf16_to_f32((u16)(r.x & 0xffff));
+                        v0.y += bf16_to_f32((u16)(r.x >> 16));
+                        v0.z += bf16_to_f32((u16)(r.y & 0xffff));
+                        v0.w += bf16_to_f32((u16)(r.y >> 16));
+                        v1.x += bf16_to_f32((u16)(r.z & 0xffff));
+                        v1.y += bf16_to_f32((u16)(r.z >> 16));
+                        v1.z += bf16_to_f32((u16)(r.w & 0xffff));
+                        v1.w += bf16_to_f32((u16)(r.w >> 16));
+                    }
+                    if (EPI == 2) {
+                        v0.x = gelu_erf(v0.x); v0.y = gelu_erf(v0.y); v0.z = gelu_erf(v0.z); v0.w = gelu_erf(v0.w);
+                        v1.x = gelu_erf(v1.x); v1.y = gelu_erf(v1.y); v1.z = gelu_erf(v1.z); v1.w = gelu_erf(v1.w);
+                    }
+                    u32x4 o;
+                    o.x = (unsigned)f32_to_bf16(v0.x) | ((unsigned)f32_to_bf16(v0.y) << 16);
+                    o.y = (unsigned)f32_to_bf16(v0.z) | ((unsigned)f32_to_bf16(v0.w) << 16);
+                    o.z = (unsigned)f32_to_bf16(v1.x) | ((unsigned)f32_to_bf16(v1.y) << 16);
+                    o.w = (unsigned)f32_to_bf16(v1.z) | ((unsigned)f32_to_bf16(v1.w) << 16);
+                    // opaque store: in a tile that lies inside M every wave issues exactly 32 of them behind the
+                    // DMAs, which the counted wait below relies on (hipcc branches around a store no lane executes)
+                    if (m < M) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(yp + 8 * ip), "v"(o) : "memory");
+                }
+            }
+        }
+        if (!has_next) break;
+        // this wave's pieces of the next tile's steps 0-2 have landed once only the 32 stores can be outstanding;
+        // the barrier publishes everyone's
+        __builtin_amdgcn_sched_barrier(0);
+        if (m0 + RBM <= M) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        read_frags(C0{}, 0);
+        tile = next;
+    }
+#undef RASS_W4_READ_A
+#undef RASS_W4_READ_B
+}
+
+template <int EPI>
+static hipError_t launch_w4(const u16* X, const u16* W, const float* bias, const u16* residual, u16* Y, int M,
+                            int M_pad, int N, int K, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_w4_kernel<EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kW4LdsBytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    static int n_cus = 0;
+    if (n_cus == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cus <= 0)
+            n_cus = 256;
+    }
+    const int tiles_total = (N / RBN) * (M_pad / RBM);
+    const int grid = tiles_total < n_cus ? tiles_total : n_cus;
+    hipLaunchKernelGGL((gemm_bf16_w4_kernel<EPI>), dim3(grid), dim3(kW4Threads), kW4LdsBytes, stream, X, W, bias,
+                       residual, Y, M, N, K, tiles_total);
+    return hipGetLastError();
+}
+
 template <int EPI>
 static hipError_t launch_epi(const u16* X, const u16* W, const float* bias, const u16* residual, u16* Y, int M,
                              int M_pad, int N, int K, hipStream_t stream) {
@@ -745,11 +1056,14 @@ static hipError_t launch_epi(const u16* X, const u16* W, const float* bias, cons
     if (N % RBN == 0 && M_pad % RBM == 0 && K % RBK == 0 && M >= 1024) {
         // Default: the persistent form of the 8-wave 256x256 ring kernel; RASS_GEMM_VARIANT=ring
         // selects the one-tile-per-block form for A/B runs (scripts/microbench/gemm_phases.hip).
-        static const bool one_tile_blocks = [] {
+        static const int variant = [] {   // 0 = pring (default), 1 = ring, 2 = w4
             const char* v = getenv("RASS_GEMM_VARIANT");
-            return v != nullptr && strcmp(v, "ring") == 0;
+            if (v != nullptr && strcmp(v, "ring") == 0) return 1;
+            if (v != nullptr && strcmp(v, "w4") == 0) return 2;
+            return 0;
         }();
-        if (one_tile_blocks) return launch_ring<EPI>(X, W, bias, residual, Y, M, M_pad, N, K, stream);
+        if (variant == 1) return launch_ring<EPI>(X, W, bias, residual, Y, M, M_pad, N, K, stream);
+        if (variant == 2 && K / RBK >= 6 && (K / RBK) % 2 == 0) return launch_w4<EPI>(X, W, bias, residual, Y, M, M_pad, N, K, stream);
         return launch_pring<EPI>(X, W, bias, residual, Y, M, M_pad, N, K, stream);
     }
     constexpr int lds_bytes = 4 * kTileBytes;  // 64 KiB

@@ -747,18 +747,23 @@ static hipError_t launch_pring(const u16* X, const u16* W, const float* bias, co
 // no second wave competing for the SIMD's issue slots).  What makes it possible:
 //   * the 256 fp32 accumulators live in AGPRs: the MFMA is issued as inline asm with "a" constraints (the builtin
 //     form made hipcc spill 115 registers and shuffle accumulators through v_accvgpr_mov, DESIGN round 1);
-//   * with one wave per SIMD nothing hides a wave's own LDS latency, so the fragments are double-buffered in
-//     registers: the 16 ds_read_b128 of step t+1 are issued between the MFMA rows of step t;
-//   * a 4-slot ring, DMA three steps ahead: a step has two full K steps to land;
+//   * with one wave per SIMD nothing hides a wave's own latencies, so everything is software-pipelined in
+//     registers: step t multiplies fragment set t&1 while the 16 ds_read_b128 of step t+1 fill the other set,
+//     the operand pieces of step t+2 (loaded from global memory into 32 staging registers during step t-1) are
+//     written to their ring slot, and the loads of step t+3 go out into the other staging set;
+//   * staging goes through registers (global_load_dwordx4 + ds_write_b128), not LDS-DMA: a global_load_lds piece
+//     costs the issuing wave 60-185 cycles (MI355X_MICROARCH.md), which a partner wave hides in the 8-wave
+//     kernel but nothing hides here — the first version of this kernel, on LDS-DMA, ran 12-17 % SLOWER than the
+//     8-wave one;
 //   * no LDS transpose in the epilogue.  The W rows are staged PERMUTED: MFMA row rho of M-tile i holds output
 //     feature 32*(rho>>2) + 4*i + (rho&3) of the wave's 128, so the 4 accumulator rows a lane owns in the 8 tiles
 //     of a token column are 32 CONSECUTIVE features — bias, residual, GELU and the bf16 pack happen in registers
-//     and a lane writes its 64 contiguous bytes with four 16-B stores (the permutation costs nothing: a DMA
-//     lane computes its own source row either way).
+//     and a lane writes its 64 contiguous bytes with four 16-B stores (the permutation costs nothing: a staging
+//     lane computes its own source row either way);
+//   * the next tile's steps 0 and 1 are loaded during the last K steps and sit in the ring before the epilogue,
+//     its step 2 waits in registers.
 constexpr int kW4Threads = 256;
-constexpr int kW4Slots = 4;
-constexpr int kW4Ahead = 3;
-constexpr int kW4LdsBytes = kW4Slots * kRingSlotBytes;  // 128 KiB
+constexpr int kW4LdsBytes = 4 * kRingSlotBytes;  // 4 slots of (W tile | X tile) = 128 KiB
 
 #define RASS_MFMA_BF16_ACC(acc, a, b) \
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b))
@@ -779,7 +784,7 @@ __global__ __launch_bounds__(kW4Threads) void gemm_bf16_w4_kernel(const u16* __r
     int tile = pos;
     if (tile >= tiles_total) return;
     const int tiles_n = N / RBN;
-    const int nk = K / RBK;  // >= kW4Ahead (launcher)
+    const int nk = K / RBK;  // even, >= 6 (launcher)
 
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
     unsigned offA0, offB0;
@@ -788,9 +793,18 @@ __global__ __launch_bounds__(kW4Threads) void gemm_bf16_w4_kernel(const u16* __r
         offA0 = rowA * 64 + (((lane >> 4) ^ (((rowA >> 3) & 1) * 3)) * 16);
         offB0 = kRingTileBytes + rowB * 64 + (((lane >> 4) ^ (((rowB >> 3) & 1) * 3)) * 16);
     }
-    // DMA: an operand tile is 16 pieces of 16 rows x 64 B; this wave moves pieces wave, wave+4, wave+8, wave+12
-    const u16* srcW[4];
-    const u16* srcX[4];
+    // Staging: an operand tile is 16 pieces of 16 rows x 64 B (lane l: row l>>2, 16-B chunk l&3, image lane-linear);
+    // this wave moves pieces wave, wave+4, wave+8, wave+12 of both operands.
+    // Sources through buffer descriptors over the whole of W and X: a piece's address is a per-lane byte offset
+    // (recomputed once per tile) plus the wave-uniform K offset in the instruction's SGPR field, so a K step costs
+    // no address arithmetic on the vector ALU (64-bit pointer bumps were 16 VALU instructions per step, issued
+    // by the same single wave that has to issue the MFMAs).
+    const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<u16*>(W), 0, (int)(unsigned)((uint64_t)N * K * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<u16*>(X), 0, (int)(unsigned)((uint64_t)(tiles_total / tiles_n) * RBM * K * 2), 0x00020000);
+    unsigned voffW[4], voffX[4];
+    int koff = 0;  // bytes into the K dimension of the step the next load_step fetches
     auto point_at = [&](int t) {
         const int tn0 = (t % tiles_n) * RBN, tm0 = (t / tiles_n) * RBM;
 #pragma unroll
@@ -800,30 +814,37 @@ __global__ __launch_bounds__(kW4Threads) void gemm_bf16_w4_kernel(const u16* __r
             // W: image row (half h, M-tile i, MFMA row rho) <- feature h*128 + 32*(rho>>2) + 4*i + (rho&3)
             const int rho = r & 15, i = (r >> 4) & 7, h = r >> 7;
             const int feat = h * 128 + 32 * (rho >> 2) + 4 * i + (rho & 3);
-            srcW[p] = W + (int64_t)(tn0 + feat) * K + c_src * 8;
-            srcX[p] = X + (int64_t)(tm0 + r) * K + c_src * 8;
+            voffW[p] = ((unsigned)(tn0 + feat) * (unsigned)K + c_src * 8) * 2u;
+            voffX[p] = ((unsigned)(tm0 + r) * (unsigned)K + c_src * 8) * 2u;
         }
+        koff = 0;
     };
-    auto stage_step = [&](int slot) {
-        unsigned char* slot_base = lds + slot * kRingSlotBytes;
+    bf16x8 g[2][8];  // staging registers: the pieces of step s wait in g[s & 1]
+    auto load_step = [&g, &voffW, &voffX, &koff, rsrcW, rsrcX](auto set_c) {
+        constexpr int set = decltype(set_c)::value;
+#ifndef RASS_W4_EXP_NO_LOADS    // timing experiment: stale registers go to LDS
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)srcW[p],
-                                             (__attribute__((address_space(3))) void*)(slot_base + (wave + 4 * p) * 1024),
-                                             16, 0, 0);
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)srcX[p],
-                (__attribute__((address_space(3))) void*)(slot_base + kRingTileBytes + (wave + 4 * p) * 1024), 16, 0, 0);
-            srcW[p] += RBK;
-            srcX[p] += RBK;
+            g[set][p] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrcW, voffW[p], koff, 0));
+            g[set][4 + p] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrcX, voffX[p], koff, 0));
         }
+#endif
+        koff += RBK * 2;
+    };
+    unsigned char* const my_piece = lds + wave * 1024 + lane * 16;
+    auto write_piece = [&g, my_piece](auto set_c, int slot, int p) {
+        constexpr int set = decltype(set_c)::value;
+#ifdef RASS_W4_EXP_NO_WRITES   // timing experiment: the loads stay alive, nothing goes to LDS
+        asm volatile("" ::"v"(g[set][p]), "v"(g[set][4 + p]));
+#else
+        *reinterpret_cast<bf16x8*>(my_piece + slot * kRingSlotBytes + p * 4096) = g[set][p];
+        *reinterpret_cast<bf16x8*>(my_piece + slot * kRingSlotBytes + kRingTileBytes + p * 4096) = g[set][4 + p];
+#endif
     };
 
     f32x4 acc[8][8];
     bf16x8 fa[2][8], fb[2][8];
     // fragments of a step: a[i] = W image rows wn*128 + 16i.., b[j] = X image rows wm*128 + 16j.. (1 KiB apart)
-#define RASS_W4_READ_A(set, i, slot) RASS_DS_READ_B128(fa[set][i], lds_base + (slot) * kRingSlotBytes + offA0, 0 + 1024 * (i))
-#define RASS_W4_READ_B(set, j, slot) RASS_DS_READ_B128(fb[set][j], lds_base + (slot) * kRingSlotBytes + offB0, 0 + 1024 * (j))
     auto read_frags = [&fa, &fb, lds_base, offA0, offB0](auto set_c, int slot) {
         constexpr int set = decltype(set_c)::value;
         const unsigned ab = lds_base + slot * kRingSlotBytes + offA0;
@@ -838,41 +859,34 @@ __global__ __launch_bounds__(kW4Threads) void gemm_bf16_w4_kernel(const u16* __r
         RASS_DS_READ_B128(fa[set][7], ab, 7168); RASS_DS_READ_B128(fb[set][7], bb, 7168);
     };
 
-    // One K step.  FIRST: the tile's first step writes the accumulators instead of adding to them.
-    // PREFETCHED: steps 1 and 2 of a tile were in flight before the previous tile's epilogue, whose own global
-    // reads (issued after them, consumed there) retired them: no DMA wait, which would also wait for that
-    // epilogue's stores.
-    // One K step, everything about its place in the tile known at compile time (no branch in the MFMA stream):
+    // One K step; its place in the tile is known at compile time (no branch in the MFMA stream):
     //   FIRST  the tile's first step writes the accumulators instead of adding to them
-    //   WAIT   own DMA pieces of step t+1: 8 = vmcnt(8) (step t+2 stays in flight), 0 = vmcnt(0), -1 = none (steps
-    //          1, 2 of a tile were prefetched and retired before the previous epilogue ended; the last step has no
-    //          successor) — a wait there would also wait for that epilogue's stores
-    //   STAGE  step t+3 exists and goes out after the barrier;  READS  step t+1 exists: its fragments are requested
-    auto kstep = [&fa, &fb, &acc, &stage_step, lds_base, offA0, offB0](auto set_c, auto first_c, auto wait_c, auto stage_c,
-                                                                    auto reads_c, int slot) {
+    //   READS  step t+1 exists: its fragments are requested (rows 1-4, so they have three rows to arrive)
+    //   WRITE  step t+2 exists: its pieces go from g[set] to slot t+2 (rows 4-7)
+    //   LOAD   0 = nothing; 1 = step t+3 of this tile into g[set^1]; 2 = a step of the NEXT tile into g[set^1]
+    //          (the caller has re-pointed the source pointers), only if there is a next tile
+    auto kstep = [&](auto set_c, auto first_c, auto reads_c, auto write_c, auto load_c, int slot, bool has_next) {
         constexpr int set = decltype(set_c)::value;
         constexpr bool first = decltype(first_c)::value;
-        constexpr int wait = decltype(wait_c)::value;
-        constexpr bool stage = decltype(stage_c)::value;
         constexpr bool reads = decltype(reads_c)::value;
-        const int slot1 = (slot + 1) & 3, slot3 = (slot + 3) & 3;
+        constexpr bool write = decltype(write_c)::value;
+        constexpr int load = decltype(load_c)::value;
+        const int slot1 = (slot + 1) & 3, slot2 = (slot + 2) & 3;
         const unsigned ab = lds_base + slot1 * kRingSlotBytes + offA0;
         const unsigned bb = lds_base + slot1 * kRingSlotBytes + offB0;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this step's fragments
+        // this step's fragments have arrived and this wave's pieces of step t+1 are in its slot
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             if (first) RASS_MFMA_BF16_NEW(acc[0][j], fa[set][0], fb[set][j]);
             else RASS_MFMA_BF16_ACC(acc[0][j], fa[set][0], fb[set][j]);
         }
-        // step t+1 has landed in every wave's pieces (own pieces: counted wait; the others': the barrier), and
-        // every wave is done reading the slot step t+3 goes into (it held step t-1)
-        if (wait == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        if (wait == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // every wave's pieces of step t+1 are in the ring, and nobody reads the slot step t+2 goes into any more
         __builtin_amdgcn_sched_barrier(0);
+#ifndef RASS_W4_EXP_NO_BARRIER
         __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        if (stage) stage_step(slot3);
+#endif
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 1; i < 8; ++i) {
@@ -881,66 +895,86 @@ __global__ __launch_bounds__(kW4Threads) void gemm_bf16_w4_kernel(const u16* __r
                 if (first) RASS_MFMA_BF16_NEW(acc[i][j], fa[set][i], fb[set][j]);
                 else RASS_MFMA_BF16_ACC(acc[i][j], fa[set][i], fb[set][j]);
             }
-            if (reads) {  // next step's fragments into the other register set, spread over the MFMA rows
+#ifndef RASS_W4_EXP_NO_READS
+            if (reads) {  // next step's fragments into the other register set
                 if (i == 1) { RASS_DS_READ_B128(fa[set ^ 1][0], ab, 0);    RASS_DS_READ_B128(fb[set ^ 1][0], bb, 0);
-                              RASS_DS_READ_B128(fb[set ^ 1][1], bb, 1024); }
-                if (i == 2) { RASS_DS_READ_B128(fb[set ^ 1][2], bb, 2048); RASS_DS_READ_B128(fb[set ^ 1][3], bb, 3072);
-                              RASS_DS_READ_B128(fb[set ^ 1][4], bb, 4096); }
-                if (i == 3) { RASS_DS_READ_B128(fb[set ^ 1][5], bb, 5120); RASS_DS_READ_B128(fb[set ^ 1][6], bb, 6144);
-                              RASS_DS_READ_B128(fb[set ^ 1][7], bb, 7168); }
-                if (i == 4) { RASS_DS_READ_B128(fa[set ^ 1][1], ab, 1024); RASS_DS_READ_B128(fa[set ^ 1][2], ab, 2048); }
-                if (i == 5) { RASS_DS_READ_B128(fa[set ^ 1][3], ab, 3072); RASS_DS_READ_B128(fa[set ^ 1][4], ab, 4096); }
-                if (i == 6) { RASS_DS_READ_B128(fa[set ^ 1][5], ab, 5120); RASS_DS_READ_B128(fa[set ^ 1][6], ab, 6144); }
-                if (i == 7) { RASS_DS_READ_B128(fa[set ^ 1][7], ab, 7168); }
+                              RASS_DS_READ_B128(fb[set ^ 1][1], bb, 1024); RASS_DS_READ_B128(fb[set ^ 1][2], bb, 2048); }
+                if (i == 2) { RASS_DS_READ_B128(fb[set ^ 1][3], bb, 3072); RASS_DS_READ_B128(fb[set ^ 1][4], bb, 4096);
+                              RASS_DS_READ_B128(fb[set ^ 1][5], bb, 5120); RASS_DS_READ_B128(fb[set ^ 1][6], bb, 6144); }
+                if (i == 3) { RASS_DS_READ_B128(fb[set ^ 1][7], bb, 7168); RASS_DS_READ_B128(fa[set ^ 1][1], ab, 1024);
+                              RASS_DS_READ_B128(fa[set ^ 1][2], ab, 2048); RASS_DS_READ_B128(fa[set ^ 1][3], ab, 3072); }
+                if (i == 4) { RASS_DS_READ_B128(fa[set ^ 1][4], ab, 4096); RASS_DS_READ_B128(fa[set ^ 1][5], ab, 5120);
+                              RASS_DS_READ_B128(fa[set ^ 1][6], ab, 6144); RASS_DS_READ_B128(fa[set ^ 1][7], ab, 7168); }
             }
+#endif
+            // loads first (row 1), writes last (rows 4-7): a piece has more than a full K step between its load
+            // and its ds_write (the wait hipcc puts in front of each write is then free)
+#ifndef RASS_W4_EXP_NO_STAGE
+            if (i == 1) {
+                if (load == 1) load_step(std::integral_constant<int, set ^ 1>{});
+                if (load == 2 && has_next) load_step(std::integral_constant<int, set ^ 1>{});
+            }
+            if (write && i >= 4) write_piece(set_c, slot2, i - 4);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
     };
     using C0 = std::integral_constant<int, 0>;
     using C1 = std::integral_constant<int, 1>;
+    using C2 = std::integral_constant<int, 2>;
     using BT = std::integral_constant<bool, true>;
     using BF = std::integral_constant<bool, false>;
-    using W8 = std::integral_constant<int, 8>;
-    using W0 = std::integral_constant<int, 0>;
-    using WN = std::integral_constant<int, -1>;
 
-    // pipeline prologue of the first tile: steps 0, 1, 2 out, all landed, step 0's fragments requested
+    // pipeline prologue of the first tile: steps 0 and 1 into the ring, step 2 into registers
     point_at(tile);
-    for (int s0 = 0; s0 < kW4Ahead; ++s0) stage_step(s0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    read_frags(C0{}, 0);
+    load_step(C0{});
+    load_step(C1{});
+#pragma unroll
+    for (int p = 0; p < 4; ++p) write_piece(C0{}, 0, p);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) write_piece(C1{}, 1, p);
+    load_step(C0{});
 
     for (;;) {
         const int n0 = (tile % tiles_n) * RBN, m0 = (tile / tiles_n) * RBM;
-        // ---- K loop (nk even, >= 6: launcher): steps 0, 1 without a DMA wait, the steady state two steps per trip
-        // (the fragment register sets alternate), the last three steps draining the ring
-        //    set  first  wait  stage reads
-        kstep(C0{}, BT{}, WN{}, BT{}, BT{}, 0);
-        kstep(C1{}, BF{}, WN{}, BT{}, BT{}, 1);
-        int slot = 2;
-        for (int t = 2; t + kW4Ahead + 1 < nk; t += 2) {
-            kstep(C0{}, BF{}, W8{}, BT{}, BT{}, slot);
-            kstep(C1{}, BF{}, W8{}, BT{}, BT{}, (slot + 1) & 3);
-            slot = (slot + 2) & 3;
-        }
-        kstep(C0{}, BF{}, W8{}, BT{}, BT{}, slot);             // t = nk - 4: the last step that stages (nk - 1)
-        kstep(C1{}, BF{}, W8{}, BF{}, BT{}, (slot + 1) & 3);   // t = nk - 3: nk - 1 may still be in flight
-        kstep(C0{}, BF{}, W0{}, BF{}, BT{}, (slot + 2) & 3);   // t = nk - 2
-        kstep(C1{}, BF{}, WN{}, BF{}, BF{}, (slot + 3) & 3);   // t = nk - 1: its barrier = every wave's reads are done
-        // every wave passed the last step's barrier with all its fragment reads done: the ring is free
         const int next = tile + G;
         const bool has_next = next < tiles_total;
+        // the tile's steps 0 and 1 are in slots 0 and 1 once every wave's writes have landed
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        read_frags(C0{}, 0);
+        // ---- K loop: the steady state two steps per trip (the register sets alternate), the last three peeled
+        //    set  first reads write load
+        kstep(C0{}, BT{}, BT{}, BT{}, C1{}, 0, has_next);
+        kstep(C1{}, BF{}, BT{}, BT{}, C1{}, 1, has_next);
+        int slot = 2;
+        for (int t = 2; t + 4 < nk; t += 2) {
+            kstep(C0{}, BF{}, BT{}, BT{}, C1{}, slot, has_next);
+            kstep(C1{}, BF{}, BT{}, BT{}, C1{}, (slot + 1) & 3, has_next);
+            slot = (slot + 2) & 3;
+        }
+        kstep(C0{}, BF{}, BT{}, BT{}, C1{}, slot, has_next);             // t = nk - 4: loads step nk - 1
+        if (has_next) point_at(next);
+        kstep(C1{}, BF{}, BT{}, BT{}, C2{}, (slot + 1) & 3, has_next);   // t = nk - 3: loads the next tile's step 0
+        kstep(C0{}, BF{}, BT{}, BF{}, C2{}, (slot + 2) & 3, has_next);   // t = nk - 2: loads the next tile's step 1
+        kstep(C1{}, BF{}, BF{}, BF{}, C0{}, (slot + 3) & 3, has_next);   // t = nk - 1: its barrier = all reads done
+        // the ring is free: the next tile's steps 0, 1 go in now, its step 2 waits in registers
+        if (has_next) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) write_piece(C0{}, 0, p);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) write_piece(C1{}, 1, p);
+        }
+
         // ---- epilogue in registers: lane (g = lane>>4, c = lane&15) owns features 32g .. 32g+31 of token 16j + c.
         // Order of this wave's memory operations (vmcnt retires in order): the epilogue's READS (bias, the whole
-        // residual tile: 128 registers the fragments no longer need), then the next tile's first three K steps
-        // (24 DMAs, which land under the epilogue), then the 32 stores.  So one counted wait covers the reads
-        // without waiting for the DMAs, and the DMAs are known to have landed once at most the stores are left.
+        // residual tile: 128 registers the fragments no longer need), then the next tile's step 2 (8 loads, which
+        // land under the epilogue), then the stores.
         {
-            const int g = lane >> 4, c = lane & 15;
-            const int fbase = n0 + wn * 128 + 32 * g;
-            // bias through opaque asm loads: a load hipcc can see stays "possibly pending" on its destination
-            // registers across the tile loop and costs a vmcnt(0) in front of the K loop's first MFMA
+            const int gq = lane >> 4, c = lane & 15;
+            const int fbase = n0 + wn * 128 + 32 * gq;
+            // bias / residual through opaque asm loads: a load hipcc can see stays "possibly pending" on its
+            // destination registers across the tile loop and costs a vmcnt(0) in front of the K loop's first MFMA
             f32x4 bv[8];
             {
                 const float* bp = bias + fbase;
@@ -968,9 +1002,8 @@ __global__ __launch_bounds__(kW4Threads) void gemm_bf16_w4_kernel(const u16* __r
             }
             __builtin_amdgcn_sched_barrier(0);
             if (has_next) {
-                point_at(next);
-                for (int s0 = 0; s0 < kW4Ahead; ++s0) stage_step(s0);
-                asm volatile("s_waitcnt vmcnt(24)" ::: "memory");  // the reads; the 24 DMAs stay in flight
+                load_step(C0{});                                   // the next tile's step 2
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // the reads; those 8 loads stay in flight
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
@@ -1000,29 +1033,18 @@ __global__ __launch_bounds__(kW4Threads) void gemm_bf16_w4_kernel(const u16* __r
                         v0.x = gelu_erf(v0.x); v0.y = gelu_erf(v0.y); v0.z = gelu_erf(v0.z); v0.w = gelu_erf(v0.w);
                         v1.x = gelu_erf(v1.x); v1.y = gelu_erf(v1.y); v1.z = gelu_erf(v1.z); v1.w = gelu_erf(v1.w);
                     }
-                    u32x4 o;
+                    uint4 o;
                     o.x = (unsigned)f32_to_bf16(v0.x) | ((unsigned)f32_to_bf16(v0.y) << 16);
                     o.y = (unsigned)f32_to_bf16(v0.z) | ((unsigned)f32_to_bf16(v0.w) << 16);
                     o.z = (unsigned)f32_to_bf16(v1.x) | ((unsigned)f32_to_bf16(v1.y) << 16);
                     o.w = (unsigned)f32_to_bf16(v1.z) | ((unsigned)f32_to_bf16(v1.w) << 16);
-                    // opaque store: in a tile that lies inside M every wave issues exactly 32 of them behind the
-                    // DMAs, which the counted wait below relies on (hipcc branches around a store no lane executes)
-                    if (m < M) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(yp + 8 * ip), "v"(o) : "memory");
+                    if (m < M) *reinterpret_cast<uint4*>(yp + 8 * ip) = o;
                 }
             }
         }
         if (!has_next) break;
-        // this wave's pieces of the next tile's steps 0-2 have landed once only the 32 stores can be outstanding;
-        // the barrier publishes everyone's
-        __builtin_amdgcn_sched_barrier(0);
-        if (m0 + RBM <= M) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        read_frags(C0{}, 0);
         tile = next;
     }
-#undef RASS_W4_READ_A
-#undef RASS_W4_READ_B
 }
 
 template <int EPI>
@@ -1063,7 +1085,9 @@ static hipError_t launch_epi(const u16* X, const u16* W, const float* bias, cons
             return 0;
         }();
         if (variant == 1) return launch_ring<EPI>(X, W, bias, residual, Y, M, M_pad, N, K, stream);
-        if (variant == 2 && K / RBK >= 6 && (K / RBK) % 2 == 0) return launch_w4<EPI>(X, W, bias, residual, Y, M, M_pad, N, K, stream);
+        if (variant == 2 && K / RBK >= 6 && (K / RBK) % 2 == 0 && (int64_t)M_pad * K * 2 < (1LL << 32) &&
+            (int64_t)N * K * 2 < (1LL << 32))
+            return launch_w4<EPI>(X, W, bias, residual, Y, M, M_pad, N, K, stream);
         return launch_pring<EPI>(X, W, bias, residual, Y, M, M_pad, N, K, stream);
     }
     constexpr int lds_bytes = 4 * kTileBytes;  // 64 KiB

@@ -405,6 +405,24 @@ class HipSentenceEncoder:
             i = j
         return out
 
+    def tokenize(self, texts: Sequence[str]):
+        """(packed token ids int32, cumulative offsets int64) of ``texts``, each ``[CLS] ... [SEP]`` (serving.py's
+        data-parallel ingest tokenises on rank 0 and encodes on every rank)."""
+        if self.tokenizer is None:
+            raise RuntimeError("this model directory has no vocab.txt")
+        if hasattr(self.tokenizer, "encode_batch"):
+            ids, cu = self.tokenizer.encode_batch(list(texts), self.cfg.max_positions)
+            return np.asarray(ids, dtype=np.int32), np.asarray(cu, dtype=np.int64)
+        seqs = [self.tokenizer.encode(t, self.cfg.max_positions) for t in texts]
+        cu = np.zeros(len(seqs) + 1, dtype=np.int64)
+        np.cumsum([len(q) for q in seqs], out=cu[1:])
+        ids = np.concatenate([np.asarray(q, dtype=np.int32) for q in seqs]) if cu[-1] else np.empty(0, np.int32)
+        return ids, cu
+
+    def encode_flat(self, ids: np.ndarray, cu: np.ndarray) -> np.ndarray:
+        """Pooled vectors of packed, already-tokenised sequences (``tokenize``'s output, or a slice of it)."""
+        return self._encode_flat(ids, cu)
+
     def encode(self, texts: List[str]) -> np.ndarray:
         if self.tokenizer is None:
             raise RuntimeError("this model directory has no vocab.txt: use encode_ids()")

@@ -38,6 +38,7 @@ Same names, argument meaning and error behaviour as the reference:
 """
 from __future__ import annotations
 
+import asyncio
 import inspect
 import logging
 from typing import Any, Callable, Dict, List, Optional, Tuple
@@ -318,22 +319,33 @@ async def ensure_index_exists(client: Any, index_name: str) -> None:
             print(f"[Error] OpenSearch Index could not be created: {e}")
 
 
-def add_documents(index_name: str, docs: List[Dict], embeddings: np.ndarray) -> List[int]:
+def add_documents(index_name: str, docs: List[Dict], embeddings: Optional[np.ndarray],
+                  texts: Optional[List[str]] = None) -> List[int]:
     """Append ``docs`` with their (un-normalised) ``embeddings`` [n, dim]; the GPU normalises
     (app/main.py:1249-1251).  ``_id = doc_id`` overwrite semantics (1260): the new rows are appended
     FIRST and the rows they supersede are tombstoned only after the append succeeded, so a failed add
-    (OOM on slab growth, HIP error) loses nothing.  Returns the row ids."""
+    (OOM on slab growth, HIP error) loses nothing.  Returns the row ids.  With ``texts`` instead of
+    ``embeddings`` (a multi-GPU index whose ranks have encoders, ``index.can_encode``) the texts are embedded
+    where their rows will live: data-parallel over the ranks, no vector leaves its GPU."""
     st = REGISTRY.get(index_name, create=True)
-    emb = np.ascontiguousarray(embeddings, dtype=np.float32)
-    if emb.ndim != 2 or emb.shape[0] != len(docs):
-        raise ValueError(f"embeddings {emb.shape} do not match {len(docs)} docs")
+    if texts is not None:
+        if len(texts) != len(docs):
+            raise ValueError(f"{len(texts)} texts do not match {len(docs)} docs")
+        emb = None
+    else:
+        emb = np.ascontiguousarray(embeddings, dtype=np.float32)
+        if emb.ndim != 2 or emb.shape[0] != len(docs):
+            raise ValueError(f"embeddings {emb.shape} do not match {len(docs)} docs")
     with st.lock:
         tags = np.array([st.tag_of(d) for d in docs], dtype=np.int32)
         # duplicates inside one batch: the last one wins, as with sequential bulk index ops
         last = {}
         for i, d in enumerate(docs):
             last[d.get("doc_id")] = i
-        first = st.index.add(emb, tags=tags, normalize=True)      # raises -> nothing was changed
+        if emb is None:
+            first = st.index.add_texts(list(texts), tags=tags, normalize=True)
+        else:
+            first = st.index.add(emb, tags=tags, normalize=True)      # raises -> nothing was changed
         rows = list(range(first, first + len(docs)))
         for d in docs:
             old = st.doc_row.pop(d.get("doc_id"), None)
@@ -399,12 +411,18 @@ async def store_fhir_docs_in_opensearch(structured_docs: List[Dict], unstructure
         _bulk(structured_docs, "structured")
     if not unstructured_docs:
         return
+    un_texts = [d["unstructuredText"] for d in unstructured_docs]
+    # a multi-GPU index whose ranks hold encoders embeds the texts where their rows will live
+    data_parallel = embed_fn is None and getattr(st.index, "can_encode", False)
     if embed_fn is None:
         from .embedding import embed_texts_in_batches as embed_fn
-    un_texts = [d["unstructuredText"] for d in unstructured_docs]
-    embeddings = await _call_embed(embed_fn, un_texts)
+    if not data_parallel:
+        embeddings = await _call_embed(embed_fn, un_texts)     # an embedding error propagates, as in the reference
     try:
-        add_documents(index_name, unstructured_docs, embeddings)
+        if data_parallel:
+            await asyncio.to_thread(add_documents, index_name, unstructured_docs, None, un_texts)
+        else:
+            add_documents(index_name, unstructured_docs, embeddings)
         if bulk is None:
             logger.info(f"Indexed {len(unstructured_docs)} unstructured docs, errors: []")
     except Exception as e:

@@ -36,7 +36,8 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-OP_SHUTDOWN, OP_OPEN, OP_SEARCH, OP_ADD, OP_DELETE, OP_COUNT, OP_GETROW, OP_DROP = range(8)
+OP_SHUTDOWN, OP_OPEN, OP_SEARCH, OP_ADD, OP_DELETE, OP_COUNT, OP_GETROW, OP_DROP, OP_ENCODE = range(9)
+ENC_BATCH_SEQS = 256          # sequences per encoder batch = the unit dealt to a rank (BASELINE configs[2]: batch 256)
 HDR_WORDS = 16
 MAX_Q = 32
 MAX_K = 32
@@ -130,8 +131,10 @@ class ShardServer:
     """Runs on EVERY rank: owns the rank's shards and executes the command stream."""
 
     def __init__(self, shard_factory: Callable[[str], object], dim: int, device: torch.device,
-                 group: Optional[dist.ProcessGroup] = None):
+                 group: Optional[dist.ProcessGroup] = None, encoder_factory: Optional[Callable[[], object]] = None):
         self.factory = shard_factory
+        self.encoder_factory = encoder_factory   # rank-local sentence encoder (data-parallel ingest), built lazily
+        self._encoder = None
         self.dim = dim
         self.device = device
         self.group = group
@@ -143,6 +146,24 @@ class ShardServer:
         self.extents: Dict[int, Extents] = {}
         # gloo moves device tensors in its collectives by staging, but its point-to-point ops want host memory
         self._p2p_on_host = dist.get_backend(group) == "gloo" and device.type != "cpu"
+
+    def encoder(self):
+        """This rank's encoder: ``tokenize(texts) -> (ids int32 flat, cu int64)`` and ``encode_flat(ids, cu) -> [n, dim]``."""
+        if self._encoder is None:
+            if self.encoder_factory is None:
+                raise RuntimeError("serving.start() was given no encoder_factory: texts cannot be encoded on the ranks")
+            self._encoder = self.encoder_factory()
+        return self._encoder
+
+    def _bcast(self, t: Optional[torch.Tensor], shape, dtype) -> torch.Tensor:
+        """Rank 0's tensor to every rank (the others allocate by the sizes the command header carried)."""
+        if self.rank != 0:
+            t = torch.empty(shape, dtype=dtype, device=self.device)
+        else:
+            t = t.to(self.device)
+        if self.world > 1:
+            dist.broadcast(t, src=0, group=self.group)
+        return t
 
     def _send(self, t: torch.Tensor, dst: int) -> None:
         dist.send(t.cpu() if self._p2p_on_host else t, dst=dst, group=self.group)
@@ -180,7 +201,8 @@ class ShardServer:
         return self.cmd[a:a + nbytes]
 
     # ---- the operations (identical code on every rank)
-    def execute(self, hdr: np.ndarray, vecs: Optional[torch.Tensor] = None, tags: Optional[torch.Tensor] = None):
+    def execute(self, hdr: np.ndarray, vecs: Optional[torch.Tensor] = None, tags: Optional[torch.Tensor] = None,
+                enc: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None):
         op, code = int(hdr[0]), int(hdr[1])
         if op == OP_OPEN:
             name = bytes(self._payload(int(hdr[2])).cpu().numpy()).decode("utf-8")
@@ -216,6 +238,34 @@ class ShardServer:
             if self.rank == owner:
                 first = shard.add(vecs, tags, normalize, gid_base)
                 self.extents[code].append(gid_base, first, n)
+            return None
+        if op == OP_ENCODE:
+            # Data-parallel ingest ("chunks are independent => pure data-parallel, no collective; each
+            # GPU appends its embeddings to its own shard"): rank 0 tokenised the texts and dealt them out in
+            # batches of <= ENC_BATCH_SEQS sequences; every rank receives the round's token ids (one broadcast per
+            # array: a 512-token chunk is 2 KB of ids against 4 KB of embedding), encodes ITS batches with its own
+            # encoder and appends the rows to its own shard under the global ids rank 0 assigned.  No embedding
+            # ever crosses ranks.  A sequence of length 0 is a blank text: a zero row (app/main.py:227-228).
+            n_batches, first_owner, gid_base, normalize = int(hdr[2]), int(hdr[3]), int(hdr[4]), bool(hdr[5])
+            total_seqs, total_tokens = int(hdr[6]), int(hdr[7])
+            lens = self._bcast(enc[0] if enc else None, (total_seqs,), torch.int32)
+            ids = self._bcast(enc[1] if enc else None, (max(total_tokens, 1),), torch.int32)
+            tg = self._bcast(enc[2] if enc else None, (total_seqs,), torch.int32)
+            lens_h = lens.cpu().numpy().astype(np.int64)
+            tok0 = np.concatenate([[0], np.cumsum(lens_h)])
+            for b in range(n_batches):
+                s0, s1 = b * ENC_BATCH_SEQS, min(total_seqs, (b + 1) * ENC_BATCH_SEQS)
+                if (first_owner + b) % self.world != self.rank:
+                    continue
+                bl = lens_h[s0:s1]
+                out = np.zeros((s1 - s0, self.dim), dtype=np.float32)
+                keep = np.nonzero(bl > 0)[0]
+                if keep.size:
+                    sub_ids = ids[int(tok0[s0]):int(tok0[s1])].cpu().numpy()
+                    cu = np.concatenate([[0], np.cumsum(bl[keep])]).astype(np.int64)
+                    out[keep] = np.asarray(self.encoder().encode_flat(sub_ids, cu), dtype=np.float32)
+                first = shard.add(torch.from_numpy(out).to(self.device), tg[s0:s1].contiguous(), normalize, gid_base + s0)
+                self.extents[code].append(gid_base + s0, first, s1 - s0)
             return None
         if op == OP_DELETE:
             ordinal = self.extents[code].ordinal_of(int(hdr[2]))
@@ -348,6 +398,55 @@ class ShardedIndex:
                 self._rows += m
             return first
 
+    @property
+    def can_encode(self) -> bool:
+        """True when the ranks have encoders (``serving.start(..., encoder_factory=...)``): texts can be ingested
+        data-parallel with ``add_texts`` instead of being embedded on rank 0 and shipped as vectors."""
+        return self.front.server.encoder_factory is not None
+
+    def add_texts(self, texts: List[str], tags: Optional[np.ndarray] = None, normalize: bool = True) -> int:
+        """Embed ``texts`` on ALL ranks and append the rows (one row per text, in order; blank texts become zero
+        rows as in app/main.py:227-228).  Rank 0 only tokenises; batches of <= ENC_BATCH_SEQS texts are dealt to
+        the ranks round-robin and each rank encodes its batches into its own shard.  Returns the global id of the
+        first row."""
+        n = len(texts)
+        t = np.zeros(n, dtype=np.int32) if tags is None else np.ascontiguousarray(tags, dtype=np.int32)
+        if t.shape != (n,) or (n and t.min() < 0):
+            raise ValueError("tags must be one non-negative int32 per row")
+        with self.front.lock:
+            s = self.front.server
+            first = self._rows
+            if n == 0:
+                return first
+            keep = [i for i, x in enumerate(texts) if x.strip()]
+            lens = np.zeros(n, dtype=np.int32)
+            flat = np.zeros(0, dtype=np.int32)
+            if keep:
+                ids, cu = s.encoder().tokenize([texts[i] for i in keep])
+                flat = np.ascontiguousarray(ids, dtype=np.int32)
+                lens[keep] = np.diff(np.asarray(cu, dtype=np.int64)).astype(np.int32)
+            tok0 = np.concatenate([[0], np.cumsum(lens.astype(np.int64))])
+            per_round = ENC_BATCH_SEQS * s.world          # one batch per rank and round
+            for a in range(0, n, per_round):
+                b = min(n, a + per_round)
+                n_batches = (b - a + ENC_BATCH_SEQS - 1) // ENC_BATCH_SEQS
+                owner0 = self._batches % s.world
+                r_ids = flat[int(tok0[a]):int(tok0[b])]
+                hdr = s.post([OP_ENCODE, self.code, n_batches, owner0, self._rows, 1 if normalize else 0, b - a,
+                              int(r_ids.size)])
+                s.execute(hdr, enc=(torch.from_numpy(lens[a:b].copy()),
+                                    torch.from_numpy(r_ids.copy() if r_ids.size else np.zeros(1, np.int32)),
+                                    torch.from_numpy(t[a:b].copy())))
+                for j in range(n_batches):
+                    owner = (owner0 + j) % s.world
+                    m = min(ENC_BATCH_SEQS, b - a - j * ENC_BATCH_SEQS)
+                    if not self._owner_rank or self._owner_rank[-1] != owner:
+                        self._owner_gid.append(self._rows)
+                        self._owner_rank.append(owner)
+                    self._rows += m
+                self._batches += n_batches
+            return first
+
     def delete(self, row: int) -> None:
         with self.front.lock:
             self._owner(row)                 # range check
@@ -398,14 +497,15 @@ class ShardedIndex:
 
 
 def start(shard_factory: Callable[[str], object], dim: int, device: Optional[torch.device] = None,
-          group: Optional[dist.ProcessGroup] = None, install_registry: bool = True) -> Optional[ShardedFront]:
+          group: Optional[dist.ProcessGroup] = None, install_registry: bool = True,
+          encoder_factory: Optional[Callable[[], object]] = None) -> Optional[ShardedFront]:
     """Call on EVERY rank after ``init_process_group``.  Rank 0 gets the front back at once (and, with
     ``install_registry``, ``docstore.REGISTRY`` now opens sharded indices, so ``HipIndexer`` /
     ``store_fhir_docs_in_opensearch`` serve the multi-GPU index unchanged); the other ranks stay inside
     this call, following rank 0, until it calls ``front.shutdown()``, and then return ``None``."""
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
-    server = ShardServer(shard_factory, dim, device, group)
+    server = ShardServer(shard_factory, dim, device, group, encoder_factory)
     if server.rank != 0:
         worker_loop(server)
         return None
@@ -414,6 +514,14 @@ def start(shard_factory: Callable[[str], object], dim: int, device: Optional[tor
         from .docstore import REGISTRY
         REGISTRY.set_index_factory(front.open_index)
     return front
+
+
+def hip_encoder_factory(model_dir: str, device_index: int) -> Callable[[], object]:
+    """One sentence encoder per process per GPU (weights loaded on first use), for ``start(encoder_factory=...)``."""
+    def make():
+        from .encoder import HipSentenceEncoder
+        return HipSentenceEncoder.from_dir(model_dir, device=device_index)
+    return make
 
 
 def hip_shard_factory(device_index: int, dim: int) -> Callable[[str], HipServingShard]:

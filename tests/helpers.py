@@ -60,3 +60,35 @@ class HashEmbedder:
                 rng = np.random.default_rng(abs(hash(w)) % (2 ** 32))
                 out[r] += rng.standard_normal(self.dim).astype(np.float32)
         return out * 3.0  # deliberately un-normalised
+
+
+class TokenHashEncoder:
+    """Process-independent stand-in for the sentence encoder with the surface serving.py's data-parallel ingest
+    uses: ``tokenize(texts) -> (ids, cu)`` on rank 0, ``encode_flat(ids, cu) -> [n, dim]`` on every rank, and
+    ``encode(texts)`` for the single-index path.  A token id is crc32(word) (no PYTHONHASHSEED dependence: the ranks
+    are different processes), a sequence's vector the sum of its tokens' seeded Gaussian vectors."""
+
+    def __init__(self, dim=1024):
+        self.dim = dim
+        self.encoded_seqs = 0
+
+    def tokenize(self, texts):
+        import zlib
+        seqs = [[zlib.crc32(w.encode("utf-8")) % 30000 + 1 for w in t.lower().split()] for t in texts]
+        cu = np.zeros(len(seqs) + 1, dtype=np.int64)
+        np.cumsum([len(q) for q in seqs], out=cu[1:])
+        ids = np.concatenate([np.asarray(q, dtype=np.int32) for q in seqs]) if cu[-1] else np.zeros(0, np.int32)
+        return ids, cu
+
+    def encode_flat(self, ids, cu):
+        n = len(cu) - 1
+        out = np.zeros((n, self.dim), dtype=np.float32)
+        for r in range(n):
+            for tok in np.asarray(ids[int(cu[r]):int(cu[r + 1])]):
+                out[r] += np.random.default_rng(int(tok)).standard_normal(self.dim).astype(np.float32)
+        self.encoded_seqs += n
+        return out * 3.0  # deliberately un-normalised
+
+    def encode(self, texts):
+        ids, cu = self.tokenize(texts)
+        return self.encode_flat(ids, cu)

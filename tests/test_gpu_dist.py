@@ -221,6 +221,82 @@ def test_shim_over_sharded_hip_index_equals_single_hip_index(gpu, tmp_path, back
     assert int(z["single_count"]) == 90 and int(z["single_rows"]) == 92 and len(z["single_sem_ids"]) == 10
 
 
+def _dp_ingest_worker(rank, world, port, out_dir, model_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from rassengine_amd import embedding, indexer, serving
+        from rassengine_amd.docstore import REGISTRY
+        from rassengine_amd.encoder import HipSentenceEncoder
+        from rassengine_amd.engine import Engine
+        front = serving.start(serving.hip_shard_factory(0, 128), 128, torch.device("cuda", 0),
+                              encoder_factory=serving.hip_encoder_factory(model_dir, 0))
+        if rank != 0:
+            open(os.path.join(out_dir, f"worker{rank}.done"), "w").write("ok")
+            return
+        import asyncio
+        enc = HipSentenceEncoder.from_dir(model_dir, device=0)
+        embedding.set_embedder(enc)
+        words = [f"w{i}" for i in range(40)]
+        rng = np.random.default_rng(3)
+        docs = [{"doc_id": f"d{i}", "doc_type": "unstructured", "patientId": f"p{i % 3}",
+                 "unstructuredText": " ".join(rng.choice(words, size=int(rng.integers(3, 40))))} for i in range(600)]
+        docs[9]["unstructuredText"] = ""
+
+        def run(name):
+            asyncio.run(indexer.store_fhir_docs_in_opensearch([], docs, None, name))       # 3 encoder batches
+            ix = indexer.HipIndexer(None, name)
+            out = {}
+            for key, d, kw in (("a", 17, {}), ("b", 411, {"patient_id": "p0"}), ("c", 599, {})):
+                h = ix.semantic_search(asyncio.run(embedding.embed_query(docs[d]["unstructuredText"])), k=5, **kw)
+                out[key + "_ids"] = [x["doc_id"] for x, _ in h]
+                out[key + "_scores"] = [float(v) for _, v in h]
+            st = REGISTRY.get(name)
+            out["rows"], out["count"] = int(st.index.rows), int(st.index.count)
+            return out
+        sharded = run("rass-idx-dp")
+        idx = REGISTRY.get("rass-idx-dp").index
+        assert isinstance(idx, serving.ShardedIndex) and idx.can_encode and sorted(set(idx._owner_rank)) == [0, 1]
+        front.shutdown()
+        REGISTRY.clear()
+        eng = Engine.get(0, 128)
+        REGISTRY.set_index_factory(lambda name: eng.open_index("single-" + name))
+        single = run("rass-idx-dp")
+        np.savez(os.path.join(out_dir, "dp.npz"), **{"sharded_" + k: np.asarray(v) for k, v in sharded.items()},
+                 **{"single_" + k: np.asarray(v) for k, v in single.items()})
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_ingest_with_hip_encoders_on_two_ranks(gpu, tmp_path):
+    """SURVEY 8e on real kernels: two ranks (sharing the test GPU), each with its own HIP encoder and shard; rank 0
+    tokenises, each rank encodes the batches dealt to it straight into its shard.  Ids, order and scores equal the
+    single-engine ingest of the same texts (the encoder's output for a sequence does not depend on its batch)."""
+    import torch.multiprocessing as mp
+    from rassengine_amd.encoder import EncoderConfig, synthetic_vocab, write_random_model_dir
+    model_dir = str(tmp_path / "tiny")
+    vocab = synthetic_vocab(300)
+    vocab[200:240] = [f"w{i}" for i in range(40)]
+    write_random_model_dir(model_dir, EncoderConfig(vocab_size=300, hidden=128, layers=2, heads=2, intermediate=512,
+                                                    max_positions=512), seed=5, vocab=vocab)
+    mp.spawn(_dp_ingest_worker, args=(2, _free_port(), str(tmp_path), model_dir), nprocs=2, join=True)
+    assert os.path.exists(os.path.join(str(tmp_path), "worker1.done"))
+    z = np.load(os.path.join(str(tmp_path), "dp.npz"))
+    for k in sorted(k[len("single_"):] for k in z.files if k.startswith("single_")):
+        a, b = z["sharded_" + k], z["single_" + k]
+        if a.dtype.kind == "f":
+            assert a.shape == b.shape and np.allclose(a, b, rtol=0, atol=2e-6), (k, a, b)
+        else:
+            assert a.tolist() == b.tolist(), (k, a, b)
+    assert int(z["single_rows"]) == 600 and z["single_a_ids"][0] == "d17" and z["single_c_ids"][0] == "d599"
+
+
 def _peer_worker(rank, world, port, n_local, out_dir):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"

@@ -168,6 +168,84 @@ def test_store_and_search_through_the_shim_equal_the_single_index(world, tmp_pat
     assert len(z["single_hs_ids"]) > 0                                  # structured rows of patient p0 exist
 
 
+def _dp_scenario(indexer, embedding, REGISTRY, name):
+    """Ingest through store_fhir_docs_in_opensearch with NO embed_fn: on a sharded index whose ranks have encoders
+    the texts are embedded data-parallel (ShardedIndex.add_texts); on a single index by the process's embedder."""
+    import asyncio
+    docs = [{"doc_id": f"n-{i}", "doc_type": "unstructured", "patientId": f"p{i % 4}",
+             "unstructuredText": f"note {i} mentions topic{i % 11} drug{i % 5} ward{i % 3}"} for i in range(700)]
+    docs[13]["unstructuredText"] = "   "            # blank: a zero row, never a hit
+    asyncio.run(indexer.store_fhir_docs_in_opensearch([], docs[:600], None, name))      # 3 encoder batches
+    asyncio.run(indexer.store_fhir_docs_in_opensearch([], docs[600:], None, name))
+    asyncio.run(indexer.store_fhir_docs_in_opensearch([], [dict(docs[5], unstructuredText="fresh words only")], None, name))
+    ix = indexer.HipIndexer(None, name)
+    out = {}
+    for key, text, kw in (("a", "note 77 mentions topic0 drug2 ward2", {}), ("b", "fresh words only", {}),
+                          ("c", "note 300 mentions topic3 drug0 ward0", {"patient_id": "p0"})):
+        h = ix.semantic_search(asyncio.run(embedding.embed_query(text)), k=8, **kw)
+        out[key + "_ids"] = [d["doc_id"] for d, _ in h]
+        out[key + "_scores"] = [float(x) for _, x in h]
+    st = REGISTRY.get(name)
+    out["count"], out["rows"] = int(st.index.count), int(st.index.rows)
+    out["row13"] = np.asarray(st.index.get_row(13), dtype=np.float32)
+    return out
+
+
+def _dp_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from rassengine_amd import embedding, indexer, serving
+        from rassengine_amd.docstore import REGISTRY
+        from tests.helpers import OracleIndex, TokenHashEncoder
+        encoders = []
+
+        def make_encoder():
+            encoders.append(TokenHashEncoder(1024))
+            return encoders[-1]
+        front = serving.start(lambda name: OracleServingShard(1024), 1024, torch.device("cpu"), encoder_factory=make_encoder)
+        seen = encoders[0].encoded_seqs if encoders else 0
+        open(os.path.join(out_dir, f"encoded{rank}.txt"), "w").write(str(seen))
+        if rank != 0:
+            return
+        embedding.set_embedder(TokenHashEncoder(1024))          # queries only: the ingest must not use it
+        sharded = _dp_scenario(indexer, embedding, REGISTRY, "rass-idx-dp")
+        idx = REGISTRY.get("rass-idx-dp").index
+        assert isinstance(idx, serving.ShardedIndex) and idx.can_encode
+        assert sorted(set(idx._owner_rank)) == list(range(world))
+        open(os.path.join(out_dir, "encoded0.txt"), "w").write(str(encoders[0].encoded_seqs))
+        front.shutdown()
+        REGISTRY.clear()
+        REGISTRY.set_index_factory(lambda name: OracleIndex(1024))
+        single = _dp_scenario(indexer, embedding, REGISTRY, "rass-idx-dp")
+        np.savez(os.path.join(out_dir, "rank0.npz"), **{"sharded_" + k: np.asarray(v) for k, v in sharded.items()},
+                 **{"single_" + k: np.asarray(v) for k, v in single.items()})
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_data_parallel_ingest_equals_the_single_index(world, tmp_path):
+    """ingest is data-parallel — every rank encodes the batches dealt to it into its own shard."""
+    mp.spawn(_dp_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    z = np.load(os.path.join(str(tmp_path), "rank0.npz"))
+    keys = sorted(k[len("single_"):] for k in z.files if k.startswith("single_"))
+    for k in keys:
+        a, b = z["sharded_" + k], z["single_" + k]
+        if a.dtype.kind == "f":
+            assert a.shape == b.shape and np.array_equal(a, b), k
+        else:
+            assert a.tolist() == b.tolist(), (k, a, b)
+    assert int(z["single_rows"]) == 701 and int(z["single_count"]) == 700
+    assert z["single_b_ids"][0] == "n-5" and "n-13" not in z["single_a_ids"].tolist()
+    assert not z["single_row13"].any()                                       # the blank text is a zero row
+    # every rank really encoded: 700 non-blank texts spread over the ranks' own encoders
+    done = [int(open(os.path.join(str(tmp_path), f"encoded{r}.txt")).read()) for r in range(world)]
+    assert all(d > 0 for d in done) and sum(done) == 700, done
+
+
 def test_extent_table():
     from rassengine_amd.serving import Extents
     e = Extents()

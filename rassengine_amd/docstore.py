@@ -132,6 +132,10 @@ class IndexState:
             _fsync_dir(os.path.dirname(prefix) or ".")
             self.generation = gen
             if prev and prev != vec_path and os.path.exists(prev):
+                # a sharded index's vector "file" is a manifest naming one shard file per rank
+                for f in (self.index.saved_files(prev) if hasattr(self.index, "saved_files") else []):
+                    if os.path.exists(f):
+                        os.remove(f)
                 os.remove(prev)
 
     @staticmethod

@@ -19,6 +19,10 @@ shard, so the collectives line up by construction:
     DELETE  the owner (global id -> (rank, ordinal) through the extent table) tombstones the row
     COUNT   all-reduce of the shards' live row counts
     GETROW  the owner sends the stored row to rank 0
+    ENCODE  data-parallel ingest: rank 0 tokenises, the round's token ids are broadcast, every rank encodes the
+            batches dealt to it with its own encoder straight into its shard (no embedding crosses ranks)
+    SAVE    every rank writes its shard file, an all-reduce tells rank 0 that all are durable, rank 0 writes the
+            manifest (world size, run table, tombstones); LOAD is the inverse and rebuilds the ranks' extent tables
     SHUTDOWN workers leave the loop; every rank then meets in a barrier (a clean collective exit: the workers
             are ordinary processes that return, nothing is re-exec'ed or killed)
 
@@ -29,6 +33,9 @@ tests/test_gpu_dist.py for the HIP shards).
 from __future__ import annotations
 
 import bisect
+import json
+import logging
+import os
 import threading
 from typing import Callable, Dict, List, Optional, Tuple
 
@@ -36,7 +43,9 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-OP_SHUTDOWN, OP_OPEN, OP_SEARCH, OP_ADD, OP_DELETE, OP_COUNT, OP_GETROW, OP_DROP, OP_ENCODE = range(9)
+logger = logging.getLogger("rassengine_amd.serving")
+
+OP_SHUTDOWN, OP_OPEN, OP_SEARCH, OP_ADD, OP_DELETE, OP_COUNT, OP_GETROW, OP_DROP, OP_ENCODE, OP_SAVE, OP_LOAD = range(11)
 ENC_BATCH_SEQS = 256          # sequences per encoder batch = the unit dealt to a rank (BASELINE configs[2]: batch 256)
 HDR_WORDS = 16
 MAX_Q = 32
@@ -94,6 +103,9 @@ class HipServingShard:
     def delete(self, ordinal: int) -> None:
         self.index.delete(ordinal)
 
+    def save(self, path: str) -> None:
+        self.index.save(path)
+
     def get_row(self, ordinal: int) -> torch.Tensor:
         return torch.from_numpy(self.index.get_row(ordinal)).to(self.device)
 
@@ -131,8 +143,10 @@ class ShardServer:
     """Runs on EVERY rank: owns the rank's shards and executes the command stream."""
 
     def __init__(self, shard_factory: Callable[[str], object], dim: int, device: torch.device,
-                 group: Optional[dist.ProcessGroup] = None, encoder_factory: Optional[Callable[[], object]] = None):
+                 group: Optional[dist.ProcessGroup] = None, encoder_factory: Optional[Callable[[], object]] = None,
+                 shard_loader: Optional[Callable[[str, str], object]] = None):
         self.factory = shard_factory
+        self.loader = shard_loader               # (name, file) -> shard, for OP_LOAD
         self.encoder_factory = encoder_factory   # rank-local sentence encoder (data-parallel ingest), built lazily
         self._encoder = None
         self.dim = dim
@@ -164,6 +178,18 @@ class ShardServer:
         if self.world > 1:
             dist.broadcast(t, src=0, group=self.group)
         return t
+
+    def _all_ok(self, ok: bool, what: str) -> None:
+        """Every rank learns whether EVERY rank succeeded (a save / load either holds on all shards or is refused)."""
+        t = torch.tensor([0 if ok else 1], dtype=torch.int64, device=self.device)
+        if self.world > 1:
+            dist.all_reduce(t, group=self.group)
+        if int(t.item()) != 0:
+            raise RuntimeError(f"{what} failed on {int(t.item())} rank(s)")
+
+    @staticmethod
+    def shard_file(base: str, rank: int, world: int) -> str:
+        return f"{base}.shard{rank}of{world}"
 
     def _send(self, t: torch.Tensor, dst: int) -> None:
         dist.send(t.cpu() if self._p2p_on_host else t, dst=dst, group=self.group)
@@ -212,6 +238,44 @@ class ShardServer:
         if op == OP_DROP:
             self.shards.pop(code, None)
             self.extents.pop(code, None)
+            return None
+        if op == OP_SAVE:
+            # every rank writes its shard next to the manifest rank 0 writes afterwards: <base>.shard<r>of<G>,
+            # temp name + rename (rass_index_save fsyncs); rank 0 only proceeds when all of them are durable
+            base = bytes(self._payload(int(hdr[2])).cpu().numpy()).decode("utf-8")
+            f = self.shard_file(base, self.rank, self.world)
+            ok = True
+            try:
+                self.shards[code].save(f + ".tmp")
+                os.replace(f + ".tmp", f)
+            except Exception as e:       # reported through the all-reduce: the ranks must stay in step
+                logger.error(f"shard save failed on rank {self.rank}: {e}")
+                ok = False
+            self._all_ok(ok, "shard save")
+            return None
+        if op == OP_LOAD:
+            plen, nlen, n_runs = int(hdr[2]), int(hdr[3]), int(hdr[4])
+            base = bytes(self._payload(plen).cpu().numpy()).decode("utf-8")
+            name = bytes(self._payload(nlen, plen).cpu().numpy()).decode("utf-8")
+            runs = self._bcast(vecs, (max(n_runs, 1), 3), torch.int64).cpu().numpy()[:n_runs]   # (gid, rank, n)
+            ok = True
+            try:
+                if self.loader is None:
+                    raise RuntimeError("serving.start() was given no shard_loader")
+                shard = self.loader(name, self.shard_file(base, self.rank, self.world))
+                ext = Extents()
+                ordinal = 0
+                for gid, owner, n in runs:      # this rank's runs, in the order it appended them
+                    if int(owner) == self.rank:
+                        ext.append(int(gid), ordinal, int(n))
+                        ordinal += int(n)
+                if ordinal != int(shard.rows):
+                    raise RuntimeError(f"shard file holds {int(shard.rows)} rows, the manifest gives this rank {ordinal}")
+                self.shards[code], self.extents[code] = shard, ext
+            except Exception as e:
+                logger.error(f"shard load failed on rank {self.rank}: {e}")
+                ok = False
+            self._all_ok(ok, "shard load")
             return None
         shard = self.shards[code]
         if op == OP_SEARCH:
@@ -324,6 +388,34 @@ class ShardedFront:
                 idx = self.indices[name] = ShardedIndex(self, name, code)
             return idx
 
+    def load_index(self, name: str, path: str) -> "ShardedIndex":
+        """``IndexState.load``'s index loader: ``path`` is the manifest ``ShardedIndex.save`` wrote; every rank loads
+        its own shard file.  Refused unless the world size equals the one that saved."""
+        with open(path, encoding="utf-8") as f:
+            man = json.load(f)
+        s = self.server
+        if man.get("format") != "rass-sharded-1" or int(man["world"]) != s.world:
+            raise ValueError(f"{path}: saved by {man.get('world')} ranks, this service has {s.world}")
+        with self.lock:
+            if name in self.indices:
+                raise ValueError(f"index {name!r} is already open")
+            code = len(self.indices)
+            base = os.path.join(os.path.dirname(path) or ".", man["base"])
+            p = np.frombuffer(base.encode("utf-8"), dtype=np.uint8)
+            nm = np.frombuffer(name.encode("utf-8"), dtype=np.uint8)
+            runs = np.array([[g, r, n] for g, r, n in man["runs"]], dtype=np.int64).reshape(-1, 3)
+            hdr = s.post([OP_LOAD, code, p.size, nm.size, runs.shape[0]], np.concatenate([p, nm]))
+            s.execute(hdr, vecs=torch.from_numpy(runs if runs.size else np.zeros((1, 3), np.int64)))
+            idx = self.indices[name] = ShardedIndex(self, name, code)
+            idx._rows, idx._batches = int(man["rows"]), int(man["batches"])
+            idx._deleted = set(int(x) for x in man["deleted"])
+            for g, r, n in man["runs"]:
+                if not idx._owner_rank or idx._owner_rank[-1] != int(r):
+                    idx._owner_gid.append(int(g))
+                    idx._owner_rank.append(int(r))
+            idx._runs = [[int(g), int(r), int(n)] for g, r, n in man["runs"]]
+            return idx
+
     def shutdown(self) -> None:
         """Clean collective exit: workers leave their loop, every rank meets in a barrier."""
         with self.lock:
@@ -347,6 +439,7 @@ class ShardedIndex:
         self._batches = 0                   # round-robin cursor
         self._owner_gid: List[int] = []     # extent table of the WHOLE index: sorted gid bases ...
         self._owner_rank: List[int] = []    # ... and the rank that holds each run
+        self._runs: List[List[int]] = []    # every appended run (gid base, rank, rows): what a saved manifest keeps
         self._deleted = set()
 
     # ---- bookkeeping
@@ -395,6 +488,7 @@ class ShardedIndex:
                 if not self._owner_rank or self._owner_rank[-1] != owner:
                     self._owner_gid.append(self._rows)
                     self._owner_rank.append(owner)
+                self._runs.append([self._rows, owner, m])
                 self._rows += m
             return first
 
@@ -443,9 +537,39 @@ class ShardedIndex:
                     if not self._owner_rank or self._owner_rank[-1] != owner:
                         self._owner_gid.append(self._rows)
                         self._owner_rank.append(owner)
+                    self._runs.append([self._rows, owner, m])
                     self._rows += m
                 self._batches += n_batches
             return first
+
+    # ---- persistence (docstore.IndexState.save / load call these through the FlatIndex surface)
+    def save(self, path: str) -> None:
+        """Every rank saves its shard to ``<base>.shard<r>of<G>`` (base = ``path`` without a trailing ``.tmp``);
+        when ALL are durable rank 0 writes the manifest — world size, the run table (gid base, rank, rows) the
+        ranks' extent tables are rebuilt from, tombstones — to ``path``, which the caller renames into place."""
+        base = path[:-4] if path.endswith(".tmp") else path
+        with self.front.lock:
+            s = self.front.server
+            raw = np.frombuffer(base.encode("utf-8"), dtype=np.uint8)
+            if raw.size > s.payload_bytes:
+                raise ValueError("path too long")
+            s.execute(s.post([OP_SAVE, self.code, raw.size], raw))
+            man = {"format": "rass-sharded-1", "world": s.world, "base": os.path.basename(base), "rows": self._rows,
+                   "batches": self._batches, "runs": self._runs, "deleted": sorted(self._deleted)}
+            with open(path, "w", encoding="utf-8") as f:
+                json.dump(man, f)
+                f.flush()
+                os.fsync(f.fileno())
+
+    def saved_files(self, manifest_path: str) -> List[str]:
+        """The shard files a manifest of this index names (``IndexState.save`` removes the previous generation's)."""
+        try:
+            with open(manifest_path, encoding="utf-8") as f:
+                man = json.load(f)
+            d = os.path.dirname(manifest_path) or "."
+            return [ShardServer.shard_file(os.path.join(d, man["base"]), r, int(man["world"])) for r in range(int(man["world"]))]
+        except (OSError, ValueError, KeyError):
+            return []
 
     def delete(self, row: int) -> None:
         with self.front.lock:
@@ -498,14 +622,15 @@ class ShardedIndex:
 
 def start(shard_factory: Callable[[str], object], dim: int, device: Optional[torch.device] = None,
           group: Optional[dist.ProcessGroup] = None, install_registry: bool = True,
-          encoder_factory: Optional[Callable[[], object]] = None) -> Optional[ShardedFront]:
+          encoder_factory: Optional[Callable[[], object]] = None,
+          shard_loader: Optional[Callable[[str, str], object]] = None) -> Optional[ShardedFront]:
     """Call on EVERY rank after ``init_process_group``.  Rank 0 gets the front back at once (and, with
     ``install_registry``, ``docstore.REGISTRY`` now opens sharded indices, so ``HipIndexer`` /
     ``store_fhir_docs_in_opensearch`` serve the multi-GPU index unchanged); the other ranks stay inside
     this call, following rank 0, until it calls ``front.shutdown()``, and then return ``None``."""
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
-    server = ShardServer(shard_factory, dim, device, group, encoder_factory)
+    server = ShardServer(shard_factory, dim, device, group, encoder_factory, shard_loader)
     if server.rank != 0:
         worker_loop(server)
         return None
@@ -522,6 +647,15 @@ def hip_encoder_factory(model_dir: str, device_index: int) -> Callable[[], objec
         from .encoder import HipSentenceEncoder
         return HipSentenceEncoder.from_dir(model_dir, device=device_index)
     return make
+
+
+def hip_shard_loader(device_index: int, dim: int) -> Callable[[str, str], "HipServingShard"]:
+    """``start(shard_loader=...)`` for HIP shards: ``rass_index_load`` of the rank's shard file."""
+    from .engine import Engine
+
+    def load(name: str, path: str) -> HipServingShard:
+        return HipServingShard(Engine.get(device_index, dim).load_index(name, path))
+    return load
 
 
 def hip_shard_factory(device_index: int, dim: int) -> Callable[[str], HipServingShard]:

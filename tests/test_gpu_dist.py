@@ -179,7 +179,8 @@ def _serving_worker(rank, world, port, out_dir, backend):
         from rassengine_amd.engine import Engine
         from tests.helpers import HashEmbedder
         from tests.test_serving_gloo import _scenario
-        front = serving.start(serving.hip_shard_factory(device, 1024), 1024, torch.device("cuda", device))
+        front = serving.start(serving.hip_shard_factory(device, 1024), 1024, torch.device("cuda", device),
+                              shard_loader=serving.hip_shard_loader(device, 1024))
         if rank != 0:
             assert front is None
             open(os.path.join(out_dir, f"worker{rank}.done"), "w").write("ok")
@@ -188,6 +189,18 @@ def _serving_worker(rank, world, port, out_dir, backend):
         sharded = _scenario(indexer, embedding, REGISTRY, config, "rass-idx-user1")
         idx = REGISTRY.get("rass-idx-user1").index
         assert isinstance(idx, serving.ShardedIndex) and sorted(set(idx._owner_rank)) == [0, 1]
+        # persistence through the front on real shard files (rass_index_save keeps the global ids)
+        import asyncio
+        from rassengine_amd.docstore import IndexState
+        st = REGISTRY.get("rass-idx-user1")
+        prefix = os.path.join(out_dir, "saved-user1")
+        st.save(prefix)
+        st2 = IndexState.load("rass-idx-restored", prefix, front.load_index)
+        qv = asyncio.run(embedding.embed_query("chunk number 12 about topic5 and drug0"))
+        a, b = st.index.search(qv, 10), st2.index.search(qv, 10)
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[0], b[0])
+        assert st2.index.count == st.index.count and st2.index.rows == st.index.rows
+        assert np.array_equal(st2.index.get_row(int(a[1][0, 0])), st.index.get_row(int(a[1][0, 0])))
         front.shutdown()
         # the same scenario on ONE HIP index in this process
         REGISTRY.clear()

@@ -50,6 +50,17 @@ class OracleServingShard:
     def delete(self, ordinal):
         self._tags[ordinal] = -1
 
+    def save(self, path):
+        with open(path, "wb") as f:
+            np.savez(f, x=self._x, tags=self._tags, gid=self._gid)
+
+    @classmethod
+    def load(cls, dim, path):
+        z = np.load(path)
+        s = cls(dim)
+        s._x, s._tags, s._gid = z["x"], z["tags"], z["gid"]
+        return s
+
     def get_row(self, ordinal):
         return torch.from_numpy(self._x[ordinal].copy())
 
@@ -125,7 +136,8 @@ def _worker(rank, world, port, out_dir):
         from rassengine_amd import config, embedding, indexer, serving
         from rassengine_amd.docstore import REGISTRY
         from tests.helpers import HashEmbedder, OracleIndex
-        front = serving.start(lambda name: OracleServingShard(1024), 1024, torch.device("cpu"))
+        front = serving.start(lambda name: OracleServingShard(1024), 1024, torch.device("cpu"),
+                              shard_loader=lambda name, path: OracleServingShard.load(1024, path))
         if rank != 0:
             assert front is None                       # the worker left its loop through the collective shutdown
             open(os.path.join(out_dir, f"worker{rank}.done"), "w").write("ok")
@@ -136,6 +148,29 @@ def _worker(rank, world, port, out_dir):
         idx = REGISTRY.get("rass-idx-user1").index
         assert isinstance(idx, serving.ShardedIndex)
         assert sorted(set(idx._owner_rank)) == list(range(min(world, 4)))
+        # persistence through the front: every rank saves its shard, rank 0 the manifest; two generations, then a
+        # load under another name must answer exactly like the live index (and the first generation's files go)
+        from rassengine_amd.docstore import IndexState
+        import asyncio
+        st = REGISTRY.get("rass-idx-user1")
+        prefix = os.path.join(out_dir, "saved-user1")
+        st.save(prefix)
+        gen1 = sorted(f for f in os.listdir(out_dir) if ".g000001." in f)
+        assert len(gen1) == 1 + world, gen1                     # manifest + one shard file per rank
+        st.save(prefix)
+        assert not [f for f in os.listdir(out_dir) if ".g000001." in f]
+        st2 = IndexState.load("rass-idx-restored", prefix, front.load_index)
+        assert isinstance(st2.index, serving.ShardedIndex) and st2.index.rows == st.index.rows
+        assert st2.index.count == st.index.count
+        qv = asyncio.run(embedding.embed_query("chunk number 12 about topic5 and drug0"))
+        PM = 0x00FFFFFF
+        a = st.index.search(qv, 10)
+        b = st2.index.search(qv, 10)
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[0], b[0])
+        st2.index.delete(int(a[1][0, 0]))                       # the restored extent tables find the owner
+        assert int(st2.index.search(qv, 10)[1][0, 0]) == int(a[1][0, 1])
+        first_new = st2.index.add(np.ones((3, 1024), dtype=np.float32))
+        assert first_new == st.index.rows and st2.index.count == st.index.count - 1 + 3
         front.shutdown()
         front.shutdown()                               # idempotent
         # the same scenario on ONE index in this very process (same HashEmbedder hash seed)

@@ -197,6 +197,17 @@ int rass_index_search_device_ex(rass_index_t* idx, const float* d_queries,
                                 const int32_t* d_q_filter_mask, int64_t id_base,
                                 float* d_out_scores, int64_t* d_out_ids);
 
+/* One pass of a k > RASS_MAX_K search over a SHARD (rassengine_amd/serving.py): query q ranks only the rows strictly
+ * after (d_after_score[q], row d_after_row[q]) in (score desc, row asc) order, i.e. score < after_score, or equal
+ * and row ordinal > after_row (-1: every tying row counts).  A multi-GPU front asks every shard for its next 32
+ * behind the previous pass's last GLOBAL hit — each rank translates that hit's id into its own row ordinals, which
+ * ascend with the ids — and merges; the reference passes the caller's top_k straight through (app/main.py:2882,
+ * 3008).  Reported ids are the index's own (caller-assigned ids where rass_index_add_ex gave them, else ordinals). */
+int rass_index_search_device_after(rass_index_t* idx, const float* d_queries, int nq, int k,
+                                   const int32_t* d_q_filter, const int32_t* d_q_filter_mask,
+                                   const float* d_after_score, const int64_t* d_after_row,
+                                   float* d_out_scores, int64_t* d_out_ids);
+
 /* Many launch groups in one call (nq <= RASS_MAX_DEVICE_BATCH, k <= RASS_MAX_K): the result is, bit for bit,
  * that of rass_index_search_device on consecutive groups of RASS_MAX_QBATCH queries, but on an fp32 index the
  * batch shares ONE normalise launch and ONE merge launch and runs the groups' score-floor sample passes back to

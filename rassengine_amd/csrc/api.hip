@@ -900,26 +900,32 @@ namespace {
 
 // One launch group (<= 32 queries) of a device search; the caller holds eng->mu and has set the device.
 int search_device_group(rass_index* idx, const float* d_queries, int nq, int k, const int32_t* d_q_filter,
-                        const int32_t* d_q_filter_mask, int64_t id_base, float* d_out_scores, int64_t* d_out_ids) {
+                        const int32_t* d_q_filter_mask, int64_t id_base, float* d_out_scores, int64_t* d_out_ids,
+                        const float* d_after_score = nullptr, const int64_t* d_after_row = nullptr) {
     rass_engine* eng = idx->eng;
     const int64_t rows = idx->rows.load(std::memory_order_acquire);
     const bool need_tags = (idx->deleted.load(std::memory_order_acquire) > 0) || (d_q_filter != nullptr);
     const bool gid = idx->has_gid.load(std::memory_order_acquire);  // caller-assigned ids: reported instead of
     if (idx->dtype == RASS_BF16) {
-        if (d_q_filter_mask) return fail(RASS_ERR_UNSUPPORTED, "masked filters are not implemented for a bf16 corpus");
+        if (d_q_filter_mask || d_after_score)
+            return fail(RASS_ERR_UNSUPPORTED, "masked filters / continuation are not implemented for a bf16 corpus");
         return bf16_scan_launch(idx, d_queries, nq, d_q_filter, k, id_base, d_out_scores, d_out_ids,
                                 need_tags ? idx->d_tags : nullptr, eng, eng->stream, gid ? idx->d_gid : nullptr);
     }
-    if (idx->prefilter && rows > 0 && k <= kPrefilterMaxK && !gid && !d_q_filter_mask)  // id_base + ordinal
+    if (idx->prefilter && rows > 0 && k <= kPrefilterMaxK && !gid && !d_q_filter_mask && !d_after_score)  // id_base + ordinal
         return prefilter_launch(idx, d_queries, nq, d_q_filter, k, id_base, d_out_scores, d_out_ids,
                                 need_tags ? idx->d_tags : nullptr, eng, eng->stream);
     ScanExt ext;
     ext.d_q_mask = d_q_filter_mask;
+    ext.d_after_s = d_after_score;
+    ext.d_after_i = d_after_row;
+    // the continuation bound names ROWS of this index (the kernel compares id_base + row): the scan runs with
+    // id_base 0 and the ids are translated afterwards, as for caller-assigned ids
     return scan_launch(idx->d_rows ? idx->d_rows : reinterpret_cast<const float*>(eng->d_scratch), rows,
                        idx->stride, need_tags ? idx->d_tags : nullptr, d_queries, idx->dim, idx->dim, nq,
-                       d_q_filter, k, gid ? 0 : id_base, d_out_scores, d_out_ids, eng->d_scratch, eng->scratch_bytes,
-                       eng->n_cus, eng->stream, eng, nullptr, gid ? idx->d_gid : nullptr,
-                       d_q_filter_mask ? &ext : nullptr);
+                       d_q_filter, k, (gid || d_after_score) ? 0 : id_base, d_out_scores, d_out_ids, eng->d_scratch,
+                       eng->scratch_bytes, eng->n_cus, eng->stream, eng, nullptr, gid ? idx->d_gid : nullptr,
+                       (d_q_filter_mask || d_after_score) ? &ext : nullptr);
 }
 
 struct BatchLayout {
@@ -1052,6 +1058,20 @@ int rass_index_search_device_ex(rass_index_t* idx, const float* d_queries, int n
     int rc = set_device(eng);
     if (rc != RASS_OK) return rc;
     return search_device_group(idx, d_queries, nq, k, d_q_filter, d_q_filter_mask, id_base, d_out_scores, d_out_ids);
+}
+
+int rass_index_search_device_after(rass_index_t* idx, const float* d_queries, int nq, int k, const int32_t* d_q_filter,
+                                   const int32_t* d_q_filter_mask, const float* d_after_score,
+                                   const int64_t* d_after_row, float* d_out_scores, int64_t* d_out_ids) {
+    if (!idx || !d_queries || !d_out_scores || !d_out_ids || !d_after_score || !d_after_row)
+        return fail(RASS_ERR_INVALID, "NULL argument");
+    if (d_q_filter_mask && !d_q_filter) return fail(RASS_ERR_INVALID, "q_filter_mask without q_filter");
+    rass_engine* eng = idx->eng;
+    std::lock_guard<std::mutex> lk(eng->mu);
+    int rc = set_device(eng);
+    if (rc != RASS_OK) return rc;
+    return search_device_group(idx, d_queries, nq, k, d_q_filter, d_q_filter_mask, 0, d_out_scores, d_out_ids,
+                               d_after_score, d_after_row);
 }
 
 int rass_index_search_device_batch(rass_index_t* idx, const float* d_queries, int nq, int k, const int32_t* d_q_filter,

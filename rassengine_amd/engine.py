@@ -262,6 +262,18 @@ class FlatIndex:
                                                     ctypes.c_void_p(d_q_filter_mask_ptr or 0), int(id_base),
                                                     ctypes.c_void_p(d_out_scores_ptr), ctypes.c_void_p(d_out_ids_ptr)))
 
+    def search_device_after(self, d_queries_ptr: int, nq: int, k: int, d_after_score_ptr: int, d_after_row_ptr: int,
+                            d_out_scores_ptr: int, d_out_ids_ptr: int, d_q_filter_ptr: int = 0,
+                            d_q_filter_mask_ptr: int = 0) -> None:
+        """One continuation pass (``rass_index_search_device_after``): only rows strictly after (after_score[q],
+        after_row[q]) in (score desc, row asc) rank for query q.  Async, device-resident, nq <= 32, k <= 32."""
+        N.check("rass_index_search_device_after",
+                self._L.rass_index_search_device_after(self._h, ctypes.c_void_p(d_queries_ptr), int(nq), int(k),
+                                                       ctypes.c_void_p(d_q_filter_ptr or 0),
+                                                       ctypes.c_void_p(d_q_filter_mask_ptr or 0),
+                                                       ctypes.c_void_p(d_after_score_ptr), ctypes.c_void_p(d_after_row_ptr),
+                                                       ctypes.c_void_p(d_out_scores_ptr), ctypes.c_void_p(d_out_ids_ptr)))
+
     def search_device_batch(self, d_queries_ptr: int, nq: int, k: int, d_out_scores_ptr: int, d_out_ids_ptr: int,
                             id_base: int = 0, d_q_filter_ptr: int = 0, out_scores_group_stride: int = 0,
                             out_ids_group_stride: int = 0) -> None:

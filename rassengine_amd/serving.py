@@ -70,6 +70,14 @@ class Extents:
         self.ordinal.append(ordinal_base)
         self.n.append(n)
 
+    def ordinal_upto(self, gid: int) -> int:
+        """The largest local ordinal whose global id is <= ``gid`` (-1: none).  Ids ascend with ordinals, so "rows with
+        a global id > gid" are exactly "rows with an ordinal > ordinal_upto(gid)" (continuation bound of a k > 32 pass)."""
+        e = bisect.bisect_right(self.gid, gid) - 1
+        if e < 0:
+            return -1
+        return self.ordinal[e] + min(gid - self.gid[e], self.n[e] - 1)
+
     def ordinal_of(self, gid: int) -> Optional[int]:
         e = bisect.bisect_right(self.gid, gid) - 1
         if e < 0 or gid >= self.gid[e] + self.n[e]:
@@ -114,11 +122,20 @@ class HipServingShard:
         ids_off = (nq * k * 4 + 7) // 8 * 8
         return ids_off, ids_off + nq * k * 8
 
-    def search_packed(self, queries: torch.Tensor, k: int, filt: Optional[torch.Tensor], mask: Optional[torch.Tensor]
-                      ) -> torch.Tensor:
+    def search_packed(self, queries: torch.Tensor, k: int, filt: Optional[torch.Tensor], mask: Optional[torch.Tensor],
+                      after: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> torch.Tensor:
+        """``after`` = (scores f32 [nq], LOCAL row ordinals i64 [nq]): rank only the rows strictly behind them."""
         nq = queries.shape[0]
         ids_off, size = self.record_bytes(nq, k)
         rec = torch.empty((size,), dtype=torch.uint8, device=self.device)
+        if after is not None:
+            a_s, a_r = after[0].to(self.device).contiguous(), after[1].to(self.device).contiguous()
+            self.index.search_device_after(queries.data_ptr(), nq, k, a_s.data_ptr(), a_r.data_ptr(), rec.data_ptr(),
+                                           rec.data_ptr() + ids_off,
+                                           d_q_filter_ptr=filt.data_ptr() if filt is not None else 0,
+                                           d_q_filter_mask_ptr=mask.data_ptr() if mask is not None else 0)
+            self._keep = (a_s, a_r)      # alive until the stream has consumed them
+            return rec
         self.index.search_device(queries.data_ptr(), nq, k, rec.data_ptr(), rec.data_ptr() + ids_off, id_base=0,
                                  d_q_filter_ptr=filt.data_ptr() if filt is not None else 0,
                                  d_q_filter_mask_ptr=mask.data_ptr() if mask is not None else 0)
@@ -154,7 +171,7 @@ class ShardServer:
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
-        self.payload_bytes = max(MAX_Q * dim * 4 + 2 * MAX_Q * 4, NAME_BYTES)
+        self.payload_bytes = max(MAX_Q * dim * 4 + 3 * MAX_Q * 4 + MAX_Q * 8, NAME_BYTES)   # queries|filter|mask|after
         self.cmd = torch.zeros((HDR_WORDS * 8 + self.payload_bytes,), dtype=torch.uint8, device=device)
         self.shards: Dict[int, object] = {}
         self.extents: Dict[int, Extents] = {}
@@ -284,7 +301,14 @@ class ShardServer:
             off = MAX_Q * self.dim * 4
             filt = self._payload(nq * 4, off).view(torch.int32) if flags & 1 else None
             mask = self._payload(nq * 4, off + MAX_Q * 4).view(torch.int32) if flags & 2 else None
-            rec = shard.search_packed(q, k, filt, mask)
+            after = None
+            if flags & 4:   # a continuation pass of a k > 32 search: the previous pass's last GLOBAL hit per query
+                a_s = self._payload(nq * 4, off + 2 * MAX_Q * 4).view(torch.float32)
+                a_g = self._payload(nq * 8, off + 3 * MAX_Q * 4).view(torch.int64).cpu().numpy()
+                ext = self.extents[code]
+                a_r = torch.tensor([ext.ordinal_upto(int(g)) for g in a_g], dtype=torch.int64)
+                after = (a_s.clone(), a_r)
+            rec = shard.search_packed(q, k, filt, mask, after) if after is not None else shard.search_packed(q, k, filt, mask)
             if self.world == 1:
                 return shard.merge_packed(rec, 1, nq, k)
             gathered = torch.empty((self.world * rec.numel(),), dtype=torch.uint8, device=rec.device)
@@ -592,20 +616,20 @@ class ShardedIndex:
         if q.ndim != 2 or q.shape[1] != self.dim:
             raise ValueError(f"expected [nq, {self.dim}] queries, got {q.shape}")
         k = int(k)
-        if not 1 <= k <= MAX_K:
-            raise ValueError(f"k must be in [1, {MAX_K}] on a sharded index (got {k})")
+        if k < 1:
+            raise ValueError("k must be >= 1")
         if q_filter_mask is not None and q_filter is None:
             raise ValueError("q_filter_mask needs q_filter")
         nq = q.shape[0]
-        out_s = np.empty((nq, k), dtype=np.float32)
-        out_i = np.empty((nq, k), dtype=np.int64)
+        out_s = np.full((nq, k), -np.inf, dtype=np.float32)
+        out_i = np.full((nq, k), -1, dtype=np.int64)
         s = self.front.server
+        off = MAX_Q * self.dim * 4
         for a in range(0, nq, MAX_Q):
             b = min(MAX_Q, nq - a)
-            payload = np.zeros(MAX_Q * self.dim * 4 + 2 * MAX_Q * 4, dtype=np.uint8)
+            payload = np.zeros(s.payload_bytes, dtype=np.uint8)
             payload[:b * self.dim * 4] = q[a:a + b].view(np.uint8).reshape(-1)
             flags = 0
-            off = MAX_Q * self.dim * 4
             if q_filter is not None:
                 flags |= 1
                 payload[off:off + b * 4] = np.ascontiguousarray(q_filter[a:a + b], dtype=np.int32).view(np.uint8)
@@ -613,10 +637,27 @@ class ShardedIndex:
                 flags |= 2
                 payload[off + MAX_Q * 4:off + MAX_Q * 4 + b * 4] = \
                     np.ascontiguousarray(q_filter_mask[a:a + b], dtype=np.int32).view(np.uint8)
-            with self.front.lock:
-                sc, ids = s.execute(s.post([OP_SEARCH, self.code, b, k, flags], payload))
-            out_s[a:a + b] = sc
-            out_i[a:a + b] = ids
+            # k > 32: passes of <= 32; pass p asks every shard for its best rows strictly behind pass p-1's last
+            # global hit (score desc, id asc) — the single-index multipass of rass_index_search_ex, across shards
+            done = 0
+            while done < k:
+                kk = min(MAX_K, k - done)
+                pf = flags
+                if done > 0:
+                    pf |= 4
+                    last_s = out_s[a:a + b, done - 1].copy()
+                    last_i = out_i[a:a + b, done - 1].copy()
+                    exhausted = last_i < 0
+                    last_s[exhausted] = -np.inf          # nothing ranks behind -inf: an exhausted query stays empty
+                    payload[off + 2 * MAX_Q * 4:off + 2 * MAX_Q * 4 + b * 4] = last_s.view(np.uint8)
+                    payload[off + 3 * MAX_Q * 4:off + 3 * MAX_Q * 4 + b * 8] = last_i.view(np.uint8)
+                with self.front.lock:
+                    sc, ids = s.execute(s.post([OP_SEARCH, self.code, b, kk, pf], payload))
+                out_s[a:a + b, done:done + kk] = sc
+                out_i[a:a + b, done:done + kk] = ids
+                done += kk
+                if np.all(ids[:, -1] < 0):               # every query of the group ran out of rows
+                    break
         return out_s, out_i
 
 

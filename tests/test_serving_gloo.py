@@ -64,13 +64,24 @@ class OracleServingShard:
     def get_row(self, ordinal):
         return torch.from_numpy(self._x[ordinal].copy())
 
-    def search_packed(self, queries, k, filt, mask):
+    def search_packed(self, queries, k, filt, mask, after=None):
         from oracle import oracle as O
         from rassengine_amd.serving import HipServingShard
         nq = queries.shape[0]
         qn = O.normalize_ref(queries.numpy().copy()).astype(np.float32)
-        s, i = O.search(self._x, qn, k, tags=self._tags, qfilter=None if filt is None else filt.numpy().copy(),
+        kk = k if after is None else max(self.rows, 1)
+        s, i = O.search(self._x, qn, kk, tags=self._tags, qfilter=None if filt is None else filt.numpy().copy(),
                         qmask=None if mask is None else mask.numpy().copy())
+        if after is not None:      # keep only what ranks strictly behind (after_score, after_row), then the best k
+            a_s, a_r = after[0].numpy(), after[1].numpy()
+            s2 = np.full((nq, k), -np.inf)
+            i2 = np.full((nq, k), -1, dtype=np.int64)
+            for q in range(nq):
+                keep = [(sv, iv) for sv, iv in zip(s[q], i[q]) if iv >= 0 and
+                        (np.float32(sv) < a_s[q] or (np.float32(sv) == a_s[q] and iv > a_r[q]))][:k]
+                for j, (sv, iv) in enumerate(keep):
+                    s2[q, j], i2[q, j] = sv, iv
+            s, i = s2, i2
         gids = np.full(i.shape, -1, dtype=np.int64)
         if self.rows:
             gids = np.where(i >= 0, self._gid[np.clip(i, 0, None)], -1).astype(np.int64)
@@ -114,7 +125,9 @@ def _scenario(indexer, embedding, REGISTRY, config, name):
     hits = {"sem": ix.semantic_search(q, k=10), "pat": ix.semantic_search(q, k=10, patient_id="p1"),
             "hyb": ix.hybrid_search("x", q, k=7), "hs": ix.hybrid_structured_search("x", q, k=5, patient_id="p0"),
             "new": ix.semantic_search(asyncio.run(embedding.embed_query("entirely new words here")), k=3),
-            "none": ix.semantic_search(q, k=5, patient_id="nobody")}
+            "none": ix.semantic_search(q, k=5, patient_id="nobody"),
+            # k > 32: continuation passes across the shards (the reference passes top_k through, main.py:2882)
+            "k50": ix.semantic_search(q, k=50), "k70p": ix.semantic_search(q, k=70, patient_id="p2")}
     for key, h in hits.items():
         out[key + "_ids"] = [d["doc_id"] for d, _ in h]
         out[key + "_scores"] = [float(s) for _, s in h]

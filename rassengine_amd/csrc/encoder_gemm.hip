@@ -522,7 +522,12 @@ __global__ __launch_bounds__(kRingThreads, 2) void gemm_bf16_pring_kernel(const 
     const u16* srcW[2];
     const u16* srcX[2];
     auto point_at = [&](int t) {
+#ifdef RASS_GEMM_EXP_SAME_TILE   // timing experiment: every workgroup streams tile 0's operands (all L2 hits)
+        const int tn0 = 0, tm0 = 0;
+        (void)t;
+#else
         const int tn0 = (t % tiles_n) * RBN, tm0 = (t / tiles_n) * RBM;
+#endif
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const int r = (wave + 8 * p) * 16 + (lane >> 2);
@@ -532,6 +537,10 @@ __global__ __launch_bounds__(kRingThreads, 2) void gemm_bf16_pring_kernel(const 
         }
     };
     auto stage_step = [&](unsigned char* slot_base) {
+#ifdef RASS_GEMM_EXP_NO_DMA      // timing experiment: no operand delivery at all (stale LDS)
+        (void)slot_base;
+        return;
+#endif
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)srcW[p],
@@ -814,8 +823,14 @@ __global__ __launch_bounds__(kW4Threads) void gemm_bf16_w4_kernel(const u16* __r
             // W: image row (half h, M-tile i, MFMA row rho) <- feature h*128 + 32*(rho>>2) + 4*i + (rho&3)
             const int rho = r & 15, i = (r >> 4) & 7, h = r >> 7;
             const int feat = h * 128 + 32 * (rho >> 2) + 4 * i + (rho & 3);
+#ifdef RASS_W4_EXP_FULL_LINES   // timing experiment (wrong results): a wave load covers 8 rows x 128 B, not 16 x 64 B
+            voffW[p] = ((unsigned)(tn0 + (wave + 4 * p) * 16 + (lane >> 3)) * (unsigned)K + (lane & 7) * 8) * 2u;
+            voffX[p] = ((unsigned)(tm0 + (wave + 4 * p) * 16 + (lane >> 3)) * (unsigned)K + (lane & 7) * 8) * 2u;
+            (void)feat; (void)c_src;
+#else
             voffW[p] = ((unsigned)(tn0 + feat) * (unsigned)K + c_src * 8) * 2u;
             voffX[p] = ((unsigned)(tm0 + r) * (unsigned)K + c_src * 8) * 2u;
+#endif
         }
         koff = 0;
     };

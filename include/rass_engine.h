@@ -48,7 +48,8 @@ typedef enum rass_status {
  * normalised queries to bf16 and runs v_mfma_f32_16x16x32_bf16 with fp32 accumulation, so a returned score is the
  * fp32-accumulated dot product of the two bf16-rounded unit vectors (|error| vs the fp32 cosine ~1e-3, the
  * north_star tolerance; recall@k vs the fp32 index is measured, bench.py --corpus-dtype bf16).  Needs dim padded to
- * a multiple of 256; masked filters, k > RASS_MAX_K, the prefilter mode and the IVF build are fp32-only. */
+ * a multiple of 256; masked filters and k > RASS_MAX_K work as on an fp32 index (the bf16 scan's EXT variant); the
+ * prefilter mode and the IVF build are fp32-only. */
 typedef enum rass_dtype {
     RASS_F32 = 0,
     RASS_BF16 = 1

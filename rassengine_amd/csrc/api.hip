@@ -399,7 +399,7 @@ int scan_launch(const float* d_corpus, int64_t n_rows, int64_t stride, const int
 // v_mfma_f32_16x16x32_bf16 with fp32 accumulation over the bf16 slab, per-workgroup top-k, merge.
 int bf16_scan_launch(rass_index* idx, const float* d_queries, int nq, const int32_t* d_q_filter, int k, int64_t id_base,
                      float* d_out_scores, int64_t* d_out_ids, const int32_t* d_row_tag, rass_engine* eng, hipStream_t st,
-                     const int64_t* id_map) {
+                     const int64_t* id_map, const ScanExt* ext = nullptr) {
     if (nq < 1 || nq > RASS_MAX_QBATCH) return fail(RASS_ERR_INVALID, "nq must be in [1, RASS_MAX_QBATCH]");
     if (k < 1 || k > RASS_MAX_K) return fail(RASS_ERR_INVALID, "k must be in [1, RASS_MAX_K]");
     const int64_t stride = idx->stride;
@@ -428,6 +428,11 @@ int bf16_scan_launch(rass_index* idx, const float* d_queries, int nq, const int3
     a.nq = nq;
     a.k = k;
     a.id_base = id_map ? 0 : id_base;
+    if (ext) {
+        a.q_filter_mask = ext->d_q_mask;
+        a.q_after_score = ext->d_after_s;
+        a.q_after_id = ext->d_after_i;
+    }
     const bool timed = eng->ev_on && (size_t)(2 * eng->ev_used + 1) < eng->ev_pool.size();
     if (timed) HIP_TRY(hipEventRecord(eng->ev_pool[2 * eng->ev_used], st));
     HIP_TRY(rass::launch_scan_bf16_topk(a, grid, st));
@@ -907,10 +912,13 @@ int search_device_group(rass_index* idx, const float* d_queries, int nq, int k, 
     const bool need_tags = (idx->deleted.load(std::memory_order_acquire) > 0) || (d_q_filter != nullptr);
     const bool gid = idx->has_gid.load(std::memory_order_acquire);  // caller-assigned ids: reported instead of
     if (idx->dtype == RASS_BF16) {
-        if (d_q_filter_mask || d_after_score)
-            return fail(RASS_ERR_UNSUPPORTED, "masked filters / continuation are not implemented for a bf16 corpus");
-        return bf16_scan_launch(idx, d_queries, nq, d_q_filter, k, id_base, d_out_scores, d_out_ids,
-                                need_tags ? idx->d_tags : nullptr, eng, eng->stream, gid ? idx->d_gid : nullptr);
+        ScanExt bext;
+        bext.d_q_mask = d_q_filter_mask;
+        bext.d_after_s = d_after_score;
+        bext.d_after_i = d_after_row;
+        return bf16_scan_launch(idx, d_queries, nq, d_q_filter, k, (gid || d_after_score) ? 0 : id_base, d_out_scores,
+                                d_out_ids, need_tags ? idx->d_tags : nullptr, eng, eng->stream,
+                                gid ? idx->d_gid : nullptr, (d_q_filter_mask || d_after_score) ? &bext : nullptr);
     }
     if (idx->prefilter && rows > 0 && k <= kPrefilterMaxK && !gid && !d_q_filter_mask && !d_after_score)  // id_base + ordinal
         return prefilter_launch(idx, d_queries, nq, d_q_filter, k, id_base, d_out_scores, d_out_ids,
@@ -1188,11 +1196,10 @@ int rass_index_search_ex(rass_index_t* idx, const float* queries, int nq, int k,
                 const bool gid = idx->has_gid.load(std::memory_order_acquire);
                 if (gid && cont)  // the continuation bound compares row ordinals, the caller would hand back global ids
                     return fail(RASS_ERR_UNSUPPORTED, "k > RASS_MAX_K on an index with caller-assigned row ids");
-                if (idx->dtype == RASS_BF16 && use_ext)
-                    return fail(RASS_ERR_UNSUPPORTED, "masked filters / k > RASS_MAX_K are not implemented for a bf16 corpus");
                 if (idx->dtype == RASS_BF16)
                     rc = bf16_scan_launch(idx, eng->d_qraw, b, d_filter, kk, 0, eng->d_out_scores, eng->d_out_ids,
-                                          need_tags ? idx->d_tags : nullptr, eng, st, gid ? idx->d_gid : nullptr);
+                                          need_tags ? idx->d_tags : nullptr, eng, st, gid ? idx->d_gid : nullptr,
+                                          use_ext ? &ext : nullptr);
                 else if (idx->prefilter && rows > 0 && k <= kPrefilterMaxK && !use_ext && !gid)
                     rc = prefilter_launch(idx, eng->d_qraw, b, d_filter, kk, 0, eng->d_out_scores, eng->d_out_ids,
                                           need_tags ? idx->d_tags : nullptr, eng, st);

@@ -90,6 +90,10 @@ struct ScanBf16Args {
     int nq;
     int k;                          // candidates kept per query (<= 32)
     int64_t id_base = 0;            // added to the reported rows (0 for the prefilter's candidate scan)
+    // EXT variant (as ScanArgs): masked tag compare and the continuation bound of a k > 32 pass
+    const int32_t* q_filter_mask = nullptr;
+    const float* q_after_score = nullptr;
+    const int64_t* q_after_id = nullptr;
 };
 hipError_t launch_scan_bf16_topk(const ScanBf16Args& a, int grid, hipStream_t stream);
 // fp32 tile16 blocks -> bf16 tile16b blocks [block0, block1) of dst.  src_block0 (default = block0): the source

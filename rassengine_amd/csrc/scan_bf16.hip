@@ -70,7 +70,7 @@ struct BTile {
     int tag;  // tag of row lane (0..63) of the tile
 };
 
-template <int CHB, int NT>
+template <int CHB, int NT, bool EXT>
 __global__ __launch_bounds__(kBThreads, 2) void scan_bf16_topk_kernel(ScanBf16Args p) {
     constexpr int NQ = NT * 16;
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [2][kBWaves][NQ][kBPitch]
@@ -95,13 +95,22 @@ __global__ __launch_bounds__(kBThreads, 2) void scan_bf16_topk_kernel(ScanBf16Ar
     TopList L[NT];
     float tau[NT];
     int qfilt[NT];
+    // EXT: masked filters ((tag & mask) == filter) and the continuation bound of a k > 32 pass (only rows strictly
+    // after (after_s, after_i) in (score desc, id asc) rank), as in the fp32 kernel
+    int qmask[NT];
+    float after_s[NT];
+    int64_t after_i[NT];
 #pragma unroll
     for (int pq = 0; pq < NT; ++pq) {
         L[pq].s = -INFINITY;
         L[pq].i = 0x7fffffff;
         tau[pq] = -INFINITY;
         const int q = pq * 16 + (lane >> 5) * 8 + wid;
-        qfilt[pq] = (p.q_filter != nullptr && q < p.nq) ? p.q_filter[q] : -1;
+        const bool live = q < p.nq;
+        qfilt[pq] = (p.q_filter != nullptr && live) ? p.q_filter[q] : -1;
+        qmask[pq] = (EXT && p.q_filter_mask != nullptr && live) ? p.q_filter_mask[q] : -1;
+        after_s[pq] = (EXT && p.q_after_score != nullptr && live) ? p.q_after_score[q] : INFINITY;
+        after_i[pq] = (EXT && p.q_after_id != nullptr && live) ? p.q_after_id[q] : (int64_t)-1;
     }
 
     auto issue = [&](BTile<CHB>& r, const BDesc& d) {
@@ -154,7 +163,13 @@ __global__ __launch_bounds__(kBThreads, 2) void scan_bf16_topk_kernel(ScanBf16Ar
                 float s = src[0];
 #pragma unroll
                 for (int w = 1; w < kBWaves; ++w) s += src[w * NQ * kBPitch];
-                const bool ok = row_ok && (qfilt[pq] < 0 || qfilt[pq] == rtag);
+                bool ok;
+                if (EXT) {
+                    ok = row_ok && (qfilt[pq] < 0 || qfilt[pq] == (rtag & qmask[pq]));
+                    ok = ok && (s < after_s[pq] || (s == after_s[pq] && (p.id_base + (int64_t)row) > after_i[pq]));
+                } else {
+                    ok = row_ok && (qfilt[pq] < 0 || qfilt[pq] == rtag);
+                }
                 insert_candidates(L[pq], tau[pq], ok ? s : -INFINITY, row, p.k);
             }
         }
@@ -188,17 +203,17 @@ __global__ __launch_bounds__(kBThreads, 2) void scan_bf16_topk_kernel(ScanBf16Ar
     }
 }
 
-template <int CHB, int NT>
+template <int CHB, int NT, bool EXT>
 static hipError_t launch_bvariant(const ScanBf16Args& a, int grid, hipStream_t stream) {
     constexpr size_t lds_bytes = (size_t)2 * kBWaves * NT * 16 * kBPitch * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_bf16_topk_kernel<CHB, NT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_bf16_topk_kernel<CHB, NT, EXT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((scan_bf16_topk_kernel<CHB, NT>), dim3(grid), dim3(kBThreads), lds_bytes, stream, a);
+    hipLaunchKernelGGL((scan_bf16_topk_kernel<CHB, NT, EXT>), dim3(grid), dim3(kBThreads), lds_bytes, stream, a);
     return hipGetLastError();
 }
 
@@ -206,13 +221,23 @@ hipError_t launch_scan_bf16_topk(const ScanBf16Args& a, int grid, hipStream_t st
     if (a.row_stride % 256 != 0) return hipErrorInvalidValue;  // 8 waves x 32-column chunks
     const int chb = (int)(a.row_stride / 256);
     const bool two = a.nq > 16;
+    const bool ext = a.q_filter_mask || a.q_after_score || a.q_after_id;
+    if (ext) {
+        if ((a.q_after_score == nullptr) != (a.q_after_id == nullptr)) return hipErrorInvalidValue;
+        if (a.q_filter_mask != nullptr && a.q_filter == nullptr) return hipErrorInvalidValue;
+    }
+#define RASS_BF16_CASE(C)                                                                                     \
+    case C:                                                                                                   \
+        if (ext) return two ? launch_bvariant<C, 2, true>(a, grid, stream) : launch_bvariant<C, 1, true>(a, grid, stream); \
+        return two ? launch_bvariant<C, 2, false>(a, grid, stream) : launch_bvariant<C, 1, false>(a, grid, stream);
     switch (chb) {
-        case 1: return two ? launch_bvariant<1, 2>(a, grid, stream) : launch_bvariant<1, 1>(a, grid, stream);
-        case 2: return two ? launch_bvariant<2, 2>(a, grid, stream) : launch_bvariant<2, 1>(a, grid, stream);
-        case 3: return two ? launch_bvariant<3, 2>(a, grid, stream) : launch_bvariant<3, 1>(a, grid, stream);
-        case 4: return two ? launch_bvariant<4, 2>(a, grid, stream) : launch_bvariant<4, 1>(a, grid, stream);
+        RASS_BF16_CASE(1)
+        RASS_BF16_CASE(2)
+        RASS_BF16_CASE(3)
+        RASS_BF16_CASE(4)
         default: return hipErrorInvalidValue;
     }
+#undef RASS_BF16_CASE
 }
 
 // fp32 tile16 slab -> bf16 tile16b slab, blocks [b0, b1).  bf16 lane (m, g) of chunk jb holds

@@ -83,12 +83,8 @@ def test_bf16_index_matches_oracle_on_rounded_operands(gpu, oracle, tmp_path):
         assert np.array_equal(back.get_rows(0, n), stored)
         s2, i2 = back.search(q, 10)
         assert np.array_equal(i2, i_b) and np.array_equal(s2, s_b)
-        # what a bf16 corpus does not do is refused, not approximated
+        # what a bf16 corpus does not do is refused, not approximated (masked filters and k > 32 are served: below)
         from rassengine_amd._native import RassError
-        with pytest.raises(RassError):
-            ix.search(q[:2], 40)
-        with pytest.raises(RassError):
-            ix.search(q[:2], 5, q_filter=np.array([1, 1], dtype=np.int32), q_filter_mask=np.array([3, 3], dtype=np.int32))
         with pytest.raises(RassError):
             ix.set_prefilter(True)
     finally:
@@ -117,5 +113,49 @@ def test_bf16_index_synthetic_fill_and_device_path(gpu):
         eng.reset_stream()
         s_h, i_h = b.search(q.cpu().numpy(), 10)
         assert np.array_equal(i.cpu().numpy(), i_h + 7000) and np.array_equal(s.cpu().numpy(), s_h)
+    finally:
+        eng.close()
+
+
+def test_bf16_index_masked_filters_and_k_beyond_32(gpu, oracle):
+    """The EXT variant of the bf16 scan: (tag & mask) == filter and exact k > 32 in continuation passes, against the
+    fp64 oracle on the bf16-rounded operands (same yardstick as above); the Python shim's hybrid_structured_search
+    (doc_type byte + patient in one masked compare) therefore works on a bf16 index too."""
+    import torch
+    from rassengine_amd import ops
+    from rassengine_amd.engine import Engine
+    rng = np.random.default_rng(9)
+    n, dim = 6000, 1024
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    patient = rng.integers(0, 5, size=n).astype(np.int32)
+    doctype = rng.integers(1, 3, size=n).astype(np.int32)
+    tags = (patient | (doctype << 24)).astype(np.int32)
+    eng = Engine(0, dim)
+    try:
+        ix = eng.open_index("b16x", dtype="bf16")
+        ix.add(x, tags=tags)
+        for r in (7, 4000):
+            ix.delete(r)
+        t_live = tags.copy()
+        t_live[[7, 4000]] = -1
+        stored = ix.get_rows(0, n)
+        q = rng.standard_normal((9, dim)).astype(np.float32)
+        qb = _bf16_round(ops.normalize_rows(torch.from_numpy(q).cuda()).cpu().numpy())
+        all64 = oracle.scores(stored, qb)
+        PM, DM = 0x00FFFFFF, 0x7F000000
+        qf = np.array([3, 2 << 24, 4 | (1 << 24), -1, 77, 1 | (2 << 24), 0, 2, 1 << 24], dtype=np.int32)
+        qm = np.array([PM, DM, PM | DM, 0, PM, -1, PM, PM, DM], dtype=np.int32)
+        for k, f, m in ((10, qf, qm), (70, None, None), (45, qf, qm), (33, np.full(9, 2, np.int32), None)):
+            s, i = ix.search(q, k, q_filter=f, q_filter_mask=m)
+            rs, ri = oracle.search(stored, qb, k, tags=t_live, qfilter=f, qmask=m, kind=oracle.KIND_F64)
+            assert _swaps_are_ties(i, ri, all64), (k, i[:1], ri[:1])
+            valid = ri >= 0
+            assert np.array_equal(i >= 0, valid), k
+            got = np.take_along_axis(all64, np.clip(i, 0, None), 1)
+            assert np.all(np.abs(s[valid].astype(np.float64) - got[valid]) <= TOL)
+            for r in range(9):      # best first, no duplicates
+                live = i[r][i[r] >= 0]
+                assert len(set(live.tolist())) == len(live)
+        assert np.all(ix.search(q, 40, q_filter=qf, q_filter_mask=qm)[1][4] == -1)      # unknown patient: nothing
     finally:
         eng.close()

@@ -585,6 +585,10 @@ __global__ __launch_bounds__(kRingThreads, 2) void gemm_bf16_pring_kernel(const 
                 stage_step(lds + s2 * kRingSlotBytes);
             }
             bf16x8 a[8], b[4];
+#ifdef RASS_GEMM_EXP_NO_MFMA    // timing experiment: the operand stream alone (DMA + waits + barriers)
+            for (int i = 0; i < 8; ++i) a[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            for (int j = 0; j < 4; ++j) b[j] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+#else
             {
                 // fragment i / j of a slot sits i / j KiB after fragment 0 (16 rows x 64 B; the swizzle
                 // term only depends on lane bits)
@@ -603,17 +607,20 @@ __global__ __launch_bounds__(kRingThreads, 2) void gemm_bf16_pring_kernel(const 
                 RASS_DS_READ_B128(a[6], ab, 6144);
                 RASS_DS_READ_B128(a[7], ab, 7168);
             }
+#endif
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (grpB) ring_wait_steps(keep);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(1);
+#ifndef RASS_GEMM_EXP_NO_MFMA
 #pragma unroll
             for (int i = 0; i < 8; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+#endif
             __builtin_amdgcn_s_setprio(0);
             if (!grpB) ring_wait_steps(keep);
             __builtin_amdgcn_sched_barrier(0);

@@ -481,9 +481,27 @@ static hipError_t launch_ring(const u16* X, const u16* W, const float* bias, con
 // land during the epilogue, and the epilogue's stores drain under the next tile's K loop.
 // LDS: the ring (3 x 32 KiB) + epilogue staging that must not overlap slots 0/1 (prefetch target):
 // waves 0-2 stage in slot 2, waves 3-7 behind the ring.
-constexpr int kPringStageBytes = 32 * 68 * 4;                                          // 8704 B per wave
-constexpr int kPringLdsBytes = kRingSlots * kRingSlotBytes + 5 * kPringStageBytes;     // 141 824 B
-static_assert(kRingSlots == 3 && 3 * kPringStageBytes <= kRingSlotBytes, "epilogue staging layout assumes a 3-slot ring");
+// RASS_PRING_SLOTS=4 (experiment): a 4-slot ring, three K steps in flight; the next tile's three first steps then
+// occupy slots 0-2 during the epilogue, so the staging shrinks to 16-token chunks (4 352 B per wave): waves 0-6 in
+// slot 3, wave 7 behind the ring.
+#ifndef RASS_PRING_SLOTS
+#define RASS_PRING_SLOTS 3
+#endif
+constexpr int kPSlots = RASS_PRING_SLOTS;
+constexpr int kPAhead = kPSlots - 1;
+constexpr int kPStageTokens = kPSlots == 3 ? 32 : 16;
+constexpr int kPringStageBytes = kPStageTokens * 68 * 4;                               // 8704 B per wave (3 slots)
+constexpr int kPringLdsBytes = kPSlots == 3 ? kPSlots * kRingSlotBytes + 5 * kPringStageBytes      // 141 824 B
+                                            : kPSlots * kRingSlotBytes + 1 * kPringStageBytes;     // 135 424 B
+static_assert(kPSlots == 3 || kPSlots == 4, "ring of 3 or 4 slots");
+static_assert(kPSlots != 3 || 3 * kPringStageBytes <= kRingSlotBytes, "3 staging areas share slot 2");
+static_assert(kPSlots != 4 || 7 * kPringStageBytes <= kRingSlotBytes, "7 staging areas share slot 3");
+// wait until at most `steps` whole K steps of this wave's DMAs (4 pieces each) are outstanding
+__device__ __forceinline__ void pring_wait_steps(int steps) {
+    if (steps >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (steps == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
 
 // K-loop fragment read as opaque asm: hipcc's waitcnt pass orders every LDS access it can see after
 // the LDS-DMA (global_load_lds) ops still in flight — in two of the three epilogue variants of the
@@ -510,7 +528,7 @@ __global__ __launch_bounds__(kRingThreads, 2) void gemm_bf16_pring_kernel(const 
     if (tile >= tiles_total) return;
     const int tiles_n = N / RBN;
     const int nk = K / RBK;
-    const int pre = nk < kRingAhead ? nk : kRingAhead;
+    const int pre = nk < kPAhead ? nk : kPAhead;
 
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
     unsigned offA0, offB0;
@@ -553,13 +571,15 @@ __global__ __launch_bounds__(kRingThreads, 2) void gemm_bf16_pring_kernel(const 
             srcX[p] += RBK;
         }
     };
-    float* const stg = reinterpret_cast<float*>(wave < 3 ? lds + 2 * kRingSlotBytes + wave * kPringStageBytes
-                                                         : lds + kRingSlots * kRingSlotBytes + (wave - 3) * kPringStageBytes);
+    float* const stg = reinterpret_cast<float*>(
+        kPSlots == 3 ? (wave < 3 ? lds + 2 * kRingSlotBytes + wave * kPringStageBytes
+                                 : lds + kPSlots * kRingSlotBytes + (wave - 3) * kPringStageBytes)
+                     : (wave < 7 ? lds + 3 * kRingSlotBytes + wave * kPringStageBytes : lds + kPSlots * kRingSlotBytes));
     const bool grpB = wave >= 4;
 
     point_at(tile);
     for (int s0 = 0; s0 < pre; ++s0) stage_step(lds + s0 * kRingSlotBytes);
-    ring_wait_steps(pre - 1);
+    pring_wait_steps(pre - 1);
     __builtin_amdgcn_s_barrier();
 
     for (;;) {
@@ -577,11 +597,12 @@ __global__ __launch_bounds__(kRingThreads, 2) void gemm_bf16_pring_kernel(const 
         if (grpB) __builtin_amdgcn_s_barrier();
         int slot = 0;
         for (int t = 0; t < nk; ++t) {
-            const bool more = t + kRingAhead < nk;
-            const int keep = more ? kRingAhead - 1 : (nk - 2 - t > 0 ? nk - 2 - t : 0);
+            const bool more = t + kPAhead < nk;
+            // steps still in flight once step t+1 has been retired: t+2 .. min(t+kPAhead, nk-1)
+            const int keep = more ? kPAhead - 1 : (nk - 2 - t > 0 ? nk - 2 - t : 0);
             if (more) {
-                int s2 = slot + kRingAhead;
-                s2 = s2 >= kRingSlots ? s2 - kRingSlots : s2;
+                int s2 = slot + kPAhead;
+                s2 = s2 >= kPSlots ? s2 - kPSlots : s2;
                 stage_step(lds + s2 * kRingSlotBytes);
             }
             bf16x8 a[8], b[4];
@@ -609,7 +630,7 @@ __global__ __launch_bounds__(kRingThreads, 2) void gemm_bf16_pring_kernel(const 
             }
 #endif
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (grpB) ring_wait_steps(keep);
+            if (grpB) pring_wait_steps(keep);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
@@ -622,11 +643,11 @@ __global__ __launch_bounds__(kRingThreads, 2) void gemm_bf16_pring_kernel(const 
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
 #endif
             __builtin_amdgcn_s_setprio(0);
-            if (!grpB) ring_wait_steps(keep);
+            if (!grpB) pring_wait_steps(keep);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            slot = slot + 1 >= kRingSlots ? 0 : slot + 1;
+            slot = slot + 1 >= kPSlots ? 0 : slot + 1;
         }
         if (!grpB) __builtin_amdgcn_s_barrier();  // groups re-aligned: every ring read is done, no DMA in flight
 #ifdef RASS_GEMM_CLOCKS
@@ -657,25 +678,25 @@ __global__ __launch_bounds__(kRingThreads, 2) void gemm_bf16_pring_kernel(const 
                 asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(bv[ic][1]) : "v"(bp));
             }
 #pragma unroll
-            for (int jc = 0; jc < 2; ++jc) {
+            for (int jc = 0; jc < 64 / kPStageTokens; ++jc) {
 #pragma unroll
                 for (int ic = 0; ic < 2; ++ic) {
                     const int nbase = n0 + wn * 128 + ic * 64 + nq * 8;
                     uint4 res[4];
                     if (EPI == 1) {
 #pragma unroll
-                        for (int pass = 0; pass < 4; ++pass) {
-                            const int m = m0 + wm * 64 + jc * 32 + pass * 8 + tl;
+                        for (int pass = 0; pass < kPStageTokens / 8; ++pass) {
+                            const int m = m0 + wm * 64 + jc * kPStageTokens + pass * 8 + tl;
                             res[pass] = m < M ? *reinterpret_cast<const uint4*>(residual + (int64_t)m * N + nbase)
                                               : uint4{0u, 0u, 0u, 0u};
                         }
                     }
 #pragma unroll
-                    for (int jj = 0; jj < 2; ++jj)
+                    for (int jj = 0; jj < kPStageTokens / 16; ++jj)
 #pragma unroll
                         for (int ii = 0; ii < 4; ++ii)
                             *reinterpret_cast<f32x4*>(stg + (jj * 16 + (lane & 15)) * kPitchF + ii * 16 + (lane >> 4) * 4) =
-                                acc[4 * ic + ii][2 * jc + jj];
+                                acc[4 * ic + ii][(kPStageTokens / 16) * jc + jj];
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     if (jc == 0 && ic == 0) {
                         // Explicit: this wave's prefetch DMAs (and the bias / first residual reads issued
@@ -684,9 +705,9 @@ __global__ __launch_bounds__(kRingThreads, 2) void gemm_bf16_pring_kernel(const 
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     }
 #pragma unroll
-                    for (int pass = 0; pass < 4; ++pass) {
+                    for (int pass = 0; pass < kPStageTokens / 8; ++pass) {
                         const int tok = pass * 8 + tl;
-                        const int m = m0 + wm * 64 + jc * 32 + tok;
+                        const int m = m0 + wm * 64 + jc * kPStageTokens + tok;
                         f32x4 v0 = *reinterpret_cast<const f32x4*>(stg + tok * kPitchF + nq * 8);
                         f32x4 v1 = *reinterpret_cast<const f32x4*>(stg + tok * kPitchF + nq * 8 + 4);
                         v0 += bv[ic][0];

@@ -54,6 +54,11 @@ NAME_BYTES = 1024
 ADD_CHUNK_ROWS = 8192
 
 
+class CollectiveFailure(RuntimeError):
+    """An operation failed on some rank; EVERY rank raises this at the same point of the command stream (the verdict
+    comes out of an all-reduce), so the workers can log it and keep following rank 0 while rank 0 reports it."""
+
+
 class Extents:
     """Which global row ids a rank holds: sorted (gid_base, ordinal_base, n) runs."""
 
@@ -202,7 +207,7 @@ class ShardServer:
         if self.world > 1:
             dist.all_reduce(t, group=self.group)
         if int(t.item()) != 0:
-            raise RuntimeError(f"{what} failed on {int(t.item())} rank(s)")
+            raise CollectiveFailure(f"{what} failed on {int(t.item())} rank(s)")
 
     @staticmethod
     def shard_file(base: str, rank: int, world: int) -> str:
@@ -351,7 +356,13 @@ class ShardServer:
                 if keep.size:
                     sub_ids = ids[int(tok0[s0]):int(tok0[s1])].cpu().numpy()
                     cu = np.concatenate([[0], np.cumsum(bl[keep])]).astype(np.int64)
-                    out[keep] = np.asarray(self.encoder().encode_flat(sub_ids, cu), dtype=np.float32)
+                    try:
+                        out[keep] = np.asarray(self.encoder().encode_flat(sub_ids, cu), dtype=np.float32)
+                    except Exception as e:
+                        # app/embedding_gen.py:165-170: an embedding error is printed and the text gets a zero vector
+                        # (never a hit).  The rows are appended all the same: every rank's bookkeeping stays in step.
+                        logger.error(f"[ERROR] encoder on rank {self.rank}: {e}; {int(keep.size)} texts get zero vectors")
+                        out[:] = 0.0
                 first = shard.add(torch.from_numpy(out).to(self.device), tg[s0:s1].contiguous(), normalize, gid_base + s0)
                 self.extents[code].append(gid_base + s0, first, s1 - s0)
             return None
@@ -384,7 +395,10 @@ def worker_loop(server: ShardServer) -> None:
         hdr = server.recv()
         if int(hdr[0]) == OP_SHUTDOWN:
             break
-        server.execute(hdr)
+        try:
+            server.execute(hdr)
+        except CollectiveFailure as e:      # raised on every rank alike: rank 0 tells its caller, the service goes on
+            logger.error(f"rank {server.rank}: {e}")
     dist.barrier(group=server.group)
 
 

@@ -294,6 +294,48 @@ def test_data_parallel_ingest_equals_the_single_index(world, tmp_path):
     assert all(d > 0 for d in done) and sum(done) == 700, done
 
 
+def _failing_encoder_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from rassengine_amd import serving
+        from tests.helpers import TokenHashEncoder
+
+        class Flaky(TokenHashEncoder):
+            def encode_flat(self, ids, cu):
+                if dist.get_rank() == 1:
+                    raise RuntimeError("device lost")
+                return super().encode_flat(ids, cu)
+        front = serving.start(lambda name: OracleServingShard(64), 64, torch.device("cpu"), encoder_factory=lambda: Flaky(64),
+                              shard_loader=lambda name, path: OracleServingShard.load(64, path))
+        if rank != 0:
+            open(os.path.join(out_dir, f"worker{rank}.done"), "w").write("ok")
+            return
+        ix = front.open_index("flaky")
+        texts = [f"alpha beta {i}" for i in range(600)]            # batches 0, 2 -> rank 0; batch 1 -> rank 1 (fails)
+        assert ix.add_texts(texts) == 0 and ix.rows == 600 and ix.count == 600
+        q = TokenHashEncoder(64).encode(["alpha beta 300", "alpha beta 10"])
+        s_, i_ = ix.search(q, 3)
+        assert i_[1, 0] == 10                                      # rank 0's batch: encoded
+        assert 300 not in i_[0].tolist() and not ix.get_row(300).any()   # rank 1's batch: zero rows, never a hit
+        with pytest.raises(serving.CollectiveFailure):             # a load nobody can satisfy: refused everywhere ...
+            json_path = os.path.join(out_dir, "bogus.json")
+            open(json_path, "w").write('{"format": "rass-sharded-1", "world": %d, "base": "nope", "rows": 0, '
+                                       '"batches": 0, "runs": [], "deleted": []}' % world)
+            front.load_index("ghost", json_path)
+        assert ix.add_texts(["gamma delta"]) == 600                # ... and the service goes on
+        front.shutdown()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_encoder_failure_and_refused_load_keep_the_ranks_in_step(tmp_path):
+    mp.spawn(_failing_encoder_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(os.path.join(str(tmp_path), "worker1.done"))
+
+
 def test_extent_table():
     from rassengine_amd.serving import Extents
     e = Extents()

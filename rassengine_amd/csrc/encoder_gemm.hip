@@ -754,6 +754,276 @@ __global__ __launch_bounds__(kRingThreads, 2) void gemm_bf16_pring_kernel(const 
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// 64-deep K steps ("p64"): the persistent ring kernel with whole cache lines per row.  With a 32-deep step every row
+// of an operand tile is asked for in 64-B segments — two L2 requests per 128-B line — and the counters showed the L2
+// request rate, not latency or misses, to be the operand stream's ceiling (L2 channels busy 78 % of the launch at
+// 58 B per request; the same bytes asked for as 128-B segments stream 40 % faster:
+// profiles/r02_gemm_w4_experiments.txt).  Here a ring slot holds K = 64: rows of 128 B, a DMA piece = 8 rows x 128 B
+// whose 8 lanes per row coalesce into ONE request, the bank-conflict swizzle of the 128 x 128 kernel (16-B chunk c
+// of row r at chunk c ^ ((r>>1)&7)).  A slot is 64 KiB, so the ring has TWO slots, one step in flight; a step is two
+// 32-deep sub-steps, each a load phase (fragment reads) and a compute phase (32 MFMAs) closed by a barrier, waves 4-7
+// one phase behind waves 0-3 as before.  Hazards: step t+1's DMAs go out in the load phase of sub-step 0 of step t
+// (group A in phase 4t, group B in 4t+1) into the slot step t-1 was read from, whose last reads (group B, phase
+// 4t-1) are behind a barrier; they are retired by a vmcnt(0) in front of the barrier that ends phase 4t+3 (group A
+// at the end of its second compute phase, group B of its second load phase), the barrier group A's first reads of
+// step t+1 follow.  Epilogue staging: waves 0-6 in slot 1, wave 7 behind the ring (the next tile's step 0 lands in
+// slot 0 meanwhile).
+constexpr int kP64TileBytes = 256 * 64 * 2;            // 32 KiB per operand per slot
+constexpr int kP64SlotBytes = 2 * kP64TileBytes;       // W tile | X tile
+constexpr int kP64StageBytes = 32 * 68 * 4;            // 8704 B per wave
+constexpr int kP64LdsBytes = 2 * kP64SlotBytes + kP64StageBytes;   // 139 776 B
+static_assert(7 * kP64StageBytes <= kP64SlotBytes, "7 staging areas share slot 1");
+
+template <int EPI>
+__global__ __launch_bounds__(kRingThreads, 2) void gemm_bf16_p64_kernel(const u16* __restrict__ X,
+                                                                       const u16* __restrict__ W,
+                                                                       const float* __restrict__ bias,
+                                                                       const u16* __restrict__ residual,
+                                                                       u16* __restrict__ Y, int M, int N, int K,
+                                                                       int tiles_total) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wn = wave >> 2, wm = wave & 3;
+    const int G = gridDim.x, orig = blockIdx.x;
+    const int pos = (G % 8 == 0) ? (orig % 8) * (G / 8) + orig / 8 : orig;
+    int tile = pos;
+    if (tile >= tiles_total) return;
+    const int tiles_n = N / RBN;
+    const int nk = K / 64;
+
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    // fragment i / j of a slot: 16 rows x 128 B = 2 KiB after fragment 0; sub-step s reads chunks 4s + (lane>>4),
+    // stored at chunk ^ ((row>>1)&7): the swizzle term only depends on lane bits, sub-step 1 = sub-step 0 ^ 64 B
+    unsigned offA[2], offB[2];
+    {
+        const int rowA = wn * 128 + (lane & 15), rowB = wm * 64 + (lane & 15);
+        const int sw = ((lane & 15) >> 1) & 7;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int ch = (sub * 4 + (lane >> 4)) ^ sw;
+            offA[sub] = rowA * 128 + ch * 16;
+            offB[sub] = kP64TileBytes + rowB * 128 + ch * 16;
+        }
+    }
+    // DMA: an operand tile is 32 pieces of 8 rows x 128 B; this wave moves pieces wave, wave+8, wave+16, wave+24
+    const u16* srcW[4];
+    const u16* srcX[4];
+    auto point_at = [&](int t) {
+        const int tn0 = (t % tiles_n) * RBN, tm0 = (t / tiles_n) * RBM;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int r = (wave + 8 * p) * 8 + (lane >> 3);
+            const int c_src = (lane & 7) ^ ((r >> 1) & 7);
+            srcW[p] = W + (int64_t)(tn0 + r) * K + c_src * 8;
+            srcX[p] = X + (int64_t)(tm0 + r) * K + c_src * 8;
+        }
+    };
+    // a step's DMAs in two halves: the X pieces first (their lines are new in every step: the long latencies), the W
+    // pieces (mostly L2 hits) half a sub-step later, so that no phase carries all eight issues
+    auto stage_x = [&](unsigned char* slot_base) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)srcX[p],
+                (__attribute__((address_space(3))) void*)(slot_base + kP64TileBytes + (wave + 8 * p) * 1024), 16, 0, 0);
+            srcX[p] += 64;
+        }
+    };
+    auto stage_w = [&](unsigned char* slot_base) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)srcW[p],
+                                             (__attribute__((address_space(3))) void*)(slot_base + (wave + 8 * p) * 1024),
+                                             16, 0, 0);
+            srcW[p] += 64;
+        }
+    };
+    auto stage_step = [&](unsigned char* slot_base) {
+        stage_x(slot_base);
+        stage_w(slot_base);
+    };
+    float* const stg = reinterpret_cast<float*>(wave < 7 ? lds + kP64SlotBytes + wave * kP64StageBytes
+                                                         : lds + 2 * kP64SlotBytes);
+    const bool grpB = wave >= 4;
+
+    point_at(tile);
+    stage_step(lds);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    for (;;) {
+        const int n0 = (tile % tiles_n) * RBN, m0 = (tile / tiles_n) * RBM;
+        f32x4 acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        if (grpB) __builtin_amdgcn_s_barrier();   // group B runs one phase behind group A
+        for (int t = 0; t < nk; ++t) {
+            const int slot = t & 1;
+            const bool more = t + 1 < nk;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                // ---- load phase
+                if (sub == 0 && more) stage_x(lds + (slot ^ 1) * kP64SlotBytes);
+                bf16x8 a[8], b[4];
+                {
+                    const unsigned ab = lds_base + slot * kP64SlotBytes + offA[sub];
+                    const unsigned bb = lds_base + slot * kP64SlotBytes + offB[sub];
+                    RASS_DS_READ_B128(b[0], bb, 0);
+                    RASS_DS_READ_B128(b[1], bb, 2048);
+                    RASS_DS_READ_B128(b[2], bb, 4096);
+                    RASS_DS_READ_B128(b[3], bb, 6144);
+                    RASS_DS_READ_B128(a[0], ab, 0);
+                    RASS_DS_READ_B128(a[1], ab, 2048);
+                    RASS_DS_READ_B128(a[2], ab, 4096);
+                    RASS_DS_READ_B128(a[3], ab, 6144);
+                    RASS_DS_READ_B128(a[4], ab, 8192);
+                    RASS_DS_READ_B128(a[5], ab, 10240);
+                    RASS_DS_READ_B128(a[6], ab, 12288);
+                    RASS_DS_READ_B128(a[7], ab, 14336);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (sub == 1 && grpB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of step t+1
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- compute phase
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                if (sub == 0 && more) stage_w(lds + (slot ^ 1) * kP64SlotBytes);
+                if (sub == 1 && !grpB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (!grpB) __builtin_amdgcn_s_barrier();  // groups re-aligned: every ring read is done, no DMA in flight
+
+        // ---- next tile's first K step goes out now and lands under the epilogue (slot 0)
+        const int next = tile + G;
+        const bool has_next = next < tiles_total;
+        if (has_next) {
+            point_at(next);
+            stage_step(lds);
+        }
+
+        // ---- epilogue (see gemm_bf16_ring_kernel): LDS transpose per wave, coalesced 16-B stores
+        {
+            constexpr int kPitchF = 68;
+            const int tl = lane >> 3, nq = lane & 7;
+            // Bias through opaque asm loads, retired by the explicit vmcnt(0) below: a load hipcc can
+            // see stays "possibly pending" on its destination registers across the tile loop, and
+            // when the K loop's fragment reads get the same registers the waitcnt pass protects them
+            // with a vmcnt(0) in EVERY K step (seen in two of the three epilogue variants).
+            f32x4 bv[2][2];
+#pragma unroll
+            for (int ic = 0; ic < 2; ++ic) {
+                const float* bp = bias + n0 + wn * 128 + ic * 64 + nq * 8;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bv[ic][0]) : "v"(bp));
+                asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(bv[ic][1]) : "v"(bp));
+            }
+#pragma unroll
+            for (int jc = 0; jc < 64 / kPStageTokens; ++jc) {
+#pragma unroll
+                for (int ic = 0; ic < 2; ++ic) {
+                    const int nbase = n0 + wn * 128 + ic * 64 + nq * 8;
+                    uint4 res[4];
+                    if (EPI == 1) {
+#pragma unroll
+                        for (int pass = 0; pass < kPStageTokens / 8; ++pass) {
+                            const int m = m0 + wm * 64 + jc * kPStageTokens + pass * 8 + tl;
+                            res[pass] = m < M ? *reinterpret_cast<const uint4*>(residual + (int64_t)m * N + nbase)
+                                              : uint4{0u, 0u, 0u, 0u};
+                        }
+                    }
+#pragma unroll
+                    for (int jj = 0; jj < kPStageTokens / 16; ++jj)
+#pragma unroll
+                        for (int ii = 0; ii < 4; ++ii)
+                            *reinterpret_cast<f32x4*>(stg + (jj * 16 + (lane & 15)) * kPitchF + ii * 16 + (lane >> 4) * 4) =
+                                acc[4 * ic + ii][(kPStageTokens / 16) * jc + jj];
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (jc == 0 && ic == 0) {
+                        // Explicit: this wave's prefetch DMAs (and the bias / first residual reads issued
+                        // after them) are complete before anything below consumes them and before the
+                        // publishing barrier after the epilogue.  No store is outstanding yet.
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
+#pragma unroll
+                    for (int pass = 0; pass < kPStageTokens / 8; ++pass) {
+                        const int tok = pass * 8 + tl;
+                        const int m = m0 + wm * 64 + jc * kPStageTokens + tok;
+                        f32x4 v0 = *reinterpret_cast<const f32x4*>(stg + tok * kPitchF + nq * 8);
+                        f32x4 v1 = *reinterpret_cast<const f32x4*>(stg + tok * kPitchF + nq * 8 + 4);
+                        v0 += bv[ic][0];
+                        v1 += bv[ic][1];
+                        if (EPI == 1) {
+                            const uint4 r = res[pass];
+                            v0.x += bf16_to_f32((u16)(r.x & 0xffff));
+                            v0.y += bf16_to_f32((u16)(r.x >> 16));
+                            v0.z += bf16_to_f32((u16)(r.y & 0xffff));
+                            v0.w += bf16_to_f32((u16)(r.y >> 16));
+                            v1.x += bf16_to_f32((u16)(r.z & 0xffff));
+                            v1.y += bf16_to_f32((u16)(r.z >> 16));
+                            v1.z += bf16_to_f32((u16)(r.w & 0xffff));
+                            v1.w += bf16_to_f32((u16)(r.w >> 16));
+                        }
+                        if (EPI == 2) {
+                            v0.x = gelu_erf(v0.x); v0.y = gelu_erf(v0.y); v0.z = gelu_erf(v0.z); v0.w = gelu_erf(v0.w);
+                            v1.x = gelu_erf(v1.x); v1.y = gelu_erf(v1.y); v1.z = gelu_erf(v1.z); v1.w = gelu_erf(v1.w);
+                        }
+                        if (m < M) {
+                            uint4 o;
+                            o.x = (unsigned)f32_to_bf16(v0.x) | ((unsigned)f32_to_bf16(v0.y) << 16);
+                            o.y = (unsigned)f32_to_bf16(v0.z) | ((unsigned)f32_to_bf16(v0.w) << 16);
+                            o.z = (unsigned)f32_to_bf16(v1.x) | ((unsigned)f32_to_bf16(v1.y) << 16);
+                            o.w = (unsigned)f32_to_bf16(v1.z) | ((unsigned)f32_to_bf16(v1.w) << 16);
+                            *reinterpret_cast<uint4*>(Y + (int64_t)m * N + nbase) = o;
+                        }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+            }
+        }
+        if (!has_next) break;
+        __builtin_amdgcn_s_barrier();
+        tile = next;
+    }
+}
+
+template <int EPI>
+static hipError_t launch_p64(const u16* X, const u16* W, const float* bias, const u16* residual, u16* Y, int M,
+                             int M_pad, int N, int K, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_p64_kernel<EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kP64LdsBytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    static int n_cus = 0;
+    if (n_cus == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cus <= 0)
+            n_cus = 256;
+    }
+    const int tiles_total = (N / RBN) * (M_pad / RBM);
+    const int grid = tiles_total < n_cus ? tiles_total : n_cus;
+    hipLaunchKernelGGL((gemm_bf16_p64_kernel<EPI>), dim3(grid), dim3(kRingThreads), kP64LdsBytes, stream, X, W, bias,
+                       residual, Y, M, N, K, tiles_total);
+    return hipGetLastError();
+}
+
 template <int EPI>
 static hipError_t launch_pring(const u16* X, const u16* W, const float* bias, const u16* residual, u16* Y, int M,
                                int M_pad, int N, int K, hipStream_t stream) {
@@ -1121,13 +1391,18 @@ static hipError_t launch_epi(const u16* X, const u16* W, const float* bias, cons
     if (N % RBN == 0 && M_pad % RBM == 0 && K % RBK == 0 && M >= 1024) {
         // Default: the persistent form of the 8-wave 256x256 ring kernel; RASS_GEMM_VARIANT=ring
         // selects the one-tile-per-block form for A/B runs (scripts/microbench/gemm_phases.hip).
-        static const int variant = [] {   // 0 = pring (default), 1 = ring, 2 = w4
+        // Default: p64, the persistent ring kernel with 64-deep K steps (whole cache lines per row), where K allows;
+        // RASS_GEMM_VARIANT=pring | ring | w4 select the 32-deep persistent kernel, its one-tile-per-block form and the
+        // 4-wave 128x128-per-wave kernel for A/B runs (scripts/probe_gemm.py, profiles/r02_gemm_w4_experiments.txt).
+        static const int variant = [] {   // 0 = p64, 1 = ring, 2 = w4, 3 = pring
             const char* v = getenv("RASS_GEMM_VARIANT");
             if (v != nullptr && strcmp(v, "ring") == 0) return 1;
             if (v != nullptr && strcmp(v, "w4") == 0) return 2;
+            if (v != nullptr && strcmp(v, "pring") == 0) return 3;
             return 0;
         }();
         if (variant == 1) return launch_ring<EPI>(X, W, bias, residual, Y, M, M_pad, N, K, stream);
+        if (variant == 0 && K % 64 == 0) return launch_p64<EPI>(X, W, bias, residual, Y, M, M_pad, N, K, stream);
         if (variant == 2 && K / RBK >= 6 && (K / RBK) % 2 == 0 && (int64_t)M_pad * K * 2 < (1LL << 32) &&
             (int64_t)N * K * 2 < (1LL << 32))
             return launch_w4<EPI>(X, W, bias, residual, Y, M, M_pad, N, K, stream);

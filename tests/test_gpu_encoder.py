@@ -26,7 +26,11 @@ def _cos(a, b):
                                        # more tiles than CUs: the persistent kernel walks several tiles per
                                        # workgroup (next-tile prefetch under the epilogue), ragged last M tile
                                        (70000, 1024, 1024, 1), (33000, 3072, 256, 0), (66000, 512, 64, 2),
-                                       (65537, 256, 32, 1)])
+                                       (65537, 256, 32, 1),
+                                       # K % 64 == 0: the 64-deep-step kernel (default), 1 / 2 / 3 / 5 steps per tile,
+                                       # odd step counts, several tiles per workgroup, ragged last M tile
+                                       (1024, 256, 64, 0), (3000, 512, 128, 1), (70001, 256, 192, 2),
+                                       (33333, 768, 320, 1), (1025, 1024, 2048, 0)])
 def test_gemm_bf16_matches_torch(gpu, M, N, K, epi):
     torch = gpu
     from rassengine_amd import _native as N_

@@ -1049,39 +1049,45 @@ static hipError_t launch_pring(const u16* X, const u16* W, const float* bias, co
 }
 
 // ------------------------------------------------------------------------------------------
-// 4-wave form: one workgroup of FOUR waves per CU, every wave a 128 x 128 tile (64 MFMAs per K step of 32 against
-// 16 fragment reads: two thirds of the 8-wave kernel's LDS reads per MFMA, one barrier per K step instead of two,
-// no second wave competing for the SIMD's issue slots).  What makes it possible:
+// 4-wave form (RASS_GEMM_VARIANT=w4l, an A/B variant: correct, slower than the 8-wave kernels on this part): one
+// workgroup of FOUR waves per CU, every wave a 128 x 128 tile (64 MFMAs per 32-deep sub-step against 16 fragment reads:
+// two thirds of the 8-wave kernel's LDS reads per MFMA, one barrier per sub-step, no second wave competing for the
+// SIMD's issue slots).  What makes it possible:
 //   * the 256 fp32 accumulators live in AGPRs: the MFMA is issued as inline asm with "a" constraints (the builtin
 //     form made hipcc spill 115 registers and shuffle accumulators through v_accvgpr_mov, DESIGN round 1);
-//   * with one wave per SIMD nothing hides a wave's own latencies, so everything is software-pipelined in
-//     registers: step t multiplies fragment set t&1 while the 16 ds_read_b128 of step t+1 fill the other set,
-//     the operand pieces of step t+2 (loaded from global memory into 32 staging registers during step t-1) are
-//     written to their ring slot, and the loads of step t+3 go out into the other staging set;
-//   * staging goes through registers (global_load_dwordx4 + ds_write_b128), not LDS-DMA: a global_load_lds piece
-//     costs the issuing wave 60-185 cycles (MI355X_MICROARCH.md), which a partner wave hides in the 8-wave
-//     kernel but nothing hides here — the first version of this kernel, on LDS-DMA, ran 12-17 % SLOWER than the
-//     8-wave one;
-//   * no LDS transpose in the epilogue.  The W rows are staged PERMUTED: MFMA row rho of M-tile i holds output
-//     feature 32*(rho>>2) + 4*i + (rho&3) of the wave's 128, so the 4 accumulator rows a lane owns in the 8 tiles
-//     of a token column are 32 CONSECUTIVE features — bias, residual, GELU and the bf16 pack happen in registers
-//     and a lane writes its 64 contiguous bytes with four 16-B stores (the permutation costs nothing: a staging
-//     lane computes its own source row either way);
-//   * the next tile's steps 0 and 1 are loaded during the last K steps and sit in the ring before the epilogue,
-//     its step 2 waits in registers.
+//   * with one wave per SIMD nothing hides a wave's own latencies, so everything is software-pipelined in registers:
+//     fragments double-buffered, operand pieces staged through 32 registers (buffer_load_dwordx4 + ds_write_b128, not
+//     LDS-DMA: a global_load_lds piece costs the issuing wave 60-185 cycles, which only a partner wave can hide);
+//   * no LDS transpose in the epilogue: the W rows are staged PERMUTED (MFMA row rho of M-tile i holds output feature
+//     32*(rho>>2) + 4*i + (rho&3) of the wave's 128), so the 4 accumulator rows a lane owns in the 8 tiles of a token
+//     column are 32 CONSECUTIVE features — bias, residual, GELU and the bf16 pack happen in registers and a lane
+//     writes its 64 contiguous bytes with four 16-B stores.
+// History and measurements of its three 64-B-segment predecessors: profiles/r02_gemm_w4_experiments.txt.
 constexpr int kW4Threads = 256;
-constexpr int kW4LdsBytes = 4 * kRingSlotBytes;  // 4 slots of (W tile | X tile) = 128 KiB
 
 #define RASS_MFMA_BF16_ACC(acc, a, b) \
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b))
 #define RASS_MFMA_BF16_NEW(acc, a, b) \
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(acc) : "v"(a), "v"(b))
 
+// ------------------------------------------------------------------------------------------
+// The kernel: the structure above (AGPR accumulators, register-pipelined fragments and staging, register epilogue
+// over permuted W rows) on the LDS layout of gemm_bf16_p64_kernel: rows of
+// 128 B (K = 64 per slot, two 64-KiB slots), so a staging load covers 8 rows x 128 B — one L2 request per row where
+// w4 asked for two 64-B halves (the L2 request rate was what bounded w4: profiles/r02_gemm_w4_experiments.txt).
+// The K loop is one stream of 32-deep SUB-steps u across tiles; HALF-loads q = 2T + h (rows 128h .. 128h+127 of both
+// operand tiles of step T) are loaded from global memory during sub-step q-4 into 32 staging registers and written
+// to LDS during sub-step q-3; the fragments of sub-step u+1 are read during sub-step u.  Slot T&1 holds step T:
+// half-load q goes into the slot whose last fragment reads (sub-step 2(T-1)+1, issued during 2(T-1)) are behind the
+// barrier of the sub-step that writes it.  K % 128 == 0, so that a tile's sub-step count is a multiple of 4 and the
+// slot / register-set parities carry over from tile to tile.
+constexpr int kW4LLdsBytes = 2 * kP64SlotBytes;  // 128 KiB
+
 template <int EPI>
-__global__ __launch_bounds__(kW4Threads) void gemm_bf16_w4_kernel(const u16* __restrict__ X, const u16* __restrict__ W,
-                                                                  const float* __restrict__ bias,
-                                                                  const u16* __restrict__ residual, u16* __restrict__ Y,
-                                                                  int M, int N, int K, int tiles_total) {
+__global__ __launch_bounds__(kW4Threads) void gemm_bf16_w4l_kernel(const u16* __restrict__ X, const u16* __restrict__ W,
+                                                                   const float* __restrict__ bias,
+                                                                   const u16* __restrict__ residual, u16* __restrict__ Y,
+                                                                   int M, int N, int K, int tiles_total) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1091,115 +1097,104 @@ __global__ __launch_bounds__(kW4Threads) void gemm_bf16_w4_kernel(const u16* __r
     int tile = pos;
     if (tile >= tiles_total) return;
     const int tiles_n = N / RBN;
-    const int nk = K / RBK;  // even, >= 6 (launcher)
+    const int nu = K / 32;  // sub-steps per tile: a multiple of 4, >= 8 (launcher)
 
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
-    unsigned offA0, offB0;
+    // fragment i / j: 16 rows x 128 B = 2 KiB after fragment 0; sub-step s reads chunk 4s + (lane>>4), stored at
+    // chunk ^ ((row>>1)&7)
+    unsigned offA[2], offB[2];
     {
         const int rowA = wn * 128 + (lane & 15), rowB = wm * 128 + (lane & 15);
-        offA0 = rowA * 64 + (((lane >> 4) ^ (((rowA >> 3) & 1) * 3)) * 16);
-        offB0 = kRingTileBytes + rowB * 64 + (((lane >> 4) ^ (((rowB >> 3) & 1) * 3)) * 16);
+        const int sw = ((lane & 15) >> 1) & 7;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int ch = (sub * 4 + (lane >> 4)) ^ sw;
+            offA[sub] = rowA * 128 + ch * 16;
+            offB[sub] = kP64TileBytes + rowB * 128 + ch * 16;
+        }
     }
-    // Staging: an operand tile is 16 pieces of 16 rows x 64 B (lane l: row l>>2, 16-B chunk l&3, image lane-linear);
-    // this wave moves pieces wave, wave+4, wave+8, wave+12 of both operands.
-    // Sources through buffer descriptors over the whole of W and X: a piece's address is a per-lane byte offset
-    // (recomputed once per tile) plus the wave-uniform K offset in the instruction's SGPR field, so a K step costs
-    // no address arithmetic on the vector ALU (64-bit pointer bumps were 16 VALU instructions per step, issued
-    // by the same single wave that has to issue the MFMAs).
     const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<u16*>(W), 0, (int)(unsigned)((uint64_t)N * K * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<u16*>(X), 0, (int)(unsigned)((uint64_t)(tiles_total / tiles_n) * RBM * K * 2), 0x00020000);
-    unsigned voffW[4], voffX[4];
-    int koff = 0;  // bytes into the K dimension of the step the next load_step fetches
+    // An operand tile of a step is 32 pieces of 8 rows x 128 B; half-load h of this wave = pieces wave + 4p + 16h.
+    // Image row r = piece*8 + (lane>>3).  X: source row = r.  W: image row (half hh, M-tile i, MFMA row rho) <- feature
+    // hh*128 + 32*(rho>>2) + 4*i + (rho&3), which for this wave's pieces is base(wave, lane) + 128h + 8p: both
+    // operands need ONE per-lane offset each, the (h, p) part goes into the load's scalar offset.
+    unsigned voffW = 0, voffX = 0;
+    int koff = 0;  // byte offset into K of the step whose half-loads go out next
+    const int lr = lane >> 3;
+    const int c_src = (lane & 7) ^ ((((wave & 1) * 8 + lr) >> 1) & 7);
+    const int featbase = 64 * (wave & 1) + 32 * (lr >> 2) + 4 * (wave >> 1) + (lr & 3);
     auto point_at = [&](int t) {
         const int tn0 = (t % tiles_n) * RBN, tm0 = (t / tiles_n) * RBM;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int r = (wave + 4 * p) * 16 + (lane >> 2);  // row of the LDS image
-            const int c_src = (lane & 3) ^ (((r >> 3) & 1) * 3);
-            // W: image row (half h, M-tile i, MFMA row rho) <- feature h*128 + 32*(rho>>2) + 4*i + (rho&3)
-            const int rho = r & 15, i = (r >> 4) & 7, h = r >> 7;
-            const int feat = h * 128 + 32 * (rho >> 2) + 4 * i + (rho & 3);
-#ifdef RASS_W4_EXP_FULL_LINES   // timing experiment (wrong results): a wave load covers 8 rows x 128 B, not 16 x 64 B
-            voffW[p] = ((unsigned)(tn0 + (wave + 4 * p) * 16 + (lane >> 3)) * (unsigned)K + (lane & 7) * 8) * 2u;
-            voffX[p] = ((unsigned)(tm0 + (wave + 4 * p) * 16 + (lane >> 3)) * (unsigned)K + (lane & 7) * 8) * 2u;
-            (void)feat; (void)c_src;
-#else
-            voffW[p] = ((unsigned)(tn0 + feat) * (unsigned)K + c_src * 8) * 2u;
-            voffX[p] = ((unsigned)(tm0 + r) * (unsigned)K + c_src * 8) * 2u;
-#endif
-        }
+        voffW = ((unsigned)(tn0 + featbase) * (unsigned)K + c_src * 8) * 2u;
+        voffX = ((unsigned)(tm0 + wave * 8 + lr) * (unsigned)K + c_src * 8) * 2u;
         koff = 0;
     };
-    bf16x8 g[2][8];  // staging registers: the pieces of step s wait in g[s & 1]
-    auto load_step = [&g, &voffW, &voffX, &koff, rsrcW, rsrcX](auto set_c) {
+    bf16x8 g[2][8];  // staging registers
+    const int rowbytes = K * 2;
+    auto load_half = [&g, &voffW, &voffX, &koff, rsrcW, rsrcX, rowbytes](auto set_c, auto h_c) {
         constexpr int set = decltype(set_c)::value;
-#ifndef RASS_W4_EXP_NO_LOADS    // timing experiment: stale registers go to LDS
+        constexpr int h = decltype(h_c)::value;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            g[set][p] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrcW, voffW[p], koff, 0));
-            g[set][4 + p] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrcX, voffX[p], koff, 0));
+            g[set][p] = __builtin_bit_cast(
+                bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrcW, voffW, koff + (128 * h + 8 * p) * rowbytes, 0));
+            g[set][4 + p] = __builtin_bit_cast(
+                bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrcX, voffX, koff + (128 * h + 32 * p) * rowbytes, 0));
         }
-#endif
-        koff += RBK * 2;
+        if (h == 1) koff += 128;
     };
     unsigned char* const my_piece = lds + wave * 1024 + lane * 16;
-    auto write_piece = [&g, my_piece](auto set_c, int slot, int p) {
+    auto write_piece = [&g, my_piece](auto set_c, int slot, int h, int p) {
         constexpr int set = decltype(set_c)::value;
-#ifdef RASS_W4_EXP_NO_WRITES   // timing experiment: the loads stay alive, nothing goes to LDS
-        asm volatile("" ::"v"(g[set][p]), "v"(g[set][4 + p]));
-#else
-        *reinterpret_cast<bf16x8*>(my_piece + slot * kRingSlotBytes + p * 4096) = g[set][p];
-        *reinterpret_cast<bf16x8*>(my_piece + slot * kRingSlotBytes + kRingTileBytes + p * 4096) = g[set][4 + p];
-#endif
+        unsigned char* dst = my_piece + slot * kP64SlotBytes + (4 * p + 16 * h) * 1024;
+        *reinterpret_cast<bf16x8*>(dst) = g[set][p];
+        *reinterpret_cast<bf16x8*>(dst + kP64TileBytes) = g[set][4 + p];
     };
 
     f32x4 acc[8][8];
     bf16x8 fa[2][8], fb[2][8];
-    // fragments of a step: a[i] = W image rows wn*128 + 16i.., b[j] = X image rows wm*128 + 16j.. (1 KiB apart)
-    auto read_frags = [&fa, &fb, lds_base, offA0, offB0](auto set_c, int slot) {
+    auto read_frags = [&fa, &fb, lds_base, &offA, &offB](auto set_c, int slot, int sub) {
         constexpr int set = decltype(set_c)::value;
-        const unsigned ab = lds_base + slot * kRingSlotBytes + offA0;
-        const unsigned bb = lds_base + slot * kRingSlotBytes + offB0;
-        RASS_DS_READ_B128(fa[set][0], ab, 0);    RASS_DS_READ_B128(fb[set][0], bb, 0);
-        RASS_DS_READ_B128(fa[set][1], ab, 1024); RASS_DS_READ_B128(fb[set][1], bb, 1024);
-        RASS_DS_READ_B128(fa[set][2], ab, 2048); RASS_DS_READ_B128(fb[set][2], bb, 2048);
-        RASS_DS_READ_B128(fa[set][3], ab, 3072); RASS_DS_READ_B128(fb[set][3], bb, 3072);
-        RASS_DS_READ_B128(fa[set][4], ab, 4096); RASS_DS_READ_B128(fb[set][4], bb, 4096);
-        RASS_DS_READ_B128(fa[set][5], ab, 5120); RASS_DS_READ_B128(fb[set][5], bb, 5120);
-        RASS_DS_READ_B128(fa[set][6], ab, 6144); RASS_DS_READ_B128(fb[set][6], bb, 6144);
-        RASS_DS_READ_B128(fa[set][7], ab, 7168); RASS_DS_READ_B128(fb[set][7], bb, 7168);
+        const unsigned ab = lds_base + slot * kP64SlotBytes + offA[sub];
+        const unsigned bb = lds_base + slot * kP64SlotBytes + offB[sub];
+        RASS_DS_READ_B128(fa[set][0], ab, 0);     RASS_DS_READ_B128(fb[set][0], bb, 0);
+        RASS_DS_READ_B128(fa[set][1], ab, 2048);  RASS_DS_READ_B128(fb[set][1], bb, 2048);
+        RASS_DS_READ_B128(fa[set][2], ab, 4096);  RASS_DS_READ_B128(fb[set][2], bb, 4096);
+        RASS_DS_READ_B128(fa[set][3], ab, 6144);  RASS_DS_READ_B128(fb[set][3], bb, 6144);
+        RASS_DS_READ_B128(fa[set][4], ab, 8192);  RASS_DS_READ_B128(fb[set][4], bb, 8192);
+        RASS_DS_READ_B128(fa[set][5], ab, 10240); RASS_DS_READ_B128(fb[set][5], bb, 10240);
+        RASS_DS_READ_B128(fa[set][6], ab, 12288); RASS_DS_READ_B128(fb[set][6], bb, 12288);
+        RASS_DS_READ_B128(fa[set][7], ab, 14336); RASS_DS_READ_B128(fb[set][7], bb, 14336);
     };
 
-    // One K step; its place in the tile is known at compile time (no branch in the MFMA stream):
-    //   FIRST  the tile's first step writes the accumulators instead of adding to them
-    //   READS  step t+1 exists: its fragments are requested (rows 1-4, so they have three rows to arrive)
-    //   WRITE  step t+2 exists: its pieces go from g[set] to slot t+2 (rows 4-7)
-    //   LOAD   0 = nothing; 1 = step t+3 of this tile into g[set^1]; 2 = a step of the NEXT tile into g[set^1]
-    //          (the caller has re-pointed the source pointers), only if there is a next tile
-    auto kstep = [&](auto set_c, auto first_c, auto reads_c, auto write_c, auto load_c, int slot, bool has_next) {
-        constexpr int set = decltype(set_c)::value;
+    // Sub-step u of a tile (SUB = u & 1 = the fragment register set it multiplies; SLOT = (u >> 1) & 1):
+    //   FIRST     the tile's first sub-step writes the accumulators
+    //   READS     fragments of sub-step u+1 (slot SLOT sub 1, or slot SLOT^1 sub 0) into the other register set
+    //   do_write  half-load q = u+3 (loaded during sub-step u-1 into g[SUB^1]) goes to its slot: half SUB^1 of slot
+    //             SLOT^1 (SUB = 0) or of slot SLOT (SUB = 1: this slot's last reads were issued a sub-step ago)
+    //   do_load   half-load q = u+4 = half SUB of step T+2 into g[SUB]
+    auto kstep = [&](auto sub_c, auto slot_c, auto first_c, auto reads_c, bool do_write, bool do_load) {
+        constexpr int sub = decltype(sub_c)::value;
+        constexpr int slot = decltype(slot_c)::value;
         constexpr bool first = decltype(first_c)::value;
         constexpr bool reads = decltype(reads_c)::value;
-        constexpr bool write = decltype(write_c)::value;
-        constexpr int load = decltype(load_c)::value;
-        const int slot1 = (slot + 1) & 3, slot2 = (slot + 2) & 3;
-        const unsigned ab = lds_base + slot1 * kRingSlotBytes + offA0;
-        const unsigned bb = lds_base + slot1 * kRingSlotBytes + offB0;
-        // this step's fragments have arrived and this wave's pieces of step t+1 are in its slot
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        constexpr int set = sub;
+        constexpr int rslot = sub == 0 ? slot : slot ^ 1, rsub = sub ^ 1;
+        constexpr int wslot = sub == 0 ? slot ^ 1 : slot, wh = sub ^ 1;
+        const unsigned ab = lds_base + rslot * kP64SlotBytes + offA[rsub];
+        const unsigned bb = lds_base + rslot * kP64SlotBytes + offB[rsub];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this sub-step's fragments, this wave's last ds_writes
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             if (first) RASS_MFMA_BF16_NEW(acc[0][j], fa[set][0], fb[set][j]);
             else RASS_MFMA_BF16_ACC(acc[0][j], fa[set][0], fb[set][j]);
         }
-        // every wave's pieces of step t+1 are in the ring, and nobody reads the slot step t+2 goes into any more
         __builtin_amdgcn_sched_barrier(0);
-#ifndef RASS_W4_EXP_NO_BARRIER
         __builtin_amdgcn_s_barrier();
-#endif
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 1; i < 8; ++i) {
@@ -1208,76 +1203,64 @@ __global__ __launch_bounds__(kW4Threads) void gemm_bf16_w4_kernel(const u16* __r
                 if (first) RASS_MFMA_BF16_NEW(acc[i][j], fa[set][i], fb[set][j]);
                 else RASS_MFMA_BF16_ACC(acc[i][j], fa[set][i], fb[set][j]);
             }
-#ifndef RASS_W4_EXP_NO_READS
-            if (reads) {  // next step's fragments into the other register set
-                if (i == 1) { RASS_DS_READ_B128(fa[set ^ 1][0], ab, 0);    RASS_DS_READ_B128(fb[set ^ 1][0], bb, 0);
-                              RASS_DS_READ_B128(fb[set ^ 1][1], bb, 1024); RASS_DS_READ_B128(fb[set ^ 1][2], bb, 2048); }
-                if (i == 2) { RASS_DS_READ_B128(fb[set ^ 1][3], bb, 3072); RASS_DS_READ_B128(fb[set ^ 1][4], bb, 4096);
-                              RASS_DS_READ_B128(fb[set ^ 1][5], bb, 5120); RASS_DS_READ_B128(fb[set ^ 1][6], bb, 6144); }
-                if (i == 3) { RASS_DS_READ_B128(fb[set ^ 1][7], bb, 7168); RASS_DS_READ_B128(fa[set ^ 1][1], ab, 1024);
-                              RASS_DS_READ_B128(fa[set ^ 1][2], ab, 2048); RASS_DS_READ_B128(fa[set ^ 1][3], ab, 3072); }
-                if (i == 4) { RASS_DS_READ_B128(fa[set ^ 1][4], ab, 4096); RASS_DS_READ_B128(fa[set ^ 1][5], ab, 5120);
-                              RASS_DS_READ_B128(fa[set ^ 1][6], ab, 6144); RASS_DS_READ_B128(fa[set ^ 1][7], ab, 7168); }
+            if (i == 1 && do_load) load_half(std::integral_constant<int, set>{}, std::integral_constant<int, sub>{});
+            if (reads) {
+                if (i == 1) { RASS_DS_READ_B128(fa[set ^ 1][0], ab, 0);     RASS_DS_READ_B128(fb[set ^ 1][0], bb, 0);
+                              RASS_DS_READ_B128(fb[set ^ 1][1], bb, 2048);  RASS_DS_READ_B128(fb[set ^ 1][2], bb, 4096); }
+                if (i == 2) { RASS_DS_READ_B128(fb[set ^ 1][3], bb, 6144);  RASS_DS_READ_B128(fb[set ^ 1][4], bb, 8192);
+                              RASS_DS_READ_B128(fb[set ^ 1][5], bb, 10240); RASS_DS_READ_B128(fb[set ^ 1][6], bb, 12288); }
+                if (i == 3) { RASS_DS_READ_B128(fb[set ^ 1][7], bb, 14336); RASS_DS_READ_B128(fa[set ^ 1][1], ab, 2048);
+                              RASS_DS_READ_B128(fa[set ^ 1][2], ab, 4096);  RASS_DS_READ_B128(fa[set ^ 1][3], ab, 6144); }
+                if (i == 4) { RASS_DS_READ_B128(fa[set ^ 1][4], ab, 8192);  RASS_DS_READ_B128(fa[set ^ 1][5], ab, 10240);
+                              RASS_DS_READ_B128(fa[set ^ 1][6], ab, 12288); RASS_DS_READ_B128(fa[set ^ 1][7], ab, 14336); }
             }
-#endif
-            // loads first (row 1), writes last (rows 4-7): a piece has more than a full K step between its load
-            // and its ds_write (the wait hipcc puts in front of each write is then free)
-#ifndef RASS_W4_EXP_NO_STAGE
-            if (i == 1) {
-                if (load == 1) load_step(std::integral_constant<int, set ^ 1>{});
-                if (load == 2 && has_next) load_step(std::integral_constant<int, set ^ 1>{});
-            }
-            if (write && i >= 4) write_piece(set_c, slot2, i - 4);
-#endif
+            if (i >= 4 && do_write) write_piece(std::integral_constant<int, set ^ 1>{}, wslot, wh, i - 4);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
     using C0 = std::integral_constant<int, 0>;
     using C1 = std::integral_constant<int, 1>;
-    using C2 = std::integral_constant<int, 2>;
     using BT = std::integral_constant<bool, true>;
     using BF = std::integral_constant<bool, false>;
 
-    // pipeline prologue of the first tile: steps 0 and 1 into the ring, step 2 into registers
+    // pipeline prologue of the first tile: half-loads 0, 1 (step 0 -> slot 0) and 2 (half 0 of step 1 -> slot 1) into
+    // LDS, half-load 3 into g[1]
     point_at(tile);
-    load_step(C0{});
-    load_step(C1{});
+    load_half(C0{}, C0{});
+    load_half(C1{}, C1{});
 #pragma unroll
-    for (int p = 0; p < 4; ++p) write_piece(C0{}, 0, p);
+    for (int p = 0; p < 4; ++p) write_piece(C0{}, 0, 0, p);
 #pragma unroll
-    for (int p = 0; p < 4; ++p) write_piece(C1{}, 1, p);
-    load_step(C0{});
+    for (int p = 0; p < 4; ++p) write_piece(C1{}, 0, 1, p);
+    load_half(C0{}, C0{});
+#pragma unroll
+    for (int p = 0; p < 4; ++p) write_piece(C0{}, 1, 0, p);
+    load_half(C1{}, C1{});
 
     for (;;) {
         const int n0 = (tile % tiles_n) * RBN, m0 = (tile / tiles_n) * RBM;
         const int next = tile + G;
         const bool has_next = next < tiles_total;
-        // the tile's steps 0 and 1 are in slots 0 and 1 once every wave's writes have landed
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        read_frags(C0{}, 0);
-        // ---- K loop: the steady state two steps per trip (the register sets alternate), the last three peeled
-        //    set  first reads write load
-        kstep(C0{}, BT{}, BT{}, BT{}, C1{}, 0, has_next);
-        kstep(C1{}, BF{}, BT{}, BT{}, C1{}, 1, has_next);
-        int slot = 2;
-        for (int t = 2; t + 4 < nk; t += 2) {
-            kstep(C0{}, BF{}, BT{}, BT{}, C1{}, slot, has_next);
-            kstep(C1{}, BF{}, BT{}, BT{}, C1{}, (slot + 1) & 3, has_next);
-            slot = (slot + 2) & 3;
+        read_frags(C0{}, 0, 0);
+        //     sub  slot first reads write load
+        kstep(C0{}, C0{}, BT{}, BT{}, true, true);
+        kstep(C1{}, C0{}, BF{}, BT{}, true, true);
+        kstep(C0{}, C1{}, BF{}, BT{}, true, true);
+        kstep(C1{}, C1{}, BF{}, BT{}, true, true);
+        for (int u = 4; u + 4 < nu; u += 4) {
+            kstep(C0{}, C0{}, BF{}, BT{}, true, true);
+            kstep(C1{}, C0{}, BF{}, BT{}, true, true);
+            kstep(C0{}, C1{}, BF{}, BT{}, true, true);
+            kstep(C1{}, C1{}, BF{}, BT{}, true, true);
         }
-        kstep(C0{}, BF{}, BT{}, BT{}, C1{}, slot, has_next);             // t = nk - 4: loads step nk - 1
+        // the tile's last four sub-steps: their half-loads (and, from the second on, writes) belong to the next tile
         if (has_next) point_at(next);
-        kstep(C1{}, BF{}, BT{}, BT{}, C2{}, (slot + 1) & 3, has_next);   // t = nk - 3: loads the next tile's step 0
-        kstep(C0{}, BF{}, BT{}, BF{}, C2{}, (slot + 2) & 3, has_next);   // t = nk - 2: loads the next tile's step 1
-        kstep(C1{}, BF{}, BF{}, BF{}, C0{}, (slot + 3) & 3, has_next);   // t = nk - 1: its barrier = all reads done
-        // the ring is free: the next tile's steps 0, 1 go in now, its step 2 waits in registers
-        if (has_next) {
-#pragma unroll
-            for (int p = 0; p < 4; ++p) write_piece(C0{}, 0, p);
-#pragma unroll
-            for (int p = 0; p < 4; ++p) write_piece(C1{}, 1, p);
-        }
+        kstep(C0{}, C0{}, BF{}, BT{}, true, has_next);       // u = nu-4: writes this tile's last half-load
+        kstep(C1{}, C0{}, BF{}, BT{}, has_next, has_next);   // u = nu-3: next tile's half-load 0 -> slot 0
+        kstep(C0{}, C1{}, BF{}, BT{}, has_next, has_next);   // u = nu-2: half-load 1 -> slot 0
+        kstep(C1{}, C1{}, BF{}, BF{}, has_next, has_next);   // u = nu-1: half-load 2 -> slot 1; 3 waits in g[1]
 
         // ---- epilogue in registers: lane (g = lane>>4, c = lane&15) owns features 32g .. 32g+31 of token 16j + c.
         // Order of this wave's memory operations (vmcnt retires in order): the epilogue's READS (bias, the whole
@@ -1314,12 +1297,7 @@ __global__ __launch_bounds__(kW4Threads) void gemm_bf16_w4_kernel(const u16* __r
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (has_next) {
-                load_step(C0{});                                   // the next tile's step 2
-                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // the reads; those 8 loads stay in flight
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the reads (and the staged half-load issued before them)
             asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs' results (inline asm: no hazard tracking)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1361,12 +1339,12 @@ __global__ __launch_bounds__(kW4Threads) void gemm_bf16_w4_kernel(const u16* __r
 }
 
 template <int EPI>
-static hipError_t launch_w4(const u16* X, const u16* W, const float* bias, const u16* residual, u16* Y, int M,
-                            int M_pad, int N, int K, hipStream_t stream) {
+static hipError_t launch_w4l(const u16* X, const u16* W, const float* bias, const u16* residual, u16* Y, int M,
+                             int M_pad, int N, int K, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_w4_kernel<EPI>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, kW4LdsBytes);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_w4l_kernel<EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kW4LLdsBytes);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
@@ -1379,7 +1357,7 @@ static hipError_t launch_w4(const u16* X, const u16* W, const float* bias, const
     }
     const int tiles_total = (N / RBN) * (M_pad / RBM);
     const int grid = tiles_total < n_cus ? tiles_total : n_cus;
-    hipLaunchKernelGGL((gemm_bf16_w4_kernel<EPI>), dim3(grid), dim3(kW4Threads), kW4LdsBytes, stream, X, W, bias,
+    hipLaunchKernelGGL((gemm_bf16_w4l_kernel<EPI>), dim3(grid), dim3(kW4Threads), kW4LLdsBytes, stream, X, W, bias,
                        residual, Y, M, N, K, tiles_total);
     return hipGetLastError();
 }
@@ -1392,20 +1370,20 @@ static hipError_t launch_epi(const u16* X, const u16* W, const float* bias, cons
         // Default: the persistent form of the 8-wave 256x256 ring kernel; RASS_GEMM_VARIANT=ring
         // selects the one-tile-per-block form for A/B runs (scripts/microbench/gemm_phases.hip).
         // Default: p64, the persistent ring kernel with 64-deep K steps (whole cache lines per row), where K allows;
-        // RASS_GEMM_VARIANT=pring | ring | w4 select the 32-deep persistent kernel, its one-tile-per-block form and the
+        // RASS_GEMM_VARIANT=pring | ring | w4l select the 32-deep persistent kernel, its one-tile-per-block form and the
         // 4-wave 128x128-per-wave kernel for A/B runs (scripts/probe_gemm.py, profiles/r02_gemm_w4_experiments.txt).
-        static const int variant = [] {   // 0 = p64, 1 = ring, 2 = w4, 3 = pring
+        static const int variant = [] {   // 0 = p64, 1 = ring, 3 = pring, 4 = w4l
             const char* v = getenv("RASS_GEMM_VARIANT");
             if (v != nullptr && strcmp(v, "ring") == 0) return 1;
-            if (v != nullptr && strcmp(v, "w4") == 0) return 2;
+            if (v != nullptr && (strcmp(v, "w4l") == 0 || strcmp(v, "w4") == 0)) return 4;
             if (v != nullptr && strcmp(v, "pring") == 0) return 3;
             return 0;
         }();
         if (variant == 1) return launch_ring<EPI>(X, W, bias, residual, Y, M, M_pad, N, K, stream);
-        if (variant == 0 && K % 64 == 0) return launch_p64<EPI>(X, W, bias, residual, Y, M, M_pad, N, K, stream);
-        if (variant == 2 && K / RBK >= 6 && (K / RBK) % 2 == 0 && (int64_t)M_pad * K * 2 < (1LL << 32) &&
+        if (variant == 4 && K % 128 == 0 && K >= 256 && (int64_t)M_pad * K * 2 < (1LL << 32) &&
             (int64_t)N * K * 2 < (1LL << 32))
-            return launch_w4<EPI>(X, W, bias, residual, Y, M, M_pad, N, K, stream);
+            return launch_w4l<EPI>(X, W, bias, residual, Y, M, M_pad, N, K, stream);
+        if ((variant == 0 || variant == 4) && K % 64 == 0) return launch_p64<EPI>(X, W, bias, residual, Y, M, M_pad, N, K, stream);
         return launch_pring<EPI>(X, W, bias, residual, Y, M, M_pad, N, K, stream);
     }
     constexpr int lds_bytes = 4 * kTileBytes;  // 64 KiB

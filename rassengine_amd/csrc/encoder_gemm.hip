@@ -823,6 +823,10 @@ __global__ __launch_bounds__(kRingThreads, 2) void gemm_bf16_p64_kernel(const u1
     // a step's DMAs in two halves: the X pieces first (their lines are new in every step: the long latencies), the W
     // pieces (mostly L2 hits) half a sub-step later, so that no phase carries all eight issues
     auto stage_x = [&](unsigned char* slot_base) {
+#ifdef RASS_GEMM_EXP_NO_DMA      // timing experiment: no operand delivery at all (stale LDS)
+        (void)slot_base;
+        return;
+#endif
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             __builtin_amdgcn_global_load_lds(
@@ -832,6 +836,10 @@ __global__ __launch_bounds__(kRingThreads, 2) void gemm_bf16_p64_kernel(const u1
         }
     };
     auto stage_w = [&](unsigned char* slot_base) {
+#ifdef RASS_GEMM_EXP_NO_DMA
+        (void)slot_base;
+        return;
+#endif
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)srcW[p],
@@ -870,6 +878,10 @@ __global__ __launch_bounds__(kRingThreads, 2) void gemm_bf16_p64_kernel(const u1
                 // ---- load phase
                 if (sub == 0 && more) stage_x(lds + (slot ^ 1) * kP64SlotBytes);
                 bf16x8 a[8], b[4];
+#ifdef RASS_GEMM_EXP_NO_MFMA    // timing experiment: the operand stream alone (DMA + waits + barriers)
+                for (int i = 0; i < 8; ++i) a[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                for (int j = 0; j < 4; ++j) b[j] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+#else
                 {
                     const unsigned ab = lds_base + slot * kP64SlotBytes + offA[sub];
                     const unsigned bb = lds_base + slot * kP64SlotBytes + offB[sub];
@@ -886,6 +898,7 @@ __global__ __launch_bounds__(kRingThreads, 2) void gemm_bf16_p64_kernel(const u1
                     RASS_DS_READ_B128(a[6], ab, 12288);
                     RASS_DS_READ_B128(a[7], ab, 14336);
                 }
+#endif
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (sub == 1 && grpB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of step t+1
                 __builtin_amdgcn_sched_barrier(0);
@@ -893,11 +906,13 @@ __global__ __launch_bounds__(kRingThreads, 2) void gemm_bf16_p64_kernel(const u1
                 __builtin_amdgcn_sched_barrier(0);
                 // ---- compute phase
                 __builtin_amdgcn_s_setprio(1);
+#ifndef RASS_GEMM_EXP_NO_MFMA
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+#endif
                 __builtin_amdgcn_s_setprio(0);
                 if (sub == 0 && more) stage_w(lds + (slot ^ 1) * kP64SlotBytes);
                 if (sub == 1 && !grpB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

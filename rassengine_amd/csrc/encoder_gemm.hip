@@ -1015,6 +1015,287 @@ __global__ __launch_bounds__(kRingThreads, 2) void gemm_bf16_p64_kernel(const u1
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// "p5": gemm_bf16_p64_kernel's whole-line operand stream with a ring of FIVE 32-KiB HALF-slots instead of two 64-KiB
+// slots.  Half-load q = 2T + h holds rows 128h .. 128h+127 of both operand tiles of the 64-deep step T (W half at
+// +0, X half at +16 KiB, rows of 128 B, swizzled as in p64) and lives in half-slot (q0 + q) % 5.  A wave's A
+// fragments come from half wn of the step, its B fragments from half wm>>1.  While step T is multiplied (two
+// half-slots), (T+1, 0) and (T+1, 1) and (T+2, 0) are in flight or landed: 1.5 steps ahead where two whole slots
+// allowed one, and the DMA issues spread evenly — every load phase issues one half of a half-load (4 pieces per
+// wave, as in the 32-deep kernel): step T issues (T+1, 1) in its first load phase and (T+2, 0) in its second, into
+// the half-slots step T-1 was read from.  The stream runs on across tiles; only the next tile's third half-load
+// waits for the epilogue to end (its 8 staging areas need three free half-slots).  Exactly 160 KiB of LDS.
+constexpr int kP5HalfBytes = 32768;
+constexpr int kP5LdsBytes = 5 * kP5HalfBytes;
+
+template <int EPI>
+__global__ __launch_bounds__(kRingThreads, 2) void gemm_bf16_p5_kernel(const u16* __restrict__ X,
+                                                                      const u16* __restrict__ W,
+                                                                      const float* __restrict__ bias,
+                                                                      const u16* __restrict__ residual,
+                                                                      u16* __restrict__ Y, int M, int N, int K,
+                                                                      int tiles_total) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wn = wave >> 2, wm = wave & 3;
+    const int G = gridDim.x, orig = blockIdx.x;
+    const int pos = (G % 8 == 0) ? (orig % 8) * (G / 8) + orig / 8 : orig;
+    int tile = pos;
+    if (tile >= tiles_total) return;
+    const int tiles_n = N / RBN;
+    const int nk = K / 64;   // >= 2 (launcher)
+
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    // fragment offsets inside a half-slot (rows of 128 B; chunk c of row r at c ^ ((r>>1)&7); sub-step s = chunks 4s..4s+3)
+    unsigned offA[2], offB[2];
+    {
+        const int sw = ((lane & 15) >> 1) & 7;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int ch = (sub * 4 + (lane >> 4)) ^ sw;
+            offA[sub] = (lane & 15) * 128 + ch * 16;
+            offB[sub] = 16384 + ((wm & 1) * 64 + (lane & 15)) * 128 + ch * 16;
+        }
+    }
+    const int hA = wn, hB = wm >> 1;  // which half of a step this wave's A / B fragments live in
+    // DMA: a half-load is 16 W pieces + 16 X pieces of 8 rows x 128 B; this wave moves pieces wave and wave + 8 of each
+    const u16* srcW[2][2];
+    const u16* srcX[2][2];
+    using H0 = std::integral_constant<int, 0>;
+    using H1 = std::integral_constant<int, 1>;
+    auto point_half = [&](int t, auto h_c) {   // sources of half h of tile t's step 0
+        constexpr int h = decltype(h_c)::value;
+        const int tn0 = (t % tiles_n) * RBN, tm0 = (t / tiles_n) * RBM;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int r = (wave + 8 * p) * 8 + (lane >> 3);   // row inside the half
+            const int c_src = (lane & 7) ^ ((r >> 1) & 7);
+            srcW[h][p] = W + (int64_t)(tn0 + 128 * h + r) * K + c_src * 8;
+            srcX[h][p] = X + (int64_t)(tm0 + 128 * h + r) * K + c_src * 8;
+        }
+    };
+    auto stage_half = [&](int hs, auto h_c) {   // hs: half-slot index 0..4
+        constexpr int h = decltype(h_c)::value;
+        unsigned char* base = lds + hs * kP5HalfBytes;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)srcX[h][p],
+                                             (__attribute__((address_space(3))) void*)(base + 16384 + (wave + 8 * p) * 1024),
+                                             16, 0, 0);
+            srcX[h][p] += 64;
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)srcW[h][p],
+                                             (__attribute__((address_space(3))) void*)(base + (wave + 8 * p) * 1024), 16, 0, 0);
+            srcW[h][p] += 64;
+        }
+    };
+    auto mod5 = [](int v) { return v >= 5 ? v - 5 : v; };
+    const bool grpB = wave >= 4;
+
+    // half-slot of the current tile's half-load 0; every tile advances it by 2 * nk (mod 5)
+    int q0 = 0;
+    const int tile_adv = (2 * nk) % 5;
+    point_half(tile, H0{});
+    point_half(tile, H1{});
+    stage_half(0, H0{});
+    stage_half(1, H1{});
+    stage_half(2, H0{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    for (;;) {
+        const int n0 = (tile % tiles_n) * RBN, m0 = (tile / tiles_n) * RBM;
+        const int next = tile + G;
+        const bool has_next = next < tiles_total;
+        f32x4 acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        if (grpB) __builtin_amdgcn_s_barrier();   // group B runs one phase behind group A
+        int hs0 = q0;                              // half-slot of (t, 0)
+        for (int t = 0; t < nk; ++t) {
+            const int hs1 = mod5(hs0 + 1), hs2 = mod5(hs0 + 2), hs3 = mod5(hs0 + 3), hs4 = mod5(hs0 + 4);
+            // half-loads this step issues: q = 2t+3 = (t+1, 1) into hs3 and q = 2t+4 = (t+2, 0) into hs4; beyond the
+            // tile they are the next tile's (whose third half-load waits for the epilogue)
+            const bool iss1 = (t + 1 < nk) || has_next;
+            const bool iss2 = (t + 2 < nk) || (has_next && t + 2 == nk);
+            const unsigned aslot = lds_base + (hA ? hs1 : hs0) * kP5HalfBytes;
+            const unsigned bslot = lds_base + (hB ? hs1 : hs0) * kP5HalfBytes;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                // ---- load phase
+                if (sub == 0 && iss1) {
+                    if (t + 1 == nk) point_half(next, H1{});   // the half-load is the next tile's (0, 1)
+                    stage_half(hs3, H1{});
+                }
+                if (sub == 1 && iss2) {
+                    if (t + 2 == nk) point_half(next, H0{});   // the next tile's (0, 0)
+                    stage_half(hs4, H0{});
+                }
+                bf16x8 a[8], b[4];
+                {
+                    const unsigned ab = aslot + offA[sub];
+                    const unsigned bb = bslot + offB[sub];
+                    RASS_DS_READ_B128(b[0], bb, 0);
+                    RASS_DS_READ_B128(b[1], bb, 2048);
+                    RASS_DS_READ_B128(b[2], bb, 4096);
+                    RASS_DS_READ_B128(b[3], bb, 6144);
+                    RASS_DS_READ_B128(a[0], ab, 0);
+                    RASS_DS_READ_B128(a[1], ab, 2048);
+                    RASS_DS_READ_B128(a[2], ab, 4096);
+                    RASS_DS_READ_B128(a[3], ab, 6144);
+                    RASS_DS_READ_B128(a[4], ab, 8192);
+                    RASS_DS_READ_B128(a[5], ab, 10240);
+                    RASS_DS_READ_B128(a[6], ab, 12288);
+                    RASS_DS_READ_B128(a[7], ab, 14336);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                // before the barrier that ends the step: this wave's pieces of (t+1, 1) have landed; (t+2, 0)'s four may fly
+                if (sub == 1 && grpB) {
+                    if (iss2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- compute phase
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                if (sub == 1 && !grpB) {
+                    if (iss2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            hs0 = hs2;
+        }
+        if (!grpB) __builtin_amdgcn_s_barrier();  // groups re-aligned: every ring read of this tile is done
+        // the next tile's half-loads 0 and 1 are landing in hs0, hs0+1 (= its q0); staging: three free half-slots
+        q0 = mod5(q0 + tile_adv);
+        float* const stg = reinterpret_cast<float*>(lds + mod5(q0 + 2 + wave / 3) * kP5HalfBytes + (wave % 3) * 8704);
+
+        // ---- epilogue (see gemm_bf16_ring_kernel): LDS transpose per wave, coalesced 16-B stores
+        {
+            constexpr int kPitchF = 68;
+            const int tl = lane >> 3, nq = lane & 7;
+            // Bias through opaque asm loads, retired by the explicit vmcnt(0) below: a load hipcc can
+            // see stays "possibly pending" on its destination registers across the tile loop, and
+            // when the K loop's fragment reads get the same registers the waitcnt pass protects them
+            // with a vmcnt(0) in EVERY K step (seen in two of the three epilogue variants).
+            f32x4 bv[2][2];
+#pragma unroll
+            for (int ic = 0; ic < 2; ++ic) {
+                const float* bp = bias + n0 + wn * 128 + ic * 64 + nq * 8;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bv[ic][0]) : "v"(bp));
+                asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(bv[ic][1]) : "v"(bp));
+            }
+#pragma unroll
+            for (int jc = 0; jc < 64 / kPStageTokens; ++jc) {
+#pragma unroll
+                for (int ic = 0; ic < 2; ++ic) {
+                    const int nbase = n0 + wn * 128 + ic * 64 + nq * 8;
+                    uint4 res[4];
+                    if (EPI == 1) {
+#pragma unroll
+                        for (int pass = 0; pass < kPStageTokens / 8; ++pass) {
+                            const int m = m0 + wm * 64 + jc * kPStageTokens + pass * 8 + tl;
+                            res[pass] = m < M ? *reinterpret_cast<const uint4*>(residual + (int64_t)m * N + nbase)
+                                              : uint4{0u, 0u, 0u, 0u};
+                        }
+                    }
+#pragma unroll
+                    for (int jj = 0; jj < kPStageTokens / 16; ++jj)
+#pragma unroll
+                        for (int ii = 0; ii < 4; ++ii)
+                            *reinterpret_cast<f32x4*>(stg + (jj * 16 + (lane & 15)) * kPitchF + ii * 16 + (lane >> 4) * 4) =
+                                acc[4 * ic + ii][(kPStageTokens / 16) * jc + jj];
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (jc == 0 && ic == 0) {
+                        // Explicit: this wave's prefetch DMAs (and the bias / first residual reads issued
+                        // after them) are complete before anything below consumes them and before the
+                        // publishing barrier after the epilogue.  No store is outstanding yet.
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
+#pragma unroll
+                    for (int pass = 0; pass < kPStageTokens / 8; ++pass) {
+                        const int tok = pass * 8 + tl;
+                        const int m = m0 + wm * 64 + jc * kPStageTokens + tok;
+                        f32x4 v0 = *reinterpret_cast<const f32x4*>(stg + tok * kPitchF + nq * 8);
+                        f32x4 v1 = *reinterpret_cast<const f32x4*>(stg + tok * kPitchF + nq * 8 + 4);
+                        v0 += bv[ic][0];
+                        v1 += bv[ic][1];
+                        if (EPI == 1) {
+                            const uint4 r = res[pass];
+                            v0.x += bf16_to_f32((u16)(r.x & 0xffff));
+                            v0.y += bf16_to_f32((u16)(r.x >> 16));
+                            v0.z += bf16_to_f32((u16)(r.y & 0xffff));
+                            v0.w += bf16_to_f32((u16)(r.y >> 16));
+                            v1.x += bf16_to_f32((u16)(r.z & 0xffff));
+                            v1.y += bf16_to_f32((u16)(r.z >> 16));
+                            v1.z += bf16_to_f32((u16)(r.w & 0xffff));
+                            v1.w += bf16_to_f32((u16)(r.w >> 16));
+                        }
+                        if (EPI == 2) {
+                            v0.x = gelu_erf(v0.x); v0.y = gelu_erf(v0.y); v0.z = gelu_erf(v0.z); v0.w = gelu_erf(v0.w);
+                            v1.x = gelu_erf(v1.x); v1.y = gelu_erf(v1.y); v1.z = gelu_erf(v1.z); v1.w = gelu_erf(v1.w);
+                        }
+                        if (m < M) {
+                            uint4 o;
+                            o.x = (unsigned)f32_to_bf16(v0.x) | ((unsigned)f32_to_bf16(v0.y) << 16);
+                            o.y = (unsigned)f32_to_bf16(v0.z) | ((unsigned)f32_to_bf16(v0.w) << 16);
+                            o.z = (unsigned)f32_to_bf16(v1.x) | ((unsigned)f32_to_bf16(v1.y) << 16);
+                            o.w = (unsigned)f32_to_bf16(v1.z) | ((unsigned)f32_to_bf16(v1.w) << 16);
+                            *reinterpret_cast<uint4*>(Y + (int64_t)m * N + nbase) = o;
+                        }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+            }
+        }
+        if (!has_next) break;
+        // every wave is done with its staging area: the next tile's third half-load may overwrite it
+        __builtin_amdgcn_s_barrier();
+        stage_half(mod5(q0 + 2), H0{});
+        tile = next;
+    }
+}
+
+template <int EPI>
+static hipError_t launch_p5(const u16* X, const u16* W, const float* bias, const u16* residual, u16* Y, int M,
+                            int M_pad, int N, int K, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_p5_kernel<EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kP5LdsBytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    static int n_cus = 0;
+    if (n_cus == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cus <= 0)
+            n_cus = 256;
+    }
+    const int tiles_total = (N / RBN) * (M_pad / RBM);
+    const int grid = tiles_total < n_cus ? tiles_total : n_cus;
+    hipLaunchKernelGGL((gemm_bf16_p5_kernel<EPI>), dim3(grid), dim3(kRingThreads), kP5LdsBytes, stream, X, W, bias,
+                       residual, Y, M, N, K, tiles_total);
+    return hipGetLastError();
+}
+
 template <int EPI>
 static hipError_t launch_p64(const u16* X, const u16* W, const float* bias, const u16* residual, u16* Y, int M,
                              int M_pad, int N, int K, hipStream_t stream) {
@@ -1384,21 +1665,24 @@ static hipError_t launch_epi(const u16* X, const u16* W, const float* bias, cons
     if (N % RBN == 0 && M_pad % RBM == 0 && K % RBK == 0 && M >= 1024) {
         // Default: the persistent form of the 8-wave 256x256 ring kernel; RASS_GEMM_VARIANT=ring
         // selects the one-tile-per-block form for A/B runs (scripts/microbench/gemm_phases.hip).
-        // Default: p64, the persistent ring kernel with 64-deep K steps (whole cache lines per row), where K allows;
-        // RASS_GEMM_VARIANT=pring | ring | w4l select the 32-deep persistent kernel, its one-tile-per-block form and the
-        // 4-wave 128x128-per-wave kernel for A/B runs (scripts/probe_gemm.py, profiles/r02_gemm_w4_experiments.txt).
-        static const int variant = [] {   // 0 = p64, 1 = ring, 3 = pring, 4 = w4l
+        // Default: p5, the persistent ring kernel with 64-deep K steps (whole cache lines per row) on a ring of five
+        // half-slots, where K allows (p64, its two-slot form, for K = 64).  RASS_GEMM_VARIANT=p64 | pring | ring | w4l select
+        // the two-slot form, the 32-deep persistent kernel, its one-tile-per-block form and the 4-wave 128x128-per-wave
+        // kernel for A/B runs (scripts/probe_gemm.py, profiles/r02_gemm_w4_experiments.txt).
+        static const int variant = [] {   // 0 = p5, 1 = ring, 3 = pring, 4 = w4l, 5 = p64
             const char* v = getenv("RASS_GEMM_VARIANT");
             if (v != nullptr && strcmp(v, "ring") == 0) return 1;
             if (v != nullptr && (strcmp(v, "w4l") == 0 || strcmp(v, "w4") == 0)) return 4;
             if (v != nullptr && strcmp(v, "pring") == 0) return 3;
+            if (v != nullptr && strcmp(v, "p64") == 0) return 5;
             return 0;
         }();
         if (variant == 1) return launch_ring<EPI>(X, W, bias, residual, Y, M, M_pad, N, K, stream);
         if (variant == 4 && K % 128 == 0 && K >= 256 && (int64_t)M_pad * K * 2 < (1LL << 32) &&
             (int64_t)N * K * 2 < (1LL << 32))
             return launch_w4l<EPI>(X, W, bias, residual, Y, M, M_pad, N, K, stream);
-        if ((variant == 0 || variant == 4) && K % 64 == 0) return launch_p64<EPI>(X, W, bias, residual, Y, M, M_pad, N, K, stream);
+        if (variant == 0 && K % 64 == 0 && K >= 128) return launch_p5<EPI>(X, W, bias, residual, Y, M, M_pad, N, K, stream);
+        if (variant != 3 && K % 64 == 0) return launch_p64<EPI>(X, W, bias, residual, Y, M, M_pad, N, K, stream);
         return launch_pring<EPI>(X, W, bias, residual, Y, M, M_pad, N, K, stream);
     }
     constexpr int lds_bytes = 4 * kTileBytes;  // 64 KiB

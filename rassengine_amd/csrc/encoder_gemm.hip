@@ -1077,6 +1077,10 @@ __global__ __launch_bounds__(kRingThreads, 2) void gemm_bf16_p5_kernel(const u16
     };
     auto stage_half = [&](int hs, auto h_c) {   // hs: half-slot index 0..4
         constexpr int h = decltype(h_c)::value;
+#ifdef RASS_GEMM_EXP_NO_DMA      // timing experiment: no operand delivery at all (stale LDS)
+        (void)hs;
+        return;
+#endif
         unsigned char* base = lds + hs * kP5HalfBytes;
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
@@ -1138,6 +1142,11 @@ __global__ __launch_bounds__(kRingThreads, 2) void gemm_bf16_p5_kernel(const u16
                     stage_half(hs4, H0{});
                 }
                 bf16x8 a[8], b[4];
+#ifdef RASS_GEMM_EXP_NO_MFMA    // timing experiment: the operand stream alone (DMA + waits + barriers)
+                for (int i = 0; i < 8; ++i) a[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                for (int j = 0; j < 4; ++j) b[j] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                (void)aslot; (void)bslot;
+#else
                 {
                     const unsigned ab = aslot + offA[sub];
                     const unsigned bb = bslot + offB[sub];
@@ -1154,6 +1163,7 @@ __global__ __launch_bounds__(kRingThreads, 2) void gemm_bf16_p5_kernel(const u16
                     RASS_DS_READ_B128(a[6], ab, 12288);
                     RASS_DS_READ_B128(a[7], ab, 14336);
                 }
+#endif
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 // before the barrier that ends the step: this wave's pieces of (t+1, 1) have landed; (t+2, 0)'s four may fly
                 if (sub == 1 && grpB) {
@@ -1165,11 +1175,13 @@ __global__ __launch_bounds__(kRingThreads, 2) void gemm_bf16_p5_kernel(const u16
                 __builtin_amdgcn_sched_barrier(0);
                 // ---- compute phase
                 __builtin_amdgcn_s_setprio(1);
+#ifndef RASS_GEMM_EXP_NO_MFMA
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+#endif
                 __builtin_amdgcn_s_setprio(0);
                 if (sub == 1 && !grpB) {
                     if (iss2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");

@@ -435,6 +435,12 @@ void* rass_encoder_get_stream(rass_encoder_t* enc);
 int rass_gemm_bf16(const void* d_x, const void* d_w, const float* d_bias,
                    const void* d_residual, void* d_y, int m, int m_pad, int n,
                    int k, int epilogue, void* stream);
+/* Same with a caller-owned fp32 scratch (d_ws, ws_bytes >= 2 * m_pad * n * 4): a GEMM over few rows (m_pad <= 256)
+ * is then split over K so that enough workgroups stream the weights — the path the encoder takes for embed_query /
+ * ollama_embed_text (app/main.py:225-237, 266-274); slices are summed in fixed order (deterministic). */
+int rass_gemm_bf16_ws(const void* d_x, const void* d_w, const float* d_bias,
+                      const void* d_residual, void* d_y, int m, int m_pad, int n, int k,
+                      int epilogue, void* d_ws, size_t ws_bytes, void* stream);
 
 /* -------------------------------------------------------------- tokenizer
  * BERT (uncased) BasicTokenizer + WordPiece on the host (C++), replacing the

@@ -79,6 +79,8 @@ struct rass_encoder {
     float* d_out = nullptr;
     float* d_stage = nullptr;  // fp32 staging for weight upload
     size_t stage_elems = 0;
+    float* d_splitk = nullptr;  // fp32 partial tiles of the split-K GEMMs of small batches (query-time embedding)
+    size_t splitk_bytes = 0;
     // The activation workspace is ONE set per encoder: a forward enqueued on stream A must finish
     // before a forward on stream B (or a reallocation) touches it.  `done` is recorded at the end of
     // every forward on `last_stream`.
@@ -169,12 +171,12 @@ int forward(rass_encoder* e, const int32_t* d_ids, const int32_t* d_cu, int nseq
                                           c.layer_norm_eps, H, c.vocab_size, c.max_positions, e->x, st));
     for (int l = 0; l < c.layers; ++l) {
         const Layer& L = e->layers[(size_t)l];
-        EHIP_TRY(rass::launch_gemm_bf16(e->x, L.w_qkv, L.b_qkv, nullptr, e->qkv, total, Tp, 3 * H, H, 0, st));
+        EHIP_TRY(rass::launch_gemm_bf16(e->x, L.w_qkv, L.b_qkv, nullptr, e->qkv, total, Tp, 3 * H, H, 0, st, e->d_splitk, e->splitk_bytes));
         EHIP_TRY(rass::launch_attention(e->qkv, d_cu, nseq, max_seqlen, H, c.heads, e->ctx, st));
-        EHIP_TRY(rass::launch_gemm_bf16(e->ctx, L.w_o, L.b_o, e->x, e->y, total, Tp, H, H, 1, st));
+        EHIP_TRY(rass::launch_gemm_bf16(e->ctx, L.w_o, L.b_o, e->x, e->y, total, Tp, H, H, 1, st, e->d_splitk, e->splitk_bytes));
         EHIP_TRY(rass::launch_layernorm(e->y, L.ln1_g, L.ln1_b, c.layer_norm_eps, total, H, e->x, st));
-        EHIP_TRY(rass::launch_gemm_bf16(e->x, L.w_up, L.b_up, nullptr, e->h, total, Tp, I, H, 2, st));
-        EHIP_TRY(rass::launch_gemm_bf16(e->h, L.w_down, L.b_down, e->x, e->y, total, Tp, H, I, 1, st));
+        EHIP_TRY(rass::launch_gemm_bf16(e->x, L.w_up, L.b_up, nullptr, e->h, total, Tp, I, H, 2, st, e->d_splitk, e->splitk_bytes));
+        EHIP_TRY(rass::launch_gemm_bf16(e->h, L.w_down, L.b_down, e->x, e->y, total, Tp, H, I, 1, st, e->d_splitk, e->splitk_bytes));
         EHIP_TRY(rass::launch_layernorm(e->y, L.ln2_g, L.ln2_b, c.layer_norm_eps, total, H, e->x, st));
     }
     EHIP_TRY(rass::launch_pool(e->x, d_cu, nseq, H, c.pooling == 1 ? 1 : 0, c.normalize ? 1 : 0, d_out, st));
@@ -213,6 +215,10 @@ int rass_encoder_create(int device, const rass_encoder_config* cfg, rass_encoder
         e->stage_elems = std::max<size_t>(I * H, 1 << 20);
         int rc;
         if ((rc = dev_alloc(e, reinterpret_cast<void**>(&e->d_stage), e->stage_elems * 4)) != RASS_OK) return rc;
+        // split-K scratch: 16 slices x 256 rows x the widest GEMM output that is split that far (H), or fewer
+        // slices of wider outputs: S * M_pad * N floats, the launcher picks S to fit
+        e->splitk_bytes = (size_t)16 * 256 * std::max(H, I / 4) * sizeof(float);
+        if ((rc = dev_alloc(e, reinterpret_cast<void**>(&e->d_splitk), e->splitk_bytes)) != RASS_OK) return rc;
         if ((rc = dev_alloc(e, &e->word, (size_t)cfg->vocab_size * H * 2)) != RASS_OK) return rc;
         if ((rc = dev_alloc(e, &e->pos, (size_t)cfg->max_positions * H * 2)) != RASS_OK) return rc;
         if ((rc = dev_alloc(e, &e->type0, H * 2)) != RASS_OK) return rc;
@@ -388,6 +394,17 @@ int rass_gemm_bf16(const void* d_x, const void* d_w, const float* d_bias, const 
     if (!d_x || !d_w || !d_bias || !d_y) return efail(RASS_ERR_INVALID, "NULL argument");
     hipError_t err = rass::launch_gemm_bf16(d_x, d_w, d_bias, d_residual, d_y, m, m_pad, n, k, epilogue,
                                             reinterpret_cast<hipStream_t>(stream));
+    if (err != hipSuccess) return efail(RASS_ERR_INVALID, std::string("gemm launch: ") + hipGetErrorString(err));
+    return RASS_OK;
+}
+
+/* Same with a caller-owned fp32 scratch: lets a GEMM over few rows (m_pad <= 256) take the split-K path the encoder
+ * uses for query-time embedding (tests). */
+int rass_gemm_bf16_ws(const void* d_x, const void* d_w, const float* d_bias, const void* d_residual, void* d_y, int m,
+                      int m_pad, int n, int k, int epilogue, void* d_ws, size_t ws_bytes, void* stream) {
+    if (!d_x || !d_w || !d_bias || !d_y) return efail(RASS_ERR_INVALID, "NULL argument");
+    hipError_t err = rass::launch_gemm_bf16(d_x, d_w, d_bias, d_residual, d_y, m, m_pad, n, k, epilogue,
+                                            reinterpret_cast<hipStream_t>(stream), static_cast<float*>(d_ws), ws_bytes);
     if (err != hipSuccess) return efail(RASS_ERR_INVALID, std::string("gemm launch: ") + hipGetErrorString(err));
     return RASS_OK;
 }

@@ -176,6 +176,117 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_bf16_kernel(const u16* _
 }
 
 // ------------------------------------------------------------------------------------------
+// Split-K form of the 128 x 128 kernel for FEW rows (a query or a handful of chunks: embed_query / ollama_embed_text,
+// reference app/main.py:225-237, 266-274).  With M <= 256 the plain kernel launches N/128 x M/128 = 8-32 workgroups, each
+// walking all of K behind one barrier per 64-deep step: FFN-down (K = 4096) took 60 us, attn-out 13 us, a one-query
+// forward 2.9 ms of which 60 % were these two (profiles/r02_encoder_b1_s16_kernel_stats.csv).  Here the K range is cut
+// into S slices so that >= ~128 workgroups stream the weights; every slice writes its fp32 partial tile (rows < M
+// only) to a scratch [S][M_pad][N], and splitk_epilogue_kernel sums the slices IN FIXED ORDER (deterministic: no
+// atomics), adds bias / residual, applies GELU and rounds to bf16 — the same arithmetic as the fused epilogue up to
+// the order of the fp32 partial sums.
+__global__ __launch_bounds__(kGemmThreads, 2) void gemm_bf16_splitk_kernel(const u16* __restrict__ X,
+                                                                          const u16* __restrict__ W,
+                                                                          float* __restrict__ partial, int M, int M_pad,
+                                                                          int N, int K, int k_per_slice) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // [2 buf][W tile | X tile]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wn = wave >> 1, wm = wave & 1;
+    const int tiles_n = N / GBN;
+    const int bn = blockIdx.x % tiles_n, bm = blockIdx.x / tiles_n;
+    const int slice = blockIdx.y;
+    const int n0 = bn * GBN, m0 = bm * GBM, k_lo = slice * k_per_slice;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = k_per_slice / GBK;
+    stage_tile(W, K, n0, k_lo, lds, wave, lane);
+    stage_tile(X, K, m0, k_lo, lds + kTileBytes, wave, lane);
+    __syncthreads();
+    int cur = 0;
+    for (int t = 0; t < nk; ++t) {
+        unsigned char* buf = lds + cur * 2 * kTileBytes;
+        if (t + 1 < nk) {
+            unsigned char* nxt = lds + (cur ^ 1) * 2 * kTileBytes;
+            stage_tile(W, K, n0, k_lo + (t + 1) * GBK, nxt, wave, lane);
+            stage_tile(X, K, m0, k_lo + (t + 1) * GBK, nxt + kTileBytes, wave, lane);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = read_frag(buf, wn * 64 + i * 16 + (lane & 15), ks * 4 + (lane >> 4));
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                b[j] = read_frag(buf + kTileBytes, wm * 64 + j * 16 + (lane & 15), ks * 4 + (lane >> 4));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    // acc[i][j]: token m = m0 + wm*64 + j*16 + (lane&15); features n0 + wn*64 + i*16 + (lane>>4)*4 + {0..3}
+    float* P = partial + (int64_t)slice * M_pad * N;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + wm * 64 + j * 16 + (lane & 15);
+        if (m >= M) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<f32x4*>(P + (int64_t)m * N + n0 + wn * 64 + i * 16 + (lane >> 4) * 4) = acc[i][j];
+    }
+}
+
+// y[m][n..n+3] = epi(sum over the S slices (ascending) + bias [+ residual]); one thread per 4 features
+template <int EPI>
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __restrict__ partial, int S, int M, int M_pad,
+                                                              int N, const float* __restrict__ bias,
+                                                              const u16* __restrict__ residual, u16* __restrict__ Y) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;   // over M * N/4
+    const int n4 = N / 4;
+    if (idx >= (int64_t)M * n4) return;
+    const int m = (int)(idx / n4), n = (int)(idx % n4) * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(partial + (int64_t)m * N + n);
+    for (int s = 1; s < S; ++s) v += *reinterpret_cast<const f32x4*>(partial + ((int64_t)s * M_pad + m) * N + n);
+    v += *reinterpret_cast<const f32x4*>(bias + n);
+    if (EPI == 1) {
+        const uint2 r = *reinterpret_cast<const uint2*>(residual + (int64_t)m * N + n);
+        v.x += bf16_to_f32((u16)(r.x & 0xffff));
+        v.y += bf16_to_f32((u16)(r.x >> 16));
+        v.z += bf16_to_f32((u16)(r.y & 0xffff));
+        v.w += bf16_to_f32((u16)(r.y >> 16));
+    }
+    if (EPI == 2) {
+        v.x = gelu_erf(v.x);
+        v.y = gelu_erf(v.y);
+        v.z = gelu_erf(v.z);
+        v.w = gelu_erf(v.w);
+    }
+    uint2 o;
+    o.x = (unsigned)f32_to_bf16(v.x) | ((unsigned)f32_to_bf16(v.y) << 16);
+    o.y = (unsigned)f32_to_bf16(v.z) | ((unsigned)f32_to_bf16(v.w) << 16);
+    *reinterpret_cast<uint2*>(Y + (int64_t)m * N + n) = o;
+}
+
+// Number of K slices for a small-M GEMM (0 = do not split): aim at >= 128 workgroups, at most 16 slices, whole
+// 64-deep steps per slice, and a scratch of S * M_pad * N floats that fits.
+static int splitk_slices(int M_pad, int N, int K, size_t ws_bytes) {
+    const int tiles = (N / GBN) * (M_pad / GBM), steps = K / GBK;
+    if (M_pad > 256 || tiles >= 96 || steps < 2) return 0;
+    int S = 1;
+    while (S < 16 && tiles * S < 128 && steps % (2 * S) == 0) S *= 2;
+    while (S > 1 && (size_t)S * M_pad * N * sizeof(float) > ws_bytes) S /= 2;
+    return S > 1 ? S : 0;
+}
+
+// ------------------------------------------------------------------------------------------
 // Large-shape kernel: 256 (N) x 256 (M) x 32 (K) tiles, 512 threads = 2 (N) x 4 (M) waves, each
 // wave 128 x 64 = 8 x 4 MFMA tiles (128 accumulator VGPRs).  Versus the 128^2 kernel above
 // it halves the staging instructions per MFMA (4 global_load_lds per 32 MFMAs per wave
@@ -1712,7 +1823,8 @@ static hipError_t launch_epi(const u16* X, const u16* W, const float* bias, cons
 }
 
 hipError_t launch_gemm_bf16(const void* X, const void* W, const float* bias, const void* residual, void* Y, int M,
-                            int M_pad, int N, int K, int epilogue, hipStream_t stream) {
+                            int M_pad, int N, int K, int epilogue, hipStream_t stream, float* splitk_ws,
+                            size_t splitk_ws_bytes) {
     if (M < 0 || M_pad < M || N <= 0 || K <= 0) return hipErrorInvalidValue;
     const bool ring_ok = N % RBN == 0 && M_pad % RBM == 0 && K % RBK == 0 && M >= 1024;
     if (!ring_ok && (M_pad % GBM != 0 || N % GBN != 0 || K % GBK != 0)) return hipErrorInvalidValue;
@@ -1721,6 +1833,34 @@ hipError_t launch_gemm_bf16(const void* X, const void* W, const float* bias, con
     const u16* w = static_cast<const u16*>(W);
     const u16* r = static_cast<const u16*>(residual);
     u16* y = static_cast<u16*>(Y);
+    if (epilogue < 0 || epilogue > 2 || (epilogue == 1 && !r)) return hipErrorInvalidValue;
+    // few rows: split K over more workgroups (the caller lends the fp32 scratch)
+    if (splitk_ws != nullptr && M_pad % GBM == 0 && N % GBN == 0 && K % GBK == 0) {
+        const int mp = (M + GBM - 1) / GBM * GBM;   // whole 128-row tiles that hold real rows (<= M_pad)
+        const int S = splitk_slices(mp, N, K, splitk_ws_bytes);
+        if (S > 0) {
+            const int M_pad = mp;
+            constexpr int lds_bytes = 4 * kTileBytes;
+            static bool attr_set = false;
+            if (!attr_set) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_splitk_kernel),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+                if (e != hipSuccess) return e;
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(gemm_bf16_splitk_kernel, dim3((N / GBN) * (M_pad / GBM), S), dim3(kGemmThreads), lds_bytes,
+                               stream, x, w, splitk_ws, M, M_pad, N, K, K / S);
+            const int64_t work = (int64_t)M * (N / 4);
+            const unsigned blocks = (unsigned)((work + 255) / 256);
+            if (epilogue == 0)
+                hipLaunchKernelGGL(splitk_epilogue_kernel<0>, dim3(blocks), dim3(256), 0, stream, splitk_ws, S, M, M_pad, N, bias, r, y);
+            else if (epilogue == 1)
+                hipLaunchKernelGGL(splitk_epilogue_kernel<1>, dim3(blocks), dim3(256), 0, stream, splitk_ws, S, M, M_pad, N, bias, r, y);
+            else
+                hipLaunchKernelGGL(splitk_epilogue_kernel<2>, dim3(blocks), dim3(256), 0, stream, splitk_ws, S, M, M_pad, N, bias, r, y);
+            return hipGetLastError();
+        }
+    }
     switch (epilogue) {
         case 0: return launch_epi<0>(x, w, bias, r, y, M, M_pad, N, K, stream);
         case 1: return r ? launch_epi<1>(x, w, bias, r, y, M, M_pad, N, K, stream) : hipErrorInvalidValue;

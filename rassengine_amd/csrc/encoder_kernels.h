@@ -10,8 +10,11 @@ namespace rass {
 
 // K5: Y = epilogue(X[M,K] * W[N,K]^T + bias); epilogue 0 bias, 1 bias+residual, 2 bias+GELU(erf).
 // M_pad (multiple of 128) rows of X / Y / residual must be allocated; N % 128 == 0, K % 64 == 0.
+// With a scratch (`splitk_ws`, fp32) a GEMM over few rows (M_pad <= 256) is split over K so that enough workgroups
+// stream the weights (query-time embedding); the result is deterministic (slices summed in fixed order).
 hipError_t launch_gemm_bf16(const void* X, const void* W, const float* bias, const void* residual, void* Y, int M,
-                            int M_pad, int N, int K, int epilogue, hipStream_t stream);
+                            int M_pad, int N, int K, int epilogue, hipStream_t stream, float* splitk_ws = nullptr,
+                            size_t splitk_ws_bytes = 0);
 
 // K4: x[t] = LayerNorm(word[ids[t]] + pos[position of t in its sequence] + type[0]) -> bf16
 hipError_t launch_embed_layernorm(const int32_t* ids, const int32_t* cu_seqlens, int nseq, int total_tokens,

@@ -61,6 +61,45 @@ def test_gemm_bf16_matches_torch(gpu, M, N, K, epi):
     assert bool((Y[M:] == 777.0).all())  # padding rows are never written
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(1, 1024, 1024, 1), (16, 3072, 1024, 0), (37, 4096, 1024, 2), (100, 1024, 4096, 1),
+                                       (129, 1024, 4096, 1), (200, 128, 128, 0), (256, 384, 512, 2)])
+def test_gemm_split_k_for_few_rows(gpu, M, N, K, epi):
+    """The query-time path (rass_gemm_bf16_ws: K split over workgroups, slices summed in fixed order) against torch,
+    and bit-identical from run to run (no atomics)."""
+    torch = gpu
+    from rassengine_amd import _native as N_
+    g = torch.Generator(device="cuda")
+    g.manual_seed(M * 11 + N + K + epi)
+    M_pad = (M + 255) // 256 * 256
+    X = torch.zeros((M_pad, K), dtype=torch.bfloat16, device="cuda")
+    X[:M] = torch.randn((M, K), generator=g, device="cuda").bfloat16()
+    W = (torch.randn((N, K), generator=g, device="cuda") / K ** 0.5).bfloat16()
+    bias = torch.randn((N,), generator=g, device="cuda") * 0.1
+    R = torch.zeros((M_pad, N), dtype=torch.bfloat16, device="cuda")
+    R[:M] = torch.randn((M, N), generator=g, device="cuda").bfloat16()
+    ws = torch.empty((16 * 256 * 1024,), dtype=torch.float32, device="cuda")
+    outs = []
+    for _ in range(2):
+        Y = torch.full((M_pad, N), 777.0, dtype=torch.bfloat16, device="cuda")
+        N_.check("rass_gemm_bf16_ws", N_.lib().rass_gemm_bf16_ws(
+            ctypes.c_void_p(X.data_ptr()), ctypes.c_void_p(W.data_ptr()), ctypes.c_void_p(bias.data_ptr()),
+            ctypes.c_void_p(R.data_ptr()) if epi == 1 else None, ctypes.c_void_p(Y.data_ptr()), M, M_pad, N, K, epi,
+            ctypes.c_void_p(ws.data_ptr()), ws.numel() * 4, ctypes.c_void_p(int(torch.cuda.current_stream().cuda_stream))))
+        torch.cuda.synchronize()
+        outs.append(Y)
+    assert torch.equal(outs[0], outs[1])
+    ref = X[:M].float() @ W.float().T + bias
+    if epi == 1:
+        ref = ref + R[:M].float()
+    if epi == 2:
+        ref = torch.nn.functional.gelu(ref)
+    got = outs[0][:M].float()
+    err = (got - ref).abs()
+    tol = 1.5 * 2.0 ** -8 * ref.abs() + 2e-3
+    assert bool((err <= tol).all()), float((err - tol).max())
+    assert bool((outs[0][M:] == 777.0).all())  # padding rows are never written
+
+
 @pytest.fixture(scope="module")
 def tiny_model(tmp_path_factory):
     from rassengine_amd.encoder import EncoderConfig, write_random_model_dir

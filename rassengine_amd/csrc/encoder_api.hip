@@ -173,11 +173,15 @@ int forward(rass_encoder* e, const int32_t* d_ids, const int32_t* d_cu, int nseq
         const Layer& L = e->layers[(size_t)l];
         EHIP_TRY(rass::launch_gemm_bf16(e->x, L.w_qkv, L.b_qkv, nullptr, e->qkv, total, Tp, 3 * H, H, 0, st, e->d_splitk, e->splitk_bytes));
         EHIP_TRY(rass::launch_attention(e->qkv, d_cu, nseq, max_seqlen, H, c.heads, e->ctx, st));
-        EHIP_TRY(rass::launch_gemm_bf16(e->ctx, L.w_o, L.b_o, e->x, e->y, total, Tp, H, H, 1, st, e->d_splitk, e->splitk_bytes));
-        EHIP_TRY(rass::launch_layernorm(e->y, L.ln1_g, L.ln1_b, c.layer_norm_eps, total, H, e->x, st));
+        // attn-out + residual + LayerNorm; the residual (e->x) is also the output: every row is read before it is written
+        // (a wave owns a row), and the big-batch form goes through e->y
+        EHIP_TRY(rass::launch_gemm_bf16_residual_layernorm(e->ctx, L.w_o, L.b_o, e->x, e->y, L.ln1_g, L.ln1_b,
+                                                           c.layer_norm_eps, e->x, total, Tp, H, H, st, e->d_splitk,
+                                                           e->splitk_bytes));
         EHIP_TRY(rass::launch_gemm_bf16(e->x, L.w_up, L.b_up, nullptr, e->h, total, Tp, I, H, 2, st, e->d_splitk, e->splitk_bytes));
-        EHIP_TRY(rass::launch_gemm_bf16(e->h, L.w_down, L.b_down, e->x, e->y, total, Tp, H, I, 1, st, e->d_splitk, e->splitk_bytes));
-        EHIP_TRY(rass::launch_layernorm(e->y, L.ln2_g, L.ln2_b, c.layer_norm_eps, total, H, e->x, st));
+        EHIP_TRY(rass::launch_gemm_bf16_residual_layernorm(e->h, L.w_down, L.b_down, e->x, e->y, L.ln2_g, L.ln2_b,
+                                                           c.layer_norm_eps, e->x, total, Tp, H, I, st, e->d_splitk,
+                                                           e->splitk_bytes));
     }
     EHIP_TRY(rass::launch_pool(e->x, d_cu, nseq, H, c.pooling == 1 ? 1 : 0, c.normalize ? 1 : 0, d_out, st));
     EHIP_TRY(hipEventRecord(e->done, st));

@@ -253,8 +253,15 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __res
     const int n4 = N / 4;
     if (idx >= (int64_t)M * n4) return;
     const int m = (int)(idx / n4), n = (int)(idx % n4) * 4;
-    f32x4 v = *reinterpret_cast<const f32x4*>(partial + (int64_t)m * N + n);
-    for (int s = 1; s < S; ++s) v += *reinterpret_cast<const f32x4*>(partial + ((int64_t)s * M_pad + m) * N + n);
+    // the slices' loads go out together (S <= 16), the sum runs in ascending slice order
+    f32x4 pv[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+        pv[s] = s < S ? *reinterpret_cast<const f32x4*>(partial + ((int64_t)s * M_pad + m) * N + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 v = pv[0];
+#pragma unroll
+    for (int s = 1; s < 16; ++s)
+        if (s < S) v += pv[s];
     v += *reinterpret_cast<const f32x4*>(bias + n);
     if (EPI == 1) {
         const uint2 r = *reinterpret_cast<const uint2*>(residual + (int64_t)m * N + n);
@@ -275,11 +282,11 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __res
     *reinterpret_cast<uint2*>(Y + (int64_t)m * N + n) = o;
 }
 
-// Number of K slices for a small-M GEMM (0 = do not split): aim at >= 128 workgroups, at most 16 slices, whole
+// Number of K slices for a GEMM with few output tiles (0 = do not split): aim at >= 128 workgroups, at most 16 slices, whole
 // 64-deep steps per slice, and a scratch of S * M_pad * N floats that fits.
 static int splitk_slices(int M_pad, int N, int K, size_t ws_bytes) {
     const int tiles = (N / GBN) * (M_pad / GBM), steps = K / GBK;
-    if (M_pad > 256 || tiles >= 96 || steps < 2) return 0;
+    if (tiles >= 96 || steps < 2) return 0;
     int S = 1;
     while (S < 16 && tiles * S < 128 && steps % (2 * S) == 0) S *= 2;
     while (S > 1 && (size_t)S * M_pad * N * sizeof(float) > ws_bytes) S /= 2;
@@ -1784,8 +1791,14 @@ static hipError_t launch_w4l(const u16* X, const u16* W, const float* bias, cons
 template <int EPI>
 static hipError_t launch_epi(const u16* X, const u16* W, const float* bias, const u16* residual, u16* Y, int M,
                              int M_pad, int N, int K, hipStream_t stream) {
-    // big shapes: the 256^2 ring kernel; small / odd shapes: the 128^2 kernel
-    if (N % RBN == 0 && M_pad % RBM == 0 && K % RBK == 0 && M >= 1024) {
+    // big shapes: the persistent 256^2 kernels; small / odd shapes: the 128^2 kernel.  "Big" = enough 256^2 tiles to
+    // keep most of the chip's CUs busy (a persistent kernel runs one tile per CU at a time): a 2 048-token upload has
+    // 32 tiles at N = 1024 and ran on 32 of 256 CUs; as 128^2 tiles (and split over K below 96 of those) it fills the
+    // chip.  An explicit RASS_GEMM_VARIANT keeps the 256^2 kernels for every shape they accept (A/B runs, tests).
+    static const bool variant_forced = getenv("RASS_GEMM_VARIANT") != nullptr;
+    const bool small_ok = M_pad % GBM == 0 && N % GBN == 0 && K % GBK == 0;   // the 128^2 kernel could take it
+    const bool enough_tiles = variant_forced || !small_ok || (int64_t)(N / RBN) * (M_pad / RBM) >= 192;
+    if (N % RBN == 0 && M_pad % RBM == 0 && K % RBK == 0 && M >= 1024 && enough_tiles) {
         // Default: the persistent form of the 8-wave 256x256 ring kernel; RASS_GEMM_VARIANT=ring
         // selects the one-tile-per-block form for A/B runs (scripts/microbench/gemm_phases.hip).
         // Default: p5, the persistent ring kernel with 64-deep K steps (whole cache lines per row) on a ring of five
@@ -1827,7 +1840,8 @@ hipError_t launch_gemm_bf16(const void* X, const void* W, const float* bias, con
                             size_t splitk_ws_bytes) {
     if (M < 0 || M_pad < M || N <= 0 || K <= 0) return hipErrorInvalidValue;
     const bool ring_ok = N % RBN == 0 && M_pad % RBM == 0 && K % RBK == 0 && M >= 1024;
-    if (!ring_ok && (M_pad % GBM != 0 || N % GBN != 0 || K % GBK != 0)) return hipErrorInvalidValue;
+    const bool small_ok = M_pad % GBM == 0 && N % GBN == 0 && K % GBK == 0;
+    if (!ring_ok && !small_ok) return hipErrorInvalidValue;
     if (M == 0) return hipSuccess;
     const u16* x = static_cast<const u16*>(X);
     const u16* w = static_cast<const u16*>(W);
@@ -1867,6 +1881,32 @@ hipError_t launch_gemm_bf16(const void* X, const void* W, const float* bias, con
         case 2: return launch_epi<2>(x, w, bias, r, y, M, M_pad, N, K, stream);
         default: return hipErrorInvalidValue;
     }
+}
+
+hipError_t launch_gemm_bf16_residual_layernorm(const void* X, const void* W, const float* bias, const void* residual,
+                                               void* y, const float* gamma, const float* beta, float eps, void* out,
+                                               int M, int M_pad, int N, int K, hipStream_t stream, float* splitk_ws,
+                                               size_t splitk_ws_bytes) {
+    if (M < 0 || M_pad < M || N <= 0 || K <= 0 || !residual) return hipErrorInvalidValue;
+    if (M == 0) return hipSuccess;
+    if (splitk_ws != nullptr && M_pad % GBM == 0 && N % GBN == 0 && K % GBK == 0 && N % 8 == 0 && N <= 2048) {
+        const int mp = (M + GBM - 1) / GBM * GBM;
+        const int S = splitk_slices(mp, N, K, splitk_ws_bytes);
+        if (S > 0) {
+            constexpr int lds_bytes = 4 * kTileBytes;
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_splitk_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(gemm_bf16_splitk_kernel, dim3((N / GBN) * (mp / GBM), S), dim3(kGemmThreads), lds_bytes,
+                               stream, static_cast<const u16*>(X), static_cast<const u16*>(W), splitk_ws, M, mp, N, K, K / S);
+            e = hipGetLastError();
+            if (e != hipSuccess) return e;
+            return launch_splitk_residual_layernorm(splitk_ws, S, M, mp, N, bias, residual, gamma, beta, eps, out, stream);
+        }
+    }
+    hipError_t e = launch_gemm_bf16(X, W, bias, residual, y, M, M_pad, N, K, 1, stream, splitk_ws, splitk_ws_bytes);
+    if (e != hipSuccess) return e;
+    return launch_layernorm(y, gamma, beta, eps, M, N, out, stream);
 }
 
 }  // namespace rass

@@ -16,6 +16,17 @@ hipError_t launch_gemm_bf16(const void* X, const void* W, const float* bias, con
                             int M_pad, int N, int K, int epilogue, hipStream_t stream, float* splitk_ws = nullptr,
                             size_t splitk_ws_bytes = 0);
 
+// out = LayerNorm(X W^T + bias + residual): launch_gemm_bf16(epilogue 1) into `y` followed by launch_layernorm, or — for
+// few rows, with a split-K scratch — the split-K GEMM and ONE kernel that reduces the slices, adds bias and residual,
+// rounds to bf16 where `y` would have been stored, and normalises (same bits, one launch less; `y` is then not written).
+hipError_t launch_gemm_bf16_residual_layernorm(const void* X, const void* W, const float* bias, const void* residual,
+                                               void* y, const float* gamma, const float* beta, float eps, void* out,
+                                               int M, int M_pad, int N, int K, hipStream_t stream, float* splitk_ws,
+                                               size_t splitk_ws_bytes);
+hipError_t launch_splitk_residual_layernorm(const float* partial, int S, int rows, int rows_pad, int hidden,
+                                            const float* bias, const void* residual, const float* gamma,
+                                            const float* beta, float eps, void* out, hipStream_t stream);
+
 // K4: x[t] = LayerNorm(word[ids[t]] + pos[position of t in its sequence] + type[0]) -> bf16
 hipError_t launch_embed_layernorm(const int32_t* ids, const int32_t* cu_seqlens, int nseq, int total_tokens,
                                   const void* word_emb, const void* pos_emb, const void* type_emb,

@@ -163,6 +163,79 @@ __global__ __launch_bounds__(kRowThreadsE) void layernorm_kernel(const u16* __re
     }
 }
 
+// Few rows (query-time embedding): the reduction of a split-K GEMM's fp32 partial tiles, bias, residual AND the
+// LayerNorm that follows in one pass — out[r] = LayerNorm(bf16(sum_s partial[s][r] + bias + residual[r])).  The sum is
+// rounded to bf16 exactly where the unfused path (splitk_epilogue_kernel<1> then layernorm_kernel) stores it, so both
+// give the same bits; fused, the residual GEMMs of a layer cost one launch less each (every kernel of a one-query
+// forward sits at the ~5 us dependent-launch floor).
+template <int S>
+__global__ __launch_bounds__(kRowThreadsE) void splitk_residual_layernorm_kernel(
+    const float* __restrict__ partial, int rows, int rows_pad, int hidden, const float* __restrict__ bias,
+    const u16* residual, const float* __restrict__ gamma, const float* __restrict__ beta, float eps, u16* out) {
+    // `residual` and `out` may be the same buffer (the encoder normalises in place): a wave reads its whole row
+    // before it writes it, and rows are independent
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    for (int r = blockIdx.x * 4 + wave; r < rows; r += gridDim.x * 4) {
+        Vals8 x[kMaxSteps];
+#pragma unroll
+        for (int s = 0; s < kMaxSteps; ++s) {
+            const int c = lane * 8 + 512 * s;
+            if (c < hidden) {
+                // all S slices' loads go out before the first add (a rolled loop waited for each in turn: with 16
+                // waves in the whole launch nothing else hides that latency); summed in ascending order, as
+                // splitk_epilogue_kernel does
+                f32x4 p0[S], p1[S];
+#pragma unroll
+                for (int sl = 0; sl < S; ++sl) {
+                    const float* q = partial + ((int64_t)sl * rows_pad + r) * hidden + c;
+                    p0[sl] = *reinterpret_cast<const f32x4*>(q);
+                    p1[sl] = *reinterpret_cast<const f32x4*>(q + 4);
+                }
+                f32x4 v0 = p0[0], v1 = p1[0];
+#pragma unroll
+                for (int sl = 1; sl < S; ++sl) {
+                    v0 += p0[sl];
+                    v1 += p1[sl];
+                }
+                v0 += *reinterpret_cast<const f32x4*>(bias + c);
+                v1 += *reinterpret_cast<const f32x4*>(bias + c + 4);
+                const Vals8 res = load8_bf16(residual + (int64_t)r * hidden + c);
+                x[s].v[0] = bf2f(f2bf(v0.x + res.v[0]));
+                x[s].v[1] = bf2f(f2bf(v0.y + res.v[1]));
+                x[s].v[2] = bf2f(f2bf(v0.z + res.v[2]));
+                x[s].v[3] = bf2f(f2bf(v0.w + res.v[3]));
+                x[s].v[4] = bf2f(f2bf(v1.x + res.v[4]));
+                x[s].v[5] = bf2f(f2bf(v1.y + res.v[5]));
+                x[s].v[6] = bf2f(f2bf(v1.z + res.v[6]));
+                x[s].v[7] = bf2f(f2bf(v1.w + res.v[7]));
+            }
+        }
+        layernorm_store(x, hidden, lane, gamma, beta, eps, out + (int64_t)r * hidden);
+    }
+}
+
+hipError_t launch_splitk_residual_layernorm(const float* partial, int S, int rows, int rows_pad, int hidden,
+                                            const float* bias, const void* residual, const float* gamma,
+                                            const float* beta, float eps, void* out, hipStream_t stream) {
+    if (hidden % 8 != 0 || hidden > 512 * kMaxSteps || S < 1) return hipErrorInvalidValue;
+    if (rows <= 0) return hipSuccess;
+    const int blocks = (rows + 3) / 4;
+    const u16* res = static_cast<const u16*>(residual);
+    u16* o = static_cast<u16*>(out);
+#define RASS_SKLN(SV)                                                                                              \
+    case SV:                                                                                                       \
+        hipLaunchKernelGGL(splitk_residual_layernorm_kernel<SV>, dim3(blocks), dim3(kRowThreadsE), 0, stream, partial, \
+                           rows, rows_pad, hidden, bias, res, gamma, beta, eps, o);                                \
+        break;
+    switch (S) {
+        RASS_SKLN(1) RASS_SKLN(2) RASS_SKLN(4) RASS_SKLN(8) RASS_SKLN(16)
+        default: return hipErrorInvalidValue;
+    }
+#undef RASS_SKLN
+    return hipGetLastError();
+}
+
 hipError_t launch_layernorm(const void* in, const float* gamma, const float* beta, float eps, int rows, int hidden,
                             void* out, hipStream_t stream) {
     if (hidden % 8 != 0 || hidden > 512 * kMaxSteps) return hipErrorInvalidValue;

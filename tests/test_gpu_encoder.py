@@ -61,8 +61,48 @@ def test_gemm_bf16_matches_torch(gpu, M, N, K, epi):
     assert bool((Y[M:] == 777.0).all())  # padding rows are never written
 
 
+_FORCED_VARIANT_SCRIPT = r"""
+import ctypes, sys, torch
+sys.path.insert(0, %r)
+from rassengine_amd import _native as N_
+ok = True
+for (M, N, K, epi) in [(1024, 256, 64, 0), (3000, 512, 128, 1), (1025, 1024, 2048, 2), (2048, 1024, 4096, 1)]:
+    g = torch.Generator(device="cuda"); g.manual_seed(M + N + K + epi)
+    M_pad = (M + 255) // 256 * 256
+    X = torch.zeros((M_pad, K), dtype=torch.bfloat16, device="cuda"); X[:M] = torch.randn((M, K), generator=g, device="cuda").bfloat16()
+    W = (torch.randn((N, K), generator=g, device="cuda") / K ** 0.5).bfloat16()
+    bias = torch.randn((N,), generator=g, device="cuda") * 0.1
+    R = torch.zeros((M_pad, N), dtype=torch.bfloat16, device="cuda"); R[:M] = torch.randn((M, N), generator=g, device="cuda").bfloat16()
+    Y = torch.full((M_pad, N), 777.0, dtype=torch.bfloat16, device="cuda")
+    N_.check("g", N_.lib().rass_gemm_bf16(ctypes.c_void_p(X.data_ptr()), ctypes.c_void_p(W.data_ptr()), ctypes.c_void_p(bias.data_ptr()),
+             ctypes.c_void_p(R.data_ptr()) if epi == 1 else None, ctypes.c_void_p(Y.data_ptr()), M, M_pad, N, K, epi,
+             ctypes.c_void_p(int(torch.cuda.current_stream().cuda_stream))))
+    torch.cuda.synchronize()
+    ref = X[:M].float() @ W.float().T + bias
+    if epi == 1: ref = ref + R[:M].float()
+    if epi == 2: ref = torch.nn.functional.gelu(ref)
+    err = (Y[:M].float() - ref).abs()
+    ok = ok and bool((err <= 1.5 * 2.0 ** -8 * ref.abs() + 2e-3).all()) and bool((Y[M:] == 777.0).all())
+print("VARIANT_OK" if ok else "VARIANT_BAD")
+"""
+
+
+@pytest.mark.parametrize("variant", ["p5", "p64", "pring", "ring", "w4l"])
+def test_gemm_forced_variants_on_few_tiles(gpu, variant):
+    """By default shapes with few 256^2 tiles take the 128^2 kernel; RASS_GEMM_VARIANT (read once per process: hence a
+    child process, started before this one's GPU state matters to it) keeps the 256^2 kernels for them — one tile per
+    workgroup, fewer tiles than CUs, ragged M."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RASS_GEMM_VARIANT=variant)
+    out = subprocess.run([sys.executable, "-c", _FORCED_VARIANT_SCRIPT % root], env=env, capture_output=True, text=True,
+                         timeout=300)
+    assert "VARIANT_OK" in out.stdout, (out.stdout[-500:], out.stderr[-1500:])
+
+
 @pytest.mark.parametrize("M,N,K,epi", [(1, 1024, 1024, 1), (16, 3072, 1024, 0), (37, 4096, 1024, 2), (100, 1024, 4096, 1),
-                                       (129, 1024, 4096, 1), (200, 128, 128, 0), (256, 384, 512, 2)])
+                                       (129, 1024, 4096, 1), (200, 128, 128, 0), (256, 384, 512, 2),
+                                       (1300, 1024, 1024, 1), (700, 1024, 4096, 0)])
 def test_gemm_split_k_for_few_rows(gpu, M, N, K, epi):
     """The query-time path (rass_gemm_bf16_ws: K split over workgroups, slices summed in fixed order) against torch,
     and bit-identical from run to run (no atomics)."""

@@ -2200,6 +2200,7 @@ int rass_peer_buffer_create(int device, size_t bytes, void** d_ptr, unsigned cha
     void* p = nullptr;
     HIP_TRY(hipMalloc(&p, bytes));
     hipError_t e = hipMemset(p, 0, bytes);
+    if (e == hipSuccess) e = hipDeviceSynchronize();   // the flags must BE zero before any peer (or stream) touches them
     hipIpcMemHandle_t h;
     if (e == hipSuccess) e = hipIpcGetMemHandle(&h, p);
     if (e != hipSuccess) {

@@ -143,6 +143,10 @@ int ensure_workspace(rass_encoder* e, int tokens_pad, int nseq) {
         EHIP_TRY(hipMemset(e->ctx, 0, T * H * 2));
         EHIP_TRY(hipMemset(e->y, 0, T * H * 2));
         EHIP_TRY(hipMemset(e->h, 0, T * I * 2));
+        // hipMemset runs on the NULL stream and may return before it has executed; the forward runs on a NON-BLOCKING
+        // stream, which the NULL stream does not order: without this wait a late memset could zero activations the first
+        // forward after a (re)allocation had already written (seen once as a wrong first embedding of a new encoder)
+        EHIP_TRY(hipDeviceSynchronize());
         e->cap_tokens = tokens_pad;
     }
     if (nseq > e->cap_seqs) {

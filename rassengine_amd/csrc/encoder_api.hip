@@ -417,4 +417,14 @@ int rass_gemm_bf16_ws(const void* d_x, const void* d_w, const float* d_bias, con
     return RASS_OK;
 }
 
+/* Stand-alone launcher of the encoder's attention (tests, micro-benchmarks). */
+int rass_attention_bf16(const void* d_qkv, const int32_t* d_cu_seqlens, int nseq, int max_seqlen, int hidden, int heads,
+                        void* d_ctx, void* stream) {
+    if (!d_qkv || !d_cu_seqlens || !d_ctx) return efail(RASS_ERR_INVALID, "NULL argument");
+    hipError_t err = rass::launch_attention(d_qkv, d_cu_seqlens, nseq, max_seqlen, hidden, heads, d_ctx,
+                                            reinterpret_cast<hipStream_t>(stream));
+    if (err != hipSuccess) return efail(RASS_ERR_INVALID, std::string("attention launch: ") + hipGetErrorString(err));
+    return RASS_OK;
+}
+
 }  // extern "C"

@@ -1,0 +1,111 @@
+"""K6 on its own (rass_attention_bf16): the encoder's varlen self-attention against a plain PyTorch fp32 reference of the
+same op (softmax(q k^T / 8) v per sequence and head, fp32 throughout, on the same bf16 inputs).
+
+Tolerance: the kernel rounds the exponentiated scores to bf16 before the second product (relative 2^-9 per term, so
+the bound follows sum_j p_j |v_j|, not the possibly cancelled result) and the output to bf16:
+|err| <= 2^-8 (sum_j p_j |v_j|) + 2^-8 |ref| + 2e-3 per element.  Both kernels are held to it: the
+32x32-tile kernel (default) and the 16x16-tile kernel of round 1 (RASS_ATTN_VARIANT=w16, read per launch)."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+LENS_EDGE = [1, 2, 15, 16, 17, 31, 32, 33, 63, 64, 65, 100, 127, 128, 129, 200, 255, 256, 257, 300, 320, 448, 511, 512]
+
+
+def _reference(torch, qkv, lens, heads):
+    hidden = qkv.shape[1] // 3
+    out = torch.empty((qkv.shape[0], hidden), dtype=torch.float32, device=qkv.device)
+    mag = torch.empty_like(out)
+    t = 0
+    for n in lens:
+        blk = qkv[t:t + n].float().view(n, 3, heads, 64)
+        q, k, v = blk[:, 0].transpose(0, 1), blk[:, 1].transpose(0, 1), blk[:, 2].transpose(0, 1)   # [heads][n][64]
+        p = torch.softmax(q @ k.transpose(1, 2) / 8.0, dim=-1)
+        out[t:t + n] = (p @ v).transpose(0, 1).reshape(n, hidden)
+        mag[t:t + n] = (p @ v.abs()).transpose(0, 1).reshape(n, hidden)
+        t += n
+    return out, mag
+
+
+def _run(torch, qkv, lens, heads, max_seqlen=None):
+    from rassengine_amd import _native as N_
+    cu = np.zeros(len(lens) + 1, dtype=np.int32)
+    np.cumsum(lens, out=cu[1:])
+    d_cu = torch.from_numpy(cu).cuda()
+    hidden = qkv.shape[1] // 3
+    ctx = torch.full((qkv.shape[0] + 3, hidden), 777.0, dtype=torch.bfloat16, device="cuda")
+    N_.check("rass_attention_bf16", N_.lib().rass_attention_bf16(
+        ctypes.c_void_p(qkv.data_ptr()), ctypes.c_void_p(d_cu.data_ptr()), len(lens), int(max_seqlen or max(lens)), hidden,
+        heads, ctypes.c_void_p(ctx.data_ptr()), ctypes.c_void_p(int(torch.cuda.current_stream().cuda_stream))))
+    torch.cuda.synchronize()
+    assert bool((ctx[qkv.shape[0]:] == 777.0).all())          # nothing written past the last token
+    return ctx[:qkv.shape[0]].float()
+
+
+def _check(torch, lens, heads, scale, seed, max_seqlen=None):
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    total = int(sum(lens))
+    qkv = (torch.randn((total, 3 * heads * 64), generator=g, device="cuda") * scale).bfloat16()
+    ref, mag = _reference(torch, qkv, lens, heads)
+    got = _run(torch, qkv, lens, heads, max_seqlen)
+    err = (got - ref).abs()
+    tol = 2.0 ** -8 * mag + 2.0 ** -8 * ref.abs() + 2e-3
+    assert bool(torch.isfinite(got).all())
+    assert bool((err <= tol).all()), (float((err - tol).max()), int((err > tol).sum()))
+
+
+@pytest.fixture(params=["", "w16"])
+def variant(request):
+    old = os.environ.get("RASS_ATTN_VARIANT")
+    if request.param:
+        os.environ["RASS_ATTN_VARIANT"] = request.param
+    else:
+        os.environ.pop("RASS_ATTN_VARIANT", None)
+    yield request.param
+    if old is None:
+        os.environ.pop("RASS_ATTN_VARIANT", None)
+    else:
+        os.environ["RASS_ATTN_VARIANT"] = old
+
+
+def test_attention_every_length_class(gpu, variant):
+    """1 .. 512 tokens: below / at / above every 32- and 64-key boundary, sequences packed back to back."""
+    _check(gpu, LENS_EDGE, heads=3, scale=1.0, seed=1)
+
+
+def test_attention_peaked_scores_and_moving_maximum(gpu, variant):
+    """|q.k| / 8 up to ~40: the running maximum moves in most key blocks (the rescale path), probabilities span
+    2^-100 .. 1."""
+    _check(gpu, [512, 77, 300, 64], heads=2, scale=2.5, seed=2)
+
+
+def test_attention_large_shape_and_padded_launch(gpu, variant):
+    """BERT-large heads (16 x 64) and max_seqlen above the longest sequence (the launch pads K / V to it)."""
+    _check(gpu, [512, 512, 1, 130, 512], heads=16, scale=1.0, seed=3)
+    _check(gpu, [40, 9, 64], heads=16, scale=1.0, seed=4, max_seqlen=512)
+
+
+def test_attention_variants_agree_closely(gpu):
+    """The two kernels implement one algorithm (same bf16 rounding points): outputs within one bf16 ulp of each other
+    almost everywhere."""
+    torch = gpu
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    lens = [512, 333, 64, 17]
+    qkv = torch.randn((sum(lens), 3 * 4 * 64), generator=g, device="cuda").bfloat16()
+    old = os.environ.pop("RASS_ATTN_VARIANT", None)
+    try:
+        a = _run(torch, qkv, lens, 4)
+        os.environ["RASS_ATTN_VARIANT"] = "w16"
+        b = _run(torch, qkv, lens, 4)
+    finally:
+        os.environ.pop("RASS_ATTN_VARIANT", None)
+        if old is not None:
+            os.environ["RASS_ATTN_VARIANT"] = old
+    assert float((a - b).abs().max()) <= 2.0 ** -7 * float(a.abs().max())
+    assert float(((a - b).abs() > 2.0 ** -8 * a.abs() + 1e-3).float().mean()) < 0.01

@@ -443,10 +443,11 @@ int rass_gemm_bf16_ws(const void* d_x, const void* d_w, const float* d_bias,
                       int epilogue, void* d_ws, size_t ws_bytes, void* stream);
 /* The encoder's self-attention on its own (what llama.cpp computes per layer behind the reference's POST to Ollama,
  * app/main.py:225-237): d_qkv bf16 [tokens][3*hidden] (q | k | v per token), sequences packed back to back with
- * d_cu_seqlens[nseq + 1] token offsets, heads of 64 (hidden = 64 * heads), every sequence <= max_seqlen <= 512,
- * softmax(q k^T / 8) v in fp32, d_ctx bf16 [tokens][hidden]. */
-int rass_attention_bf16(const void* d_qkv, const int32_t* d_cu_seqlens, int nseq, int max_seqlen,
-                        int hidden, int heads, void* d_ctx, void* stream);
+ * d_cu_seqlens[nseq + 1] token offsets (total_tokens = the last one, as the host knows it), heads of 64
+ * (hidden = 64 * heads), every sequence <= max_seqlen <= 512, softmax(q k^T / 8) v in fp32, d_ctx bf16
+ * [total_tokens][hidden]. */
+int rass_attention_bf16(const void* d_qkv, const int32_t* d_cu_seqlens, int nseq, int total_tokens,
+                        int max_seqlen, int hidden, int heads, void* d_ctx, void* stream);
 
 /* -------------------------------------------------------------- tokenizer
  * BERT (uncased) BasicTokenizer + WordPiece on the host (C++), replacing the

@@ -176,7 +176,7 @@ int forward(rass_encoder* e, const int32_t* d_ids, const int32_t* d_cu, int nseq
     for (int l = 0; l < c.layers; ++l) {
         const Layer& L = e->layers[(size_t)l];
         EHIP_TRY(rass::launch_gemm_bf16(e->x, L.w_qkv, L.b_qkv, nullptr, e->qkv, total, Tp, 3 * H, H, 0, st, e->d_splitk, e->splitk_bytes));
-        EHIP_TRY(rass::launch_attention(e->qkv, d_cu, nseq, max_seqlen, H, c.heads, e->ctx, st));
+        EHIP_TRY(rass::launch_attention(e->qkv, d_cu, nseq, total, max_seqlen, H, c.heads, e->ctx, st));
         // attn-out + residual + LayerNorm; the residual (e->x) is also the output: every row is read before it is written
         // (a wave owns a row), and the big-batch form goes through e->y
         EHIP_TRY(rass::launch_gemm_bf16_residual_layernorm(e->ctx, L.w_o, L.b_o, e->x, e->y, L.ln1_g, L.ln1_b,
@@ -418,10 +418,10 @@ int rass_gemm_bf16_ws(const void* d_x, const void* d_w, const float* d_bias, con
 }
 
 /* Stand-alone launcher of the encoder's attention (tests, micro-benchmarks). */
-int rass_attention_bf16(const void* d_qkv, const int32_t* d_cu_seqlens, int nseq, int max_seqlen, int hidden, int heads,
-                        void* d_ctx, void* stream) {
+int rass_attention_bf16(const void* d_qkv, const int32_t* d_cu_seqlens, int nseq, int total_tokens, int max_seqlen,
+                        int hidden, int heads, void* d_ctx, void* stream) {
     if (!d_qkv || !d_cu_seqlens || !d_ctx) return efail(RASS_ERR_INVALID, "NULL argument");
-    hipError_t err = rass::launch_attention(d_qkv, d_cu_seqlens, nseq, max_seqlen, hidden, heads, d_ctx,
+    hipError_t err = rass::launch_attention(d_qkv, d_cu_seqlens, nseq, total_tokens, max_seqlen, hidden, heads, d_ctx,
                                             reinterpret_cast<hipStream_t>(stream));
     if (err != hipSuccess) return efail(RASS_ERR_INVALID, std::string("attention launch: ") + hipGetErrorString(err));
     return RASS_OK;

@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_bf16.h>
 #include <stdint.h>
+#include <type_traits>
 #include <stdlib.h>
 #include <string.h>
 
@@ -187,32 +188,45 @@ __global__ __launch_bounds__(kAttnThreads) void attention_kernel(const u16* __re
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// attention32_kernel: the same algorithm on 32x32 tiles (v_mfma_f32_32x32x16_bf16), 8 waves of 32 queries.
+// attention64_kernel: the kernel for batches of LONG sequences (the ingest shape: 256 chunks x 512 tokens), on 32x32
+// tiles (v_mfma_f32_32x32x16_bf16).
 //
-// Why (counted on the 16x16 kernel's ISA, prices from MI355X_MICROARCH "vector-instruction ISSUE cost"): per 64 keys a
-// wave of the 16x16 kernel spends ~80 plain VALU issues + 16 v_exp on 16 scores per lane — 33 of them the maximum
-// (canonicalising v_max before every fmaxf on an MFMA output, two ds_bpermute rounds with lgkmcnt(0) each), 6 the row
-// sum's shuffles — and reads 16 KiB of K / V fragments from LDS for 16 queries.  Here:
+// Counted on the 16x16 kernel's ISA (prices: MI355X_MICROARCH "vector-instruction ISSUE cost"): per 64 keys a wave
+// spends ~80 plain VALU issues + 16 v_exp on 16 scores per lane — 33 of them the maximum (a canonicalising v_max before
+// every fmaxf on an MFMA output, two ds_bpermute rounds with lgkmcnt(0) each), 6 the row sum's shuffles — and reads
+// 16 KiB of K / V fragments from LDS for 16 queries; and every workgroup (one per CU: the image takes the LDS) first
+// waits ~10 k cycles for its 128 KiB (138 of 469 us per launch measured with the loads removed).  Here:
 //   * S^T tile = 32 keys x 32 queries: lane (q = lane & 31, h = lane >> 5) holds keys (r&3) + 8(r>>2) + 4h of the tile,
-//     so a query's scores live in TWO lanes: the block maximum is 16 v_max3_f32 in the lane + one v_permlane32_swap
-//     (no LDS round trip), and the row sum stays a per-lane partial until the epilogue (both lanes of a query scale it
-//     by the same alpha), one swap per 512 keys instead of two shuffles per 64;
-//   * a K or V fragment (1 KiB of LDS traffic) now feeds 32 queries: half the LDS bytes per score;
+//     so a query's scores live in TWO lanes: the tile maximum is 8 v_max3_f32 in the lane + one v_permlane32_swap (no
+//     LDS round trip; this file is built with -fno-honor-nans, so no canonicalisation either), and the row sum stays a
+//     per-lane partial until the epilogue — both lanes of a query scale it by the same factor;
 //   * the exponentiated scores are still the next MFMA's B operand as they lie (k-slot j of lane half h <-> key
 //     (j&3) + 8(j>>2) + 4h of a 16-key step; the V^T operand is fetched in that key order: two ds_read_b64_tr_b16 at
-//     rows +0 and +8);
-//   * QK^T of block kb+1 is issued BEFORE the softmax of block kb (two score buffers, the loop unrolled by two), so
-//     the matrix pipe works under the wave's own VALU phase and not only under the other wave's;
-//   * V rows have the K pitch (128 B) with the 64-byte halves exchanged on rows with bit 1 set: the 4 rows x 64 B a
-//     half-wave's transposed read touches fall on 64 distinct banks; K + V = 128 KiB at S = 512;
-//   * O is exchanged between the two lanes of a query (v_permlane32_swap) so that each stores 16 contiguous bytes.
-constexpr int kA32Threads = 512;
-constexpr int kA32Waves = kA32Threads / 64;
-
+//     rows +0 and +8); V rows have the K pitch (128 B) with the 64-byte halves exchanged on rows with bit 1 set: the
+//     4 rows x 64 B a half-wave's transposed read touches fall on 64 distinct banks; K + V = 128 KiB at S = 512;
+//   * O is exchanged between the two lanes of a query (v_permlane32_swap) so that each stores 16 contiguous bytes;
+//   * four COMPUTE waves (one per SIMD), each with two 32-query tiles A and B software-pipelined half a step apart in
+//     ONE instruction stream (step = one 32-key tile):
+//
+//       block 1(kt):  MFMA { S_A = K Q_A^T (kt) ; O_A += V^T P_A(kt-1) }  beside  VALU { P_B(kt-1) = exp2(..) } ; max_A(kt)
+//       block 2(kt):  MFMA { S_B = K Q_B^T (kt) ; O_B += V^T P_B(kt-1) }  beside  VALU { P_A(kt)   = exp2(..) } ; max_B(kt)
+//
+//     Two waves per SIMD running the same QK^T -> max -> exp -> PV chain (an 8-wave version of this kernel, in the
+//     history) left the SIMD idle half the time — matrix pipe busy 28 % of the launch, each wave issuing 35 % of its
+//     cycles, stalled behind an MFMA 35 %, parked 30 % — and forcing them into opposite phases with barriers cost
+//     more than it gave.  Here every block holds 8 MFMAs and an INDEPENDENT ~300 issue cycles of VALU, K and V^T
+//     fragments are read from LDS once per key tile for both query tiles, a block ahead of their MFMAs, and only the
+//     maximum's swap and the rescale branch sit at a block's end (counters: profiles/r02_attention_experiments.txt);
+//   * the reference maximum only moves when a score exceeds it by more than 2^8, so after the first tile the rescale of
+//     O is the rare branch (with an exact running maximum, 32 queries make it the usual one);
+//   * persistent: workgroup b takes items b, b + grid, ...; four LOADER waves (one per SIMD) hold the NEXT item's
+//     128 KiB in registers (128 per thread — a compute wave has none to spare), issue its loads right after barrier 1,
+//     sleep at barrier 2 while the compute waves work, and write the image when everyone is done with the old one.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-// fmaxf on MFMA outputs: this file is built with -fno-honor-nans (Makefile), so no canonicalising v_max precedes each
-// one and chains fold into v_max3_f32 (scores are finite or the -inf of a masked key, never NaN)
+// fmaxf on MFMA outputs: with -fno-honor-nans chains fold into v_max3_f32 (scores are finite or the -inf of a masked
+// key, never NaN)
 __device__ __forceinline__ float max3f(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
 __device__ __forceinline__ float max2f(float a, float b) { return __builtin_fmaxf(a, b); }
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
@@ -221,14 +235,27 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {  // v_cvt_pk_b
     return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
 }
 
-// One sequence-head's K and V rows, held in registers between their loads (issued while the PREVIOUS item is being
-// computed) and their LDS writes: chunk e = threadIdx.x + 512 i  ->  key e >> 3, 16-B column chunk e & 7.
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-struct KvRegs {
-    u32x4 k[8], v[8];
+// one MFMA, then N VALU issues, eight times: asks the scheduler to spread a block's MFMAs over its VALU work (measured:
+// no change for N = 7 / 9 / 11; off)
+#ifdef RASS_ATTN_SGB
+#define RASS_ATTN_SPREAD()                                     \
+    do {                                                       \
+        _Pragma("unroll") for (int g_ = 0; g_ < 8; ++g_) {     \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); \
+            __builtin_amdgcn_sched_group_barrier(0x002, RASS_ATTN_SGB, 0); \
+        }                                                      \
+    } while (0)
+#else
+#define RASS_ATTN_SPREAD() do { } while (0)
+#endif
+constexpr int kA64Threads = 512;
+constexpr int kA64Waves = 4;  // compute waves
+
+struct KvRegs64 {
+    u32x4 k[16], v[16];
 };
 
-__global__ __launch_bounds__(kA32Threads) void attention32_kernel(const u16* __restrict__ qkv,
+__global__ __launch_bounds__(kA64Threads) void attention64_kernel(const u16* __restrict__ qkv,
                                                                   const int32_t* __restrict__ cu, int hidden, int heads,
                                                                   int s_pad, int n_items, u16* __restrict__ ctx) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -238,14 +265,11 @@ __global__ __launch_bounds__(kA32Threads) void attention32_kernel(const u16* __r
     const int wave = threadIdx.x >> 6;
     const int ld = 3 * hidden;
     const int h = lane >> 5, qi = lane & 31;
-    // transposed V read: lane i of a 16-lane group addresses key row (i >> 2), d columns 4 (i & 3) .. +3 of the group's
-    // 16-d block (block 2 dt + ((lane >> 4) & 1)); the row's swizzle bit is (i >> 3) & 1 for every row this lane touches
     const int vi = lane & 15;
     const int v_sw = (vi >> 3) & 1;
     const int v_lane_off = (4 * h + (vi >> 2)) * 128 + (2 * ((lane >> 4) & 1) + ((vi & 3) >> 1)) * 16 + (vi & 1) * 8;
     constexpr float kScale = 0.18033688011112042f;  // 1/8 * log2(e)
 
-    // rows of item `it` (sequence it / heads, head it % heads): token offset and length
     const int total = cu[n_items / heads];
     if (total <= 0) return;
     auto item_rows = [&](int it, int& t0, int& S) {
@@ -254,19 +278,18 @@ __global__ __launch_bounds__(kA32Threads) void attention32_kernel(const u16* __r
         S = cu[seq + 1] - t0;
         if (S > s_pad) S = s_pad;
     };
+    auto clamp_tok = [&](int tok) { return tok < 0 ? 0 : (tok < total ? tok : total - 1); };
     // Issue the loads of an item's K / V rows.  NO branch around any of them (a row past the sequence re-reads its last
-    // row and is zeroed at store time; an item past the last re-reads the current one): the compiler counts the loads
-    // in flight per basic block, and one conditional load among them turns the wait for the Q fragments below into
-    // "all but 7 done" — the whole prefetch waited for before the first MFMA.
-    auto load_kv = [&](int it, KvRegs& r) {
+    // row and is zeroed at store time): the compiler counts the loads in flight per basic block, and one conditional load
+    // among them turns every later counted wait into a conservative one.
+    auto load_kv = [&](int it, KvRegs64& r) {
         int t0, S;
         item_rows(it, t0, S);
         const u16* kb_ = qkv + (it % heads) * kHeadDim + hidden + (threadIdx.x & 7) * 8;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int key = (threadIdx.x >> 3) + 64 * i;
-            int tok = t0 + (key < S ? key : S - 1);
-            tok = tok < 0 ? 0 : (tok < total ? tok : total - 1);
+        for (int i = 0; i < 16; ++i) {
+            const int key = ((threadIdx.x & 255) >> 3) + 32 * i;
+            const int tok = clamp_tok(t0 + (key < S ? key : S - 1));
 #ifndef RASS_ATTN_EXP_NO_STAGE
             r.k[i] = *reinterpret_cast<const u32x4*>(kb_ + (int64_t)tok * ld);
             r.v[i] = *reinterpret_cast<const u32x4*>(kb_ + hidden + (int64_t)tok * ld);
@@ -276,174 +299,233 @@ __global__ __launch_bounds__(kA32Threads) void attention32_kernel(const u16* __r
 #endif
         }
     };
-    auto store_kv = [&](int S, const KvRegs& r) {  // keys >= S: zeros — masked later, but they must be finite
+    auto store_kv = [&](int S, const KvRegs64& r) {  // keys >= S: zeros — masked later, but they must be finite
         const int c = threadIdx.x & 7;
         const int rows = (S + 63) / 64 * 64;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int key = (threadIdx.x >> 3) + 64 * i;
+        for (int i = 0; i < 16; ++i) {
+            const int key = ((threadIdx.x & 255) >> 3) + 32 * i;
             if (key < rows) {
-                const unsigned keep = key < S ? 0xffffffffu : 0u;  // a value mask: no select between two lvalues
+                const unsigned keep = key < S ? 0xffffffffu : 0u;
                 *reinterpret_cast<u32x4*>(Kl + key * 128 + ((c ^ ((key >> 1) & 7)) * 16)) = r.k[i] & keep;
                 *reinterpret_cast<u32x4*>(Vl + key * 128 + ((c ^ (((key >> 1) & 1) << 2)) * 16)) = r.v[i] & keep;
             }
         }
     };
+    // Q fragments of the wave's two tiles in pass `ps` of an item: B operand of S^T = K Q^T, Q[q][16 ks + 8 h .. +7]
+    auto load_q = [&](int t0, int S, int head, int ps, bf16x8 (&qf)[2][4]) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int q = ps * kA64Waves * 64 + wave * 64 + 32 * t + qi;
+            const int tok = clamp_tok(t0 + (q < S ? q : S - 1));
+            const u16* qrow = qkv + (int64_t)tok * ld + head * kHeadDim + 8 * h;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) qf[t][ks] = *reinterpret_cast<const bf16x8*>(qrow + 16 * ks);
+        }
+    };
 
-    // Persistent: workgroup b takes items b, b + grid, b + 2 grid, ...  While item i is being computed, the K / V rows
-    // of item i + 1 are on their way into 64 registers per thread (all of LDS belongs to item i: the 128 KiB leave no
-    // room for a second image), so the ~9-12 k cycles every workgroup of a one-workgroup-per-CU kernel spends waiting
-    // for its 128 KiB at ~11 B/clk/CU (MI355X_MICROARCH "prologue HBM burst"; 138 of 469 us per launch measured with
-    // the loads removed) run under the previous item's MFMAs.
-    KvRegs kv;
     int item = blockIdx.x;
-    load_kv(item, kv);
-    while (true) {
+    if (wave >= kA64Waves) {  // ---- loader waves
+        KvRegs64 kv;
+        load_kv(item, kv);
+        while (true) {
+            int t0, S;
+            item_rows(item, t0, S);
+            store_kv(S, kv);
+            __syncthreads();  // barrier 1: the image is complete
+            const int next = item + gridDim.x;
+            if (next >= n_items) break;
+            load_kv(next, kv);
+            item = next;
+            __syncthreads();  // barrier 2: every compute wave is done with the old image
+        }
+        return;
+    }
+    while (true) {  // ---- compute waves
         int t0, S;
         item_rows(item, t0, S);
         const int head = item % heads;
-        const int n_kb = (S + 63) / 64;
-        // this item's Q fragments for both passes first (vmcnt retires in order: a Q load issued after the next item's
-        // 16 K / V loads would wait for all of them), B operand of S^T = K Q^T: Q[q][16 ks + 8 h .. +7]
-        bf16x8 qf[2][4];
-#pragma unroll
-        for (int ps = 0; ps < 2; ++ps) {
-            const int q = ps * kA32Waves * 32 + wave * 32 + qi;
-            int tok = t0 + (q < S ? q : S - 1);
-            tok = tok < 0 ? 0 : (tok < total ? tok : total - 1);
-            const u16* qrow = qkv + (int64_t)tok * ld + head * kHeadDim + 8 * h;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) qf[ps][ks] = *reinterpret_cast<const bf16x8*>(qrow + 16 * ks);
-        }
-        store_kv(S, kv);
-        __syncthreads();
         const int next = item + gridDim.x;
-        load_kv(next < n_items ? next : item, kv);
+        bf16x8 qA[2][4];
+        load_q(t0, S, head, 0, qA);
+        __syncthreads();  // barrier 1
 
-        auto run_pass = [&](int q0, const bf16x8 (&qq)[4]) {
-            const int q = q0 + qi;
-            float m_run = -INFINITY, l_part = 0.f;
-            f32x16 O[2];
+        auto run_pass = [&](int q0, const bf16x8 (&qq)[2][4]) {
+            // one step = one 32-key tile of one query tile: 4 + 4 MFMAs beside 16 exponentials
+            const int n_kt = (S + 31) / 32;
+            float m_ref[2] = {-INFINITY, -INFINITY}, l_part[2] = {0.f, 0.f};
+            f32x16 O[2][2], s[2];
+            bf16x8 pf[2][2];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { O[0][r] = 0.f; O[1][r] = 0.f; }
-            for (int kb = 0; kb < n_kb; ++kb) {
-                f32x16 s[2];
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int kt = 0; kt < 2; ++kt) {
+                for (int r = 0; r < 16; ++r) { O[t][0][r] = 0.f; O[t][1][r] = 0.f; }
+
+            // K fragments of key tile kt (A operand rows = keys) and V^T fragments (two transposed reads per 16-key
+            // step and 32-d block): the same for both query tiles, so each is read from LDS once per key tile, one
+            // block ahead of its first MFMA
+            bf16x8 kf[4], vf[2][2];
+            auto load_k = [&](int kt) {
+                const int krow = kt * 32 + qi;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
-                    const int krow = kb * 64 + kt * 32 + qi;  // A operand row = key
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int c = (2 * ks + h) ^ ((krow >> 1) & 7);
+                    kf[ks] = *reinterpret_cast<const bf16x8*>(Kl + krow * 128 + c * 16);
+                }
+            };
+            auto load_v = [&](int kt) {
 #pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) {
-                        const int c = (2 * ks + h) ^ ((krow >> 1) & 7);
-                        const bf16x8 a = *reinterpret_cast<const bf16x8*>(Kl + krow * 128 + c * 16);
-                        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qq[ks], s[kt], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) {
+                    const unsigned char* vblk = Vl + (kt * 32 + 16 * j) * 128 + v_lane_off;
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        const unsigned char* va = vblk + ((dt ^ v_sw) * 64);
+                        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) bf16x4*)(va));
+                        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) bf16x4*)(va + 8 * 128));
+                        vf[j][dt][0] = lo[0]; vf[j][dt][1] = lo[1]; vf[j][dt][2] = lo[2]; vf[j][dt][3] = lo[3];
+                        vf[j][dt][4] = hi[0]; vf[j][dt][5] = hi[1]; vf[j][dt][6] = hi[2]; vf[j][dt][7] = hi[3];
                     }
                 }
-                if (kb * 64 + 64 > S) {  // wave-uniform: the ragged last block
+            };
+            auto qk = [&](int t) {
 #pragma unroll
-                    for (int kt = 0; kt < 2; ++kt)
+                for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
 #pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            if (kb * 64 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h >= S) s[kt][r] = -INFINITY;
+                for (int ks = 0; ks < 4; ++ks)
+                    s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qq[t][ks], s[t], 0, 0, 0);
+            };
+            auto pv = [&](int t) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt)
+                        O[t][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[j][dt], pf[t][j], O[t][dt], 0, 0, 0);
+            };
+            // Tile kt's scores of query tile t just arrived: mask the ragged tail, tile maximum.  The reference maximum
+            // m_ref only moves when a score exceeds it by more than 2^8 (the probabilities are then <= 256: bf16 and
+            // the fp32 sums have the exponent range for it and rounding is relative), so after the first tile the
+            // rescale of O is the rare branch — with an exact running maximum 32 queries make it the usual one.
+            auto maxres = [&](int t, int kt, auto last_tile) {
+                // only a sequence's LAST key tile can hold keys >= S; its steps are a copy of the loop body with the
+                // mask in it (a wave-uniform branch here would cut the block between the MFMAs and this maximum, and the
+                // maximum's dependent chain would run with nothing beside it)
+                if constexpr (decltype(last_tile)::value) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h >= S) s[t][r] = -INFINITY;
                 }
-#ifndef RASS_ATTN_EXP_NO_SOFTMAX
-                // 32 scores -> 1: a tree of v_max3_f32 (depth 4), then the partner lane's
-                float t1[11];
-#pragma unroll
-                for (int i = 0; i < 5; ++i) {
-                    t1[i] = max3f(s[0][3 * i], s[0][3 * i + 1], s[0][3 * i + 2]);
-                    t1[5 + i] = max3f(s[1][3 * i], s[1][3 * i + 1], s[1][3 * i + 2]);
-                }
-                t1[10] = max2f(s[0][15], s[1][15]);
-                const float t2a = max3f(t1[0], t1[1], t1[2]), t2b = max3f(t1[3], t1[4], t1[5]);
-                const float t2c = max3f(t1[6], t1[7], t1[8]), t2d = max2f(t1[9], t1[10]);
-                float mx = max2f(max3f(t2a, t2b, t2c), t2d);
+                const float a0 = max3f(s[t][0], s[t][1], s[t][2]), a1 = max3f(s[t][3], s[t][4], s[t][5]);
+                const float a2 = max3f(s[t][6], s[t][7], s[t][8]), a3 = max3f(s[t][9], s[t][10], s[t][11]);
+                const float a4 = max3f(s[t][12], s[t][13], s[t][14]);
+                float mx = max3f(max3f(a0, a1, a2), max3f(a3, a4, s[t][15]), a0);
                 {
                     const auto sw =
                         __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
                     mx = max2f(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
                 }
-                const float m_new = max2f(m_run, mx * kScale);  // finite: key 0 of block 0 is always valid
-                if (__any(m_new > m_run)) {
-                    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // 1 where the maximum did not move
-                    l_part *= alpha;
-                    O[0] *= alpha;
-                    O[1] *= alpha;
-                    m_run = m_new;
+                mx *= kScale;  // finite in tile 0 (key 0 is always valid); -inf for a fully masked query never happens
+                if (__any(mx > m_ref[t] + 8.f)) {
+                    const float m_new = max2f(m_ref[t], mx);
+                    const float alpha = __builtin_amdgcn_exp2f(m_ref[t] - m_new);  // 1 where m_ref did not move
+                    l_part[t] *= alpha;
+                    O[t][0] *= alpha;
+                    O[t][1] *= alpha;
+                    m_ref[t] = m_new;
                 }
-                f32x16 negm;
+            };
+            // P = exp2(S * scale - m_ref) of query tile t -> bf16 operand fragments, row-sum partials
+            auto exps = [&](int t) {
+                f32x16 pe;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) negm[r] = -m_run;
-                f32x16 acc;
+                for (int r = 0; r < 16; ++r) pe[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][r], kScale, -m_ref[t]));
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                for (int j = 0; j < 2; ++j) {
+                    u32x4 pw;
 #pragma unroll
-                for (int kt = 0; kt < 2; ++kt) {
-                    const f32x16 ex = s[kt] * kScale + negm;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) s[kt][r] = __builtin_amdgcn_exp2f(ex[r]);
-                    acc += s[kt];
+                    for (int i = 0; i < 4; ++i) pw[i] = pack_bf16(pe[8 * j + 2 * i], pe[8 * j + 2 * i + 1]);
+                    pf[t][j] = __builtin_bit_cast(bf16x8, pw);
                 }
-                l_part += ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7])) +
-                          ((acc[8] + acc[9]) + (acc[10] + acc[11])) + ((acc[12] + acc[13]) + (acc[14] + acc[15]));
-#endif
+                l_part[t] += (((pe[0] + pe[1]) + (pe[2] + pe[3])) + ((pe[4] + pe[5]) + (pe[6] + pe[7]))) +
+                             (((pe[8] + pe[9]) + (pe[10] + pe[11])) + ((pe[12] + pe[13]) + (pe[14] + pe[15])));
+                // pin the exponentials HERE, in the block of the other tile's MFMAs: left alone, the optimiser sinks them
+                // past the branches of maxres() to their first use, in front of the MFMAs that wait for them
+                asm volatile("" : "+v"(pf[t][0]), "+v"(pf[t][1]), "+v"(l_part[t]));
+            };
+
+            // tile A leads, tile B follows half a step behind; QK^T goes first in a block (its scores feed the block's
+            // closing maximum), the fragments of the next block's MFMAs are fetched before that maximum's branches
+            constexpr std::true_type kMasked{};
+            constexpr std::false_type kFull{};
+            load_k(0);
+            qk(0);
+            maxres(0, 0, kMasked);
+            qk(1);
+            load_k(n_kt > 1 ? 1 : 0);
+            load_v(0);
+            exps(0);
+            maxres(1, 0, kMasked);
+            // every MFMA of a block finds its LDS operands already in registers: K fragments of tile kt + 1 and V^T
+            // fragments of tile kt are fetched in the second block of step kt, behind the last MFMAs that read the old ones
+            auto step = [&](int kt, auto last_tile) {
+                qk(0);            // S_A(kt)
+                pv(0);            // O_A += V^T P_A(kt-1)
+                exps(1);          // P_B(kt-1)
+                RASS_ATTN_SPREAD();
+                maxres(0, kt, last_tile);
+                qk(1);            // S_B(kt)
+                pv(1);            // O_B += V^T P_B(kt-1)
+                load_k(kt + 1 < n_kt ? kt + 1 : kt);
+                load_v(kt);
+                exps(0);          // P_A(kt)
+                RASS_ATTN_SPREAD();
+                maxres(1, kt, last_tile);
+            };
+            for (int kt = 1; kt < n_kt - 1; ++kt) step(kt, kFull);
+            if (n_kt > 1) step(n_kt - 1, kMasked);
+            pv(0);
+            exps(1);
+            pv(1);
+
 #pragma unroll
-                for (int kt = 0; kt < 2; ++kt) {
+            for (int t = 0; t < 2; ++t) {
+                const int q = q0 + 32 * t + qi;
+                // the query's sum = this lane's partial + its partner's; O^T[d = 32 dt + (r&3) + 8(r>>2) + 4h][q]
+                float l_run;
+                {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_part[t]),
+                                                                     __float_as_uint(l_part[t]), false, false);
+                    l_run = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+                }
+                const float inv_l = 1.f / l_run;
+                u16* dst = ctx + (int64_t)(t0 + (q < S ? q : 0)) * hidden + head * kHeadDim + 8 * h;
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
-                        u32x4v pw;
+                for (int dt = 0; dt < 2; ++dt) {
+                    unsigned w[8];
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) pw[i] = pack_bf16(s[kt][8 * j + 2 * i], s[kt][8 * j + 2 * i + 1]);
-                        const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
-                        const unsigned char* vblk = Vl + (kb * 64 + kt * 32 + 16 * j) * 128 + v_lane_off;
+                    for (int i = 0; i < 8; ++i)
+                        w[i] = pack_bf16(O[t][dt][2 * i] * inv_l, O[t][dt][2 * i + 1] * inv_l);
+                    // (w0,w1) = d 4h+0..3, (w2,w3) = d 8+4h.., (w4,w5) = d 16+4h.., (w6,w7) = d 24+4h..  ->  the low
+                    // lane keeps d 0-7 and 16-23 of the 32-block, the high lane d 8-15 and 24-31
 #pragma unroll
-                        for (int dt = 0; dt < 2; ++dt) {
-                            const unsigned char* va = vblk + ((dt ^ v_sw) * 64);
-                            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                                (__attribute__((address_space(3))) bf16x4*)(va));
-                            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                                (__attribute__((address_space(3))) bf16x4*)(va + 8 * 128));
-                            bf16x8 vf;
-                            vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
-                            vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
-                            O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, O[dt], 0, 0, 0);
-                        }
+                    for (int p = 0; p < 2; ++p) {
+                        const auto s0 = __builtin_amdgcn_permlane32_swap(w[4 * p + 0], w[4 * p + 2], false, false);
+                        const auto s1 = __builtin_amdgcn_permlane32_swap(w[4 * p + 1], w[4 * p + 3], false, false);
+                        if (q < S)
+                            *reinterpret_cast<u32x4*>(dst + 32 * dt + 16 * p) = u32x4{s0[0], s1[0], s0[1], s1[1]};
                     }
                 }
             }
-            // the query's sum = this lane's partial + its partner's; O^T[d = 32 dt + (r&3) + 8(r>>2) + 4h][q]
-            float l_run;
-            {
-                const auto sw =
-                    __builtin_amdgcn_permlane32_swap(__float_as_uint(l_part), __float_as_uint(l_part), false, false);
-                l_run = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-            }
-            const float inv_l = 1.f / l_run;
-            u16* dst = ctx + (int64_t)(t0 + (q < S ? q : 0)) * hidden + head * kHeadDim + 8 * h;
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                unsigned w[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) w[i] = pack_bf16(O[dt][2 * i] * inv_l, O[dt][2 * i + 1] * inv_l);
-                // (w0,w1) = d 4h+0..3, (w2,w3) = d 8+4h.., (w4,w5) = d 16+4h.., (w6,w7) = d 24+4h..  ->  the low lane
-                // keeps d 0-7 and 16-23 of the 32-block, the high lane d 8-15 and 24-31
-#pragma unroll
-                for (int p = 0; p < 2; ++p) {
-                    const auto s0 = __builtin_amdgcn_permlane32_swap(w[4 * p + 0], w[4 * p + 2], false, false);
-                    const auto s1 = __builtin_amdgcn_permlane32_swap(w[4 * p + 1], w[4 * p + 3], false, false);
-                    if (q < S)
-                        *reinterpret_cast<uint4*>(dst + 32 * dt + 16 * p) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
-                }
-            }
         };
-        if (wave * 32 < S) run_pass(wave * 32, qf[0]);
-        if (kA32Waves * 32 + wave * 32 < S) run_pass(kA32Waves * 32 + wave * 32, qf[1]);
-
+        if (wave * 64 < S) run_pass(wave * 64, qA);
+        if (kA64Waves * 64 + wave * 64 < S) {
+            load_q(t0, S, head, 1, qA);
+            run_pass(kA64Waves * 64 + wave * 64, qA);
+        }
         if (next >= n_items) break;
         item = next;
-        __syncthreads();  // every wave is done reading this item's K / V image
+        __syncthreads();  // barrier 2
     }
 }
 
@@ -465,22 +547,28 @@ static const char* attn_variant() {
     return v ? v : "";
 }
 
-hipError_t launch_attention(const void* qkv, const int32_t* cu_seqlens, int nseq, int max_seqlen, int hidden,
-                            int heads, void* ctx, hipStream_t stream) {
-    if (hidden != heads * kHeadDim || max_seqlen < 1 || max_seqlen > 512) return hipErrorInvalidValue;
-    if (nseq <= 0) return hipSuccess;
+hipError_t launch_attention(const void* qkv, const int32_t* cu_seqlens, int nseq, int total_tokens, int max_seqlen,
+                            int hidden, int heads, void* ctx, hipStream_t stream) {
+    if (hidden != heads * kHeadDim || max_seqlen < 1 || max_seqlen > 512 || total_tokens < 0) return hipErrorInvalidValue;
+    if (nseq <= 0 || total_tokens == 0) return hipSuccess;
     const int s_pad = (max_seqlen + 63) / 64 * 64;
-    if (strcmp(attn_variant(), "w16") != 0) {
+    // Mostly-long sequences (mean >= 384 tokens): the 32x32-tile persistent kernel (+9 % on 256 x 512).  Short or very
+    // ragged batches keep the 16x16 kernel: 16 queries per wave fill a CU from 256 tokens on, and its one workgroup
+    // per item is balanced by the dispatcher (measured equal on lengths uniform in 64..512, 3 % ahead on 32 x 64 and
+    // on one 16-token query).  RASS_ATTN_VARIANT=w4 / w16 forces one (tests, A/B).
+    const char* variant = attn_variant();
+    const bool long_rows = (long long)total_tokens >= 384LL * nseq;
+    if (strcmp(variant, "w4") == 0 || (long_rows && strcmp(variant, "w16") != 0)) {
         const size_t lds_bytes = (size_t)s_pad * 256;  // 128 KiB at S = 512
-        static size_t attr32_bytes = 0;
-        if (lds_bytes > attr32_bytes) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention32_kernel),
+        static size_t attr64_bytes = 0;
+        if (lds_bytes > attr64_bytes) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention64_kernel),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
             if (e != hipSuccess) return e;
-            attr32_bytes = lds_bytes;
+            attr64_bytes = lds_bytes;
         }
         const int n_items = nseq * heads;
-        hipLaunchKernelGGL(attention32_kernel, dim3(n_items < attn_cus() ? n_items : attn_cus()), dim3(kA32Threads),
+        hipLaunchKernelGGL(attention64_kernel, dim3(n_items < attn_cus() ? n_items : attn_cus()), dim3(kA64Threads),
                            lds_bytes, stream, static_cast<const u16*>(qkv), cu_seqlens, hidden, heads, s_pad, n_items,
                            static_cast<u16*>(ctx));
         return hipGetLastError();

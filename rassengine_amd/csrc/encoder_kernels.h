@@ -38,9 +38,10 @@ hipError_t launch_layernorm(const void* in, const float* gamma, const float* bet
                             void* out, hipStream_t stream);
 
 // K6: varlen self-attention, heads of 64, S <= 512 per sequence, softmax scale 1/8.
-// qkv: [tokens][3*hidden] (q | k | v), ctx: [tokens][hidden]
-hipError_t launch_attention(const void* qkv, const int32_t* cu_seqlens, int nseq, int max_seqlen, int hidden,
-                            int heads, void* ctx, hipStream_t stream);
+// qkv: [total_tokens][3*hidden] (q | k | v), ctx: [total_tokens][hidden]; total_tokens (= cu_seqlens[nseq], known to the
+// host) also picks the kernel: mostly-long sequences take the 32x32-tile persistent kernel
+hipError_t launch_attention(const void* qkv, const int32_t* cu_seqlens, int nseq, int total_tokens, int max_seqlen,
+                            int hidden, int heads, void* ctx, hipStream_t stream);
 
 // K8: pooled[s] = cls (first token) or mean over the sequence's tokens of x, fp32 [nseq][hidden];
 // optional L2 normalise with the reference's formula (app/main.py:1249-1251)

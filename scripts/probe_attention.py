@@ -13,7 +13,7 @@ ap.add_argument("--varlen", action="store_true")
 ap.add_argument("--heads", type=int, default=16)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--rounds", type=int, default=3)
-ap.add_argument("--variants", default=",w16")
+ap.add_argument("--variants", default="w4,w16")
 a = ap.parse_args()
 rng = np.random.default_rng(0)
 lens = rng.integers(64, 513, size=a.batch) if a.varlen else np.full(a.batch, a.seqlen)
@@ -25,7 +25,7 @@ d_cu = torch.from_numpy(cu).cuda()
 L = N.lib()
 st = ctypes.c_void_p(int(torch.cuda.current_stream().cuda_stream))
 def run():
-    N.check("attn", L.rass_attention_bf16(ctypes.c_void_p(qkv.data_ptr()), ctypes.c_void_p(d_cu.data_ptr()), a.batch,
+    N.check("attn", L.rass_attention_bf16(ctypes.c_void_p(qkv.data_ptr()), ctypes.c_void_p(d_cu.data_ptr()), a.batch, T,
                                           int(lens.max()), H, a.heads, ctypes.c_void_p(ctx.data_ptr()), st))
 flops = 4.0 * 64 * a.heads * float((lens.astype(np.float64) ** 2).sum())
 for rnd in range(a.rounds):

@@ -3,8 +3,9 @@ same op (softmax(q k^T / 8) v per sequence and head, fp32 throughout, on the sam
 
 Tolerance: the kernel rounds the exponentiated scores to bf16 before the second product (relative 2^-9 per term, so
 the bound follows sum_j p_j |v_j|, not the possibly cancelled result) and the output to bf16:
-|err| <= 2^-8 (sum_j p_j |v_j|) + 2^-8 |ref| + 2e-3 per element.  Both kernels are held to it: the
-32x32-tile kernel (default) and the 16x16-tile kernel of round 1 (RASS_ATTN_VARIANT=w16, read per launch)."""
+|err| <= 2^-8 (sum_j p_j |v_j|) + 2^-8 |ref| + 2e-3 per element.  Both kernels are held to it on every case: the
+32x32-tile persistent kernel (RASS_ATTN_VARIANT=w4; the default for batches of mostly-long sequences) and the 16x16-tile
+kernel (w16; the default otherwise); the variable is read per launch."""
 import ctypes
 import os
 
@@ -39,8 +40,8 @@ def _run(torch, qkv, lens, heads, max_seqlen=None):
     hidden = qkv.shape[1] // 3
     ctx = torch.full((qkv.shape[0] + 3, hidden), 777.0, dtype=torch.bfloat16, device="cuda")
     N_.check("rass_attention_bf16", N_.lib().rass_attention_bf16(
-        ctypes.c_void_p(qkv.data_ptr()), ctypes.c_void_p(d_cu.data_ptr()), len(lens), int(max_seqlen or max(lens)), hidden,
-        heads, ctypes.c_void_p(ctx.data_ptr()), ctypes.c_void_p(int(torch.cuda.current_stream().cuda_stream))))
+        ctypes.c_void_p(qkv.data_ptr()), ctypes.c_void_p(d_cu.data_ptr()), len(lens), int(cu[-1]),
+        int(max_seqlen or max(lens)), hidden, heads, ctypes.c_void_p(ctx.data_ptr()), ctypes.c_void_p(int(torch.cuda.current_stream().cuda_stream))))
     torch.cuda.synchronize()
     assert bool((ctx[qkv.shape[0]:] == 777.0).all())          # nothing written past the last token
     return ctx[:qkv.shape[0]].float()
@@ -59,7 +60,7 @@ def _check(torch, lens, heads, scale, seed, max_seqlen=None):
     assert bool((err <= tol).all()), (float((err - tol).max()), int((err > tol).sum()))
 
 
-@pytest.fixture(params=["", "w16"])
+@pytest.fixture(params=["w4", "w16", ""])
 def variant(request):
     old = os.environ.get("RASS_ATTN_VARIANT")
     if request.param:
@@ -90,6 +91,14 @@ def test_attention_large_shape_and_padded_launch(gpu, variant):
     _check(gpu, [40, 9, 64], heads=16, scale=1.0, seed=4, max_seqlen=512)
 
 
+def test_attention_more_items_than_workgroups(gpu, variant):
+    """40 sequences x 16 heads = 640 (sequence, head) items: the persistent kernel's workgroups (one per CU) walk 2-3
+    items each, of different lengths, with the next item's K / V prefetched under the current one."""
+    rng = np.random.default_rng(11)
+    lens = [512, 1, 257, 300] + [int(x) for x in rng.integers(1, 513, size=36)]
+    _check(gpu, lens, heads=16, scale=1.0, seed=6)
+
+
 def test_attention_variants_agree_closely(gpu):
     """The two kernels implement one algorithm (same bf16 rounding points): outputs within one bf16 ulp of each other
     almost everywhere."""
@@ -100,6 +109,7 @@ def test_attention_variants_agree_closely(gpu):
     qkv = torch.randn((sum(lens), 3 * 4 * 64), generator=g, device="cuda").bfloat16()
     old = os.environ.pop("RASS_ATTN_VARIANT", None)
     try:
+        os.environ["RASS_ATTN_VARIANT"] = "w4"
         a = _run(torch, qkv, lens, 4)
         os.environ["RASS_ATTN_VARIANT"] = "w16"
         b = _run(torch, qkv, lens, 4)

@@ -394,20 +394,32 @@ __global__ __launch_bounds__(kA64Threads) void attention64_kernel(const u16* __r
                 for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks)
+#ifdef RASS_ATTN_EXP_NO_MFMA
+                    s[t][ks] += __builtin_bit_cast(float, (int)kf[ks][0] + (int)qq[t][ks][0]);
+#else
                     s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qq[t][ks], s[t], 0, 0, 0);
+#endif
             };
             auto pv = [&](int t) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int dt = 0; dt < 2; ++dt)
+#ifdef RASS_ATTN_EXP_NO_MFMA
+                        O[t][dt][j] += __builtin_bit_cast(float, (int)vf[j][dt][0] + (int)pf[t][j][0]);
+#else
                         O[t][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[j][dt], pf[t][j], O[t][dt], 0, 0, 0);
+#endif
             };
             // Tile kt's scores of query tile t just arrived: mask the ragged tail, tile maximum.  The reference maximum
             // m_ref only moves when a score exceeds it by more than 2^8 (the probabilities are then <= 256: bf16 and
             // the fp32 sums have the exponent range for it and rounding is relative), so after the first tile the
             // rescale of O is the rare branch — with an exact running maximum 32 queries make it the usual one.
             auto maxres = [&](int t, int kt, auto last_tile) {
+#ifdef RASS_ATTN_EXP_NO_MAX
+                if (kt == 0) m_ref[t] = 0.f;
+                return;
+#endif
                 // only a sequence's LAST key tile can hold keys >= S; its steps are a copy of the loop body with the
                 // mask in it (a wave-uniform branch here would cut the block between the MFMAs and this maximum, and the
                 // maximum's dependent chain would run with nothing beside it)
@@ -426,7 +438,7 @@ __global__ __launch_bounds__(kA64Threads) void attention64_kernel(const u16* __r
                     mx = max2f(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
                 }
                 mx *= kScale;  // finite in tile 0 (key 0 is always valid); -inf for a fully masked query never happens
-                if (__any(mx > m_ref[t] + 8.f)) {
+                if (__builtin_expect(__any(mx > m_ref[t] + 8.f), 0)) {  // out of line: the usual path falls through
                     const float m_new = max2f(m_ref[t], mx);
                     const float alpha = __builtin_amdgcn_exp2f(m_ref[t] - m_new);  // 1 where m_ref did not move
                     l_part[t] *= alpha;
@@ -439,7 +451,11 @@ __global__ __launch_bounds__(kA64Threads) void attention64_kernel(const u16* __r
             auto exps = [&](int t) {
                 f32x16 pe;
 #pragma unroll
+#ifdef RASS_ATTN_EXP_NO_EXP
+                for (int r = 0; r < 16; ++r) pe[r] = __builtin_fmaf(s[t][r], kScale, -m_ref[t]);
+#else
                 for (int r = 0; r < 16; ++r) pe[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][r], kScale, -m_ref[t]));
+#endif
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     u32x4 pw;

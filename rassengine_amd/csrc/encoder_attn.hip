@@ -189,7 +189,7 @@ __global__ __launch_bounds__(kAttnThreads) void attention_kernel(const u16* __re
 
 // ------------------------------------------------------------------------------------------------------------------
 // attention64_kernel: the kernel for batches of LONG sequences (the ingest shape: 256 chunks x 512 tokens), on 32x32
-// tiles (v_mfma_f32_32x32x16_bf16).
+// tiles (v_mfma_f32_32x32x16_bf16).  How it got here, with every number: profiles/r02_attention_experiments.txt.
 //
 // Counted on the 16x16 kernel's ISA (prices: MI355X_MICROARCH "vector-instruction ISSUE cost"): per 64 keys a wave
 // spends ~80 plain VALU issues + 16 v_exp on 16 scores per lane — 33 of them the maximum (a canonicalising v_max before
@@ -205,23 +205,28 @@ __global__ __launch_bounds__(kAttnThreads) void attention_kernel(const u16* __re
 //     rows +0 and +8); V rows have the K pitch (128 B) with the 64-byte halves exchanged on rows with bit 1 set: the
 //     4 rows x 64 B a half-wave's transposed read touches fall on 64 distinct banks; K + V = 128 KiB at S = 512;
 //   * O is exchanged between the two lanes of a query (v_permlane32_swap) so that each stores 16 contiguous bytes;
-//   * four COMPUTE waves (one per SIMD), each with two 32-query tiles A and B software-pipelined half a step apart in
-//     ONE instruction stream (step = one 32-key tile):
+//   * eight waves, each with TWO 32-query tiles A and B (a sequence of up to 512 tokens is one pass), software-
+//     pipelined half a step apart in ONE instruction stream (step = one 32-key tile):
 //
 //       block 1(kt):  MFMA { S_A = K Q_A^T (kt) ; O_A += V^T P_A(kt-1) }  beside  VALU { P_B(kt-1) = exp2(..) } ; max_A(kt)
 //       block 2(kt):  MFMA { S_B = K Q_B^T (kt) ; O_B += V^T P_B(kt-1) }  beside  VALU { P_A(kt)   = exp2(..) } ; max_B(kt)
 //
-//     Two waves per SIMD running the same QK^T -> max -> exp -> PV chain (an 8-wave version of this kernel, in the
-//     history) left the SIMD idle half the time — matrix pipe busy 28 % of the launch, each wave issuing 35 % of its
-//     cycles, stalled behind an MFMA 35 %, parked 30 % — and forcing them into opposite phases with barriers cost
-//     more than it gave.  Here every block holds 8 MFMAs and an INDEPENDENT ~300 issue cycles of VALU, K and V^T
-//     fragments are read from LDS once per key tile for both query tiles, a block ahead of their MFMAs, and only the
-//     maximum's swap and the rescale branch sit at a block's end (counters: profiles/r02_attention_experiments.txt);
-//   * the reference maximum only moves when a score exceeds it by more than 2^8, so after the first tile the rescale of
-//     O is the rare branch (with an exact running maximum, 32 queries make it the usual one);
-//   * persistent: workgroup b takes items b, b + grid, ...; four LOADER waves (one per SIMD) hold the NEXT item's
-//     128 KiB in registers (128 per thread — a compute wave has none to spare), issue its loads right after barrier 1,
-//     sleep at barrier 2 while the compute waves work, and write the image when everyone is done with the old one.
+//     every block holds 8 MFMAs and an INDEPENDENT ~300 issue cycles of VALU; K and V^T fragments are read from LDS
+//     once per key tile for both query tiles, a block ahead of their MFMAs; only the maximum's swap and the (out of
+//     line) rescale branch sit at a block's end.  The same stream on one wave per SIMD ran 5 % slower: one in-order
+//     wave issues a vector instruction every ~9 cycles where independent ones issue in 4;
+//   * the reference maximum only moves when a score exceeds it by more than 2^8 (probabilities <= 256: bf16 and the
+//     fp32 sums have the exponent range for it and rounding is relative), so after the first tile the rescale of O is
+//     the rare branch — with an exact running maximum, 32 queries make it the usual one;
+//   * persistent (workgroup b takes items b, b + grid, ...), and the K / V image is replaced IN PLACE, 128 rows (a
+//     chunk = 4 key tiles) at a time, by LDS-DMA (global_load_lds, 1 KiB per wave instruction: 8 rows x 128 B, the
+//     row's 16-B chunks permuted on the global side so that the lane-linear LDS image is the swizzled one).
+//     Boundary b (between key tiles 4b-1 and 4b): vmcnt(0) + barrier — every wave is done reading chunk b-1 of this
+//     item and every DMA issued a quarter of an item ago has landed — then the NEXT item's chunk b-1 is sent into the
+//     dead rows: no staging phase, no registers held for it.  Rows past the sequence's end are copies of its last row
+//     (finite; their scores are masked and their probabilities are exactly 0).
+// Vector issue is what bounds it now (two waves per SIMD issue 74 % of the cycles: ~97 vector instructions per block
+// beside 8 MFMAs; matrix pipe busy 30 %).
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -235,29 +240,11 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {  // v_cvt_pk_b
     return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
 }
 
-// one MFMA, then N VALU issues, eight times: asks the scheduler to spread a block's MFMAs over its VALU work (measured:
-// no change for N = 7 / 9 / 11; off)
-#ifdef RASS_ATTN_SGB
-#define RASS_ATTN_SPREAD()                                     \
-    do {                                                       \
-        _Pragma("unroll") for (int g_ = 0; g_ < 8; ++g_) {     \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); \
-            __builtin_amdgcn_sched_group_barrier(0x002, RASS_ATTN_SGB, 0); \
-        }                                                      \
-    } while (0)
-#else
-#define RASS_ATTN_SPREAD() do { } while (0)
-#endif
 constexpr int kA64Threads = 512;
-constexpr int kA64Waves = 4;  // compute waves
-
-struct KvRegs64 {
-    u32x4 k[16], v[16];
-};
 
 __global__ __launch_bounds__(kA64Threads) void attention64_kernel(const u16* __restrict__ qkv,
-                                                                  const int32_t* __restrict__ cu, int hidden, int heads,
-                                                                  int s_pad, int n_items, u16* __restrict__ ctx) {
+                                                                    const int32_t* __restrict__ cu, int hidden, int heads,
+                                                                    int s_pad, int n_items, u16* __restrict__ ctx) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char* Kl = lds;                            // [s_pad][128 B], 16-B chunk c at c ^ ((key >> 1) & 7)
     unsigned char* Vl = lds + (size_t)s_pad * 128;      // [s_pad][128 B], 16-B chunk c at c ^ (((key >> 1) & 1) << 2)
@@ -279,44 +266,30 @@ __global__ __launch_bounds__(kA64Threads) void attention64_kernel(const u16* __r
         if (S > s_pad) S = s_pad;
     };
     auto clamp_tok = [&](int tok) { return tok < 0 ? 0 : (tok < total ? tok : total - 1); };
-    // Issue the loads of an item's K / V rows.  NO branch around any of them (a row past the sequence re-reads its last
-    // row and is zeroed at store time): the compiler counts the loads in flight per basic block, and one conditional load
-    // among them turns every later counted wait into a conservative one.
-    auto load_kv = [&](int it, KvRegs64& r) {
+    // chunk j (rows 128 j .. +127) of item `it`: 16 K pieces + 16 V pieces of 8 rows; wave w sends pieces w and w + 8
+    auto dma_chunk = [&](int it, int j) {
         int t0, S;
         item_rows(it, t0, S);
-        const u16* kb_ = qkv + (it % heads) * kHeadDim + hidden + (threadIdx.x & 7) * 8;
+        const u16* base = qkv + (it % heads) * kHeadDim + hidden;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int key = ((threadIdx.x & 255) >> 3) + 32 * i;
-            const int tok = clamp_tok(t0 + (key < S ? key : S - 1));
-#ifndef RASS_ATTN_EXP_NO_STAGE
-            r.k[i] = *reinterpret_cast<const u32x4*>(kb_ + (int64_t)tok * ld);
-            r.v[i] = *reinterpret_cast<const u32x4*>(kb_ + hidden + (int64_t)tok * ld);
-#else
-            r.k[i] = u32x4{(unsigned)tok, 0u, 0u, 0u};
-            r.v[i] = u32x4{0u, (unsigned)tok, 0u, 0u};
-#endif
+        for (int pp = 0; pp < 2; ++pp) {
+            const int row0 = 128 * j + 8 * (wave + 8 * pp);
+            const int row = row0 + (lane >> 3);
+            const int tok = clamp_tok(t0 + (row < S ? row : S - 1));
+            const int ck = (lane & 7) ^ ((row >> 1) & 7);
+            const int cv = (lane & 7) ^ (((row >> 1) & 1) << 2);
+            const u16* src = base + (int64_t)tok * ld;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + ck * 8),
+                                             (__attribute__((address_space(3))) void*)(Kl + row0 * 128), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + hidden + cv * 8),
+                                             (__attribute__((address_space(3))) void*)(Vl + row0 * 128), 16, 0, 0);
         }
     };
-    auto store_kv = [&](int S, const KvRegs64& r) {  // keys >= S: zeros — masked later, but they must be finite
-        const int c = threadIdx.x & 7;
-        const int rows = (S + 63) / 64 * 64;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int key = ((threadIdx.x & 255) >> 3) + 32 * i;
-            if (key < rows) {
-                const unsigned keep = key < S ? 0xffffffffu : 0u;
-                *reinterpret_cast<u32x4*>(Kl + key * 128 + ((c ^ ((key >> 1) & 7)) * 16)) = r.k[i] & keep;
-                *reinterpret_cast<u32x4*>(Vl + key * 128 + ((c ^ (((key >> 1) & 1) << 2)) * 16)) = r.v[i] & keep;
-            }
-        }
-    };
-    // Q fragments of the wave's two tiles in pass `ps` of an item: B operand of S^T = K Q^T, Q[q][16 ks + 8 h .. +7]
-    auto load_q = [&](int t0, int S, int head, int ps, bf16x8 (&qf)[2][4]) {
+    // Q fragments of the wave's two tiles: B operand of S^T = K Q^T, Q[q][16 ks + 8 h .. +7]
+    auto load_q = [&](int t0, int S, int head, bf16x8 (&qf)[2][4]) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const int q = ps * kA64Waves * 64 + wave * 64 + 32 * t + qi;
+            const int q = wave * 64 + 32 * t + qi;
             const int tok = clamp_tok(t0 + (q < S ? q : S - 1));
             const u16* qrow = qkv + (int64_t)tok * ld + head * kHeadDim + 8 * h;
 #pragma unroll
@@ -325,34 +298,41 @@ __global__ __launch_bounds__(kA64Threads) void attention64_kernel(const u16* __r
     };
 
     int item = blockIdx.x;
-    if (wave >= kA64Waves) {  // ---- loader waves
-        KvRegs64 kv;
-        load_kv(item, kv);
-        while (true) {
-            int t0, S;
-            item_rows(item, t0, S);
-            store_kv(S, kv);
-            __syncthreads();  // barrier 1: the image is complete
-            const int next = item + gridDim.x;
-            if (next >= n_items) break;
-            load_kv(next, kv);
-            item = next;
-            __syncthreads();  // barrier 2: every compute wave is done with the old image
-        }
-        return;
+    bool sync0 = true;  // does this item's first chunk still need a wait + barrier?
+    bf16x8 qq[2][4];
+    {
+        int t0, S;
+        item_rows(item, t0, S);
+        load_q(t0, S, item % heads, qq);
+        for (int j = 0; j < (S + 127) / 128; ++j) dma_chunk(item, j);
     }
-    while (true) {  // ---- compute waves
+    while (true) {
         int t0, S;
         item_rows(item, t0, S);
         const int head = item % heads;
+        const int n_kt = (S + 31) / 32, nc = (S + 127) / 128;
         const int next = item + gridDim.x;
-        bf16x8 qA[2][4];
-        load_q(t0, S, head, 0, qA);
-        __syncthreads();  // barrier 1
-
-        auto run_pass = [&](int q0, const bf16x8 (&qq)[2][4]) {
+        const bool has_next = next < n_items;
+        int nc_next = 0;
+        if (has_next) {
+            int nt0, nS;
+            item_rows(next, nt0, nS);
+            nc_next = (nS + 127) / 128;
+        }
+        if (sync0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        for (int j = nc; j < nc_next; ++j) dma_chunk(next, j);  // rows this item never touches
+        // boundary b >= 1, between key tiles 4b-1 and 4b
+        auto boundary = [&](int b) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (b - 1 < nc_next) dma_chunk(next, b - 1);
+        };
+        const int q0 = wave * 64;
+        if (q0 < S) {
             // one step = one 32-key tile of one query tile: 4 + 4 MFMAs beside 16 exponentials
-            const int n_kt = (S + 31) / 32;
             float m_ref[2] = {-INFINITY, -INFINITY}, l_part[2] = {0.f, 0.f};
             f32x16 O[2][2], s[2];
             bf16x8 pf[2][2];
@@ -482,28 +462,38 @@ __global__ __launch_bounds__(kA64Threads) void attention64_kernel(const u16* __r
             load_v(0);
             exps(0);
             maxres(1, 0, kMasked);
-            // every MFMA of a block finds its LDS operands already in registers: K fragments of tile kt + 1 and V^T
-            // fragments of tile kt are fetched in the second block of step kt, behind the last MFMAs that read the old ones
             auto step = [&](int kt, auto last_tile) {
                 qk(0);            // S_A(kt)
                 pv(0);            // O_A += V^T P_A(kt-1)
                 exps(1);          // P_B(kt-1)
-                RASS_ATTN_SPREAD();
                 maxres(0, kt, last_tile);
                 qk(1);            // S_B(kt)
                 pv(1);            // O_B += V^T P_B(kt-1)
                 load_k(kt + 1 < n_kt ? kt + 1 : kt);
                 load_v(kt);
                 exps(0);          // P_A(kt)
-                RASS_ATTN_SPREAD();
                 maxres(1, kt, last_tile);
             };
-            for (int kt = 1; kt < n_kt - 1; ++kt) step(kt, kFull);
-            if (n_kt > 1) step(n_kt - 1, kMasked);
+            for (int kt = 1; kt < n_kt - 1; ++kt) {
+                if ((kt & 3) == 0) boundary(kt >> 2);
+                step(kt, kFull);
+            }
+            if (n_kt > 1) {
+                if (((n_kt - 1) & 3) == 0) boundary((n_kt - 1) >> 2);
+                step(n_kt - 1, kMasked);
+            }
             pv(0);
             exps(1);
             pv(1);
-
+            // end of the item: everyone is done with the last chunk
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (has_next) {
+                int nt0, nS;
+                item_rows(next, nt0, nS);
+                load_q(nt0, nS, next % heads, qq);  // before the chunk below: vmcnt retires in order
+                if (nc - 1 < nc_next) dma_chunk(next, nc - 1);
+            }
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int q = q0 + 32 * t + qi;
@@ -533,15 +523,20 @@ __global__ __launch_bounds__(kA64Threads) void attention64_kernel(const u16* __r
                     }
                 }
             }
-        };
-        if (wave * 64 < S) run_pass(wave * 64, qA);
-        if (kA64Waves * 64 + wave * 64 < S) {
-            load_q(t0, S, head, 1, qA);
-            run_pass(kA64Waves * 64 + wave * 64, qA);
+        } else {  // a wave without queries keeps the rhythm and moves its share of the rows
+            for (int b = 1; b < nc; ++b) boundary(b);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (has_next) {
+                int nt0, nS;
+                item_rows(next, nt0, nS);
+                load_q(nt0, nS, next % heads, qq);
+                if (nc - 1 < nc_next) dma_chunk(next, nc - 1);
+            }
         }
-        if (next >= n_items) break;
+        if (!has_next) break;
+        sync0 = nc < 3;  // chunk 1 (nc == 2) or chunk 0 (nc == 1) of the next item was only just sent
         item = next;
-        __syncthreads();  // barrier 2
     }
 }
 
@@ -568,14 +563,15 @@ hipError_t launch_attention(const void* qkv, const int32_t* cu_seqlens, int nseq
     if (hidden != heads * kHeadDim || max_seqlen < 1 || max_seqlen > 512 || total_tokens < 0) return hipErrorInvalidValue;
     if (nseq <= 0 || total_tokens == 0) return hipSuccess;
     const int s_pad = (max_seqlen + 63) / 64 * 64;
-    // Mostly-long sequences (mean >= 384 tokens): the 32x32-tile persistent kernel (+9 % on 256 x 512).  Short or very
+    // Mostly-long sequences (mean >= 384 tokens): the 32x32-tile persistent kernel (256 x 512: 396-405 us against 480).  Short or very
     // ragged batches keep the 16x16 kernel: 16 queries per wave fill a CU from 256 tokens on, and its one workgroup
     // per item is balanced by the dispatcher (measured equal on lengths uniform in 64..512, 3 % ahead on 32 x 64 and
-    // on one 16-token query).  RASS_ATTN_VARIANT=w4 / w16 forces one (tests, A/B).
+    // on one 16-token query).  RASS_ATTN_VARIANT=w8 / w16 forces one (tests, A/B).
     const char* variant = attn_variant();
     const bool long_rows = (long long)total_tokens >= 384LL * nseq;
-    if (strcmp(variant, "w4") == 0 || (long_rows && strcmp(variant, "w16") != 0)) {
-        const size_t lds_bytes = (size_t)s_pad * 256;  // 128 KiB at S = 512
+    if (strcmp(variant, "w8") == 0 || (long_rows && strcmp(variant, "w16") != 0)) {
+        const int s_pad128 = (max_seqlen + 127) / 128 * 128;  // whole 128-row chunks are sent
+        const size_t lds_bytes = (size_t)s_pad128 * 256;      // 128 KiB at S = 512
         static size_t attr64_bytes = 0;
         if (lds_bytes > attr64_bytes) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention64_kernel),
@@ -585,7 +581,7 @@ hipError_t launch_attention(const void* qkv, const int32_t* cu_seqlens, int nseq
         }
         const int n_items = nseq * heads;
         hipLaunchKernelGGL(attention64_kernel, dim3(n_items < attn_cus() ? n_items : attn_cus()), dim3(kA64Threads),
-                           lds_bytes, stream, static_cast<const u16*>(qkv), cu_seqlens, hidden, heads, s_pad, n_items,
+                           lds_bytes, stream, static_cast<const u16*>(qkv), cu_seqlens, hidden, heads, s_pad128, n_items,
                            static_cast<u16*>(ctx));
         return hipGetLastError();
     }

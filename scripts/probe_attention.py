@@ -13,7 +13,7 @@ ap.add_argument("--varlen", action="store_true")
 ap.add_argument("--heads", type=int, default=16)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--rounds", type=int, default=3)
-ap.add_argument("--variants", default="w4,w16")
+ap.add_argument("--variants", default="w8,w16")
 a = ap.parse_args()
 rng = np.random.default_rng(0)
 lens = rng.integers(64, 513, size=a.batch) if a.varlen else np.full(a.batch, a.seqlen)

@@ -240,6 +240,13 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {  // v_cvt_pk_b
     return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
 }
 
+// one LDS-DMA wave instruction: lane l's 16 bytes at gptr land at lds_piece + 16 l (lds_piece wave-uniform)
+__device__ __forceinline__ void dma16(const void* gptr, const unsigned char* lds_piece) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane(
+        (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)lds_piece);
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(gptr) : "memory");  // nothing else in this kernel uses M0
+}
+
 constexpr int kA64Threads = 512;
 
 __global__ __launch_bounds__(kA64Threads) void attention64_kernel(const u16* __restrict__ qkv,
@@ -279,10 +286,11 @@ __global__ __launch_bounds__(kA64Threads) void attention64_kernel(const u16* __r
             const int ck = (lane & 7) ^ ((row >> 1) & 7);
             const int cv = (lane & 7) ^ (((row >> 1) & 1) << 2);
             const u16* src = base + (int64_t)tok * ld;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + ck * 8),
-                                             (__attribute__((address_space(3))) void*)(Kl + row0 * 128), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + hidden + cv * 8),
-                                             (__attribute__((address_space(3))) void*)(Vl + row0 * 128), 16, 0, 0);
+            // opaque to the compiler on purpose: with the builtin it puts an s_waitcnt vmcnt(0) in front of the LDS reads
+            // of every step (any LDS read may alias an LDS-DMA write), i.e. each boundary's DMA is waited for at once;
+            // the waits that order these writes against the reads are the boundaries' own vmcnt(0) + barrier
+            dma16(src + ck * 8, Kl + row0 * 128);
+            dma16(src + hidden + cv * 8, Vl + row0 * 128);
         }
     };
     // Q fragments of the wave's two tiles: B operand of S^T = K Q^T, Q[q][16 ks + 8 h .. +7]
@@ -293,13 +301,22 @@ __global__ __launch_bounds__(kA64Threads) void attention64_kernel(const u16* __r
             const int tok = clamp_tok(t0 + (q < S ? q : S - 1));
             const u16* qrow = qkv + (int64_t)tok * ld + head * kHeadDim + 8 * h;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) qf[t][ks] = *reinterpret_cast<const bf16x8*>(qrow + 16 * ks);
+            for (int ks = 0; ks < 4; ++ks)  // opaque like the DMA (the compiler's counted waits would not see those)
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(qf[t][ks]) : "v"(qrow + 16 * ks) : "memory");
         }
     };
 
     int item = blockIdx.x;
     bool sync0 = true;  // does this item's first chunk still need a wait + barrier?
     bf16x8 qq[2][4];
+    // everything this wave has in flight (DMA pieces, Q fragments, stores) is done; the operands tie the uses of qq behind it
+    auto wait_all = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(qq[0][0]), "+v"(qq[0][1]), "+v"(qq[0][2]), "+v"(qq[0][3]), "+v"(qq[1][0]), "+v"(qq[1][1]),
+                       "+v"(qq[1][2]), "+v"(qq[1][3])
+                     :
+                     : "memory");
+    };
     {
         int t0, S;
         item_rows(item, t0, S);
@@ -320,9 +337,18 @@ __global__ __launch_bounds__(kA64Threads) void attention64_kernel(const u16* __r
             nc_next = (nS + 127) / 128;
         }
         if (sync0) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wait_all();
             __syncthreads();
         }
+        // the next item's Q fragments: issued as soon as this item's last QK^T has read the old ones, a block before
+        // the end-of-item wait
+        auto load_q_next = [&]() {
+            if (has_next) {
+                int nt0, nS;
+                item_rows(next, nt0, nS);
+                load_q(nt0, nS, next % heads, qq);
+            }
+        };
         for (int j = nc; j < nc_next; ++j) dma_chunk(next, j);  // rows this item never touches
         // boundary b >= 1, between key tiles 4b-1 and 4b
         auto boundary = [&](int b) {
@@ -458,6 +484,7 @@ __global__ __launch_bounds__(kA64Threads) void attention64_kernel(const u16* __r
             qk(0);
             maxres(0, 0, kMasked);
             qk(1);
+            if (n_kt == 1) load_q_next();
             load_k(n_kt > 1 ? 1 : 0);
             load_v(0);
             exps(0);
@@ -468,6 +495,7 @@ __global__ __launch_bounds__(kA64Threads) void attention64_kernel(const u16* __r
                 exps(1);          // P_B(kt-1)
                 maxres(0, kt, last_tile);
                 qk(1);            // S_B(kt)
+                if constexpr (decltype(last_tile)::value) load_q_next();
                 pv(1);            // O_B += V^T P_B(kt-1)
                 load_k(kt + 1 < n_kt ? kt + 1 : kt);
                 load_v(kt);
@@ -485,15 +513,10 @@ __global__ __launch_bounds__(kA64Threads) void attention64_kernel(const u16* __r
             pv(0);
             exps(1);
             pv(1);
-            // end of the item: everyone is done with the last chunk
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // end of the item: everyone is done with the last chunk (and the next item's Q fragments have arrived)
+            wait_all();
             __syncthreads();
-            if (has_next) {
-                int nt0, nS;
-                item_rows(next, nt0, nS);
-                load_q(nt0, nS, next % heads, qq);  // before the chunk below: vmcnt retires in order
-                if (nc - 1 < nc_next) dma_chunk(next, nc - 1);
-            }
+            if (nc - 1 < nc_next) dma_chunk(next, nc - 1);
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int q = q0 + 32 * t + qi;
@@ -525,14 +548,10 @@ __global__ __launch_bounds__(kA64Threads) void attention64_kernel(const u16* __r
             }
         } else {  // a wave without queries keeps the rhythm and moves its share of the rows
             for (int b = 1; b < nc; ++b) boundary(b);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            load_q_next();
+            wait_all();
             __syncthreads();
-            if (has_next) {
-                int nt0, nS;
-                item_rows(next, nt0, nS);
-                load_q(nt0, nS, next % heads, qq);
-                if (nc - 1 < nc_next) dma_chunk(next, nc - 1);
-            }
+            if (nc - 1 < nc_next) dma_chunk(next, nc - 1);
         }
         if (!has_next) break;
         sync0 = nc < 3;  // chunk 1 (nc == 2) or chunk 0 (nc == 1) of the next item was only just sent

@@ -146,20 +146,86 @@ hipError_t launch_embed_layernorm(const int32_t* ids, const int32_t* cu_seqlens,
     return hipGetLastError();
 }
 
+// The streaming form for whole batches (2 x 268 MB per call at 256 x 512 tokens, twice per layer = 6 % of a forward):
+// a wave walks rows r, r + stride, ...; gamma / beta of its 8 * STEPS columns are loaded ONCE (the per-row form fetched
+// 128 B of them per lane for every 32 B of data) and the next row's data is on its way while this one is reduced.
+// Arithmetic and its order are layernorm_store's, bit for bit.
+template <int STEPS>
 __global__ __launch_bounds__(kRowThreadsE) void layernorm_kernel(const u16* __restrict__ in,
                                                                  const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta, float eps, int rows,
                                                                  int hidden, u16* __restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    for (int r = blockIdx.x * 4 + wave; r < rows; r += gridDim.x * 4) {
-        Vals8 x[kMaxSteps];
+    f32x4 g[STEPS][2], b[STEPS][2];
 #pragma unroll
-        for (int s = 0; s < kMaxSteps; ++s) {
+    for (int s = 0; s < STEPS; ++s) {
+        const int c = lane * 8 + 512 * s;
+        const int cc = c < hidden ? c : 0;
+        g[s][0] = *reinterpret_cast<const f32x4*>(gamma + cc);
+        g[s][1] = *reinterpret_cast<const f32x4*>(gamma + cc + 4);
+        b[s][0] = *reinterpret_cast<const f32x4*>(beta + cc);
+        b[s][1] = *reinterpret_cast<const f32x4*>(beta + cc + 4);
+    }
+    const int stride = gridDim.x * 4;
+    int r = blockIdx.x * 4 + wave;
+    if (r >= rows) return;
+    uint4 cur[STEPS], nxt[STEPS];
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+        const int c = lane * 8 + 512 * s;
+        cur[s] = *reinterpret_cast<const uint4*>(in + (int64_t)r * hidden + (c < hidden ? c : 0));
+    }
+    for (; r < rows; r += stride) {
+        const int rn = r + stride < rows ? r + stride : r;  // no branch around the loads: the waits stay counted
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
             const int c = lane * 8 + 512 * s;
-            if (c < hidden) x[s] = load8_bf16(in + (int64_t)r * hidden + c);
+            nxt[s] = *reinterpret_cast<const uint4*>(in + (int64_t)rn * hidden + (c < hidden ? c : 0));
         }
-        layernorm_store(x, hidden, lane, gamma, beta, eps, out + (int64_t)r * hidden);
+        Vals8 x[STEPS];
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+            x[s].v[0] = bf2f((u16)(cur[s].x & 0xffff)); x[s].v[1] = bf2f((u16)(cur[s].x >> 16));
+            x[s].v[2] = bf2f((u16)(cur[s].y & 0xffff)); x[s].v[3] = bf2f((u16)(cur[s].y >> 16));
+            x[s].v[4] = bf2f((u16)(cur[s].z & 0xffff)); x[s].v[5] = bf2f((u16)(cur[s].z >> 16));
+            x[s].v[6] = bf2f((u16)(cur[s].w & 0xffff)); x[s].v[7] = bf2f((u16)(cur[s].w >> 16));
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s)
+            if (lane * 8 + 512 * s < hidden)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sum += x[s].v[e];
+        const float mean = wave_sum_e(sum) / (float)hidden;
+        float sq = 0.f;
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s)
+            if (lane * 8 + 512 * s < hidden)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float d = x[s].v[e] - mean;
+                    sq = fmaf(d, d, sq);
+                }
+        const float rstd = rsqrtf(wave_sum_e(sq) / (float)hidden + eps);
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+            const int c = lane * 8 + 512 * s;
+            if (c < hidden) {
+                Vals8 o;
+                o.v[0] = (x[s].v[0] - mean) * rstd * g[s][0].x + b[s][0].x;
+                o.v[1] = (x[s].v[1] - mean) * rstd * g[s][0].y + b[s][0].y;
+                o.v[2] = (x[s].v[2] - mean) * rstd * g[s][0].z + b[s][0].z;
+                o.v[3] = (x[s].v[3] - mean) * rstd * g[s][0].w + b[s][0].w;
+                o.v[4] = (x[s].v[4] - mean) * rstd * g[s][1].x + b[s][1].x;
+                o.v[5] = (x[s].v[5] - mean) * rstd * g[s][1].y + b[s][1].y;
+                o.v[6] = (x[s].v[6] - mean) * rstd * g[s][1].z + b[s][1].z;
+                o.v[7] = (x[s].v[7] - mean) * rstd * g[s][1].w + b[s][1].w;
+                store8_bf16(out + (int64_t)r * hidden + c, o);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) cur[s] = nxt[s];
     }
 }
 
@@ -240,10 +306,19 @@ hipError_t launch_layernorm(const void* in, const float* gamma, const float* bet
                             void* out, hipStream_t stream) {
     if (hidden % 8 != 0 || hidden > 512 * kMaxSteps) return hipErrorInvalidValue;
     if (rows <= 0) return hipSuccess;
+    // one row per wave while that fills the device; beyond 8 workgroups per CU the waves walk rows (the hoisted
+    // gamma / beta and the prefetch pay from the second row on: 16 rows per wave at 256 x 512 tokens)
     int blocks = (rows + 3) / 4;
-    if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(layernorm_kernel, dim3(blocks), dim3(kRowThreadsE), 0, stream, static_cast<const u16*>(in),
-                       gamma, beta, eps, rows, hidden, static_cast<u16*>(out));
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    const int steps = (hidden + 511) / 512;
+    const u16* x = static_cast<const u16*>(in);
+    u16* y = static_cast<u16*>(out);
+    switch (steps) {
+        case 1: hipLaunchKernelGGL(layernorm_kernel<1>, dim3(blocks), dim3(kRowThreadsE), 0, stream, x, gamma, beta, eps, rows, hidden, y); break;
+        case 2: hipLaunchKernelGGL(layernorm_kernel<2>, dim3(blocks), dim3(kRowThreadsE), 0, stream, x, gamma, beta, eps, rows, hidden, y); break;
+        case 3: hipLaunchKernelGGL(layernorm_kernel<3>, dim3(blocks), dim3(kRowThreadsE), 0, stream, x, gamma, beta, eps, rows, hidden, y); break;
+        default: hipLaunchKernelGGL(layernorm_kernel<4>, dim3(blocks), dim3(kRowThreadsE), 0, stream, x, gamma, beta, eps, rows, hidden, y); break;
+    }
     return hipGetLastError();
 }
 

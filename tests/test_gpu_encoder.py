@@ -219,6 +219,29 @@ def test_base_shape_encoder_through_the_persistent_gemm(gpu, tmp_path_factory):
     assert np.all(c >= 0.999), c
 
 
+@pytest.mark.parametrize("hidden,heads", [(1536, 24), (2048, 32)])
+def test_wide_hidden_sizes(gpu, tmp_path_factory, hidden, heads):
+    """hidden 1536 / 2048 (the widest the C ABI accepts): LayerNorm rows of 3 and 4 x 512 columns, 24 / 32 heads, both in
+    the few-row path (one short sequence) and in the batch path (> 1024 packed tokens, long sequences)."""
+    from oracle import bert_ref
+    from rassengine_amd.encoder import EncoderConfig, HipSentenceEncoder, write_random_model_dir
+    d = str(tmp_path_factory.mktemp(f"wide_{hidden}"))
+    cfg = EncoderConfig(vocab_size=1000, hidden=hidden, layers=1, heads=heads, intermediate=512, max_positions=512,
+                        pooling="mean")
+    write_random_model_dir(d, cfg, seed=hidden)
+    rng = np.random.default_rng(hidden)
+    enc = HipSentenceEncoder.from_dir(d, device=0)
+    try:
+        for lens in ((9,), (512, 480, 400, 33)):
+            seqs = [list(rng.integers(0, 1000, size=n)) for n in lens]
+            got = enc.encode_ids(seqs)
+            ref = bert_ref.pool(bert_ref.forward_plain(d, seqs), "mean")
+            assert got.shape == (len(lens), hidden) and np.all(np.isfinite(got))
+            assert np.all(_cos(got, ref) >= 0.999), (lens, _cos(got, ref))
+    finally:
+        enc.close()
+
+
 def test_embedding_shim_over_hip_encoder(gpu, tiny_model):
     """embed_texts_in_batches / embed_query (reference app/main.py:240-274) over the HIP encoder."""
     import asyncio

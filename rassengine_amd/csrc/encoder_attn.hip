@@ -244,14 +244,15 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {  // v_cvt_pk_b
 __device__ __forceinline__ void dma16(const void* gptr, const unsigned char* lds_piece) {
     const unsigned dst = __builtin_amdgcn_readfirstlane(
         (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)lds_piece);
-    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(gptr) : "memory");  // nothing else in this kernel uses M0
+    // M0 = the piece's LDS address (nothing else in these kernels uses M0)
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(gptr) : "memory");
 }
 
 constexpr int kA64Threads = 512;
 
 __global__ __launch_bounds__(kA64Threads) void attention64_kernel(const u16* __restrict__ qkv,
-                                                                    const int32_t* __restrict__ cu, int hidden, int heads,
-                                                                    int s_pad, int n_items, u16* __restrict__ ctx) {
+                                                                  const int32_t* __restrict__ cu, int hidden, int heads,
+                                                                  int s_pad, int n_items, u16* __restrict__ ctx) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char* Kl = lds;                            // [s_pad][128 B], 16-B chunk c at c ^ ((key >> 1) & 7)
     unsigned char* Vl = lds + (size_t)s_pad * 128;      // [s_pad][128 B], 16-B chunk c at c ^ (((key >> 1) & 1) << 2)

@@ -80,6 +80,7 @@ def main():
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    coll = "gloo (ranks sharing one GPU: a rehearsal, not a measurement)" if share else "RCCL"
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if share:
@@ -199,8 +200,8 @@ def main():
             "corpus_dtype": "bf16 only (fp32-accumulated bf16 MFMA)" if bf16 else
                             "f32" if not args.prefilter else "f32 + bf16 candidate copy (exact fp32 re-rank)",
             "layout": "tile16b" if bf16 else "tile16", "mode": "prefilter" if args.prefilter else "flat",
-            "cross_shard_exchange": ("peer stores + flags" if args.merge == "peer" else "RCCL all-gather") if world > 1 else None, "sharding": f"row-sharded x{world}, RCCL all-gather merge"
-            if world > 1 else "single shard",
+            "cross_shard_exchange": ("peer stores + flags" if args.merge == "peer" else f"{coll} all-gather") if world > 1 else None,
+            "sharding": f"row-sharded x{world}, {coll} all-gather merge" if world > 1 else "single shard",
             "aggregate_scan_GBps": round(bytes_per_launch * world * args.steps * LPS / elapsed / 1e9, 1),
         },
         "roofline": {

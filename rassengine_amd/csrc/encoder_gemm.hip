@@ -282,6 +282,99 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __res
     *reinterpret_cast<uint2*>(Y + (int64_t)m * N + n) = o;
 }
 
+// ------------------------------------------------------------------------------------------
+// A few rows against a WIDE weight matrix (one query: QKV, N = 3072, and FFN-up, N = 4096, at K = 1024): no split-K and
+// no second kernel.  One wave per 16 output features walks all of K straight from global memory / L2 — its 16 weight
+// rows are 32 KiB, read once, 16 B per lane and MFMA (A = W rows, B = X rows: D[feature][token]) with 8 loads in
+// flight — and applies the epilogue itself; N / 16 >= 128 waves stream the matrix.  Every launch of a one-query forward
+// costs ~5 us whatever it does (a hipGraph replay does not change that), so the two launches saved per layer are a
+// fifth of the forward.  ROWS = number of 16-token blocks (tokens <= 64).
+template <int EPI, int ROWS>
+__global__ __launch_bounds__(256) void gemm_bf16_fewrows_kernel(const u16* __restrict__ X, const u16* __restrict__ W,
+                                                                const float* __restrict__ bias,
+                                                                const u16* __restrict__ residual, u16* __restrict__ Y,
+                                                                int M, int N, int K) {
+    // a workgroup = 16 output features; its four waves take a quarter of K each (every weight load of the wave in
+    // flight at once: K / 4 / 32 <= 16 loads of 16 B per lane), then wave 0 adds the four partial tiles in wave order
+    __shared__ f32x4 part[4][ROWS][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int n0 = blockIdx.x * 16;
+    const int g = lane >> 4, i = lane & 15;
+    const int kq = K / 4, k_lo = wave * kq;
+    const u16* wrow = W + (int64_t)(n0 + i) * K + k_lo + 8 * g;   // A operand: W[n0 + i][k_lo + 32 ks + 8 g .. +7]
+    const u16* xrow = X + (int64_t)i * K + k_lo + 8 * g;          // B operand: X[16 rb + i][..] (rows < M_pad exist)
+    f32x4 acc[ROWS];
+#pragma unroll
+    for (int rb = 0; rb < ROWS; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int U = 8;
+    for (int k0 = 0; k0 < kq; k0 += 32 * U) {   // one trip at K = 1024, two at 2048
+        bf16x8 a[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) a[u] = *reinterpret_cast<const bf16x8*>(wrow + k0 + 32 * u);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int rb = 0; rb < ROWS; ++rb) {
+                const bf16x8 b = *reinterpret_cast<const bf16x8*>(xrow + (int64_t)rb * 16 * K + k0 + 32 * u);
+                acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u], b, acc[rb], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int rb = 0; rb < ROWS; ++rb) part[wave][rb][lane] = acc[rb];
+    __syncthreads();
+    if (wave != 0) return;
+    // token m = 16 rb + i, features n0 + 4 g + {0..3}
+    const int n = n0 + 4 * g;
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n);
+#pragma unroll
+    for (int rb = 0; rb < ROWS; ++rb) {
+        const int m = 16 * rb + i;
+        if (m >= M) continue;
+        f32x4 v = ((part[0][rb][lane] + part[1][rb][lane]) + part[2][rb][lane]) + part[3][rb][lane];
+        v += bv;
+        if (EPI == 1) {
+            const uint2 r = *reinterpret_cast<const uint2*>(residual + (int64_t)m * N + n);
+            v.x += bf16_to_f32((u16)(r.x & 0xffff));
+            v.y += bf16_to_f32((u16)(r.x >> 16));
+            v.z += bf16_to_f32((u16)(r.y & 0xffff));
+            v.w += bf16_to_f32((u16)(r.y >> 16));
+        }
+        if (EPI == 2) {
+            v.x = gelu_erf(v.x);
+            v.y = gelu_erf(v.y);
+            v.z = gelu_erf(v.z);
+            v.w = gelu_erf(v.w);
+        }
+        uint2 o;
+        o.x = (unsigned)f32_to_bf16(v.x) | ((unsigned)f32_to_bf16(v.y) << 16);
+        o.y = (unsigned)f32_to_bf16(v.z) | ((unsigned)f32_to_bf16(v.w) << 16);
+        *reinterpret_cast<uint2*>(Y + (int64_t)m * N + n) = o;
+    }
+}
+
+// tokens <= 64, a matrix wide enough for >= 128 workgroups, K = whole 256-deep trips per wave and short enough
+static bool fewrows_ok(int M, int N, int K) { return M >= 1 && M <= 64 && N % 16 == 0 && N >= 2048 && K % 1024 == 0 && K <= 2048; }
+
+static bool fewrows_enabled() {  // RASS_GEMM_FEWROWS=0: the split-K pair instead (A/B; read per launch)
+    const char* v = getenv("RASS_GEMM_FEWROWS");
+    return !(v && v[0] == '0');
+}
+
+template <int EPI>
+static hipError_t launch_fewrows(const u16* x, const u16* w, const float* bias, const u16* r, u16* y, int M, int N, int K,
+                                 hipStream_t stream) {
+    const dim3 grid(N / 16), block(256);
+    switch ((M + 15) / 16) {
+        case 1: hipLaunchKernelGGL((gemm_bf16_fewrows_kernel<EPI, 1>), grid, block, 0, stream, x, w, bias, r, y, M, N, K); break;
+        case 2: hipLaunchKernelGGL((gemm_bf16_fewrows_kernel<EPI, 2>), grid, block, 0, stream, x, w, bias, r, y, M, N, K); break;
+        case 3: hipLaunchKernelGGL((gemm_bf16_fewrows_kernel<EPI, 3>), grid, block, 0, stream, x, w, bias, r, y, M, N, K); break;
+        default: hipLaunchKernelGGL((gemm_bf16_fewrows_kernel<EPI, 4>), grid, block, 0, stream, x, w, bias, r, y, M, N, K); break;
+    }
+    return hipGetLastError();
+}
+
 // Number of K slices for a GEMM with few output tiles (0 = do not split): aim at >= 128 workgroups, at most 16 slices, whole
 // 64-deep steps per slice, and a scratch of S * M_pad * N floats that fits.
 static int splitk_slices(int M_pad, int N, int K, size_t ws_bytes) {
@@ -1848,6 +1941,15 @@ hipError_t launch_gemm_bf16(const void* X, const void* W, const float* bias, con
     const u16* r = static_cast<const u16*>(residual);
     u16* y = static_cast<u16*>(Y);
     if (epilogue < 0 || epilogue > 2 || (epilogue == 1 && !r)) return hipErrorInvalidValue;
+    // a few rows against a wide matrix: one launch, epilogue included (query-time embedding; chosen with the scratch
+    // lent, i.e. on the same calls that would otherwise be split over K)
+    if (splitk_ws != nullptr && fewrows_ok(M, N, K) && M_pad >= 64 && fewrows_enabled()) {
+        switch (epilogue) {
+            case 0: return launch_fewrows<0>(x, w, bias, r, y, M, N, K, stream);
+            case 1: return launch_fewrows<1>(x, w, bias, r, y, M, N, K, stream);
+            default: return launch_fewrows<2>(x, w, bias, r, y, M, N, K, stream);
+        }
+    }
     // few rows: split K over more workgroups (the caller lends the fp32 scratch)
     if (splitk_ws != nullptr && M_pad % GBM == 0 && N % GBN == 0 && K % GBK == 0) {
         const int mp = (M + GBM - 1) / GBM * GBM;   // whole 128-row tiles that hold real rows (<= M_pad)

@@ -100,13 +100,18 @@ def test_gemm_forced_variants_on_few_tiles(gpu, variant):
     assert "VARIANT_OK" in out.stdout, (out.stdout[-500:], out.stderr[-1500:])
 
 
+@pytest.mark.parametrize("fewrows", ["1", "0"])
 @pytest.mark.parametrize("M,N,K,epi", [(1, 1024, 1024, 1), (16, 3072, 1024, 0), (37, 4096, 1024, 2), (100, 1024, 4096, 1),
                                        (129, 1024, 4096, 1), (200, 128, 128, 0), (256, 384, 512, 2),
-                                       (1300, 1024, 1024, 1), (700, 1024, 4096, 0)])
-def test_gemm_split_k_for_few_rows(gpu, M, N, K, epi):
-    """The query-time path (rass_gemm_bf16_ws: K split over workgroups, slices summed in fixed order) against torch,
-    and bit-identical from run to run (no atomics)."""
+                                       (1300, 1024, 1024, 1), (700, 1024, 4096, 0),
+                                       # a few rows against a wide matrix: the one-launch kernel (one wave per 16 features)
+                                       (1, 3072, 1024, 0), (64, 2048, 2048, 1), (49, 4096, 1024, 2), (17, 2048, 1024, 1)])
+def test_gemm_split_k_for_few_rows(gpu, M, N, K, epi, fewrows, monkeypatch):
+    """The query-time paths (rass_gemm_bf16_ws) against torch, bit-identical from run to run (no atomics): K split over
+    workgroups with the slices summed in fixed order, and — tokens <= 64, N >= 2048, K <= 2048 — the one-launch kernel
+    (RASS_GEMM_FEWROWS=0, read per launch, keeps the split-K pair for those shapes too)."""
     torch = gpu
+    monkeypatch.setenv("RASS_GEMM_FEWROWS", fewrows)
     from rassengine_amd import _native as N_
     g = torch.Generator(device="cuda")
     g.manual_seed(M * 11 + N + K + epi)

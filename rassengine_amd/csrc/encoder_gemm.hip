@@ -289,26 +289,26 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __res
 // flight — and applies the epilogue itself; N / 16 >= 128 waves stream the matrix.  Every launch of a one-query forward
 // costs ~5 us whatever it does (a hipGraph replay does not change that), so the two launches saved per layer are a
 // fifth of the forward.  ROWS = number of 16-token blocks (tokens <= 64).
-template <int EPI, int ROWS>
-__global__ __launch_bounds__(256) void gemm_bf16_fewrows_kernel(const u16* __restrict__ X, const u16* __restrict__ W,
+template <int EPI, int ROWS, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void gemm_bf16_fewrows_kernel(const u16* __restrict__ X, const u16* __restrict__ W,
                                                                 const float* __restrict__ bias,
                                                                 const u16* __restrict__ residual, u16* __restrict__ Y,
                                                                 int M, int N, int K) {
-    // a workgroup = 16 output features; its four waves take a quarter of K each (every weight load of the wave in
-    // flight at once: K / 4 / 32 <= 16 loads of 16 B per lane), then wave 0 adds the four partial tiles in wave order
-    __shared__ f32x4 part[4][ROWS][64];
+    // a workgroup = 16 output features; its WAVES (4, or 16 for K >= 4096) waves take an equal share of K each (8 weight
+    // loads of 16 B per lane in flight per trip), then wave 0 adds the partial tiles in wave order
+    __shared__ f32x4 part[WAVES][ROWS][64];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int n0 = blockIdx.x * 16;
     const int g = lane >> 4, i = lane & 15;
-    const int kq = K / 4, k_lo = wave * kq;
+    const int kq = K / WAVES, k_lo = wave * kq;
     const u16* wrow = W + (int64_t)(n0 + i) * K + k_lo + 8 * g;   // A operand: W[n0 + i][k_lo + 32 ks + 8 g .. +7]
     const u16* xrow = X + (int64_t)i * K + k_lo + 8 * g;          // B operand: X[16 rb + i][..] (rows < M_pad exist)
     f32x4 acc[ROWS];
 #pragma unroll
     for (int rb = 0; rb < ROWS; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
     constexpr int U = 8;
-    for (int k0 = 0; k0 < kq; k0 += 32 * U) {   // one trip at K = 1024, two at 2048
+    for (int k0 = 0; k0 < kq; k0 += 32 * U) {   // one trip at K = 1024 (4 waves) and 4096 (16 waves)
         bf16x8 a[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) a[u] = *reinterpret_cast<const bf16x8*>(wrow + k0 + 32 * u);
@@ -332,7 +332,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_fewrows_kernel(const u16* __res
     for (int rb = 0; rb < ROWS; ++rb) {
         const int m = 16 * rb + i;
         if (m >= M) continue;
-        f32x4 v = ((part[0][rb][lane] + part[1][rb][lane]) + part[2][rb][lane]) + part[3][rb][lane];
+        f32x4 v = part[0][rb][lane];
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) v += part[w][rb][lane];
         v += bv;
         if (EPI == 1) {
             const uint2 r = *reinterpret_cast<const uint2*>(residual + (int64_t)m * N + n);
@@ -354,25 +356,44 @@ __global__ __launch_bounds__(256) void gemm_bf16_fewrows_kernel(const u16* __res
     }
 }
 
-// tokens <= 64, a matrix wide enough for >= 128 workgroups, K = whole 256-deep trips per wave and short enough
-static bool fewrows_ok(int M, int N, int K) { return M >= 1 && M <= 64 && N % 16 == 0 && N >= 2048 && K % 1024 == 0 && K <= 2048; }
+// tokens <= 64; K = whole 256-deep trips per wave: 4 waves per workgroup (K <= 3072), 16 for whole multiples of 4096
+static int fewrows_waves(int M, int N, int K) {
+    if (M < 1 || M > 64 || N % 16 != 0 || N < 1024) return 0;
+    if (K % 4096 == 0 && K <= 8192) return 16;
+    if (K % 1024 == 0 && K <= 3072) return 4;
+    return 0;
+}
 
 static bool fewrows_enabled() {  // RASS_GEMM_FEWROWS=0: the split-K pair instead (A/B; read per launch)
     const char* v = getenv("RASS_GEMM_FEWROWS");
     return !(v && v[0] == '0');
 }
 
-template <int EPI>
-static hipError_t launch_fewrows(const u16* x, const u16* w, const float* bias, const u16* r, u16* y, int M, int N, int K,
-                                 hipStream_t stream) {
-    const dim3 grid(N / 16), block(256);
+// the residual GEMMs (N = hidden) take the one-launch kernel only for the fewest rows: from 3 row blocks on the split-K
+// pair is faster (measured at 48 and 64 tokens); RASS_GEMM_FEWROWS_RES=<rows> moves the limit (A/B)
+static int fewrows_residual_max_rows() {
+    const char* v = getenv("RASS_GEMM_FEWROWS_RES");
+    return v ? atoi(v) : 16;
+}
+
+template <int EPI, int WAVES>
+static hipError_t launch_fewrows_w(const u16* x, const u16* w, const float* bias, const u16* r, u16* y, int M, int N, int K,
+                                   hipStream_t stream) {
+    const dim3 grid(N / 16), block(64 * WAVES);
     switch ((M + 15) / 16) {
-        case 1: hipLaunchKernelGGL((gemm_bf16_fewrows_kernel<EPI, 1>), grid, block, 0, stream, x, w, bias, r, y, M, N, K); break;
-        case 2: hipLaunchKernelGGL((gemm_bf16_fewrows_kernel<EPI, 2>), grid, block, 0, stream, x, w, bias, r, y, M, N, K); break;
-        case 3: hipLaunchKernelGGL((gemm_bf16_fewrows_kernel<EPI, 3>), grid, block, 0, stream, x, w, bias, r, y, M, N, K); break;
-        default: hipLaunchKernelGGL((gemm_bf16_fewrows_kernel<EPI, 4>), grid, block, 0, stream, x, w, bias, r, y, M, N, K); break;
+        case 1: hipLaunchKernelGGL((gemm_bf16_fewrows_kernel<EPI, 1, WAVES>), grid, block, 0, stream, x, w, bias, r, y, M, N, K); break;
+        case 2: hipLaunchKernelGGL((gemm_bf16_fewrows_kernel<EPI, 2, WAVES>), grid, block, 0, stream, x, w, bias, r, y, M, N, K); break;
+        case 3: hipLaunchKernelGGL((gemm_bf16_fewrows_kernel<EPI, 3, WAVES>), grid, block, 0, stream, x, w, bias, r, y, M, N, K); break;
+        default: hipLaunchKernelGGL((gemm_bf16_fewrows_kernel<EPI, 4, WAVES>), grid, block, 0, stream, x, w, bias, r, y, M, N, K); break;
     }
     return hipGetLastError();
+}
+
+template <int EPI>
+static hipError_t launch_fewrows(const u16* x, const u16* w, const float* bias, const u16* r, u16* y, int M, int N, int K,
+                                 int waves, hipStream_t stream) {
+    return waves == 16 ? launch_fewrows_w<EPI, 16>(x, w, bias, r, y, M, N, K, stream)
+                       : launch_fewrows_w<EPI, 4>(x, w, bias, r, y, M, N, K, stream);
 }
 
 // Number of K slices for a GEMM with few output tiles (0 = do not split): aim at >= 128 workgroups, at most 16 slices, whole
@@ -1943,11 +1964,11 @@ hipError_t launch_gemm_bf16(const void* X, const void* W, const float* bias, con
     if (epilogue < 0 || epilogue > 2 || (epilogue == 1 && !r)) return hipErrorInvalidValue;
     // a few rows against a wide matrix: one launch, epilogue included (query-time embedding; chosen with the scratch
     // lent, i.e. on the same calls that would otherwise be split over K)
-    if (splitk_ws != nullptr && fewrows_ok(M, N, K) && M_pad >= 64 && fewrows_enabled()) {
+    if (const int fw = splitk_ws != nullptr && M_pad >= 64 && fewrows_enabled() ? fewrows_waves(M, N, K) : 0) {
         switch (epilogue) {
-            case 0: return launch_fewrows<0>(x, w, bias, r, y, M, N, K, stream);
-            case 1: return launch_fewrows<1>(x, w, bias, r, y, M, N, K, stream);
-            default: return launch_fewrows<2>(x, w, bias, r, y, M, N, K, stream);
+            case 0: return launch_fewrows<0>(x, w, bias, r, y, M, N, K, fw, stream);
+            case 1: return launch_fewrows<1>(x, w, bias, r, y, M, N, K, fw, stream);
+            default: return launch_fewrows<2>(x, w, bias, r, y, M, N, K, fw, stream);
         }
     }
     // few rows: split K over more workgroups (the caller lends the fp32 scratch)
@@ -1991,6 +2012,13 @@ hipError_t launch_gemm_bf16_residual_layernorm(const void* X, const void* W, con
                                                size_t splitk_ws_bytes) {
     if (M < 0 || M_pad < M || N <= 0 || K <= 0 || !residual) return hipErrorInvalidValue;
     if (M == 0) return hipSuccess;
+    // a query's few rows: the one-launch GEMM (bias + residual in its epilogue) and the row-wise LayerNorm — two launches
+    // like the split-K pair below, but 5 + 5 us where that pair takes 6 + 7.4 (16 slices read back by 16 waves)
+    if (splitk_ws != nullptr && M_pad >= 64 && fewrows_enabled() && M <= fewrows_residual_max_rows() && fewrows_waves(M, N, K) != 0) {
+        hipError_t e = launch_gemm_bf16(X, W, bias, residual, y, M, M_pad, N, K, 1, stream, splitk_ws, splitk_ws_bytes);
+        if (e != hipSuccess) return e;
+        return launch_layernorm(y, gamma, beta, eps, M, N, out, stream);
+    }
     if (splitk_ws != nullptr && M_pad % GBM == 0 && N % GBN == 0 && K % GBK == 0 && N % 8 == 0 && N <= 2048) {
         const int mp = (M + GBM - 1) / GBM * GBM;
         const int S = splitk_slices(mp, N, K, splitk_ws_bytes);

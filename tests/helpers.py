@@ -1,5 +1,7 @@
 """Test doubles: a CPU stand-in for FlatIndex (oracle-backed) so the host-side shim logic
 can be exercised without a GPU.  Lives under tests/ — never imported by the product."""
+import zlib
+
 import numpy as np
 
 from oracle import oracle as O
@@ -57,7 +59,7 @@ class HashEmbedder:
         out = np.zeros((len(texts), self.dim), dtype=np.float32)
         for r, t in enumerate(texts):
             for w in t.lower().split():
-                rng = np.random.default_rng(abs(hash(w)) % (2 ** 32))
+                rng = np.random.default_rng(zlib.crc32(w.encode("utf-8")))   # not hash(): that is salted per process
                 out[r] += rng.standard_normal(self.dim).astype(np.float32)
         return out * 3.0  # deliberately un-normalised
 

@@ -105,7 +105,8 @@ def test_gemm_forced_variants_on_few_tiles(gpu, variant):
                                        (129, 1024, 4096, 1), (200, 128, 128, 0), (256, 384, 512, 2),
                                        (1300, 1024, 1024, 1), (700, 1024, 4096, 0),
                                        # a few rows against a wide matrix: the one-launch kernel (one wave per 16 features)
-                                       (1, 3072, 1024, 0), (64, 2048, 2048, 1), (49, 4096, 1024, 2), (17, 2048, 1024, 1)])
+                                       (1, 3072, 1024, 0), (64, 2048, 2048, 1), (49, 4096, 1024, 2), (17, 2048, 1024, 1),
+                                       (33, 1024, 4096, 1), (64, 1024, 8192, 0), (5, 1024, 3072, 2)])
 def test_gemm_split_k_for_few_rows(gpu, M, N, K, epi, fewrows, monkeypatch):
     """The query-time paths (rass_gemm_bf16_ws) against torch, bit-identical from run to run (no atomics): K split over
     workgroups with the slices summed in fixed order, and — tokens <= 64, N >= 2048, K <= 2048 — the one-launch kernel

@@ -106,7 +106,12 @@ def test_every_intent_of_ask_on_the_hip_index(gpu, oracle):
         texts = [d["unstructuredText"] for d in docs + [twin]]
         xn = oracle.normalize_ref(asyncio.run(embedding.embed_texts_in_batches(texts))).astype(np.float32)
         rs, ri = oracle.search(xn, oracle.normalize_ref(q).astype(np.float32), 150)
-        assert [d["doc_id"] for d, _ in big] == [(docs + [twin])[i]["doc_id"] for i in ri[0]]
+        # the oracle's order; two rows may only trade places if their scores are a rounding apart (the GPU's normalise is
+        # within 2 ulp of numpy's).  The texts' vectors come from crc32-seeded words: the same in every process.
+        want = [(docs + [twin])[i]["doc_id"] for i in ri[0]]
+        score_of = dict(zip(want, rs[0]))
+        for got_doc, want_doc in zip([d["doc_id"] for d, _ in big], want):
+            assert got_doc == want_doc or abs(score_of[got_doc] - score_of[want_doc]) <= 4e-6, (got_doc, want_doc)
     finally:
         embedding.set_embedder(None)
         REGISTRY.set_index_factory(None)

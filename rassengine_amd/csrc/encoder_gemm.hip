@@ -293,7 +293,10 @@ template <int EPI, int ROWS, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void gemm_bf16_fewrows_kernel(const u16* __restrict__ X, const u16* __restrict__ W,
                                                                 const float* __restrict__ bias,
                                                                 const u16* __restrict__ residual, u16* __restrict__ Y,
-                                                                int M, int N, int K) {
+                                                                int M, int N, int K, float* __restrict__ partial,
+                                                                int rows_pad) {
+    // EPI = -1: K is also cut over gridDim.y workgroups; each writes its fp32 partial tile [slice][rows_pad][N] and the
+    // fused reduce + residual + LayerNorm kernel follows (FFN-down: K = 4096 needs more than 64 workgroups)
     // a workgroup = 16 output features; its WAVES (4, or 16 for K >= 4096) waves take an equal share of K each (8 weight
     // loads of 16 B per lane in flight per trip), then wave 0 adds the partial tiles in wave order
     __shared__ f32x4 part[WAVES][ROWS][64];
@@ -301,7 +304,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_bf16_fewrows_kernel(const u16
     const int wave = threadIdx.x >> 6;
     const int n0 = blockIdx.x * 16;
     const int g = lane >> 4, i = lane & 15;
-    const int kq = K / WAVES, k_lo = wave * kq;
+    const int kq = K / (WAVES * (int)gridDim.y), k_lo = ((int)blockIdx.y * WAVES + wave) * kq;
     const u16* wrow = W + (int64_t)(n0 + i) * K + k_lo + 8 * g;   // A operand: W[n0 + i][k_lo + 32 ks + 8 g .. +7]
     const u16* xrow = X + (int64_t)i * K + k_lo + 8 * g;          // B operand: X[16 rb + i][..] (rows < M_pad exist)
     f32x4 acc[ROWS];
@@ -327,7 +330,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_bf16_fewrows_kernel(const u16
     if (wave != 0) return;
     // token m = 16 rb + i, features n0 + 4 g + {0..3}
     const int n = n0 + 4 * g;
-    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n);
+    const f32x4 bv = EPI < 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(bias + n);
 #pragma unroll
     for (int rb = 0; rb < ROWS; ++rb) {
         const int m = 16 * rb + i;
@@ -335,6 +338,10 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_bf16_fewrows_kernel(const u16
         f32x4 v = part[0][rb][lane];
 #pragma unroll
         for (int w = 1; w < WAVES; ++w) v += part[w][rb][lane];
+        if constexpr (EPI < 0) {
+            *reinterpret_cast<f32x4*>(partial + ((int64_t)blockIdx.y * rows_pad + m) * N + n) = v;
+            continue;
+        }
         v += bv;
         if (EPI == 1) {
             const uint2 r = *reinterpret_cast<const uint2*>(residual + (int64_t)m * N + n);
@@ -378,13 +385,13 @@ static int fewrows_residual_max_rows() {
 
 template <int EPI, int WAVES>
 static hipError_t launch_fewrows_w(const u16* x, const u16* w, const float* bias, const u16* r, u16* y, int M, int N, int K,
-                                   hipStream_t stream) {
-    const dim3 grid(N / 16), block(64 * WAVES);
+                                   hipStream_t stream, float* partial = nullptr, int rows_pad = 0, int slices = 1) {
+    const dim3 grid(N / 16, slices), block(64 * WAVES);
     switch ((M + 15) / 16) {
-        case 1: hipLaunchKernelGGL((gemm_bf16_fewrows_kernel<EPI, 1, WAVES>), grid, block, 0, stream, x, w, bias, r, y, M, N, K); break;
-        case 2: hipLaunchKernelGGL((gemm_bf16_fewrows_kernel<EPI, 2, WAVES>), grid, block, 0, stream, x, w, bias, r, y, M, N, K); break;
-        case 3: hipLaunchKernelGGL((gemm_bf16_fewrows_kernel<EPI, 3, WAVES>), grid, block, 0, stream, x, w, bias, r, y, M, N, K); break;
-        default: hipLaunchKernelGGL((gemm_bf16_fewrows_kernel<EPI, 4, WAVES>), grid, block, 0, stream, x, w, bias, r, y, M, N, K); break;
+        case 1: hipLaunchKernelGGL((gemm_bf16_fewrows_kernel<EPI, 1, WAVES>), grid, block, 0, stream, x, w, bias, r, y, M, N, K, partial, rows_pad); break;
+        case 2: hipLaunchKernelGGL((gemm_bf16_fewrows_kernel<EPI, 2, WAVES>), grid, block, 0, stream, x, w, bias, r, y, M, N, K, partial, rows_pad); break;
+        case 3: hipLaunchKernelGGL((gemm_bf16_fewrows_kernel<EPI, 3, WAVES>), grid, block, 0, stream, x, w, bias, r, y, M, N, K, partial, rows_pad); break;
+        default: hipLaunchKernelGGL((gemm_bf16_fewrows_kernel<EPI, 4, WAVES>), grid, block, 0, stream, x, w, bias, r, y, M, N, K, partial, rows_pad); break;
     }
     return hipGetLastError();
 }
@@ -2015,6 +2022,14 @@ hipError_t launch_gemm_bf16_residual_layernorm(const void* X, const void* W, con
     // a query's few rows: the one-launch GEMM (bias + residual in its epilogue) and the row-wise LayerNorm — two launches
     // like the split-K pair below, but 5 + 5 us where that pair takes 6 + 7.4 (16 slices read back by 16 waves)
     if (splitk_ws != nullptr && M_pad >= 64 && fewrows_enabled() && M <= fewrows_residual_max_rows() && fewrows_waves(M, N, K) != 0) {
+        // K = 4096 (FFN-down): 64 workgroups of 16 waves took 9.4 us; 4 x 64 workgroups of 4 waves write partial tiles and
+        // the fused reduce + residual + LayerNorm kernel (4 slices) follows
+        if (K % 4096 == 0 && K / 4 <= 3072 && N % 8 == 0 && N <= 2048 && (size_t)4 * 64 * N * sizeof(float) <= splitk_ws_bytes) {
+            hipError_t e = launch_fewrows_w<-1, 4>(static_cast<const u16*>(X), static_cast<const u16*>(W), nullptr, nullptr,
+                                                   nullptr, M, N, K, stream, splitk_ws, 64, 4);
+            if (e != hipSuccess) return e;
+            return launch_splitk_residual_layernorm(splitk_ws, 4, M, 64, N, bias, residual, gamma, beta, eps, out, stream);
+        }
         hipError_t e = launch_gemm_bf16(X, W, bias, residual, y, M, M_pad, N, K, 1, stream, splitk_ws, splitk_ws_bytes);
         if (e != hipSuccess) return e;
         return launch_layernorm(y, gamma, beta, eps, M, N, out, stream);

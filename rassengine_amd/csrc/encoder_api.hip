@@ -179,10 +179,17 @@ int forward(rass_encoder* e, const int32_t* d_ids, const int32_t* d_cu, int nseq
         EHIP_TRY(rass::launch_attention(e->qkv, d_cu, nseq, total, max_seqlen, H, c.heads, e->ctx, st));
         // attn-out + residual + LayerNorm; the residual (e->x) is also the output: every row is read before it is written
         // (a wave owns a row), and the big-batch form goes through e->y
-        EHIP_TRY(rass::launch_gemm_bf16_residual_layernorm(e->ctx, L.w_o, L.b_o, e->x, e->y, L.ln1_g, L.ln1_b,
-                                                           c.layer_norm_eps, e->x, total, Tp, H, H, st, e->d_splitk,
-                                                           e->splitk_bytes));
-        EHIP_TRY(rass::launch_gemm_bf16(e->x, L.w_up, L.b_up, nullptr, e->h, total, Tp, I, H, 2, st, e->d_splitk, e->splitk_bytes));
+        if (rass::gemm_bf16_ln_input_ok(total, I, H)) {
+            // a query: y = ctx W_o^T + b_o + x, then FFN-up normalises y itself (and stores x = LayerNorm(y) once)
+            EHIP_TRY(rass::launch_gemm_bf16(e->ctx, L.w_o, L.b_o, e->x, e->y, total, Tp, H, H, 1, st, e->d_splitk, e->splitk_bytes));
+            EHIP_TRY(rass::launch_gemm_bf16_ln_input(e->y, L.ln1_g, L.ln1_b, c.layer_norm_eps, e->x, L.w_up, L.b_up, e->h,
+                                                     total, I, H, 2, st));
+        } else {
+            EHIP_TRY(rass::launch_gemm_bf16_residual_layernorm(e->ctx, L.w_o, L.b_o, e->x, e->y, L.ln1_g, L.ln1_b,
+                                                               c.layer_norm_eps, e->x, total, Tp, H, H, st, e->d_splitk,
+                                                               e->splitk_bytes));
+            EHIP_TRY(rass::launch_gemm_bf16(e->x, L.w_up, L.b_up, nullptr, e->h, total, Tp, I, H, 2, st, e->d_splitk, e->splitk_bytes));
+        }
         EHIP_TRY(rass::launch_gemm_bf16_residual_layernorm(e->h, L.w_down, L.b_down, e->x, e->y, L.ln2_g, L.ln2_b,
                                                            c.layer_norm_eps, e->x, total, Tp, H, I, st, e->d_splitk,
                                                            e->splitk_bytes));

@@ -363,6 +363,125 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_bf16_fewrows_kernel(const u16
     }
 }
 
+// The few-rows GEMM whose input is LayerNorm(Yin), recomputed by EVERY workgroup into its LDS X tile (<= 16 rows of
+// K = 1024: 32 KiB of L2 reads, issued behind the weight loads already in flight) instead of a LayerNorm launch in
+// front: a launch costs ~4 us here whatever it does.  Workgroup 0 also stores the normalised rows (x_out: the next
+// residual).  The row arithmetic is layernorm_kernel's (wave per row, lane = 8 columns + 512 s, fp32 two-pass,
+// xor-shuffle sums), so x_out has the bits the separate launch would have written.
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_bf16_lnin_kernel(const u16* __restrict__ Yin, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float eps,
+                                                             u16* __restrict__ x_out, const u16* __restrict__ W,
+                                                             const float* __restrict__ bias, u16* __restrict__ Y, int M,
+                                                             int N) {
+    constexpr int K = 1024, kPitch = K + 8;   // + 16 B: the 16 rows of a B fragment fall on different banks
+    __shared__ __attribute__((aligned(16))) u16 xs[16][kPitch];
+    __shared__ f32x4 part[4][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int n0 = blockIdx.x * 16;
+    const int g = lane >> 4, i = lane & 15;
+    const int k_lo = wave * (K / 4);
+    const u16* wrow = W + (int64_t)(n0 + i) * K + k_lo + 8 * g;
+    bf16x8 a[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] = *reinterpret_cast<const bf16x8*>(wrow + 32 * u);
+    // rows wave, wave + 4, wave + 8, wave + 12: all their loads first
+    uint4 raw[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = wave + 4 * j;
+        const int rc = r < M ? r : 0;
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+            raw[j][st] = *reinterpret_cast<const uint4*>(Yin + (int64_t)rc * K + lane * 8 + 512 * st);
+    }
+    f32x4 gm[2][2], bt[2][2];
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        const int c = lane * 8 + 512 * st;
+        gm[st][0] = *reinterpret_cast<const f32x4*>(gamma + c);
+        gm[st][1] = *reinterpret_cast<const f32x4*>(gamma + c + 4);
+        bt[st][0] = *reinterpret_cast<const f32x4*>(beta + c);
+        bt[st][1] = *reinterpret_cast<const f32x4*>(beta + c + 4);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = wave + 4 * j;
+        float x[2][8];
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            x[st][0] = bf16_to_f32((u16)(raw[j][st].x & 0xffff)); x[st][1] = bf16_to_f32((u16)(raw[j][st].x >> 16));
+            x[st][2] = bf16_to_f32((u16)(raw[j][st].y & 0xffff)); x[st][3] = bf16_to_f32((u16)(raw[j][st].y >> 16));
+            x[st][4] = bf16_to_f32((u16)(raw[j][st].z & 0xffff)); x[st][5] = bf16_to_f32((u16)(raw[j][st].z >> 16));
+            x[st][6] = bf16_to_f32((u16)(raw[j][st].w & 0xffff)); x[st][7] = bf16_to_f32((u16)(raw[j][st].w >> 16));
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sum += x[st][e];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+        const float mean = sum / (float)K;
+        float sq = 0.f;
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = x[st][e] - mean;
+                sq = fmaf(d, d, sq);
+            }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
+        const float rstd = rsqrtf(sq / (float)K + eps);
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const int c = lane * 8 + 512 * st;
+            float o[8];
+            o[0] = (x[st][0] - mean) * rstd * gm[st][0].x + bt[st][0].x;
+            o[1] = (x[st][1] - mean) * rstd * gm[st][0].y + bt[st][0].y;
+            o[2] = (x[st][2] - mean) * rstd * gm[st][0].z + bt[st][0].z;
+            o[3] = (x[st][3] - mean) * rstd * gm[st][0].w + bt[st][0].w;
+            o[4] = (x[st][4] - mean) * rstd * gm[st][1].x + bt[st][1].x;
+            o[5] = (x[st][5] - mean) * rstd * gm[st][1].y + bt[st][1].y;
+            o[6] = (x[st][6] - mean) * rstd * gm[st][1].z + bt[st][1].z;
+            o[7] = (x[st][7] - mean) * rstd * gm[st][1].w + bt[st][1].w;
+            uint4 pk;
+            pk.x = (unsigned)f32_to_bf16(o[0]) | ((unsigned)f32_to_bf16(o[1]) << 16);
+            pk.y = (unsigned)f32_to_bf16(o[2]) | ((unsigned)f32_to_bf16(o[3]) << 16);
+            pk.z = (unsigned)f32_to_bf16(o[4]) | ((unsigned)f32_to_bf16(o[5]) << 16);
+            pk.w = (unsigned)f32_to_bf16(o[6]) | ((unsigned)f32_to_bf16(o[7]) << 16);
+            if (r >= M) pk = make_uint4(0, 0, 0, 0);   // rows past the batch: finite zeros in the operand tile
+            *reinterpret_cast<uint4*>(&xs[r][c]) = pk;
+            if (blockIdx.x == 0 && r < M) *reinterpret_cast<uint4*>(x_out + (int64_t)r * K + c) = pk;
+        }
+    }
+    __syncthreads();
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const bf16x8 b = *reinterpret_cast<const bf16x8*>(&xs[i][k_lo + 32 * u + 8 * g]);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u], b, acc, 0, 0, 0);
+    }
+    part[wave][lane] = acc;
+    __syncthreads();
+    if (wave != 0 || i >= M) return;
+    const int n = n0 + 4 * g;
+    f32x4 v = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+    v += *reinterpret_cast<const f32x4*>(bias + n);
+    if (EPI == 2) {
+        v.x = gelu_erf(v.x);
+        v.y = gelu_erf(v.y);
+        v.z = gelu_erf(v.z);
+        v.w = gelu_erf(v.w);
+    }
+    uint2 o;
+    o.x = (unsigned)f32_to_bf16(v.x) | ((unsigned)f32_to_bf16(v.y) << 16);
+    o.y = (unsigned)f32_to_bf16(v.z) | ((unsigned)f32_to_bf16(v.w) << 16);
+    *reinterpret_cast<uint2*>(Y + (int64_t)i * N + n) = o;
+}
+
 // tokens <= 64; K = whole 256-deep trips per wave: 4 waves per workgroup (K <= 3072), 16 for whole multiples of 4096
 static int fewrows_waves(int M, int N, int K) {
     if (M < 1 || M > 64 || N % 16 != 0 || N < 1024) return 0;
@@ -2052,6 +2171,24 @@ hipError_t launch_gemm_bf16_residual_layernorm(const void* X, const void* W, con
     hipError_t e = launch_gemm_bf16(X, W, bias, residual, y, M, M_pad, N, K, 1, stream, splitk_ws, splitk_ws_bytes);
     if (e != hipSuccess) return e;
     return launch_layernorm(y, gamma, beta, eps, M, N, out, stream);
+}
+
+bool gemm_bf16_ln_input_ok(int M, int N, int K) {
+    return M >= 1 && M <= 16 && K == 1024 && N % 16 == 0 && N >= 1024 && fewrows_enabled();
+}
+
+hipError_t launch_gemm_bf16_ln_input(const void* Yin, const float* gamma, const float* beta, float eps, void* x_out,
+                                     const void* W, const float* bias, void* Y, int M, int N, int K, int epilogue,
+                                     hipStream_t stream) {
+    if (!gemm_bf16_ln_input_ok(M, N, K) || (epilogue != 0 && epilogue != 2)) return hipErrorInvalidValue;
+    const dim3 grid(N / 16), block(256);
+    if (epilogue == 0)
+        hipLaunchKernelGGL(gemm_bf16_lnin_kernel<0>, grid, block, 0, stream, static_cast<const u16*>(Yin), gamma, beta, eps,
+                           static_cast<u16*>(x_out), static_cast<const u16*>(W), bias, static_cast<u16*>(Y), M, N);
+    else
+        hipLaunchKernelGGL(gemm_bf16_lnin_kernel<2>, grid, block, 0, stream, static_cast<const u16*>(Yin), gamma, beta, eps,
+                           static_cast<u16*>(x_out), static_cast<const u16*>(W), bias, static_cast<u16*>(Y), M, N);
+    return hipGetLastError();
 }
 
 }  // namespace rass

@@ -23,6 +23,13 @@ hipError_t launch_gemm_bf16_residual_layernorm(const void* X, const void* W, con
                                                void* y, const float* gamma, const float* beta, float eps, void* out,
                                                int M, int M_pad, int N, int K, hipStream_t stream, float* splitk_ws,
                                                size_t splitk_ws_bytes);
+// A query's few rows (M <= 16, K = 1024): Y = epilogue(LayerNorm(Yin) W^T + bias), epilogue 0 bias / 2 bias + GELU, with
+// the LayerNorm recomputed by every workgroup into its operand tile (one launch less than layernorm + GEMM; a launch
+// costs ~4 us whatever it does) and stored once to x_out (the bits launch_layernorm would write).
+bool gemm_bf16_ln_input_ok(int M, int N, int K);
+hipError_t launch_gemm_bf16_ln_input(const void* Yin, const float* gamma, const float* beta, float eps, void* x_out,
+                                     const void* W, const float* bias, void* Y, int M, int N, int K, int epilogue,
+                                     hipStream_t stream);
 hipError_t launch_splitk_residual_layernorm(const float* partial, int S, int rows, int rows_pad, int hidden,
                                             const float* bias, const void* residual, const float* gamma,
                                             const float* beta, float eps, void* out, hipStream_t stream);

@@ -583,12 +583,13 @@ hipError_t launch_attention(const void* qkv, const int32_t* cu_seqlens, int nseq
     if (hidden != heads * kHeadDim || max_seqlen < 1 || max_seqlen > 512 || total_tokens < 0) return hipErrorInvalidValue;
     if (nseq <= 0 || total_tokens == 0) return hipSuccess;
     const int s_pad = (max_seqlen + 63) / 64 * 64;
-    // Mostly-long sequences (mean >= 384 tokens): the 32x32-tile persistent kernel (256 x 512: 396-405 us against 480).  Short or very
-    // ragged batches keep the 16x16 kernel: 16 queries per wave fill a CU from 256 tokens on, and its one workgroup
-    // per item is balanced by the dispatcher (measured equal on lengths uniform in 64..512, 3 % ahead on 32 x 64 and
-    // on one 16-token query).  RASS_ATTN_VARIANT=w8 / w16 forces one (tests, A/B).
+    // Mostly-long sequences (mean >= 320 tokens): the 32x32-tile persistent kernel (256 x 512: 396-405 us against 480;
+    // lengths ~ N(420, 60): 341 against 387; N(340, 80): 286 against 298).  Short or very ragged batches keep the 16x16
+    // kernel: 16 queries per wave fill a CU from 256 tokens on, and its one workgroup per item is balanced by the
+    // dispatcher (equal at a mean of 256-300 tokens, 9 % ahead at 192, 50 % at 128, 3 % on one 16-token query).
+    // RASS_ATTN_VARIANT=w8 / w16 forces one (tests, A/B).
     const char* variant = attn_variant();
-    const bool long_rows = (long long)total_tokens >= 384LL * nseq;
+    const bool long_rows = (long long)total_tokens >= 320LL * nseq;
     if (strcmp(variant, "w8") == 0 || (long_rows && strcmp(variant, "w16") != 0)) {
         const int s_pad128 = (max_seqlen + 127) / 128 * 128;  // whole 128-row chunks are sent
         const size_t lds_bytes = (size_t)s_pad128 * 256;      // 128 KiB at S = 512

@@ -10,6 +10,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=256)
 ap.add_argument("--seqlen", type=int, default=512)
 ap.add_argument("--varlen", action="store_true")
+ap.add_argument("--normal", default="", help="MEAN:STD of the sequence lengths (clipped to 16..512)")
 ap.add_argument("--heads", type=int, default=16)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--rounds", type=int, default=3)
@@ -17,6 +18,10 @@ ap.add_argument("--variants", default="w8,w16")
 a = ap.parse_args()
 rng = np.random.default_rng(0)
 lens = rng.integers(64, 513, size=a.batch) if a.varlen else np.full(a.batch, a.seqlen)
+if a.normal:
+    mu, sd = (float(v) for v in a.normal.split(":"))
+    lens = np.clip(rng.normal(mu, sd, size=a.batch).round().astype(np.int64), 16, 512)
+    print(f"lengths ~ N({mu}, {sd}) clipped: mean {lens.mean():.0f}, min {lens.min()}, max {lens.max()}", flush=True)
 cu = np.zeros(a.batch + 1, dtype=np.int32); np.cumsum(lens, out=cu[1:])
 T = int(cu[-1]); H = a.heads * 64
 qkv = torch.randn((T, 3 * H), device="cuda").bfloat16()

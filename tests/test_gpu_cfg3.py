@@ -142,7 +142,12 @@ def test_device_handoff_equals_host_path(large):
         torch.cuda.synchronize()
         eng.reset_stream()
         assert first == len(seqs) and dev_idx.rows == len(seqs) + 5
-        assert np.array_equal(dev_idx.get_rows(first, 5), host_idx.get_rows(0, 5))
+        # the right rows at the right ids.  Not bit for bit: which GEMM / attention kernel runs depends on the batch (rows,
+        # mean sequence length), so the same text embedded in another batch agrees to the kernels' tolerance, not to the
+        # bit; the SAME batch gives the same bits (asserted above and in test_gpu_encoder)
+        a, b = dev_idx.get_rows(first, 5), host_idx.get_rows(0, 5)
+        cos = np.sum(a.astype(np.float64) * b, axis=1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
+        assert np.all(cos >= 0.9999), cos
     finally:
         eng.close()
 

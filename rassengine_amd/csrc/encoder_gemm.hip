@@ -368,15 +368,16 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_bf16_fewrows_kernel(const u16
 // front: a launch costs ~4 us here whatever it does.  Workgroup 0 also stores the normalised rows (x_out: the next
 // residual).  The row arithmetic is layernorm_kernel's (wave per row, lane = 8 columns + 512 s, fp32 two-pass,
 // xor-shuffle sums), so x_out has the bits the separate launch would have written.
-template <int EPI>
+template <int EPI, int ROWS>
 __global__ __launch_bounds__(256) void gemm_bf16_lnin_kernel(const u16* __restrict__ Yin, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float eps,
                                                              u16* __restrict__ x_out, const u16* __restrict__ W,
                                                              const float* __restrict__ bias, u16* __restrict__ Y, int M,
                                                              int N) {
     constexpr int K = 1024, kPitch = K + 8;   // + 16 B: the 16 rows of a B fragment fall on different banks
-    __shared__ __attribute__((aligned(16))) u16 xs[16][kPitch];
-    __shared__ f32x4 part[4][64];
+    extern __shared__ __attribute__((aligned(16))) unsigned char lnin_lds[];
+    u16 (*xs)[kPitch] = reinterpret_cast<u16 (*)[kPitch]>(lnin_lds);                       // [16 ROWS][kPitch]
+    f32x4 (*part)[ROWS][64] = reinterpret_cast<f32x4 (*)[ROWS][64]>(lnin_lds + (size_t)16 * ROWS * kPitch * 2);  // [4]
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int n0 = blockIdx.x * 16;
@@ -386,10 +387,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_lnin_kernel(const u16* __restri
     bf16x8 a[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) a[u] = *reinterpret_cast<const bf16x8*>(wrow + 32 * u);
-    // rows wave, wave + 4, wave + 8, wave + 12: all their loads first
-    uint4 raw[4][2];
+    // rows wave, wave + 4, ...: all their loads first
+    constexpr int RPW = 4 * ROWS;   // rows per wave
+    uint4 raw[RPW][2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < RPW; ++j) {
         const int r = wave + 4 * j;
         const int rc = r < M ? r : 0;
 #pragma unroll
@@ -406,7 +408,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_lnin_kernel(const u16* __restri
         bt[st][1] = *reinterpret_cast<const f32x4*>(beta + c + 4);
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < RPW; ++j) {
         const int r = wave + 4 * j;
         float x[2][8];
 #pragma unroll
@@ -458,28 +460,40 @@ __global__ __launch_bounds__(256) void gemm_bf16_lnin_kernel(const u16* __restri
         }
     }
     __syncthreads();
-    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[ROWS];
+#pragma unroll
+    for (int rb = 0; rb < ROWS; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-        const bf16x8 b = *reinterpret_cast<const bf16x8*>(&xs[i][k_lo + 32 * u + 8 * g]);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u], b, acc, 0, 0, 0);
+#pragma unroll
+        for (int rb = 0; rb < ROWS; ++rb) {
+            const bf16x8 b = *reinterpret_cast<const bf16x8*>(&xs[16 * rb + i][k_lo + 32 * u + 8 * g]);
+            acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u], b, acc[rb], 0, 0, 0);
+        }
     }
-    part[wave][lane] = acc;
+#pragma unroll
+    for (int rb = 0; rb < ROWS; ++rb) part[wave][rb][lane] = acc[rb];
     __syncthreads();
-    if (wave != 0 || i >= M) return;
+    if (wave != 0) return;
     const int n = n0 + 4 * g;
-    f32x4 v = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
-    v += *reinterpret_cast<const f32x4*>(bias + n);
-    if (EPI == 2) {
-        v.x = gelu_erf(v.x);
-        v.y = gelu_erf(v.y);
-        v.z = gelu_erf(v.z);
-        v.w = gelu_erf(v.w);
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n);
+#pragma unroll
+    for (int rb = 0; rb < ROWS; ++rb) {
+        const int m = 16 * rb + i;
+        if (m >= M) continue;
+        f32x4 v = ((part[0][rb][lane] + part[1][rb][lane]) + part[2][rb][lane]) + part[3][rb][lane];
+        v += bv;
+        if (EPI == 2) {
+            v.x = gelu_erf(v.x);
+            v.y = gelu_erf(v.y);
+            v.z = gelu_erf(v.z);
+            v.w = gelu_erf(v.w);
+        }
+        uint2 o;
+        o.x = (unsigned)f32_to_bf16(v.x) | ((unsigned)f32_to_bf16(v.y) << 16);
+        o.y = (unsigned)f32_to_bf16(v.z) | ((unsigned)f32_to_bf16(v.w) << 16);
+        *reinterpret_cast<uint2*>(Y + (int64_t)m * N + n) = o;
     }
-    uint2 o;
-    o.x = (unsigned)f32_to_bf16(v.x) | ((unsigned)f32_to_bf16(v.y) << 16);
-    o.y = (unsigned)f32_to_bf16(v.z) | ((unsigned)f32_to_bf16(v.w) << 16);
-    *reinterpret_cast<uint2*>(Y + (int64_t)i * N + n) = o;
 }
 
 // tokens <= 64; K = whole 256-deep trips per wave: 4 waves per workgroup (K <= 3072), 16 for whole multiples of 4096
@@ -499,7 +513,7 @@ static bool fewrows_enabled() {  // RASS_GEMM_FEWROWS=0: the split-K pair instea
 // pair is faster (measured at 48 and 64 tokens); RASS_GEMM_FEWROWS_RES=<rows> moves the limit (A/B)
 static int fewrows_residual_max_rows() {
     const char* v = getenv("RASS_GEMM_FEWROWS_RES");
-    return v ? atoi(v) : 16;
+    return v ? atoi(v) : 32;
 }
 
 template <int EPI, int WAVES>
@@ -2174,21 +2188,38 @@ hipError_t launch_gemm_bf16_residual_layernorm(const void* X, const void* W, con
 }
 
 bool gemm_bf16_ln_input_ok(int M, int N, int K) {
-    return M >= 1 && M <= 16 && K == 1024 && N % 16 == 0 && N >= 1024 && fewrows_enabled();
+    return M >= 1 && M <= 32 && K == 1024 && N % 16 == 0 && N >= 1024 && fewrows_enabled();
+}
+
+template <int EPI, int ROWS>
+static hipError_t launch_lnin(const u16* yin, const float* gamma, const float* beta, float eps, u16* x_out, const u16* w,
+                              const float* bias, u16* y, int M, int N, hipStream_t stream) {
+    constexpr int lds_bytes = 16 * ROWS * (1024 + 8) * 2 + 4 * ROWS * 64 * 16;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_lnin_kernel<EPI, ROWS>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_bf16_lnin_kernel<EPI, ROWS>), dim3(N / 16), dim3(256), lds_bytes, stream, yin, gamma, beta, eps,
+                       x_out, w, bias, y, M, N);
+    return hipGetLastError();
 }
 
 hipError_t launch_gemm_bf16_ln_input(const void* Yin, const float* gamma, const float* beta, float eps, void* x_out,
                                      const void* W, const float* bias, void* Y, int M, int N, int K, int epilogue,
                                      hipStream_t stream) {
     if (!gemm_bf16_ln_input_ok(M, N, K) || (epilogue != 0 && epilogue != 2)) return hipErrorInvalidValue;
-    const dim3 grid(N / 16), block(256);
-    if (epilogue == 0)
-        hipLaunchKernelGGL(gemm_bf16_lnin_kernel<0>, grid, block, 0, stream, static_cast<const u16*>(Yin), gamma, beta, eps,
-                           static_cast<u16*>(x_out), static_cast<const u16*>(W), bias, static_cast<u16*>(Y), M, N);
-    else
-        hipLaunchKernelGGL(gemm_bf16_lnin_kernel<2>, grid, block, 0, stream, static_cast<const u16*>(Yin), gamma, beta, eps,
-                           static_cast<u16*>(x_out), static_cast<const u16*>(W), bias, static_cast<u16*>(Y), M, N);
-    return hipGetLastError();
+    const u16* yin = static_cast<const u16*>(Yin);
+    const u16* w = static_cast<const u16*>(W);
+    u16* xo = static_cast<u16*>(x_out);
+    u16* y = static_cast<u16*>(Y);
+    if (M <= 16)
+        return epilogue == 0 ? launch_lnin<0, 1>(yin, gamma, beta, eps, xo, w, bias, y, M, N, stream)
+                             : launch_lnin<2, 1>(yin, gamma, beta, eps, xo, w, bias, y, M, N, stream);
+    return epilogue == 0 ? launch_lnin<0, 2>(yin, gamma, beta, eps, xo, w, bias, y, M, N, stream)
+                         : launch_lnin<2, 2>(yin, gamma, beta, eps, xo, w, bias, y, M, N, stream);
 }
 
 }  // namespace rass

@@ -193,17 +193,21 @@ def test_large_encoder_sample_matches_oracle(gpu, tmp_path_factory):
     seqs = [list(rng.integers(0, 30522, size=n)) for n in (32, 20, 7)]
     one = [list(rng.integers(0, 30522, size=11))]      # a query: <= 16 rows, every linear through the few-rows kernels
     two = [list(rng.integers(0, 30522, size=n)) for n in (9, 7)]
+    longer = [list(rng.integers(0, 30522, size=23))]          # 17..32 rows: the same kernels on two row blocks
+    three = [list(rng.integers(0, 30522, size=n)) for n in (12, 15, 5)]
     enc = HipSentenceEncoder.from_dir(d, device=0)
     try:
         got = enc.encode_ids(seqs)
         got_one = enc.encode_ids(one)
         got_two = enc.encode_ids(two)
+        got_longer = enc.encode_ids(longer)
+        got_three = enc.encode_ids(three)
     finally:
         enc.close()
     ref = bert_ref.pool(bert_ref.forward_plain(d, seqs), "mean")
     c = _cos(got, ref)
     assert np.all(c >= 0.999), c
-    for g, sq in ((got_one, one), (got_two, two)):
+    for g, sq in ((got_one, one), (got_two, two), (got_longer, longer), (got_three, three)):
         c = _cos(g, bert_ref.pool(bert_ref.forward_plain(d, sq), "mean"))
         assert np.all(c >= 0.999), c
 

@@ -7,12 +7,17 @@ in HBM (BASELINE.json metric; N=1 workload = configs[1], "1M x 1024-d flat cosin
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
+N = 1 runs BASELINE configs[1] (1 M rows on the GPU); N > 1 runs BASELINE configs[3] by default: the FIXED
+10 M x 1024 corpus row-sharded over the N ranks ("strong" scaling; --weak keeps 1 M rows per GPU instead), with
+proof in the line itself that RCCL saw N ranks and that the merged result equals a CPU merge of the shards' lists.
+At N = 1 the line also carries `ingest`: BASELINE configs[2]'s encoder forward (batch 256 x 512 tokens ->
+rass_encode_device -> rass_index_add_device), timed OUTSIDE the search region, against the bf16 MFMA peak.
+
 A step = one pass of the hot path over one batch of 1 024 synthetic queries.  The scan kernel
 answers <= 32 queries per launch (two 16-wide MFMA N tiles), so a step is 32 LAUNCH GROUPS of
 32 queries, each: query normalise, fused scan + top-k over the rank's shard, merge; for N > 1
 also the query broadcast, the RCCL all-gather of per-shard top-k and the cross-shard merge
-(weak scaling: every GPU holds ROWS_PER_GPU rows, the global corpus is N x ROWS_PER_GPU rows,
-each query is answered over all of it).  (Round 1 called ONE launch group a step: 0.7 ms, so
+(each query is answered over all N shards).  (Round 1 called ONE launch group a step: 0.7 ms, so
 a driver run of --warmup 5 --steps 20 timed 14 ms of GPU work that began 3.5 ms after the GPU
 left idle — inside the ~20 ms the clocks take to settle — and hid 40 extra scans in front to
 compensate.  A 1 024-query step is 22 ms: --warmup is exactly what runs, and it is enough.)
@@ -30,6 +35,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy ceiling ~6290
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md; not the 2:1-sparsity headline)
+CONFIGS3_ROWS = 10_000_000      # BASELINE configs[3]: "10M x 1024-d sharded flat cosine top-10, 8 x MI355X"
 
 
 def main():
@@ -38,9 +45,13 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--rows-per-gpu", type=int, default=1_000_000)
-    ap.add_argument("--rows-global", type=int, default=0,
-                    help="STRONG scaling instead: a fixed global corpus (BASELINE configs[3]: 10000000) split "
-                         "into contiguous row ranges over the ranks; overrides --rows-per-gpu")
+    ap.add_argument("--rows-global", type=int, default=-1,
+                    help="a fixed global corpus split into contiguous row ranges over the ranks (STRONG scaling). "
+                         "Default: 10000000 (BASELINE configs[3]) when --gpus > 1, off at --gpus 1 (configs[1])")
+    ap.add_argument("--weak", action="store_true",
+                    help="N > 1: weak scaling instead (every GPU holds --rows-per-gpu rows, corpus = N x that)")
+    ap.add_argument("--no-ingest", action="store_true", help="skip the encoder (configs[2]) leg of the N = 1 line")
+    ap.add_argument("--ingest-batches", type=int, default=4, help="timed 256 x 512-token forwards of the ingest leg")
     ap.add_argument("--dim", type=int, default=1024)
     ap.add_argument("--batch", type=int, default=32, help="queries per scan launch (<= 32)")
     ap.add_argument("--launches-per-step", type=int, default=32,
@@ -48,7 +59,7 @@ def main():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--query-pool", type=int, default=4096)
     ap.add_argument("--cpu-sample-rows", type=int, default=200_000)
-    ap.add_argument("--cpu-hnsw-rows", type=int, default=8_000,
+    ap.add_argument("--cpu-hnsw-rows", type=int, default=10_000,
                     help="rows of the HNSW restatement's sample (cpu_baseline.hnsw); 0 disables it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--per-group", action="store_true",
@@ -92,6 +103,10 @@ def main():
     from rassengine_amd.engine import Engine, scan_kernel_name
 
     dim, B, k = args.dim, args.batch, args.k
+    if args.rows_global < 0:
+        args.rows_global = CONFIGS3_ROWS if (world > 1 and not args.weak) else 0
+    if args.weak:
+        args.rows_global = 0
     strong = args.rows_global > 0
     rows_global = args.rows_global if strong else args.rows_per_gpu * world
     row_lo, row_hi = shard_bounds(rows_global, world)[rank]
@@ -192,8 +207,9 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": f"{rows_global} x {dim}-d flat cosine top-{k}, {world} x MI355X, precomputed embeddings "
-                        + ("(BASELINE configs[3] corpus, fixed, row-sharded)" if strong else
-                           "(BASELINE configs[1] shard per GPU)"),
+                        + (("(BASELINE configs[3]: fixed corpus, row-sharded, all-gather merge)" if rows_global == CONFIGS3_ROWS
+                            else "(fixed corpus, row-sharded)") if strong else
+                           "(BASELINE configs[1])" if world == 1 else "(BASELINE configs[1] shard per GPU, weak scaling)"),
             "rows_per_gpu": n_local, "rows_global": rows_global, "dim": dim, "k": k, "query_batch": B,
             "queries_per_step": B * LPS, "launch_groups_per_step": LPS,
             "engine_calls_per_step": 1 if batched else LPS,
@@ -212,6 +228,14 @@ def main():
             "avg_launch_us": round(scan_ms / max(scan_launches, 1) * 1e3, 2), "launches": scan_launches,
         },
     }
+
+    if world > 1:
+        result.update(multi_gpu_proof(np, torch, dist, search, shard, pool, dev, rank, world, local_rank, row_lo, n_local,
+                                      k, B, scan_ms, scan_launches, bytes_per_launch, isinstance(search, ShardedSearch)))
+        result["scaling_note"] = (
+            "strong scaling over a FIXED corpus: the N = 1 line of this bench is BASELINE configs[1] (1 M rows), not "
+            "this corpus on one GPU; the workload-independent figure to compare across N is row_queries_per_s "
+            "(= value x rows_global)") if strong else "weak scaling: rows_global grows N x; compare row_queries_per_s"
 
     # `traffic` = HBM bytes per launch from PMC counters.  They cannot be read from inside this process, so the
     # field stays null in an ordinary run; a run under `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` is summarised
@@ -276,6 +300,12 @@ def main():
     elif rank == 0 and world == 1 and not args.no_cpu_baseline:
         result.update(cpu_baseline_and_recall(np, torch, eng, idx, pool, args, n_local, dim, B, k))
 
+    if rank == 0 and world == 1 and not args.no_ingest and not bf16 and not args.prefilter and dim == 1024:
+        # BASELINE configs[2]'s larger half (the "embedding" of "embedding + ANN"): after the timed search region and
+        # outside it.  The search index is dropped first so the encoder does not share HBM bandwidth accounting with it.
+        eng.synchronize()
+        result["ingest"] = ingest_leg(np, torch, local_rank, args.ingest_batches)
+
     if rank == 0:
         print(json.dumps(result), flush=True)
     if isinstance(search, PeerMergeSearch):
@@ -285,6 +315,119 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     eng.close()
+
+
+def multi_gpu_proof(np, torch, dist, search, shard, pool, dev, rank, world, local_rank, row_lo, n_local, k, B, scan_ms,
+                    scan_launches, bytes_per_launch, can_check):
+    """Outside the timed region: what makes an N > 1 line self-proving.  (1) who took part: world size and backend as
+    torch.distributed reports them, and per rank the device index, PCI bus id, rows held and its own average scan launch
+    (hipEvents) — N distinct bus ids = N GPUs.  (2) `sharded_equals_merge_of_shards`: for one batch of queries every rank's
+    LOCAL top-k (its shard only, global ids) is gathered as Python objects, merged on the CPU with numpy lexsort
+    (score desc, id asc) and compared BIT FOR BIT with what the engine's exchange + merge kernels returned."""
+    props = torch.cuda.get_device_properties(dev)
+    bus = None
+    if hasattr(props, "pci_bus_id"):
+        bus = "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), props.pci_bus_id, getattr(props, "pci_device_id", 0))
+    avg_us = scan_ms / max(scan_launches, 1) * 1e3
+    mine = {"rank": rank, "device_index": local_rank, "pci_bus_id": bus, "device_name": props.name,
+            "uuid": str(getattr(props, "uuid", "")) or None, "rows_held": n_local, "row_lo": row_lo,
+            "avg_launch_us": round(avg_us, 2), "launches": scan_launches,
+            "frac": round(bytes_per_launch / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4) if avg_us > 0 else None}
+    ranks = [None] * world
+    dist.all_gather_object(ranks, mine)
+    out = {"ranks_seen": dist.get_world_size(), "backend": dist.get_backend(), "ranks": ranks,
+           "distinct_pci_bus_ids": len({r["pci_bus_id"] for r in ranks if r["pci_bus_id"]}),
+           "roofline_per_rank": {"avg_launch_us_min": min(r["avg_launch_us"] for r in ranks),
+                                 "avg_launch_us_max": max(r["avg_launch_us"] for r in ranks),
+                                 "frac_min": min(r["frac"] for r in ranks), "frac_max": max(r["frac"] for r in ranks)}}
+    q = pool[:B].contiguous().clone()
+    if can_check:
+        merged_s, merged_i = search.search(q, k)          # broadcast + local scan + all-gather + merge kernel
+        loc_s, loc_i = shard.search_local(q, k)           # this rank's shard alone, global ids
+        torch.cuda.synchronize()
+        lists = [None] * world
+        dist.all_gather_object(lists, (loc_s.cpu().numpy(), loc_i.cpu().numpy()))
+        if rank == 0:
+            cs = np.concatenate([l[0] for l in lists], axis=1)        # [B, world * k]
+            ci = np.concatenate([l[1] for l in lists], axis=1)
+            ok = True
+            ms, mi = merged_s.cpu().numpy(), merged_i.cpu().numpy()
+            for r in range(B):
+                live = ci[r] >= 0
+                order = np.lexsort((ci[r][live], -cs[r][live].astype(np.float64)))[:k]
+                ok = ok and np.array_equal(ci[r][live][order], mi[r][:order.size]) and \
+                    np.array_equal(cs[r][live][order].view(np.uint32), ms[r][:order.size].view(np.uint32))
+            out["sharded_equals_merge_of_shards"] = bool(ok)
+            out["sharded_check"] = f"{B} queries, top-{k}: numpy lexsort merge of the {world} ranks' local lists vs the engine"
+    else:
+        out["sharded_equals_merge_of_shards"] = None
+    return out
+
+
+def ingest_leg(np, torch, device, timed_batches):
+    """BASELINE configs[2] / SURVEY §8d cfg 3: the BERT-large-class encoder (24 x 1024 x 16 heads x 4096, vocab 30 522,
+    bf16 weights — seeded random, no real weights offline) on batches of 256 chunks x 512 random tokens (seed 99),
+    device-resident: rass_encode_device -> rass_index_add_device on the encoder's stream, 2 warm + `timed_batches`
+    timed, bracketed by hipEvents on that stream.  FLOPs per SURVEY §8d: 604.0 MFLOP per token in the linears +
+    98 304 x S per token in attention."""
+    from rassengine_amd.encoder import EncoderConfig, HipSentenceEncoder, random_weights
+    from rassengine_amd.engine import Engine, HipTimer
+    cfg = EncoderConfig(pooling="mean")
+    t0 = time.perf_counter()
+    enc = HipSentenceEncoder(cfg, random_weights(cfg, seed=1), None, device=device)
+    setup_s = time.perf_counter() - t0
+    eng2 = Engine(device=device, dim=cfg.hidden)
+    try:
+        nseq, S = 256, 512
+        warm = 2
+        idx2 = eng2.open_index("bench-ingest", capacity_rows=(warm + timed_batches) * nseq)
+        rng = np.random.default_rng(99)
+        batches = []
+        for _ in range(2):   # two different token batches, alternated (random data, not zeros: the clocks depend on it)
+            ids = torch.from_numpy(rng.integers(0, cfg.vocab_size, size=nseq * S).astype(np.int32)).to(f"cuda:{device}")
+            batches.append(ids)
+        cu = torch.arange(0, (nseq + 1) * S, S, dtype=torch.int32, device=f"cuda:{device}")
+        out = torch.empty((nseq, cfg.hidden), dtype=torch.float32, device=f"cuda:{device}")
+        torch.cuda.synchronize()
+        stream = enc.stream
+        eng2.set_stream(stream)
+        timer = HipTimer()
+
+        def one(b):
+            enc.encode_device(batches[b % 2].data_ptr(), cu.data_ptr(), nseq, nseq * S, S, out.data_ptr(), stream)
+            idx2.add_device(out.data_ptr(), nseq, normalize=True)
+
+        for b in range(warm):
+            one(b)
+        eng2.synchronize()
+        timer.start(stream)
+        for b in range(timed_batches):
+            one(warm + b)
+        timer.stop(stream)
+        eng2.synchronize()
+        ms = timer.elapsed_ms() / timed_batches
+        rows = idx2.get_rows((warm + timed_batches - 1) * nseq, nseq)
+        norms = np.linalg.norm(rows.astype(np.float64), axis=1)
+        tokens = nseq * S
+        flops = tokens * (604.0e6 + 98304.0 * S)
+        tflops = flops / (ms * 1e-3) / 1e12
+        st = enc.stats()
+        return {
+            "workload": "BASELINE configs[2] encoder leg: BERT-large-class (mxbai-embed-large shape) bf16, batch 256 x 512 "
+                        "tokens, rass_encode_device -> rass_index_add_device (normalise + pack into the HBM index)",
+            "chunks_per_s": round(nseq / (ms * 1e-3), 1), "tokens_per_s": round(tokens / (ms * 1e-3)),
+            "ms_per_batch": round(ms, 3), "timed_batches": timed_batches, "warmup_batches": warm,
+            "tflops": round(tflops, 1), "flop_per_batch": flops, "dtype": "bf16 (fp32 accumulate)",
+            "roofline": {"bound": "mfma_bf16", "achieved": round(tflops, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(tflops / MFMA_BF16_PEAK_TFLOPS, 4)},
+            "rows_in_index": int(idx2.rows), "forwards": st["forwards"],
+            "last_batch_rows_finite_and_unit_norm": bool(np.all(np.isfinite(rows)) and np.abs(norms - 1.0).max() < 1e-5),
+            "extrapolated_1M_chunks_s": round(1e6 / (nseq / (ms * 1e-3)), 1),
+            "weights": "seeded random (numpy PCG64 seed 1), data: random token ids seed 99", "setup_s": round(setup_s, 1),
+        }
+    finally:
+        eng2.close()
+        enc.close()
 
 
 def pmc_traffic(kernel: str, bytes_per_launch: int):

@@ -429,6 +429,10 @@ int rass_encode_device(rass_encoder_t* enc, const int32_t* d_token_ids,
                        int max_seqlen, float* d_out, void* stream);
 /* The hipStream_t rass_encode() and rass_encode_device(stream = NULL) run on. */
 void* rass_encoder_get_stream(rass_encoder_t* enc);
+/* Counters since create: out[0] forwards launched (rass_encode + rass_encode_device), out[1] sequences, out[2]
+ * tokens.  What the embed micro-batcher's tests read: N concurrent embed_query coroutines (app/main.py:2800, up to
+ * MAX_EMBED_CONCURRENCY in flight, 250-260) must arrive as one or two forwards, not N. */
+int rass_encoder_stats(rass_encoder_t* enc, int64_t out[3]);
 /* The encoder's GEMM on its own: Y[m,n] = epi(X[m,k] W[n,k]^T + bias), bf16
  * operands; epilogue 0 bias, 1 bias+residual, 2 bias+GELU(erf).  m_pad
  * (multiple of 128) rows must be allocated; n % 128 == 0, k % 64 == 0. */

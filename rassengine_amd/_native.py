@@ -133,6 +133,7 @@ SIGNATURES = {
     "rass_encoder_destroy": (None, [ctypes.c_void_p]),
     "rass_encoder_hidden": (ctypes.c_int, [ctypes.c_void_p]),
     "rass_encoder_get_stream": (ctypes.c_void_p, [ctypes.c_void_p]),
+    "rass_encoder_stats": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "rass_encoder_set_weight": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int64]),
     "rass_encoder_finalize": (ctypes.c_int, [ctypes.c_void_p]),
     "rass_encode": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),

@@ -172,3 +172,156 @@ class CrossIndexBatcher:
             except (asyncio.CancelledError, Exception):
                 pass
             self._task = None
+
+
+class EmbedBatcher:
+    """Coalesces concurrent EMBED requests into one varlen encoder forward.
+
+    The reference keeps up to ``MAX_EMBED_CONCURRENCY`` = 5 embed requests in flight, one text each
+    (app/main.py:250-260), and every ``/ask`` awaits ``embed_query`` (app/main.py:2800) — the one place where an
+    unmodified ``ask()`` yields the event loop, i.e. the only place where requests of different users can meet.
+    A forward of 32 short queries costs about as much as a forward of one (the few-rows GEMMs stream the same
+    weights), so callers enqueue their texts and ONE worker thread — which owns every encoder call of the
+    process — takes whatever has arrived, up to ``max_seqs`` sequences, and runs one ``encode`` for all of it;
+    the rows go back to their futures on the loops they came from.
+
+    Who waits for what: while a forward runs, arrivals pile up and form the next batch (no timer involved).  From
+    idle, the worker lingers until the queue has been quiet for ``quiet_us`` (default 50 us) but never longer
+    than ``max_delay_ms`` (default 0.2 ms) after the first arrival, so a lone caller pays the quiet gap, not the
+    full delay.  (The linger is a ``threading.Condition`` wait: asyncio timers on the selector loop round up to
+    whole milliseconds.)  Entries of more than ``max_seqs`` texts — upload slices — run on their own, behind any
+    waiting small entries, so a query never queues behind more than one upload slice.
+
+    Errors are per entry, as the reference's are per text: if a coalesced forward fails, every entry is retried
+    on its own and only the ones that fail again see the exception.
+    """
+
+    def __init__(self, encode, max_seqs: int = 64, max_delay_ms: float = 0.2, quiet_us: float = 50.0):
+        import collections
+        import threading
+        if max_seqs < 1:
+            raise ValueError("max_seqs must be >= 1")
+        self._encode = encode               # callable: List[str] -> np.ndarray [n, dim] (runs on the worker thread)
+        self.max_seqs = int(max_seqs)
+        self.max_delay = max(0.0, float(max_delay_ms)) / 1e3
+        self.quiet = max(0.0, float(quiet_us)) / 1e6
+        self._cv = threading.Condition()
+        self._small = collections.deque()   # entries (texts, loop, future) with <= max_seqs texts
+        self._big = collections.deque()
+        self._arrivals = 0                  # bumped on every submit (the linger watches it)
+        self._stop = False
+        self._thread: Optional["threading.Thread"] = None
+        self.forwards = 0                   # encode() calls issued for coalesced batches
+        self.served = 0                     # entries answered
+        self.retries = 0                    # entries re-run alone after a failed batch
+
+    # ------------------------------------------------------------------ caller side (any event loop)
+    async def embed(self, texts: List[str]) -> np.ndarray:
+        """fp32 [len(texts), dim] for NON-BLANK texts, in order."""
+        if not texts:
+            raise ValueError("embed() needs at least one text")
+        loop = asyncio.get_running_loop()
+        fut = loop.create_future()
+        entry = (list(texts), loop, fut)
+        with self._cv:
+            if self._stop:
+                raise RuntimeError("EmbedBatcher is closed")
+            if self._thread is None:
+                import threading
+                self._thread = threading.Thread(target=self._worker, name="rass-embed-batcher", daemon=True)
+                self._thread.start()
+            (self._small if len(entry[0]) <= self.max_seqs else self._big).append(entry)
+            self._arrivals += 1
+            self._cv.notify()
+        return await fut
+
+    # ------------------------------------------------------------------ worker side
+    def _take(self):
+        """Called with the lock held and at least one entry queued: the entries of the next forward."""
+        if self._small:
+            batch, total = [], 0
+            while self._small and total + len(self._small[0][0]) <= self.max_seqs:
+                e = self._small.popleft()
+                batch.append(e)
+                total += len(e[0])
+            return batch
+        return [self._big.popleft()]
+
+    def _worker(self) -> None:
+        import time
+        while True:
+            with self._cv:
+                while not self._small and not self._big and not self._stop:
+                    self._cv.wait()
+                if self._stop and not self._small and not self._big:
+                    return
+                if self._small and self.max_delay > 0:
+                    # linger: until quiet for `quiet`, at most `max_delay` after the first arrival, or the cap is met
+                    t_end = time.perf_counter() + self.max_delay
+                    while sum(len(e[0]) for e in self._small) < self.max_seqs and not self._stop:
+                        seen = self._arrivals
+                        left = t_end - time.perf_counter()
+                        if left <= 0:
+                            break
+                        self._cv.wait(min(self.quiet, left))
+                        if self._arrivals == seen:
+                            break
+                batch = self._take()
+            self._run(batch)
+
+    @staticmethod
+    def _deliver(entries_results) -> None:
+        """Results / exceptions back to their futures, one thread-safe call per event loop."""
+        by_loop = {}
+        for (texts, loop, fut), res in entries_results:
+            by_loop.setdefault(loop, []).append((fut, res))
+
+        def settle(pairs):
+            for fut, res in pairs:
+                if fut.done():          # the caller was cancelled
+                    continue
+                if isinstance(res, BaseException):
+                    fut.set_exception(res)
+                else:
+                    fut.set_result(res)
+
+        for loop, pairs in by_loop.items():
+            try:
+                loop.call_soon_threadsafe(settle, pairs)
+            except RuntimeError:        # that loop is closed: nobody is waiting any more
+                pass
+
+    def _run(self, batch) -> None:
+        texts = [t for e in batch for t in e[0]]
+        try:
+            vecs = np.asarray(self._encode(texts), dtype=np.float32)
+            if vecs.ndim != 2 or vecs.shape[0] != len(texts):
+                raise RuntimeError(f"encoder returned shape {vecs.shape} for {len(texts)} texts")
+            self.forwards += 1
+            out, pos = [], 0
+            for e in batch:
+                n = len(e[0])
+                out.append((e, np.array(vecs[pos:pos + n], dtype=np.float32, order="C")))
+                pos += n
+        except BaseException as ex:  # noqa: BLE001 - every waiter must hear about it
+            if len(batch) == 1:
+                out = [(batch[0], ex)]
+            else:
+                out = []
+                for e in batch:
+                    self.retries += 1
+                    try:
+                        out.append((e, np.array(self._encode(e[0]), dtype=np.float32, order="C")))
+                    except BaseException as ex1:  # noqa: BLE001
+                        out.append((e, ex1))
+        self.served += len(batch)
+        self._deliver(out)
+
+    def close(self) -> None:
+        """Stops the worker after it has answered what is queued."""
+        with self._cv:
+            self._stop = True
+            self._cv.notify_all()
+            t = self._thread
+        if t is not None:
+            t.join(timeout=30)

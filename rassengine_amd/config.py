@@ -23,6 +23,14 @@ RASS_MODEL_DIR = os.getenv("RASS_MODEL_DIR", "")           # local dir with enco
 RASS_SCORE_MODE = os.getenv("RASS_SCORE_MODE", "opensearch")  # "opensearch": 1/(2-cos); "cosine": raw
 RASS_RETURN_EMBEDDING = os.getenv("RASS_RETURN_EMBEDDING", "0") == "1"
 RASS_POOLING = os.getenv("RASS_POOLING", "")               # "cls" | "mean" | "" (from the model dir)
+# embed micro-batcher (batcher.EmbedBatcher): sequences per coalesced forward (0 = off: one encoder call per request),
+# the longest a request waits for company from idle, and the quiet gap that ends the wait early
+RASS_EMBED_BATCH_MAX = _int("RASS_EMBED_BATCH_MAX", 64)
+try:
+    RASS_EMBED_BATCH_DELAY_MS = float(os.getenv("RASS_EMBED_BATCH_DELAY_MS", "0.2"))
+    RASS_EMBED_BATCH_QUIET_US = float(os.getenv("RASS_EMBED_BATCH_QUIET_US", "50"))
+except ValueError:
+    RASS_EMBED_BATCH_DELAY_MS, RASS_EMBED_BATCH_QUIET_US = 0.2, 50.0
 
 
 def get_index_name(user_id: str) -> str:

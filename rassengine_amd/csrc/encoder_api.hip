@@ -87,6 +87,7 @@ struct rass_encoder {
     hipEvent_t done = nullptr;
     hipStream_t last_stream = nullptr;
     bool done_recorded = false;
+    int64_t n_forwards = 0, n_seqs = 0, n_tokens = 0;  // rass_encoder_stats (under mu)
 };
 
 namespace {
@@ -198,6 +199,9 @@ int forward(rass_encoder* e, const int32_t* d_ids, const int32_t* d_cu, int nseq
     EHIP_TRY(hipEventRecord(e->done, st));
     e->last_stream = st;
     e->done_recorded = true;
+    e->n_forwards += 1;
+    e->n_seqs += nseq;
+    e->n_tokens += total;
     return RASS_OK;
 }
 
@@ -400,6 +404,15 @@ int rass_encode(rass_encoder_t* e, const int32_t* token_ids, const int32_t* cu_s
 }
 
 void* rass_encoder_get_stream(rass_encoder_t* e) { return e ? reinterpret_cast<void*>(e->own_stream) : nullptr; }
+
+int rass_encoder_stats(rass_encoder_t* e, int64_t out[3]) {
+    if (!e || !out) return efail(RASS_ERR_INVALID, "NULL argument");
+    std::lock_guard<std::mutex> lk(e->mu);
+    out[0] = e->n_forwards;
+    out[1] = e->n_seqs;
+    out[2] = e->n_tokens;
+    return RASS_OK;
+}
 
 int rass_encoder_hidden(const rass_encoder_t* e) { return e ? e->cfg.hidden : efail(RASS_ERR_INVALID, "encoder is NULL"); }
 

@@ -112,7 +112,9 @@ class IndexState:
     # the old manifest (whose vector file still exists) or the new one (whose vector file is complete).
     def save(self, prefix: str) -> None:
         with self.lock:
-            gen = self.generation + 1
+            # never reuse a file name the live manifest references: a state built WITHOUT load() starts at generation 0
+            # and would otherwise overwrite `<prefix>.g000001.rass` in place before the new manifest is committed
+            gen = max(self.generation, self._manifest_generation(prefix)) + 1
             prev = self._manifest_vectors(prefix)
             vec_name = f"{os.path.basename(prefix)}.g{gen:06d}.rass"
             vec_path = os.path.join(os.path.dirname(prefix) or ".", vec_name)
@@ -137,6 +139,27 @@ class IndexState:
                     if os.path.exists(f):
                         os.remove(f)
                 os.remove(prev)
+
+    @staticmethod
+    def _manifest_generation(prefix: str) -> int:
+        """Generation of the manifest on disk (0 when there is none / it is unreadable); a vector file of a later
+        generation left behind by a crash between the two renames counts too."""
+        gen = 0
+        try:
+            with open(prefix + ".meta.json", encoding="utf-8") as f:
+                gen = int(json.load(f).get("generation", 0))
+        except (OSError, ValueError, TypeError):
+            pass
+        d, base = os.path.dirname(prefix) or ".", os.path.basename(prefix)
+        try:
+            for fn in os.listdir(d):
+                if fn.startswith(base + ".g") and fn.endswith(".rass"):
+                    digits = fn[len(base) + 2:-5]
+                    if digits.isdigit():
+                        gen = max(gen, int(digits))
+        except OSError:
+            pass
+        return gen
 
     @staticmethod
     def _manifest_vectors(prefix: str) -> Optional[str]:

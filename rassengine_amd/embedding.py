@@ -22,8 +22,11 @@ Contract reproduced:
   ``semantic_search`` tests (1534); else ``[1, EMBED_DIM]`` fp32; no query prompt prefix.
 
 The reference bounds concurrency with ``Semaphore(MAX_EMBED_CONCURRENCY)`` around one
-request per text; here a whole batch is one GPU call, run in a worker thread so the event
-loop is not blocked.
+request per text (app/main.py:250-260); here every embed request of the process — the query of each
+``/ask`` (app/main.py:2800), single texts, upload slices — goes through ONE ``batcher.EmbedBatcher``:
+requests that are in flight together are answered by one varlen encoder forward on the batcher's
+worker thread (the event loop is never blocked), a lone request by a forward of its own.
+``RASS_EMBED_BATCH_MAX=0`` turns the coalescing off (one encoder call per request, on a worker thread).
 """
 from __future__ import annotations
 
@@ -48,12 +51,39 @@ class Embedder(Protocol):
 
 _embedder: Optional[Embedder] = None
 _lock = threading.Lock()
+_batcher = None          # batcher.EmbedBatcher, made on first use
+UPLOAD_SLICE = 1024      # texts per upload entry: the encoder pipelines tokeniser and GPU inside one call, and a
+                         # query arriving during an upload waits for at most one slice (small entries go first)
 
 
 def set_embedder(embedder: Optional[Embedder]) -> None:
     global _embedder
     with _lock:
         _embedder = embedder
+
+
+def get_batcher():
+    """The process-wide embed micro-batcher (None when ``RASS_EMBED_BATCH_MAX`` is 0)."""
+    global _batcher
+    if config.RASS_EMBED_BATCH_MAX <= 0:
+        return None
+    with _lock:
+        if _batcher is None:
+            from .batcher import EmbedBatcher
+            # the embedder is looked up per call, so set_embedder() takes effect without a new batcher
+            _batcher = EmbedBatcher(lambda texts: get_embedder().encode(texts), max_seqs=config.RASS_EMBED_BATCH_MAX,
+                                    max_delay_ms=config.RASS_EMBED_BATCH_DELAY_MS,
+                                    quiet_us=config.RASS_EMBED_BATCH_QUIET_US)
+        return _batcher
+
+
+def reset_batcher() -> None:
+    """Stops the worker thread (tests; a new batcher is made on the next request)."""
+    global _batcher
+    with _lock:
+        b, _batcher = _batcher, None
+    if b is not None:
+        b.close()
 
 
 def get_embedder() -> Embedder:
@@ -70,14 +100,22 @@ def get_embedder() -> Embedder:
         return _embedder
 
 
-def _encode_nonblank(texts: List[str]) -> np.ndarray:
-    """Blank texts -> zero rows (app/main.py:227-228); the rest go through the encoder."""
-    enc = get_embedder()
-    out = np.zeros((len(texts), enc.dim), dtype=np.float32)
+async def _encode_nonblank(texts: List[str]) -> np.ndarray:
+    """Blank texts -> zero rows (app/main.py:227-228); the rest go through the encoder — coalesced with whatever
+    other requests are in flight (``EmbedBatcher``)."""
     keep = [i for i, t in enumerate(texts) if t.strip()]
-    if keep:
-        vecs = np.asarray(enc.encode([texts[i] for i in keep]), dtype=np.float32)
-        out[keep] = vecs
+    if not keep:
+        return np.zeros((len(texts), get_embedder().dim), dtype=np.float32)
+    sub = [texts[i] for i in keep]
+    b = get_batcher()
+    if b is not None:
+        vecs = await b.embed(sub)
+    else:
+        vecs = np.asarray(await asyncio.to_thread(lambda: get_embedder().encode(sub)), dtype=np.float32)
+    if len(keep) == len(texts):
+        return vecs
+    out = np.zeros((len(texts), vecs.shape[1]), dtype=np.float32)
+    out[keep] = vecs
     return out
 
 
@@ -85,7 +123,7 @@ async def ollama_embed_text(text: str) -> List[float]:
     """Get an embedding for a single text (app/main.py:225-237)."""
     if not text.strip():
         return [0.0] * EMBED_DIM
-    vec = await asyncio.to_thread(_encode_nonblank, [text])
+    vec = await _encode_nonblank([text])
     return vec[0].tolist()
 
 
@@ -97,10 +135,11 @@ async def embed_texts_in_batches(texts: List[str], batch_size: int = BATCH_SIZE)
     # Here a slice is ONE encoder call that batches on its own (<= 256 sequences / 131 072 tokens per
     # forward, tokenisation overlapped), so slices are made large enough to keep the GPU busy; the
     # result does not depend on the slicing (order-preserving, each text embedded independently).
-    step = max(int(batch_size), 2048)
+    # A short list (<= RASS_EMBED_BATCH_MAX texts) shares its forward with concurrent requests.
+    step = max(int(batch_size), UPLOAD_SLICE)
     all_embeddings = []
     for i in range(0, len(texts), step):
-        all_embeddings.append(await asyncio.to_thread(_encode_nonblank, texts[i:i + step]))
+        all_embeddings.append(await _encode_nonblank(texts[i:i + step]))
     return np.ascontiguousarray(np.concatenate(all_embeddings, axis=0), dtype=np.float32)
 
 
@@ -118,18 +157,18 @@ async def gen_ollama_embed_text(text: str) -> List[float]:
     if not text.strip():
         return [0.0] * EMBED_DIM
     try:
-        vec = await asyncio.to_thread(_encode_nonblank, [text])
+        vec = await _encode_nonblank([text])
         return vec[0].tolist()
     except Exception as ex:
         print("[ERROR] Ollama embed request:", ex)
         return [0.0] * EMBED_DIM
 
 
-def _encode_or_zero(texts: List[str]) -> np.ndarray:
-    """One encoder call for the slice; if it fails, every text is retried on its own so that only the
+async def _encode_or_zero(texts: List[str]) -> np.ndarray:
+    """One encoder request for the slice; if it fails, every text is retried on its own so that only the
     texts that really fail become zero rows (the reference's errors are per text, 168-170)."""
     try:
-        return _encode_nonblank(texts)
+        return await _encode_nonblank(texts)
     except Exception as ex:
         if len(texts) == 1:
             print("[ERROR] Ollama embed request:", ex)
@@ -137,7 +176,7 @@ def _encode_or_zero(texts: List[str]) -> np.ndarray:
     rows = []
     for t in texts:
         try:
-            rows.append(_encode_nonblank([t]))
+            rows.append(await _encode_nonblank([t]))
         except Exception as ex:
             print("[ERROR] Ollama embed request:", ex)
             rows.append(np.zeros((1, EMBED_DIM), dtype=np.float32))
@@ -148,10 +187,10 @@ async def gen_embed_texts_in_batches(texts: List[str]) -> np.ndarray:
     """embedding_gen.py:173-192."""
     if not texts:
         return np.zeros((0, EMBED_DIM), dtype=np.float32)
-    step = max(int(BATCH_SIZE), 2048)   # see embed_texts_in_batches: a slice is one self-batching encoder call
+    step = max(int(BATCH_SIZE), UPLOAD_SLICE)   # see embed_texts_in_batches: a slice is one self-batching encoder call
     out = []
     for i in range(0, len(texts), step):
-        out.append(await asyncio.to_thread(_encode_or_zero, texts[i:i + step]))
+        out.append(await _encode_or_zero(texts[i:i + step]))
     return np.ascontiguousarray(np.concatenate(out, axis=0), dtype=np.float32)
 
 

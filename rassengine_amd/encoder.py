@@ -106,11 +106,10 @@ def load_weights(path: str) -> Dict[str, np.ndarray]:
     return out
 
 
-def write_random_model_dir(path: str, cfg: EncoderConfig, seed: int = 0, vocab: Optional[Sequence[str]] = None) -> None:
-    """Seeded random weights in the Hugging Face BERT layout (bit-identical on every host:
-    numpy PCG64), scaled so activations stay O(1) through ``cfg.layers`` post-LN layers."""
-    from safetensors.numpy import save_file
-    os.makedirs(path, exist_ok=True)
+def random_weights(cfg: EncoderConfig, seed: int = 0) -> Dict[str, np.ndarray]:
+    """Seeded random weights by bare BERT name (bit-identical on every host: numpy PCG64), scaled so activations
+    stay O(1) through ``cfg.layers`` post-LN layers.  No weights exist offline: parity tests and the
+    benchmark run on these."""
     rng = np.random.default_rng(seed)
     H, I = cfg.hidden, cfg.intermediate
     shapes = {"embeddings.word_embeddings.weight": (cfg.vocab_size, H),
@@ -132,6 +131,15 @@ def write_random_model_dir(path: str, cfg: EncoderConfig, seed: int = 0, vocab: 
                 "attention" not in name else (H, H)
             t = rng.standard_normal(shape, dtype=np.float32) * np.float32(1.0 / np.sqrt(shape[1]))
         tensors[name] = np.ascontiguousarray(t, dtype=np.float32)
+    return tensors
+
+
+def write_random_model_dir(path: str, cfg: EncoderConfig, seed: int = 0, vocab: Optional[Sequence[str]] = None) -> None:
+    """``random_weights`` in the Hugging Face BERT layout, plus config.json / 1_Pooling / vocab.txt."""
+    from safetensors.numpy import save_file
+    os.makedirs(path, exist_ok=True)
+    H = cfg.hidden
+    tensors = random_weights(cfg, seed)
     save_file(tensors, os.path.join(path, "model.safetensors"))
     with open(os.path.join(path, "config.json"), "w", encoding="utf-8") as f:
         json.dump(cfg.to_hf_dict(), f)
@@ -358,6 +366,12 @@ class HipSentenceEncoder:
         """The encoder's own hipStream_t (as int): what ``rass_encode`` and ``rass_encode_device(stream=NULL)``
         run on.  Hand it to ``Engine.set_stream`` for the device-resident ingest hand-off."""
         return int(self._L.rass_encoder_get_stream(self._h) or 0)
+
+    def stats(self) -> Dict[str, int]:
+        """Forwards / sequences / tokens since the encoder was created (``rass_encoder_stats``)."""
+        out = (ctypes.c_int64 * 3)()
+        N.check("rass_encoder_stats", self._L.rass_encoder_stats(self._h, out))
+        return {"forwards": int(out[0]), "sequences": int(out[1]), "tokens": int(out[2])}
 
     def encode_device(self, d_token_ids_ptr: int, d_cu_seqlens_ptr: int, nseq: int, total_tokens: int,
                       max_seqlen: int, d_out_ptr: int, stream_ptr: int = 0) -> None:

@@ -28,3 +28,17 @@ def gpu():
     import rassengine_amd._native as N
     N.lib()  # raises loudly if librass_hip.so is absent
     return torch
+
+
+@pytest.fixture(scope="session")
+def large_model(gpu, tmp_path_factory):
+    """(model dir, HipSentenceEncoder) of the BERT-large-class shape (24 x 1024 x 16 heads x 4096, mean pooling) with the
+    seed of the committed encoder fixtures: built once per session (334 M seeded weights take ~15 s to write and load)."""
+    import numpy as np
+    from rassengine_amd.encoder import EncoderConfig, HipSentenceEncoder, write_random_model_dir
+    fx = np.load(os.path.join(ROOT, "tests", "golden", "encoder_large_S32_B2.npz"))
+    d = str(tmp_path_factory.mktemp("large_model"))
+    write_random_model_dir(d, EncoderConfig(pooling="mean"), seed=int(fx["seed"]))
+    enc = HipSentenceEncoder.from_dir(d, device=0)
+    yield d, enc
+    enc.close()

@@ -164,6 +164,20 @@ def test_metadata_persistence_roundtrip(tmp_path):
         st3 = IndexState.load("idx-p", prefix, loader)
         assert st3.generation == 2 and st3.row_doc[st3.doc_row["d5"]]["unstructuredText"] == "again"
 
+        # a state built WITHOUT load() (generation 0) saving over a live manifest must not reuse the file
+        # name that manifest references (it would be overwritten before the new manifest is committed)
+        fresh = IndexState("idx-p", good)
+        fresh.row_doc, fresh.doc_row, fresh.structured = list(st.row_doc), dict(st.doc_row), dict(st.structured)
+        for p in st.patients.names():
+            fresh.patients.encode(p)
+        for t in st.doc_types.names():
+            fresh.doc_types.encode(t)
+        assert fresh.generation == 0
+        fresh.save(prefix)
+        assert fresh.generation == 3 and json.load(open(prefix + ".meta.json"))["vectors"] == "shard0.g000003.rass"
+        assert sorted(os.listdir(tmp_path)) == ["shard0.g000003.rass", "shard0.meta.json"]
+        st.generation = 3
+
         # a manifest that does not belong to its vector file is rejected, not silently loaded
         meta = json.load(open(prefix + ".meta.json"))
         meta["row_doc"] = meta["row_doc"][:-1]

@@ -1,0 +1,55 @@
+"""bench.py's JSON line, end to end on the GPU box (VERDICT r2 #2a, #4, #5): the N = 1 line carries `roofline`,
+`cpu_baseline` and the `ingest` leg (BASELINE configs[2]'s encoder forward at batch 256 x 512); an N > 1 launch — two
+ranks sharing the test GPU over gloo, the rehearsal mode — defaults to BASELINE configs[3] (the fixed 10 M-row corpus,
+strong scaling) and proves in the line itself who took part and that the merged result is the merge of the shards."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _line(cmd, env=None, timeout=900):
+    e = dict(os.environ)
+    e.update(env or {})
+    r = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]          # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line_has_roofline_cpu_baseline_and_ingest(gpu):
+    j = _line([sys.executable, "bench.py", "--steps", "3", "--warmup", "2", "--cpu-sample-rows", "50000",
+               "--cpu-hnsw-rows", "2000", "--ingest-batches", "2"])
+    assert j["n_gpus"] == 1 and j["scaling"] == "weak" and j["dtype"] == "f32" and j["vs_baseline"] is None
+    assert "configs[1]" in j["config"]["workload"] and j["config"]["rows_global"] == 1_000_000
+    rf = j["roofline"]
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and 0.5 < rf["frac"] < 1.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["bytes_per_launch"] == 1_000_000 * 1024 * 4
+    assert j["recall_at_k"] == 1.0 and j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["cores"] >= 1
+    ing = j["ingest"]
+    assert ing["roofline"]["bound"] == "mfma_bf16" and ing["roofline"]["peak"] == 2500.0
+    assert ing["last_batch_rows_finite_and_unit_norm"] is True and ing["rows_in_index"] == 4 * 256
+    assert ing["chunks_per_s"] > 1500 and 0.2 < ing["roofline"]["frac"] < 1.0
+    assert abs(ing["tflops"] - ing["flop_per_batch"] / (ing["ms_per_batch"] * 1e-3) / 1e12) < 1.0
+
+
+def test_two_rank_line_defaults_to_configs3_and_proves_itself(gpu):
+    port = 29500 + os.getpid() % 400
+    j = _line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1"],
+              env={"RASS_BENCH_SHARE_GPU": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and "configs[3]" in j["config"]["workload"]
+    assert j["config"]["rows_global"] == 10_000_000 and j["config"]["rows_per_gpu"] == 5_000_000
+    assert j["ranks_seen"] == 2 and j["backend"] == "gloo"          # the rehearsal backend; a real run says nccl
+    assert [r["rank"] for r in j["ranks"]] == [0, 1] and sum(r["rows_held"] for r in j["ranks"]) == 10_000_000
+    assert j["ranks"][1]["row_lo"] == 5_000_000 and all(r["launches"] == 2 * 32 for r in j["ranks"])
+    assert j["sharded_equals_merge_of_shards"] is True
+    assert j["roofline_per_rank"]["avg_launch_us_min"] > 0
+    assert "ingest" not in j and "cpu_baseline" not in j                # rank 0 at N = 1 only

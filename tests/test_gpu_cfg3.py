@@ -35,15 +35,9 @@ def _unpack(ids, cu):
 
 
 @pytest.fixture(scope="module")
-def large(gpu, tmp_path_factory):
+def large(large_model):
     """(model dir, HipSentenceEncoder) of the BERT-large-class shape, the seed of the committed fixtures."""
-    from rassengine_amd.encoder import EncoderConfig, HipSentenceEncoder, write_random_model_dir
-    fx = np.load(os.path.join(GOLDEN, "encoder_large_S32_B2.npz"))
-    d = str(tmp_path_factory.mktemp("large_model_cfg3"))
-    write_random_model_dir(d, EncoderConfig(pooling="mean"), seed=int(fx["seed"]))
-    enc = HipSentenceEncoder.from_dir(d, device=0)
-    yield d, enc
-    enc.close()
+    return large_model
 
 
 def test_large_fixture_S32_B2(large):
@@ -150,6 +144,68 @@ def test_device_handoff_equals_host_path(large):
         assert np.all(cos >= 0.9999), cos
     finally:
         eng.close()
+
+
+def _ingest_batch_checks(large, torch, seqs, sample):
+    """One ingest batch at cfg 3's shape through BOTH paths: rass_encode -> rass_index_add (host) and rass_encode_device ->
+    rass_index_add_device (K8, no host round trip).  Every stored row finite and unit-norm, the two paths' rows and
+    embeddings bit-equal, `sample` sequences >= 0.999 cosine to the fp32 CPU oracle, and the same `sample` sequences
+    embedded as a batch of their own within the kernels' tolerance (cosine >= 0.9999: other GEMM / attention kernels run
+    for 4 sequences than for 256)."""
+    from oracle import bert_ref
+    from rassengine_amd.engine import Engine
+    d, enc = large
+    n = len(seqs)
+    s0 = enc.stats()
+    emb = enc.encode_ids(seqs)
+    s1 = enc.stats()
+    assert s1["forwards"] - s0["forwards"] == 1 and s1["tokens"] - s0["tokens"] == sum(len(s) for s in seqs)
+    assert emb.shape == (n, 1024) and np.all(np.isfinite(emb))
+    eng = Engine(0, 1024)
+    try:
+        host_idx, dev_idx = eng.open_index("cfg3-full-host"), eng.open_index("cfg3-full-dev")
+        assert host_idx.add(emb, normalize=True) == 0
+        eng.set_stream(enc.stream)
+        out, keep = _encode_device(enc, seqs, torch)
+        assert dev_idx.add_device(out.data_ptr(), n, normalize=True) == 0
+        torch.cuda.synchronize()
+        eng.reset_stream()
+        assert np.array_equal(out.cpu().numpy(), emb)                     # the same batch gives the same bits
+        rows = dev_idx.get_rows(0, n)
+        assert np.array_equal(rows, host_idx.get_rows(0, n))              # device hand-off == host path
+        assert np.all(np.isfinite(rows)) and np.abs(np.linalg.norm(rows.astype(np.float64), axis=1) - 1.0).max() < 1e-5
+        s, i = dev_idx.search(emb[sample], 1)
+        assert np.array_equal(i[:, 0], np.asarray(sample)) and np.all(s[:, 0] > 0.99999)
+    finally:
+        eng.close()
+    sub = [seqs[j] for j in sample]
+    ref = bert_ref.pool(bert_ref.forward_plain(d, sub), "mean")
+    c_ref = _cos(emb[sample], ref)
+    alone = enc.encode_ids(sub)
+    c_alone = _cos(emb[sample], alone)
+    print(f"cfg-3 batch of {n} sequences / {sum(len(s) for s in seqs)} tokens: cosine vs fp32 oracle >= {c_ref.min():.6f}, "
+          f"vs the same sequences in a batch of {len(sub)} >= {c_alone.min():.7f}")
+    assert np.all(c_ref >= 0.999), c_ref
+    assert np.all(c_alone >= 0.9999), c_alone
+
+
+def test_cfg3_full_batch_256x512(large):
+    """BASELINE cfg 3 at its stated shape: ONE forward of 256 sequences x 512 tokens = 131 072 packed tokens (the 256^2
+    persistent GEMM on 512 row tiles, attention64_kernel on 4 096 (sequence, head) items)."""
+    import torch
+    rng = np.random.default_rng(99)
+    seqs = [rng.integers(0, 30522, size=512).tolist() for _ in range(256)]
+    _ingest_batch_checks(large, torch, seqs, sample=[0, 85, 170, 255])
+
+
+def test_cfg3_ragged_batch_256(large):
+    """256 sequences with lengths uniform in [64, 512] (varlen packing, the second length profile of SURVEY §8d cfg 3)."""
+    import torch
+    rng = np.random.default_rng(100)
+    lens = rng.integers(64, 513, size=256)
+    lens[[3, 77]] = [64, 512]
+    seqs = [rng.integers(0, 30522, size=int(n)).tolist() for n in lens]
+    _ingest_batch_checks(large, torch, seqs, sample=[3, 77, 128, 254])
 
 
 def test_end_to_end_embed_index_search(large, oracle):

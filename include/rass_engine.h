@@ -113,6 +113,12 @@ int64_t rass_index_count(const rass_index_t* idx);
 int64_t rass_index_rows(const rass_index_t* idx);
 int rass_index_dim(const rass_index_t* idx);
 int rass_index_row_stride(const rass_index_t* idx); /* elements, dim padded to 128 */
+/* RASS_F32 / RASS_BF16 as given to rass_index_open (or read back by rass_index_load). */
+int rass_index_dtype(const rass_index_t* idx);
+/* != 0 once any row carries a caller-assigned GLOBAL id (rass_index_add_ex: a shard of a multi-GPU index).  Together
+ * with the dtype and the row count this is what decides whether an index may join a cross-index batch
+ * (rass_index_search_multi: fp32, plain row ids, <= 65 536 tiles of 32 rows per batch). */
+int rass_index_has_global_ids(const rass_index_t* idx);
 
 /* Replaces the vector half of store_fhir_docs_in_opensearch (app/main.py:
  * 1245-1282: normalise 1249-1251 + bulk index).  Appends n rows of `dim`

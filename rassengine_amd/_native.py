@@ -52,6 +52,8 @@ SIGNATURES = {
     "rass_index_drop": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p]),
     "rass_index_count": (ctypes.c_int64, [ctypes.c_void_p]),
     "rass_index_rows": (ctypes.c_int64, [ctypes.c_void_p]),
+    "rass_index_dtype": (ctypes.c_int, [ctypes.c_void_p]),
+    "rass_index_has_global_ids": (ctypes.c_int, [ctypes.c_void_p]),
     "rass_index_dim": (ctypes.c_int, [ctypes.c_void_p]),
     "rass_index_row_stride": (ctypes.c_int, [ctypes.c_void_p]),
     "rass_index_add": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,

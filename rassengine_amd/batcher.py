@@ -142,27 +142,90 @@ class CrossIndexBatcher:
                     break
             await self._run(batch)
 
-    async def _run(self, batch: List[tuple]) -> None:
+    MAX_TILES = 65536     # rass_index_search_multi's budget: 32-row tiles over the distinct indices of one call
+
+    @staticmethod
+    def _filters(entries):
+        codes = np.array([e[3][0] for e in entries], dtype=np.int64)
+        masks = np.array([e[3][1] if e[3][0] >= 0 else 0 for e in entries], dtype=np.int64)
+        f = m = None
+        if bool((codes >= 0).any()):
+            f = codes.astype(np.int32)
+            if not bool((masks[codes >= 0] == -1).all()):
+                m = (masks & 0xFFFFFFFF).astype(np.uint32).view(np.int32)
+        return f, m
+
+    def _plan(self, batch: List[tuple]):
+        """Split a drained batch into calls the engine accepts.  ``multi`` groups: entries whose DISTINCT indices fit
+        the cross-index tile budget together (``index.multi_tiles``: 0 = this index cannot join — bf16 corpus,
+        caller-assigned ids, more than half the budget on its own); ``solo``: per index, entries answered by that
+        index's own ``search`` (one scan for all of them).  Nobody's request fails because of who else is in the batch."""
+        multi, solo = [], {}
+        cur, cur_tiles, cur_seen = [], 0, {}
+        for e in batch:
+            ix = e[0]
+            tiles = int(getattr(ix, "multi_tiles", 0) or 0)
+            if tiles <= 0:
+                solo.setdefault(id(ix), []).append(e)
+                continue
+            extra = 0 if id(ix) in cur_seen else tiles
+            if cur and cur_tiles + extra > self.MAX_TILES:
+                multi.append(cur)
+                cur, cur_tiles, cur_seen = [], 0, {}
+                extra = tiles
+            cur.append(e)
+            cur_tiles += extra
+            cur_seen[id(ix)] = True
+        if cur:
+            multi.append(cur)
+        return multi, list(solo.values())
+
+    @staticmethod
+    def _answer(entries, scores, ids) -> None:
+        for i, (_, _, k, _, fut) in enumerate(entries):
+            if not fut.done():
+                fut.set_result((scores[i, :k].copy(), ids[i, :k].copy()))
+
+    async def _run_solo(self, entries) -> None:
+        """One index's entries through its own search (any dtype / id scheme / size)."""
         try:
-            qs = np.stack([b[1] for b in batch])
-            kmax = min(32, max(b[2] for b in batch))
-            codes = np.array([b[3][0] for b in batch], dtype=np.int64)
-            masks = np.array([b[3][1] if b[3][0] >= 0 else 0 for b in batch], dtype=np.int64)
-            f = m = None
-            if bool((codes >= 0).any()):
-                f = codes.astype(np.int32)
-                if not bool((masks[codes >= 0] == -1).all()):
-                    m = (masks & 0xFFFFFFFF).astype(np.uint32).view(np.int32)
-            scores, ids = await asyncio.to_thread(self.engine.search_multi, [b[0] for b in batch], qs, kmax, f, m)
+            qs = np.stack([e[1] for e in entries])
+            kmax = max(e[2] for e in entries)
+            f, m = self._filters(entries)
+            if f is None:
+                scores, ids = await asyncio.to_thread(entries[0][0].search, qs, kmax)
+            elif m is None:
+                scores, ids = await asyncio.to_thread(entries[0][0].search, qs, kmax, f)
+            else:
+                scores, ids = await asyncio.to_thread(entries[0][0].search, qs, kmax, f, m)
             self.scans += 1
-            self.served += len(batch)
-            for i, (_, _, k, _, fut) in enumerate(batch):
-                if not fut.done():
-                    fut.set_result((scores[i, :k].copy(), ids[i, :k].copy()))
+            self._answer(entries, scores, ids)
         except Exception as e:
-            for b in batch:
-                if not b[4].done():
-                    b[4].set_exception(e)
+            for en in entries:
+                if not en[4].done():
+                    en[4].set_exception(e)
+
+    async def _run(self, batch: List[tuple]) -> None:
+        multi, solo = self._plan(batch)
+        for entries in multi:
+            try:
+                qs = np.stack([e[1] for e in entries])
+                kmax = min(32, max(e[2] for e in entries))
+                f, m = self._filters(entries)
+                scores, ids = await asyncio.to_thread(self.engine.search_multi, [e[0] for e in entries], qs, kmax, f, m)
+                self.scans += 1
+                self._answer(entries, scores, ids)
+            except Exception:
+                # the engine refused the group (e.g. an index grew past the budget since it was planned): every index
+                # of the group is served on its own instead
+                per_index = {}
+                for e in entries:
+                    per_index.setdefault(id(e[0]), []).append(e)
+                for group in per_index.values():
+                    await self._run_solo(group)
+        for entries in solo:
+            await self._run_solo(entries)
+        self.served += len(batch)
 
     async def close(self) -> None:
         if self._task is not None:
@@ -185,11 +248,11 @@ class EmbedBatcher:
     process — takes whatever has arrived, up to ``max_seqs`` sequences, and runs one ``encode`` for all of it;
     the rows go back to their futures on the loops they came from.
 
-    Who waits for what: while a forward runs, arrivals pile up and form the next batch (no timer involved).  From
-    idle, the worker lingers until the queue has been quiet for ``quiet_us`` (default 50 us) but never longer
-    than ``max_delay_ms`` (default 0.2 ms) after the first arrival, so a lone caller pays the quiet gap, not the
-    full delay.  (The linger is a ``threading.Condition`` wait: asyncio timers on the selector loop round up to
-    whole milliseconds.)  Entries of more than ``max_seqs`` texts — upload slices — run on their own, behind any
+    Who waits for what: while a forward runs, arrivals pile up and form the next batch (no timer involved).  When
+    the previous forward had company (more than one entry) the worker also lingers until the queue has been quiet
+    for ``quiet_us`` (default 50 us), never longer than ``max_delay_ms`` (default 0.2 ms) after the first arrival;
+    a lone caller in a quiet process — the previous forward served one entry — is not held back at all.  (The linger
+    is a ``threading.Condition`` wait: asyncio timers on the selector loop round up to whole milliseconds.)  Entries of more than ``max_seqs`` texts — upload slices — run on their own, behind any
     waiting small entries, so a query never queues behind more than one upload slice.
 
     Errors are per entry, as the reference's are per text: if a coalesced forward fails, every entry is retried
@@ -214,6 +277,7 @@ class EmbedBatcher:
         self.forwards = 0                   # encode() calls issued for coalesced batches
         self.served = 0                     # entries answered
         self.retries = 0                    # entries re-run alone after a failed batch
+        self._company = False               # the previous forward served more than one entry
 
     # ------------------------------------------------------------------ caller side (any event loop)
     async def embed(self, texts: List[str]) -> np.ndarray:
@@ -255,7 +319,7 @@ class EmbedBatcher:
                     self._cv.wait()
                 if self._stop and not self._small and not self._big:
                     return
-                if self._small and self.max_delay > 0:
+                if self._small and self.max_delay > 0 and self._company:
                     # linger: until quiet for `quiet`, at most `max_delay` after the first arrival, or the cap is met
                     t_end = time.perf_counter() + self.max_delay
                     while sum(len(e[0]) for e in self._small) < self.max_seqs and not self._stop:
@@ -267,6 +331,7 @@ class EmbedBatcher:
                         if self._arrivals == seen:
                             break
                 batch = self._take()
+                self._company = len(batch) > 1
             self._run(batch)
 
     @staticmethod

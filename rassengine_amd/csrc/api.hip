@@ -750,6 +750,10 @@ int rass_index_get_prefilter(const rass_index_t* idx) { return (idx && idx->pref
 int64_t rass_index_count(const rass_index_t* idx) { return idx ? idx->rows.load() - idx->deleted.load() : 0; }
 int64_t rass_index_rows(const rass_index_t* idx) { return idx ? idx->rows.load() : (int64_t)0; }
 int rass_index_dim(const rass_index_t* idx) { return idx ? idx->dim : fail(RASS_ERR_INVALID, "index is NULL"); }
+int rass_index_dtype(const rass_index_t* idx) { return idx ? (int)idx->dtype : fail(RASS_ERR_INVALID, "index is NULL"); }
+int rass_index_has_global_ids(const rass_index_t* idx) {
+    return idx ? (idx->has_gid.load() ? 1 : 0) : fail(RASS_ERR_INVALID, "index is NULL");
+}
 int rass_index_row_stride(const rass_index_t* idx) {
     return idx ? (int)idx->stride : fail(RASS_ERR_INVALID, "index is NULL");
 }
@@ -851,7 +855,14 @@ int rass_index_delete(rass_index_t* idx, int64_t row) {
     if (byte & bit) return RASS_OK;  // idempotent
     int rc = set_device(idx->eng);
     if (rc != RASS_OK) return rc;
-    HIP_TRY(rass::launch_fill_i32(idx->d_tags + row, 1, RASS_ROW_TAG_DELETED, idx->eng->stream));
+    {
+        // A search holds eng->mu for its whole enqueue sequence (sample-floor pass, scan, further passes of a k > 32
+        // search): without it this fill could land BETWEEN them — the floor was computed from k rows, one of which is
+        // now a tombstone, and the scan would reject live rows below it and return fewer than k hits.  Lock order
+        // idx->mu then eng->mu, as in add_common: a search sees a tombstone before its first pass or after its merge.
+        std::lock_guard<std::mutex> elk(idx->eng->mu);
+        HIP_TRY(rass::launch_fill_i32(idx->d_tags + row, 1, RASS_ROW_TAG_DELETED, idx->eng->stream));
+    }
     byte |= bit;
     idx->deleted += 1;
     return RASS_OK;

@@ -147,8 +147,10 @@ async def embed_query(query: str) -> np.ndarray:
     """Embedding of a single query, shape [1, EMBED_DIM] (app/main.py:266-274)."""
     if not query.strip():
         return np.array([])
-    emb_list = await ollama_embed_text(query)
-    return np.array([emb_list], dtype=np.float32)
+    # the reference builds np.array([emb_list], dtype=np.float32) from ollama_embed_text's list of Python floats; the
+    # encoder's fp32 row IS that array (float32 -> float -> float32 is exact), without 1 024 boxed floats per query
+    vec = await _encode_nonblank([query])
+    return np.ascontiguousarray(vec[:1], dtype=np.float32)
 
 
 # ------------------------------------------------------------------ app/embedding_gen.py:152-192

@@ -160,6 +160,25 @@ class FlatIndex:
     def row_stride(self) -> int:
         return int(self._L.rass_index_row_stride(self._h))
 
+    MULTI_MAX_TILES = 65536      # rass_index_search_multi: 32-row tiles per cross-index batch (kMultiMaxItems)
+
+    @property
+    def dtype(self) -> str:
+        return "bf16" if int(self._L.rass_index_dtype(self._h)) == 1 else "f32"
+
+    @property
+    def has_global_ids(self) -> bool:
+        return int(self._L.rass_index_has_global_ids(self._h)) != 0
+
+    @property
+    def multi_tiles(self) -> int:
+        """Tiles this index would take of a cross-index batch's budget; 0 = it cannot join one (bf16 corpus,
+        caller-assigned ids, or too large on its own): search it through its own batcher."""
+        if self.dtype != "f32" or self.has_global_ids:
+            return 0
+        tiles = (self.rows + 31) // 32
+        return tiles if tiles <= self.MULTI_MAX_TILES // 2 else 0
+
     @property
     def device_rows_ptr(self) -> int:
         """Device pointer of the tile16 slab (invalidated by growth)."""

@@ -7,9 +7,11 @@ the FastAPI process and serves ``HipIndexer`` over a ``ShardedIndex`` front, ran
 ``number_of_shards = SHARD_COUNT`` (app/main.py:89, 357) with the coordinator merging per-shard top-k; here the
 shards are GPUs, the coordinator is rank 0 and the exchange is ONE RCCL all-gather of packed per-shard top-k.
 
-Command stream: every operation starts with ONE broadcast (src 0) of a fixed-size buffer
-``[16 x int64 header | query / filter / name payload]``; every rank then executes the same operation on its
-shard, so the collectives line up by construction:
+Command stream: every operation starts with ONE broadcast (src 0) of a 16 x int64 header over a HOST-side gloo
+group (``ShardServer.ctl``) — idle workers block in a socket read: no RCCL kernel spins on their GPUs and no NCCL
+watchdog (10-minute default) can time the wait out; the group is created with a timeout of years — followed, when
+the operation has one, by a broadcast of its payload (queries / filters / name) over the data group (RCCL); every
+rank then executes the same operation on its shard, so the collectives line up by construction:
 
     OPEN    every rank opens its local shard of the named index
     ADD     rows are dealt to the ranks ROUND-ROBIN BY BATCH (batch b -> rank b mod G); the batch travels
@@ -26,6 +28,13 @@ shard, so the collectives line up by construction:
     SHUTDOWN workers leave the loop; every rank then meets in a barrier (a clean collective exit: the workers
             are ordinary processes that return, nothing is re-exec'ed or killed)
 
+Failures: the LOCAL part of every operation runs under try / except on every rank, the operation's data collectives
+are carried out regardless (with stand-in data), and the operation ends with a verdict every rank takes part in (an
+all-gather of one status word; SEARCH carries it in the tail of the record it gathers anyway): either no rank raises,
+or EVERY rank raises ``CollectiveFailure`` at the same point of the stream — a worker logs it and keeps following
+rank 0, rank 0 reports it to its caller.  Rank 0 commits its bookkeeping (rows, runs, owners) only after the verdict;
+global ids an operation may already have consumed on some rank are never reused (they become holes).
+
 Because a shard's ids ascend with its append order and ties are broken by (score desc, id asc) both inside a
 shard and in the merge, the sharded result equals the single-index result bit for bit (tests/test_serving_gloo.py;
 tests/test_gpu_dist.py for the HIP shards).
@@ -33,6 +42,7 @@ tests/test_gpu_dist.py for the HIP shards).
 from __future__ import annotations
 
 import bisect
+import datetime
 import json
 import logging
 import os
@@ -54,9 +64,17 @@ NAME_BYTES = 1024
 ADD_CHUNK_ROWS = 8192
 
 
+CTL_TIMEOUT = datetime.timedelta(days=3650)   # an idle service is not an error
+
+
 class CollectiveFailure(RuntimeError):
     """An operation failed on some rank; EVERY rank raises this at the same point of the command stream (the verdict
-    comes out of an all-reduce), so the workers can log it and keep following rank 0 while rank 0 reports it."""
+    comes out of a collective), so the workers can log it and keep following rank 0 while rank 0 reports it.
+    ``failed_ranks``: who failed."""
+
+    def __init__(self, msg: str, failed_ranks=()):
+        super().__init__(msg)
+        self.failed_ranks = tuple(int(r) for r in failed_ranks)
 
 
 class Extents:
@@ -127,12 +145,16 @@ class HipServingShard:
         ids_off = (nq * k * 4 + 7) // 8 * 8
         return ids_off, ids_off + nq * k * 8
 
+    strided_records = True     # search_packed(out=...) writes in place, merge_packed(stride_bytes=...) reads records with tails
+
     def search_packed(self, queries: torch.Tensor, k: int, filt: Optional[torch.Tensor], mask: Optional[torch.Tensor],
-                      after: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> torch.Tensor:
-        """``after`` = (scores f32 [nq], LOCAL row ordinals i64 [nq]): rank only the rows strictly behind them."""
+                      after: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, out: Optional[torch.Tensor] = None
+                      ) -> torch.Tensor:
+        """``after`` = (scores f32 [nq], LOCAL row ordinals i64 [nq]): rank only the rows strictly behind them.
+        ``out``: a caller-owned buffer of at least the record size (8-byte aligned) to write the record into."""
         nq = queries.shape[0]
         ids_off, size = self.record_bytes(nq, k)
-        rec = torch.empty((size,), dtype=torch.uint8, device=self.device)
+        rec = torch.empty((size,), dtype=torch.uint8, device=self.device) if out is None else out
         if after is not None:
             a_s, a_r = after[0].to(self.device).contiguous(), after[1].to(self.device).contiguous()
             self.index.search_device_after(queries.data_ptr(), nq, k, a_s.data_ptr(), a_r.data_ptr(), rec.data_ptr(),
@@ -146,16 +168,18 @@ class HipServingShard:
                                  d_q_filter_mask_ptr=mask.data_ptr() if mask is not None else 0)
         return rec
 
-    def merge_packed(self, gathered: torch.Tensor, world: int, nq: int, k: int) -> Tuple[np.ndarray, np.ndarray]:
+    def merge_packed(self, gathered: torch.Tensor, world: int, nq: int, k: int, stride_bytes: int = 0
+                     ) -> Tuple[np.ndarray, np.ndarray]:
         import ctypes
         from . import _native as N
         ids_off, size = self.record_bytes(nq, k)
+        stride = stride_bytes or size          # records may carry a tail (the status word of ShardServer's SEARCH)
         out_s = torch.empty((nq, k), dtype=torch.float32, device=self.device)
         out_i = torch.empty((nq, k), dtype=torch.int64, device=self.device)
         base = gathered.data_ptr()
         N.check("rass_topk_merge_strided",
-                N.lib().rass_topk_merge_strided(ctypes.c_void_p(base), ctypes.c_void_p(base + ids_off), size // 4,
-                                                size // 8, world, nq, k, ctypes.c_void_p(out_s.data_ptr()),
+                N.lib().rass_topk_merge_strided(ctypes.c_void_p(base), ctypes.c_void_p(base + ids_off), stride // 4,
+                                                stride // 8, world, nq, k, ctypes.c_void_p(out_s.data_ptr()),
                                                 ctypes.c_void_p(out_i.data_ptr()),
                                                 ctypes.c_void_p(int(torch.cuda.current_stream(self.device).cuda_stream))))
         return out_s.cpu().numpy(), out_i.cpu().numpy()
@@ -166,7 +190,8 @@ class ShardServer:
 
     def __init__(self, shard_factory: Callable[[str], object], dim: int, device: torch.device,
                  group: Optional[dist.ProcessGroup] = None, encoder_factory: Optional[Callable[[], object]] = None,
-                 shard_loader: Optional[Callable[[str, str], object]] = None):
+                 shard_loader: Optional[Callable[[str, str], object]] = None,
+                 ctl_group: Optional[dist.ProcessGroup] = None):
         self.factory = shard_factory
         self.loader = shard_loader               # (name, file) -> shard, for OP_LOAD
         self.encoder_factory = encoder_factory   # rank-local sentence encoder (data-parallel ingest), built lazily
@@ -177,7 +202,13 @@ class ShardServer:
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.payload_bytes = max(MAX_Q * dim * 4 + 3 * MAX_Q * 4 + MAX_Q * 8, NAME_BYTES)   # queries|filter|mask|after
-        self.cmd = torch.zeros((HDR_WORDS * 8 + self.payload_bytes,), dtype=torch.uint8, device=device)
+        self.cmd = torch.zeros((self.payload_bytes,), dtype=torch.uint8, device=device)      # the payload, on the device
+        self.hdr = torch.zeros((HDR_WORDS,), dtype=torch.int64)                              # the header, on the host
+        # the control channel: a gloo group of the same ranks (collective creation: every rank constructs its
+        # ShardServer at the same point, in serving.start)
+        self.ctl = ctl_group if ctl_group is not None else \
+            dist.new_group(ranks=dist.get_process_group_ranks(group) if group is not None else None,
+                           backend="gloo", timeout=CTL_TIMEOUT)
         self.shards: Dict[int, object] = {}
         self.extents: Dict[int, Extents] = {}
         # gloo moves device tensors in its collectives by staging, but its point-to-point ops want host memory
@@ -201,13 +232,19 @@ class ShardServer:
             dist.broadcast(t, src=0, group=self.group)
         return t
 
-    def _all_ok(self, ok: bool, what: str) -> None:
-        """Every rank learns whether EVERY rank succeeded (a save / load either holds on all shards or is refused)."""
+    def _verdict(self, ok: bool, what: str) -> None:
+        """Every rank learns whether EVERY rank succeeded, and who did not: all raise ``CollectiveFailure`` or none."""
         t = torch.tensor([0 if ok else 1], dtype=torch.int64, device=self.device)
         if self.world > 1:
-            dist.all_reduce(t, group=self.group)
-        if int(t.item()) != 0:
-            raise CollectiveFailure(f"{what} failed on {int(t.item())} rank(s)")
+            g = torch.empty((self.world,), dtype=torch.int64, device=self.device)
+            dist.all_gather_into_tensor(g, t, group=self.group)
+            t = g
+        self._raise_if_failed(t.cpu().numpy(), what)
+
+    def _raise_if_failed(self, status: np.ndarray, what: str) -> None:
+        failed = [r for r, v in enumerate(np.asarray(status).reshape(-1)) if int(v) != 0]
+        if failed:
+            raise CollectiveFailure(f"{what} failed on rank(s) {failed}", failed)
 
     @staticmethod
     def shard_file(base: str, rank: int, world: int) -> str:
@@ -226,36 +263,65 @@ class ShardServer:
         return t
 
     # ---- command transport
-    def post(self, header: List[int], payload: Optional[np.ndarray] = None) -> np.ndarray:
-        """Rank 0: fill and broadcast the command buffer.  Returns the header."""
-        host = np.zeros(self.cmd.numel(), dtype=np.uint8)
+    def post(self, header: List[int], payload: Optional[np.ndarray] = None, payload_len: Optional[int] = None) -> np.ndarray:
+        """Rank 0: broadcast the header over the host-side control group, then the payload (its first ``payload_len``
+        bytes; default: all of what was given) over the data group.  Returns the header."""
         hdr = np.zeros(HDR_WORDS, dtype=np.int64)
         hdr[:len(header)] = header
-        host[:HDR_WORDS * 8] = hdr.view(np.uint8)
+        nbytes = 0
         if payload is not None:
-            raw = np.ascontiguousarray(payload).view(np.uint8).reshape(-1)
-            host[HDR_WORDS * 8:HDR_WORDS * 8 + raw.size] = raw
-        self.cmd.copy_(torch.from_numpy(host))
-        dist.broadcast(self.cmd, src=0, group=self.group)
+            raw = np.array(payload, copy=True).view(np.uint8).reshape(-1)     # (np.frombuffer views are read-only)
+            nbytes = raw.size if payload_len is None else int(payload_len)
+            if nbytes > self.payload_bytes:
+                raise ValueError("command payload too large")
+        hdr[HDR_WORDS - 1] = nbytes
+        self.hdr.copy_(torch.from_numpy(hdr))
+        if self.world > 1:
+            dist.broadcast(self.hdr, src=0, group=self.ctl)
+        if nbytes:
+            self.cmd[:nbytes].copy_(torch.from_numpy(raw[:nbytes]))
+            if self.world > 1:
+                dist.broadcast(self.cmd[:nbytes], src=0, group=self.group)
         return hdr
 
     def recv(self) -> np.ndarray:
-        """Ranks > 0: wait for rank 0's next command.  Returns the header."""
-        dist.broadcast(self.cmd, src=0, group=self.group)
-        return self.cmd[:HDR_WORDS * 8].cpu().numpy().view(np.int64).copy()
+        """Ranks > 0: wait (on the host, in the control group) for rank 0's next command.  Returns the header."""
+        dist.broadcast(self.hdr, src=0, group=self.ctl)
+        hdr = self.hdr.numpy().copy()
+        nbytes = int(hdr[HDR_WORDS - 1])
+        if nbytes:
+            dist.broadcast(self.cmd[:nbytes], src=0, group=self.group)
+        return hdr
 
     def _payload(self, nbytes: int, offset: int = 0) -> torch.Tensor:
-        a = HDR_WORDS * 8 + offset
-        return self.cmd[a:a + nbytes]
+        return self.cmd[offset:offset + nbytes]
 
     # ---- the operations (identical code on every rank)
     def execute(self, hdr: np.ndarray, vecs: Optional[torch.Tensor] = None, tags: Optional[torch.Tensor] = None,
                 enc: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None):
+        """One operation, the same code on every rank.  The local part of each operation is fenced by try / except, its
+        data collectives always take place, and it ends in a verdict (see the module docstring): a failure on ANY rank
+        raises ``CollectiveFailure`` on EVERY rank, after the last collective of the operation."""
         op, code = int(hdr[0]), int(hdr[1])
+        ok = True
+
+        def failed(what: str, e: BaseException) -> bool:
+            logger.error(f"{what} failed on rank {self.rank}: {e}")
+            return False
+
         if op == OP_OPEN:
-            name = bytes(self._payload(int(hdr[2])).cpu().numpy()).decode("utf-8")
-            self.shards[code] = self.factory(name)
-            self.extents[code] = Extents()
+            try:
+                name = bytes(self._payload(int(hdr[2])).cpu().numpy()).decode("utf-8")
+                self.shards[code] = self.factory(name)
+                self.extents[code] = Extents()
+            except Exception as e:
+                ok = failed("open", e)
+            try:
+                self._verdict(ok, "open")
+            except CollectiveFailure:      # an index is open on all ranks or on none
+                self.shards.pop(code, None)
+                self.extents.pop(code, None)
+                raise
             return None
         if op == OP_DROP:
             self.shards.pop(code, None)
@@ -264,24 +330,21 @@ class ShardServer:
         if op == OP_SAVE:
             # every rank writes its shard next to the manifest rank 0 writes afterwards: <base>.shard<r>of<G>,
             # temp name + rename (rass_index_save fsyncs); rank 0 only proceeds when all of them are durable
-            base = bytes(self._payload(int(hdr[2])).cpu().numpy()).decode("utf-8")
-            f = self.shard_file(base, self.rank, self.world)
-            ok = True
             try:
+                base = bytes(self._payload(int(hdr[2])).cpu().numpy()).decode("utf-8")
+                f = self.shard_file(base, self.rank, self.world)
                 self.shards[code].save(f + ".tmp")
                 os.replace(f + ".tmp", f)
-            except Exception as e:       # reported through the all-reduce: the ranks must stay in step
-                logger.error(f"shard save failed on rank {self.rank}: {e}")
-                ok = False
-            self._all_ok(ok, "shard save")
+            except Exception as e:       # reported through the verdict: the ranks must stay in step
+                ok = failed("shard save", e)
+            self._verdict(ok, "shard save")
             return None
         if op == OP_LOAD:
             plen, nlen, n_runs = int(hdr[2]), int(hdr[3]), int(hdr[4])
-            base = bytes(self._payload(plen).cpu().numpy()).decode("utf-8")
-            name = bytes(self._payload(nlen, plen).cpu().numpy()).decode("utf-8")
             runs = self._bcast(vecs, (max(n_runs, 1), 3), torch.int64).cpu().numpy()[:n_runs]   # (gid, rank, n)
-            ok = True
             try:
+                base = bytes(self._payload(plen).cpu().numpy()).decode("utf-8")
+                name = bytes(self._payload(nlen, plen).cpu().numpy()).decode("utf-8")
                 if self.loader is None:
                     raise RuntimeError("serving.start() was given no shard_loader")
                 shard = self.loader(name, self.shard_file(base, self.rank, self.world))
@@ -295,30 +358,52 @@ class ShardServer:
                     raise RuntimeError(f"shard file holds {int(shard.rows)} rows, the manifest gives this rank {ordinal}")
                 self.shards[code], self.extents[code] = shard, ext
             except Exception as e:
-                logger.error(f"shard load failed on rank {self.rank}: {e}")
-                ok = False
-            self._all_ok(ok, "shard load")
+                ok = failed("shard load", e)
+            try:
+                self._verdict(ok, "shard load")
+            except CollectiveFailure:
+                self.shards.pop(code, None)
+                self.extents.pop(code, None)
+                raise
             return None
-        shard = self.shards[code]
+        shard = self.shards.get(code)
         if op == OP_SEARCH:
             nq, k, flags = int(hdr[2]), int(hdr[3]), int(hdr[4])
-            q = self._payload(nq * self.dim * 4).view(torch.float32).view(nq, self.dim)
-            off = MAX_Q * self.dim * 4
-            filt = self._payload(nq * 4, off).view(torch.int32) if flags & 1 else None
-            mask = self._payload(nq * 4, off + MAX_Q * 4).view(torch.int32) if flags & 2 else None
-            after = None
-            if flags & 4:   # a continuation pass of a k > 32 search: the previous pass's last GLOBAL hit per query
-                a_s = self._payload(nq * 4, off + 2 * MAX_Q * 4).view(torch.float32)
-                a_g = self._payload(nq * 8, off + 3 * MAX_Q * 4).view(torch.int64).cpu().numpy()
-                ext = self.extents[code]
-                a_r = torch.tensor([ext.ordinal_upto(int(g)) for g in a_g], dtype=torch.int64)
-                after = (a_s.clone(), a_r)
-            rec = shard.search_packed(q, k, filt, mask, after) if after is not None else shard.search_packed(q, k, filt, mask)
+            ids_off, size = HipServingShard.record_bytes(nq, k)
+            # the record every rank contributes carries its status in an 8-byte tail: the all-gather that moves the
+            # per-shard top-k IS the verdict (no extra collective on the query path)
+            buf = torch.zeros((size + 8,), dtype=torch.uint8, device=self.device)
+            try:
+                q = self._payload(nq * self.dim * 4).view(torch.float32).view(nq, self.dim)
+                off = MAX_Q * self.dim * 4
+                filt = self._payload(nq * 4, off).view(torch.int32) if flags & 1 else None
+                mask = self._payload(nq * 4, off + MAX_Q * 4).view(torch.int32) if flags & 2 else None
+                after = None
+                if flags & 4:   # a continuation pass of a k > 32 search: the previous pass's last GLOBAL hit per query
+                    a_s = self._payload(nq * 4, off + 2 * MAX_Q * 4).view(torch.float32)
+                    a_g = self._payload(nq * 8, off + 3 * MAX_Q * 4).view(torch.int64).cpu().numpy()
+                    ext = self.extents[code]
+                    a_r = torch.tensor([ext.ordinal_upto(int(g)) for g in a_g], dtype=torch.int64)
+                    after = (a_s.clone(), a_r)
+                if getattr(shard, "strided_records", False):
+                    shard.search_packed(q, k, filt, mask, after, out=buf)
+                else:
+                    rec = shard.search_packed(q, k, filt, mask, after) if after is not None else shard.search_packed(q, k, filt, mask)
+                    buf[:size].copy_(rec)
+            except Exception as e:
+                ok = failed("search", e)
+                buf[size:].view(torch.int64).fill_(1)
             if self.world == 1:
-                return shard.merge_packed(rec, 1, nq, k)
-            gathered = torch.empty((self.world * rec.numel(),), dtype=torch.uint8, device=rec.device)
-            dist.all_gather_into_tensor(gathered, rec, group=self.group)
-            return shard.merge_packed(gathered, self.world, nq, k) if self.rank == 0 else None
+                self._raise_if_failed([0 if ok else 1], "search")
+                return shard.merge_packed(buf[:size], 1, nq, k)
+            gathered = torch.empty((self.world, size + 8), dtype=torch.uint8, device=buf.device)
+            dist.all_gather_into_tensor(gathered.view(-1), buf, group=self.group)
+            self._raise_if_failed(gathered[:, size:].contiguous().view(torch.int64).cpu().numpy(), "search")
+            if self.rank != 0:
+                return None
+            if getattr(shard, "strided_records", False):
+                return shard.merge_packed(gathered.view(-1), self.world, nq, k, stride_bytes=size + 8)
+            return shard.merge_packed(gathered[:, :size].contiguous().view(-1), self.world, nq, k)
         if op == OP_ADD:
             n, owner, gid_base, normalize = int(hdr[2]), int(hdr[3]), int(hdr[4]), bool(hdr[5])
             if owner != 0:   # the batch travels to its owner only
@@ -329,8 +414,8 @@ class ShardServer:
                     vecs = self._recv((n, self.dim), torch.float32, 0)
                     tags = self._recv((n,), torch.int32, 0)
             if self.rank == owner:
-                first = shard.add(vecs, tags, normalize, gid_base)
-                self.extents[code].append(gid_base, first, n)
+                ok = self._append(code, shard, vecs, tags, normalize, gid_base, n)
+            self._verdict(ok, "add")
             return None
         if op == OP_ENCODE:
             # Data-parallel ingest ("chunks are independent => pure data-parallel, no collective; each
@@ -344,49 +429,89 @@ class ShardServer:
             lens = self._bcast(enc[0] if enc else None, (total_seqs,), torch.int32)
             ids = self._bcast(enc[1] if enc else None, (max(total_tokens, 1),), torch.int32)
             tg = self._bcast(enc[2] if enc else None, (total_seqs,), torch.int32)
-            lens_h = lens.cpu().numpy().astype(np.int64)
-            tok0 = np.concatenate([[0], np.cumsum(lens_h)])
-            for b in range(n_batches):
-                s0, s1 = b * ENC_BATCH_SEQS, min(total_seqs, (b + 1) * ENC_BATCH_SEQS)
-                if (first_owner + b) % self.world != self.rank:
-                    continue
-                bl = lens_h[s0:s1]
-                out = np.zeros((s1 - s0, self.dim), dtype=np.float32)
-                keep = np.nonzero(bl > 0)[0]
-                if keep.size:
-                    sub_ids = ids[int(tok0[s0]):int(tok0[s1])].cpu().numpy()
-                    cu = np.concatenate([[0], np.cumsum(bl[keep])]).astype(np.int64)
-                    try:
-                        out[keep] = np.asarray(self.encoder().encode_flat(sub_ids, cu), dtype=np.float32)
-                    except Exception as e:
-                        # app/embedding_gen.py:165-170: an embedding error is printed and the text gets a zero vector
-                        # (never a hit).  The rows are appended all the same: every rank's bookkeeping stays in step.
-                        logger.error(f"[ERROR] encoder on rank {self.rank}: {e}; {int(keep.size)} texts get zero vectors")
-                        out[:] = 0.0
-                first = shard.add(torch.from_numpy(out).to(self.device), tg[s0:s1].contiguous(), normalize, gid_base + s0)
-                self.extents[code].append(gid_base + s0, first, s1 - s0)
+            try:
+                lens_h = lens.cpu().numpy().astype(np.int64)
+                tok0 = np.concatenate([[0], np.cumsum(lens_h)])
+                for b in range(n_batches):
+                    s0, s1 = b * ENC_BATCH_SEQS, min(total_seqs, (b + 1) * ENC_BATCH_SEQS)
+                    if (first_owner + b) % self.world != self.rank:
+                        continue
+                    bl = lens_h[s0:s1]
+                    out = np.zeros((s1 - s0, self.dim), dtype=np.float32)
+                    keep = np.nonzero(bl > 0)[0]
+                    if keep.size:
+                        sub_ids = ids[int(tok0[s0]):int(tok0[s1])].cpu().numpy()
+                        cu = np.concatenate([[0], np.cumsum(bl[keep])]).astype(np.int64)
+                        try:
+                            out[keep] = np.asarray(self.encoder().encode_flat(sub_ids, cu), dtype=np.float32)
+                        except Exception as e:
+                            # app/embedding_gen.py:165-170: an embedding error is printed and the text gets a zero vector
+                            # (never a hit).  The rows are appended all the same: every rank's bookkeeping stays in step.
+                            logger.error(f"[ERROR] encoder on rank {self.rank}: {e}; {int(keep.size)} texts get zero vectors")
+                            out[:] = 0.0
+                    if not self._append(code, shard, torch.from_numpy(out).to(self.device), tg[s0:s1].contiguous(), normalize,
+                                        gid_base + s0, s1 - s0):
+                        ok = False
+            except Exception as e:
+                ok = failed("encode", e)
+            self._verdict(ok, "encode")
             return None
         if op == OP_DELETE:
-            ordinal = self.extents[code].ordinal_of(int(hdr[2]))
-            if ordinal is not None:
-                shard.delete(ordinal)
+            try:
+                ordinal = self.extents[code].ordinal_of(int(hdr[2]))
+                if ordinal is not None:
+                    shard.delete(ordinal)
+            except Exception as e:
+                ok = failed("delete", e)
+            self._verdict(ok, "delete")
             return None
         if op == OP_COUNT:
-            t = torch.tensor([shard.count, shard.rows], dtype=torch.int64, device=self.device)
+            try:
+                vals = [int(shard.count), int(shard.rows), 0]
+            except Exception as e:
+                failed("count", e)
+                vals = [0, 0, 1]
+            t = torch.tensor(vals, dtype=torch.int64, device=self.device)     # the verdict rides on the reduction
             if self.world > 1:
                 dist.all_reduce(t, group=self.group)
-            return [int(v) for v in t.cpu()]
+            live, rows, bad = (int(v) for v in t.cpu())
+            if bad:
+                raise CollectiveFailure(f"count failed on {bad} rank(s)")
+            return [live, rows]
         if op == OP_GETROW:
             gid, owner = int(hdr[2]), int(hdr[3])
             row = None
             if self.rank == owner:
-                row = shard.get_row(self.extents[code].ordinal_of(gid))
+                try:
+                    row = shard.get_row(self.extents[code].ordinal_of(gid))
+                except Exception as e:
+                    ok = failed("get_row", e)
+                    row = torch.zeros((self.dim,), dtype=torch.float32, device=self.device)   # rank 0 is waiting for a row
                 if owner != 0:
                     self._send(row, 0)
             elif self.rank == 0:
                 row = self._recv((self.dim,), torch.float32, owner)
+            self._verdict(ok, "get_row")
             return row.cpu().numpy() if (self.rank == 0 and row is not None) else None
         raise RuntimeError(f"unknown serving op {op}")
+
+    def _append(self, code: int, shard, vecs: torch.Tensor, tags: torch.Tensor, normalize: bool, gid_base: int, n: int) -> bool:
+        """The owner's append.  On failure nothing of the batch stays visible: rows a partial append may have published
+        are tombstoned, the extent table is untouched."""
+        before = None
+        try:
+            before = int(shard.rows)
+            first = shard.add(vecs, tags, normalize, gid_base)
+            self.extents[code].append(gid_base, first, n)
+            return True
+        except Exception as e:
+            logger.error(f"append of {n} rows failed on rank {self.rank}: {e}")
+            try:
+                for o in range(before if before is not None else 0, int(shard.rows) if before is not None else 0):
+                    shard.delete(o)
+            except Exception:
+                pass
+            return False
 
 
 def worker_loop(server: ShardServer) -> None:
@@ -399,6 +524,8 @@ def worker_loop(server: ShardServer) -> None:
             server.execute(hdr)
         except CollectiveFailure as e:      # raised on every rank alike: rank 0 tells its caller, the service goes on
             logger.error(f"rank {server.rank}: {e}")
+        # anything else (a communicator error, a bug) is not survivable in step with the others: it propagates, the process
+        # exits non-zero and the launcher (torchrun) tears the job down and starts fresh processes
     dist.barrier(group=server.group)
 
 
@@ -422,7 +549,7 @@ class ShardedFront:
                 if raw.size > NAME_BYTES:
                     raise ValueError("index name too long")
                 hdr = self.server.post([OP_OPEN, code, raw.size], raw)
-                self.server.execute(hdr)
+                self.server.execute(hdr)         # CollectiveFailure: open on no rank, and not registered here
                 idx = self.indices[name] = ShardedIndex(self, name, code)
             return idx
 
@@ -494,10 +621,32 @@ class ShardedIndex:
             return live
 
     def _owner(self, gid: int) -> int:
+        """The rank that holds global row ``gid``; -1 for a HOLE: an id an append consumed before it failed."""
         e = bisect.bisect_right(self._owner_gid, gid) - 1
         if e < 0 or not 0 <= gid < self._rows:
             raise IndexError(f"row {gid} out of range")
         return self._owner_rank[e]
+
+    def _commit_run(self, owner: int, m: int) -> None:
+        """Rank 0's bookkeeping for ``m`` global ids starting at the cursor: a run held by ``owner``, or a hole
+        (``owner`` -1) when the append that was to store them failed — the cursor advances either way: once an ADD /
+        ENCODE was posted a rank may have used those ids, and an id is never given out twice."""
+        if not self._owner_rank or self._owner_rank[-1] != owner:
+            self._owner_gid.append(self._rows)
+            self._owner_rank.append(owner)
+        self._runs.append([self._rows, owner, m])
+        self._rows += m
+
+    def _rollback(self, committed: List[Tuple[int, int]]) -> None:
+        """A multi-part append failed half-way: tombstone the parts that went in (the caller registers none of the
+        batch's documents, so those rows must not take slots in anyone's top-k).  Best effort."""
+        for gid, m in committed:
+            for g in range(gid, gid + m):
+                try:
+                    self.delete(g)
+                except Exception as e:      # the service is degraded anyway; the caller hears about the original failure
+                    logger.error(f"rollback of row {g} failed: {e}")
+                    return
 
     # ---- write path
     def add(self, vecs: np.ndarray, tags: Optional[np.ndarray] = None, normalize: bool = True) -> int:
@@ -517,17 +666,20 @@ class ShardedIndex:
                 return first
             owner = self._batches % s.world
             self._batches += 1
+            committed: List[Tuple[int, int]] = []
             for a in range(0, n, ADD_CHUNK_ROWS):
                 m = min(ADD_CHUNK_ROWS, n - a)
                 dv = torch.from_numpy(v[a:a + m]).to(s.device)
                 dt = torch.from_numpy(t[a:a + m]).to(s.device)
                 hdr = s.post([OP_ADD, self.code, m, owner, self._rows, 1 if normalize else 0])
-                s.execute(hdr, dv, dt)
-                if not self._owner_rank or self._owner_rank[-1] != owner:
-                    self._owner_gid.append(self._rows)
-                    self._owner_rank.append(owner)
-                self._runs.append([self._rows, owner, m])
-                self._rows += m
+                try:
+                    s.execute(hdr, dv, dt)
+                except CollectiveFailure:
+                    self._commit_run(-1, m)          # the owner stored nothing; the ids are burnt
+                    self._rollback(committed)
+                    raise
+                committed.append((self._rows, m))
+                self._commit_run(owner, m)           # only after the verdict
             return first
 
     @property
@@ -559,6 +711,7 @@ class ShardedIndex:
                 lens[keep] = np.diff(np.asarray(cu, dtype=np.int64)).astype(np.int32)
             tok0 = np.concatenate([[0], np.cumsum(lens.astype(np.int64))])
             per_round = ENC_BATCH_SEQS * s.world          # one batch per rank and round
+            committed: List[Tuple[int, int]] = []
             for a in range(0, n, per_round):
                 b = min(n, a + per_round)
                 n_batches = (b - a + ENC_BATCH_SEQS - 1) // ENC_BATCH_SEQS
@@ -566,18 +719,28 @@ class ShardedIndex:
                 r_ids = flat[int(tok0[a]):int(tok0[b])]
                 hdr = s.post([OP_ENCODE, self.code, n_batches, owner0, self._rows, 1 if normalize else 0, b - a,
                               int(r_ids.size)])
-                s.execute(hdr, enc=(torch.from_numpy(lens[a:b].copy()),
-                                    torch.from_numpy(r_ids.copy() if r_ids.size else np.zeros(1, np.int32)),
-                                    torch.from_numpy(t[a:b].copy())))
+                failed_ranks = None
+                try:
+                    s.execute(hdr, enc=(torch.from_numpy(lens[a:b].copy()),
+                                        torch.from_numpy(r_ids.copy() if r_ids.size else np.zeros(1, np.int32)),
+                                        torch.from_numpy(t[a:b].copy())))
+                except CollectiveFailure as e:
+                    failed_ranks, failure = set(e.failed_ranks), e
+                # one batch per rank and round: a rank's status is its batch's.  Batches of the ranks that succeeded ARE
+                # in their shards (under the ids assigned here) and are committed — and rolled back below when the round
+                # failed; batches of failed ranks are holes.  The cursors advance in every case.
                 for j in range(n_batches):
                     owner = (owner0 + j) % s.world
                     m = min(ENC_BATCH_SEQS, b - a - j * ENC_BATCH_SEQS)
-                    if not self._owner_rank or self._owner_rank[-1] != owner:
-                        self._owner_gid.append(self._rows)
-                        self._owner_rank.append(owner)
-                    self._runs.append([self._rows, owner, m])
-                    self._rows += m
+                    if failed_ranks is not None and owner in failed_ranks:
+                        self._commit_run(-1, m)
+                    else:
+                        committed.append((self._rows, m))
+                        self._commit_run(owner, m)
                 self._batches += n_batches
+                if failed_ranks is not None:
+                    self._rollback(committed)
+                    raise failure
             return first
 
     # ---- persistence (docstore.IndexState.save / load call these through the FlatIndex surface)
@@ -621,7 +784,10 @@ class ShardedIndex:
     def get_row(self, row: int) -> np.ndarray:
         with self.front.lock:
             s = self.front.server
-            return s.execute(s.post([OP_GETROW, self.code, int(row), self._owner(row)]))
+            owner = self._owner(row)
+            if owner < 0:
+                raise IndexError(f"row {row} was never stored (the append that consumed its id failed)")
+            return s.execute(s.post([OP_GETROW, self.code, int(row), owner]))
 
     # ---- read path
     def search(self, queries: np.ndarray, k: int, q_filter: Optional[np.ndarray] = None,
@@ -666,7 +832,9 @@ class ShardedIndex:
                     payload[off + 2 * MAX_Q * 4:off + 2 * MAX_Q * 4 + b * 4] = last_s.view(np.uint8)
                     payload[off + 3 * MAX_Q * 4:off + 3 * MAX_Q * 4 + b * 8] = last_i.view(np.uint8)
                 with self.front.lock:
-                    sc, ids = s.execute(s.post([OP_SEARCH, self.code, b, kk, pf], payload))
+                    # an unfiltered first pass moves only its queries; filters / continuation bounds sit behind them
+                    sc, ids = s.execute(s.post([OP_SEARCH, self.code, b, kk, pf], payload,
+                                               payload_len=b * self.dim * 4 if pf == 0 else None))
                 out_s[a:a + b, done:done + kk] = sc
                 out_i[a:a + b, done:done + kk] = ids
                 done += kk

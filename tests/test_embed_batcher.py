@@ -208,3 +208,89 @@ def test_batcher_caps_and_close():
         asyncio.run(b.embed(["late"]))
     with pytest.raises(ValueError):
         EmbedBatcher(enc, max_seqs=0)
+
+
+# ------------------------------------------------------------------ CrossIndexBatcher: who may share a launch
+class _FakeIndex:
+    """FlatIndex's surface as far as the batcher sees it: search() + multi_tiles."""
+
+    def __init__(self, name, rows, dtype="f32", gids=False):
+        self.name, self.rows, self.dtype, self.has_global_ids = name, rows, dtype, gids
+        self.solo_calls = []
+
+    @property
+    def multi_tiles(self):
+        if self.dtype != "f32" or self.has_global_ids:
+            return 0
+        t = (self.rows + 31) // 32
+        return t if t <= 65536 // 2 else 0
+
+    def search(self, qs, k, f=None, m=None):
+        self.solo_calls.append(qs.shape[0])
+        return (np.full((qs.shape[0], k), 0.5, np.float32), np.full((qs.shape[0], k), hash(self.name) % 1000, np.int64))
+
+
+class _FakeEngine:
+    """rass_index_search_multi's admission rules (api.hip): fp32, plain ids, <= 65 536 tiles over the distinct indices."""
+
+    def __init__(self):
+        self.calls = []
+
+    def search_multi(self, indices, qs, k, f=None, m=None):
+        tiles = sum((ix.rows + 31) // 32 for ix in {id(i): i for i in indices}.values())
+        if tiles > 65536 or any(ix.dtype != "f32" or ix.has_global_ids for ix in indices):
+            raise RuntimeError("RASS_ERR_UNSUPPORTED")
+        self.calls.append([ix.name for ix in indices])
+        return (np.full((len(indices), k), 0.25, np.float32),
+                np.stack([np.full(k, hash(ix.name) % 1000, np.int64) for ix in indices]))
+
+
+def test_cross_index_batcher_never_fails_a_batch_over_its_company():
+    """One user with 3 M rows, two users with 1.1 M rows each (together over the 2 M-row budget), a bf16 index and a
+    shard with global ids in the SAME 20 ms window as small per-user indices: everybody is answered."""
+    from rassengine_amd.batcher import CrossIndexBatcher
+    eng = _FakeEngine()
+    small = [_FakeIndex(f"small{i}", 10_000) for i in range(6)]
+    huge = _FakeIndex("huge", 3_000_000)
+    mid = [_FakeIndex("midA", 1_040_000), _FakeIndex("midB", 1_040_000)]   # each under half the budget, together over it
+    bf16 = _FakeIndex("bf16", 50_000, dtype="bf16")
+    shard = _FakeIndex("shard", 50_000, gids=True)
+    b = CrossIndexBatcher(eng, max_batch=32, max_delay_ms=20.0)
+    who = small + [huge, huge, mid[0], mid[1], bf16, shard, small[0]]
+
+    async def go():
+        out = await asyncio.gather(*[b.search(ix, np.ones(8, np.float32), 3) for ix in who])
+        await b.close()
+        return out
+
+    out = asyncio.run(go())
+    assert len(out) == len(who)
+    for ix, (s, i) in zip(who, out):
+        assert s.shape == (3,) and int(i[0]) == hash(ix.name) % 1000      # everyone got an answer from ITS index
+    assert huge.solo_calls == [2]                   # too large for any cross-index batch: ONE scan of its own for both
+    assert bf16.solo_calls == [1] and shard.solo_calls == [1]
+    flat = [n for c in eng.calls for n in c]
+    assert sorted(flat) == sorted([ix.name for ix in small] + ["small0", "midA", "midB"])
+    assert len(eng.calls) == 2                      # the two mid-size users could not share ONE launch: two groups
+    assert not ({"midA", "midB"} <= set(eng.calls[0])) and not ({"midA", "midB"} <= set(eng.calls[1]))
+    assert b.served == len(who)
+
+
+def test_cross_index_batcher_falls_back_when_the_engine_refuses():
+    from rassengine_amd.batcher import CrossIndexBatcher
+
+    class Refusing(_FakeEngine):
+        def search_multi(self, *a, **k):
+            raise RuntimeError("RASS_ERR_UNSUPPORTED: grew past the budget since it was planned")
+
+    a, c = _FakeIndex("a", 1000), _FakeIndex("c", 2000)
+    b = CrossIndexBatcher(Refusing(), max_delay_ms=20.0)
+
+    async def go():
+        out = await asyncio.gather(b.search(a, np.ones(8, np.float32), 2), b.search(c, np.ones(8, np.float32), 2),
+                                   b.search(a, np.ones(8, np.float32), 1))
+        await b.close()
+        return out
+
+    out = asyncio.run(go())
+    assert [o[0].shape for o in out] == [(2,), (2,), (1,)] and a.solo_calls == [2] and c.solo_calls == [1]

@@ -336,6 +336,143 @@ def test_encoder_failure_and_refused_load_keep_the_ranks_in_step(tmp_path):
     assert os.path.exists(os.path.join(str(tmp_path), "worker1.done"))
 
 
+def _failing_shard_worker(rank, world, port, out_dir, fail_rank):
+    """a shard whose add / search raises on ONE rank (rank 0 itself or a worker) must fail the operation on
+    EVERY rank together, keep the workers in the loop, never reuse a global id, and leave row -> doc mapping intact."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import asyncio
+        from rassengine_amd import embedding, indexer, serving
+        from rassengine_amd.docstore import REGISTRY
+        from tests.helpers import HashEmbedder, TokenHashEncoder
+        D = 64
+
+        class FlakyShard(OracleServingShard):
+            def add(self, vecs, tags, normalize, first_global_id):
+                t = tags.numpy()
+                if dist.get_rank() == fail_rank and (t == 999).any():
+                    raise MemoryError("slab growth failed")
+                return super().add(vecs, tags, normalize, first_global_id)
+
+            def search_packed(self, queries, k, filt, mask, after=None):
+                if dist.get_rank() == fail_rank and float(queries[0, 0]) == 12345.0:
+                    raise RuntimeError("scan launch failed")
+                return super().search_packed(queries, k, filt, mask, after)
+
+        front = serving.start(lambda name: FlakyShard(D), D, torch.device("cpu"), encoder_factory=lambda: TokenHashEncoder(D))
+        if rank != 0:
+            open(os.path.join(out_dir, f"worker{rank}.done"), "w").write("ok")   # left the loop through the shutdown
+            return
+        assert dist.get_backend(front.server.ctl) == "gloo"            # the idle wait is a host-side socket read
+        ix = front.open_index("flaky")
+        rng = np.random.default_rng(0)
+
+        def batch(n, tag=1):
+            return rng.standard_normal((n, D)).astype(np.float32), np.full(n, tag, dtype=np.int32)
+
+        va, ta = batch(30)
+        assert ix.add(va, ta) == 0                                     # batch 0 -> rank 0
+        vb, tb = batch(30)
+        assert ix.add(vb, tb) == 30                                    # batch 1 -> rank 1
+        if fail_rank == 1:
+            vc, tc = batch(5)
+            assert ix.add(vc, tc) == 60                                # batch 2 -> rank 0, so that batch 3 -> rank 1
+        rows0, live0 = ix.rows, ix.count
+        bad_v, bad_t = batch(7, tag=999)
+        with pytest.raises(serving.CollectiveFailure) as ei:
+            ix.add(bad_v, bad_t)                                       # the owner (= fail_rank) raises
+        assert ei.value.failed_ranks == (fail_rank,)
+        assert ix.rows == rows0 + 7 and ix.count == live0              # the ids are burnt, nothing was stored
+        with pytest.raises(IndexError):
+            ix.get_row(rows0 + 3)                                      # a hole
+        vd, td = batch(4)
+        first = ix.add(vd, td)
+        assert first == rows0 + 7                                      # never the failed batch's ids again
+        s_, i_ = ix.search(vd, 1)
+        assert i_[:, 0].tolist() == list(range(first, first + 4))      # the new rows answer under their own ids
+        assert np.allclose(ix.get_row(first + 2), vd[2] / (np.linalg.norm(vd[2]) + 1e-9), atol=1e-6)
+
+        # a search that fails on one rank fails everywhere, once; the next one is served
+        qbad = vd[:1].copy()
+        qbad[0, 0] = 12345.0
+        with pytest.raises(serving.CollectiveFailure):
+            ix.search(qbad, 3)
+        assert ix.search(vd[:1], 1)[1][0, 0] == first
+
+        # a multi-chunk add whose SECOND chunk fails: the first chunk is rolled back (tombstoned), ids burnt
+        n_big = serving.ADD_CHUNK_ROWS + 10
+        vbig = rng.standard_normal((n_big, D)).astype(np.float32)
+        tbig = np.ones(n_big, dtype=np.int32)
+        tbig[-1] = 999
+        # make sure this batch's owner is the failing rank
+        while ix._batches % world != fail_rank:
+            ix.add(*batch(1))
+        rows1, live1 = ix.rows, ix.count
+        with pytest.raises(serving.CollectiveFailure):
+            ix.add(vbig, tbig)
+        assert ix.rows == rows1 + n_big and ix.count == live1
+        assert ix.search(vbig[:1], 1)[1][0, 0] != rows1                # the rolled-back row is no hit
+
+        # data-parallel ingest: the append of ONE rank's batch fails -> the round fails as a whole, the other rank's
+        # batch is rolled back, the cursor moved past all of it
+        texts = [f"alpha beta {i}" for i in range(600)]                # 3 batches over 2 ranks
+        ttags = np.ones(600, dtype=np.int32)
+        owners = [(ix._batches + j) % world for j in range(3)]
+        ttags[256 * owners.index(fail_rank)] = 999
+        rows2, live2 = ix.rows, ix.count
+        with pytest.raises(serving.CollectiveFailure):
+            ix.add_texts(texts, tags=ttags)
+        # (the cursor moved past every round that was posted: 512 texts per round of 2 ranks, the failing round included)
+        assert ix.rows in (rows2 + 512, rows2 + 600) and ix.count == live2
+        rows3 = ix.rows
+        assert ix.add_texts(["gamma delta"]) == rows3 and ix.count == live2 + 1
+
+        # through the shim: a failed store registers nothing and shifts nothing (row -> doc stays right)
+        REGISTRY.clear()
+        REGISTRY.set_index_factory(front.open_index)
+        embedding.set_embedder(HashEmbedder(D))
+
+        def docs(a, b, patient="p1"):
+            return [{"doc_id": f"d{i}", "doc_type": "unstructured", "patientId": patient,
+                     "unstructuredText": f"chunk number {i} about topic{i % 7}"} for i in range(a, b)]
+        from rassengine_amd import config
+        config.EMBED_DIM = D
+        asyncio.run(indexer.store_fhir_docs_in_opensearch([], docs(0, 20), None, "flaky-shim", embed_fn=lambda t: _embed(t)))
+        st = REGISTRY.get("flaky-shim")
+        while st.index._batches % world != fail_rank:
+            asyncio.run(indexer.store_fhir_docs_in_opensearch([], docs(1000 + st.index._batches, 1001 + st.index._batches), None,
+                                                              "flaky-shim", embed_fn=lambda t: _embed(t)))
+        # the 999th patient code does not exist; make the tag 999 through the shard's eyes: patch tag_of for one store
+        orig_tag_of = st.tag_of
+        st.tag_of = lambda d: 999
+        asyncio.run(indexer.store_fhir_docs_in_opensearch([], docs(20, 30), None, "flaky-shim", embed_fn=lambda t: _embed(t)))
+        st.tag_of = orig_tag_of
+        assert "d25" not in st.doc_row                                  # logged, nothing registered (main.py:1279-1281)
+        asyncio.run(indexer.store_fhir_docs_in_opensearch([], docs(30, 40), None, "flaky-shim", embed_fn=lambda t: _embed(t)))
+        ixr = indexer.HipIndexer(None, "flaky-shim")
+        for i in (3, 17, 33, 39):
+            q = asyncio.run(_embed([f"chunk number {i} about topic{i % 7}"]))
+            hits = ixr.semantic_search(q, k=1)
+            assert hits and hits[0][0]["doc_id"] == f"d{i}", (i, hits)
+        front.shutdown()
+    finally:
+        dist.destroy_process_group()
+
+
+async def _embed(texts):
+    from tests.helpers import HashEmbedder
+    return HashEmbedder(64).encode(list(texts))
+
+
+@pytest.mark.parametrize("fail_rank", [0, 1])
+def test_a_failing_shard_fails_every_rank_together_and_corrupts_nothing(fail_rank, tmp_path):
+    mp.spawn(_failing_shard_worker, args=(2, _free_port(), str(tmp_path), fail_rank), nprocs=2, join=True)
+    assert os.path.exists(os.path.join(str(tmp_path), "worker1.done"))
+
+
 def test_extent_table():
     from rassengine_amd.serving import Extents
     e = Extents()

@@ -236,7 +236,8 @@ int rass_encoder_create(int device, const rass_encoder_config* cfg, rass_encoder
         if ((rc = dev_alloc(e, reinterpret_cast<void**>(&e->d_stage), e->stage_elems * 4)) != RASS_OK) return rc;
         // split-K scratch: 16 slices x 256 rows x the widest GEMM output that is split that far (H), or fewer
         // slices of wider outputs: S * M_pad * N floats, the launcher picks S to fit
-        e->splitk_bytes = (size_t)16 * 256 * std::max(H, I / 4) * sizeof(float);
+        // (the mid-size kernel splits K for batches up to ~2 000 tokens: 4 slices x 1 024 rows x the widest output)
+        e->splitk_bytes = std::max((size_t)16 * 256 * std::max(H, I / 4), (size_t)4 * 1024 * std::max(3 * H, I)) * sizeof(float);
         if ((rc = dev_alloc(e, reinterpret_cast<void**>(&e->d_splitk), e->splitk_bytes)) != RASS_OK) return rc;
         if ((rc = dev_alloc(e, &e->word, (size_t)cfg->vocab_size * H * 2)) != RASS_OK) return rc;
         if ((rc = dev_alloc(e, &e->pos, (size_t)cfg->max_positions * H * 2)) != RASS_OK) return rc;

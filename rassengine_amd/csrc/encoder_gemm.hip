@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_bf16.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -536,13 +537,34 @@ static hipError_t launch_fewrows(const u16* x, const u16* w, const float* bias, 
                        : launch_fewrows_w<EPI, 4>(x, w, bias, r, y, M, N, K, stream);
 }
 
-// Number of K slices for a GEMM with few output tiles (0 = do not split): aim at >= 128 workgroups, at most 16 slices, whole
-// 64-deep steps per slice, and a scratch of S * M_pad * N floats that fits.
+// Number of K slices for a GEMM with few output tiles (0 = do not split), whole 64-deep steps per slice, a scratch of
+// S * M_pad * N floats that fits.  Measured on MI355X (scripts/probe_gemm_mid.py, profiles/r03_gemm_mid_sweep.txt; every
+// combination of the four encoder GEMMs x 128 .. 3 072 rows x S): what bounds these kernels is the rate at which ONE CU
+// can fill its LDS (one 128^2 workgroup takes ~0.9 us per 64-deep step however deep its prefetch ring is — a four-slot
+// ring with counted waits measured the SAME times as this two-buffer loop and was removed), so a short K (1 024) wants
+// >= 128 workgroups of >= 4 steps and a long K (4 096) up to 512 workgroups of >= 16 steps; beyond that the fp32 partials
+// cost more than the split wins.  The rule was then settled on whole forwards (cold weights: scripts/sweep_splitk_rule.sh,
+// same file), where more workgroups pull harder on HBM than the warm micro-benchmark shows.  Round 2 split only below 96
+// tiles and aimed at 128 workgroups: FFN-down ran 64 serial steps at 96+ tiles (1 024 rows 29 -> 22 us, 1 536 rows
+// 45 -> 28, 2 048 rows 46 -> 34).
 static int splitk_slices(int M_pad, int N, int K, size_t ws_bytes) {
     const int tiles = (N / GBN) * (M_pad / GBM), steps = K / GBK;
-    if (tiles >= 96 || steps < 2) return 0;
+    if (const char* v = getenv("RASS_GEMM_SPLITK_S")) {   // sweeps (scripts/probe_gemm_mid.py)
+        int S = atoi(v);
+        if (S < 2 || S > 16 || steps % S != 0 || (size_t)S * M_pad * N * sizeof(float) > ws_bytes) return 0;
+        return S;
+    }
+    if (steps < 2) return 0;
     int S = 1;
-    while (S < 16 && tiles * S < 128 && steps % (2 * S) == 0) S *= 2;
+    if (K < 2048) {
+        // short K (16 steps): the smallest split that gives >= 128 workgroups, slices of >= 4 steps
+        while (S < 4 && tiles * S < 128 && steps % (2 * S) == 0) S *= 2;
+    } else {
+        // long K (64 steps): the largest split that stays within 512 workgroups (two resident per CU); slices of >= 16 steps
+        // from 48 tiles on, >= 8 below, >= 4 for a single row of tiles
+        const int cap = tiles <= 8 ? 16 : tiles < 48 ? 8 : 4;
+        while (S < cap && tiles * S * 2 <= 512 && steps % (2 * S) == 0) S *= 2;
+    }
     while (S > 1 && (size_t)S * M_pad * N * sizeof(float) > ws_bytes) S /= 2;
     return S > 1 ? S : 0;
 }

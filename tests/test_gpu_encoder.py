@@ -100,6 +100,48 @@ def test_gemm_forced_variants_on_few_tiles(gpu, variant):
     assert "VARIANT_OK" in out.stdout, (out.stdout[-500:], out.stderr[-1500:])
 
 
+@pytest.mark.parametrize("mid_s", ["auto", "2", "4", "8", "16"])
+@pytest.mark.parametrize("M,N,K,epi", [(384, 3072, 1024, 0), (200, 1024, 1024, 1), (384, 4096, 1024, 2), (129, 1024, 4096, 1),
+                                       (1000, 1024, 4096, 0), (65, 128, 128, 2), (640, 256, 64, 1), (2047, 3072, 1024, 0)])
+def test_gemm_mid_size_split_k(gpu, M, N, K, epi, mid_s, monkeypatch):
+    """Mid-size batches (65 .. ~2 000 rows: N concurrent queries coalesced by the embed micro-batcher, small uploads) on
+    the 128^2 kernels: the slice count the launcher picks (round 3's rule: ~64 workgroups for K = 1 024, ~256 for K = 4 096)
+    and every forced count (RASS_GEMM_SPLITK_S, read per launch), against torch within bf16 rounding; bit-identical
+    from run to run (fp32 partials summed in fixed order)."""
+    torch = gpu
+    if mid_s != "auto":
+        monkeypatch.setenv("RASS_GEMM_SPLITK_S", mid_s)
+    from rassengine_amd import _native as N_
+    g = torch.Generator(device="cuda")
+    g.manual_seed(M * 13 + N + K + epi)
+    M_pad = (M + 255) // 256 * 256
+    X = torch.zeros((M_pad, K), dtype=torch.bfloat16, device="cuda")
+    X[:M] = torch.randn((M, K), generator=g, device="cuda").bfloat16()
+    W = (torch.randn((N, K), generator=g, device="cuda") / K ** 0.5).bfloat16()
+    bias = torch.randn((N,), generator=g, device="cuda") * 0.1
+    R = torch.zeros((M_pad, N), dtype=torch.bfloat16, device="cuda")
+    R[:M] = torch.randn((M, N), generator=g, device="cuda").bfloat16()
+    ws = torch.empty((16 * 2048 * 1024,), dtype=torch.float32, device="cuda")
+    outs = []
+    for _ in range(2):
+        Y = torch.full((M_pad, N), 777.0, dtype=torch.bfloat16, device="cuda")
+        N_.check("rass_gemm_bf16_ws", N_.lib().rass_gemm_bf16_ws(
+            ctypes.c_void_p(X.data_ptr()), ctypes.c_void_p(W.data_ptr()), ctypes.c_void_p(bias.data_ptr()),
+            ctypes.c_void_p(R.data_ptr()) if epi == 1 else None, ctypes.c_void_p(Y.data_ptr()), M, M_pad, N, K, epi,
+            ctypes.c_void_p(ws.data_ptr()), ws.numel() * 4, ctypes.c_void_p(int(torch.cuda.current_stream().cuda_stream))))
+        torch.cuda.synchronize()
+        outs.append(Y)
+    ref = X[:M].float() @ W.float().T + bias
+    if epi == 1:
+        ref = ref + R[:M].float()
+    if epi == 2:
+        ref = torch.nn.functional.gelu(ref)
+    err = (outs[0][:M].float() - ref).abs()
+    tol = 1.5 * 2.0 ** -8 * ref.abs() + 2e-3
+    assert bool((err <= tol).all()), float((err - tol).max())
+    assert bool((outs[0][M:] == 777.0).all()) and torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("fewrows", ["1", "0"])
 @pytest.mark.parametrize("M,N,K,epi", [(1, 1024, 1024, 1), (16, 3072, 1024, 0), (37, 4096, 1024, 2), (100, 1024, 4096, 1),
                                        (129, 1024, 4096, 1), (200, 128, 128, 0), (256, 384, 512, 2),

@@ -82,7 +82,10 @@ int rass_device_count(void);
 
 /* ---------------------------------------------------------------- engine */
 
-/* One engine per process per GPU.  `dim` = EMBED_DIM (app/main.py:80). */
+/* One engine per process per GPU.  `dim` = EMBED_DIM (app/main.py:80), 1 .. 2048.  Up to 1024 columns every feature of
+ * this header applies; a WIDE-row engine (1024 < dim <= 2048: what an encoder of hidden size 1536 / 2048 emits) serves
+ * fp32 flat indices — add / delete / get / save / load and every search entry point incl. masked filters and k > 32 —
+ * while a bf16 corpus, the prefilter mode, the IVF build and cross-index batches answer RASS_ERR_UNSUPPORTED. */
 int rass_engine_create(int device, int dim, rass_engine_t** out);
 void rass_engine_destroy(rass_engine_t* eng);
 int rass_engine_dim(const rass_engine_t* eng);
@@ -112,7 +115,7 @@ int64_t rass_index_count(const rass_index_t* idx);
 /* Rows ever appended (live + tombstoned) = next row id. */
 int64_t rass_index_rows(const rass_index_t* idx);
 int rass_index_dim(const rass_index_t* idx);
-int rass_index_row_stride(const rass_index_t* idx); /* elements, dim padded to 128 */
+int rass_index_row_stride(const rass_index_t* idx); /* elements: dim padded to 128 (dim <= 1024) or to 256 (above) */
 /* RASS_F32 / RASS_BF16 as given to rass_index_open (or read back by rass_index_load). */
 int rass_index_dtype(const rass_index_t* idx);
 /* != 0 once any row carries a caller-assigned GLOBAL id (rass_index_add_ex: a shard of a multi-GPU index).  Together
@@ -262,8 +265,9 @@ size_t rass_scan_workspace_bytes(int nq, int k);
  *   (r>>4)*16*row_stride + (c>>4)*256 + ((((c>>2)&3)*16 + (r&15))*4) + (c&3)
  * floats from the slab base.  Every wave-level load of the scan is then a fully
  * coalesced 1 KiB burst that already is the MFMA A operand.  row_stride = dim
- * rounded up to 128, zero padded; a slab holds whole blocks (rows rounded up
- * to 16).  The two converters below move between row-major and tile16. */
+ * rounded up to 128 (to 256 above 1024 columns), zero padded; a slab holds
+ * whole blocks (rows rounded up to 16).  The two converters below move between
+ * row-major and tile16. */
 int rass_pack_rows_f32(const float* d_in, int64_t in_stride, float* d_packed,
                        int64_t row_stride, int64_t first_row, int64_t n, int dim,
                        int normalize, void* stream);
@@ -274,8 +278,9 @@ int rass_unpack_rows_f32(const float* d_packed, int64_t row_stride,
 /* K1+K2: fused flat cosine scan + per-workgroup top-k + merge over a tile16
  * fp32 corpus slab in HBM.  Rows must already be normalised (rass_pack_rows_f32
  * with normalize=1 does both); d_queries (nq x dim, row-major) are normalised
- * by the launcher.  row_stride is in elements, a multiple of 128 with zero
- * padding beyond dim; the slab must hold ceil(n_rows/16) whole blocks.
+ * by the launcher.  row_stride is in elements, 128 * {1..8} or (wide rows)
+ * 256 * {5..8}, with zero padding beyond dim; the slab must hold
+ * ceil(n_rows/16) whole blocks.
  * d_row_tag / d_q_filter may be NULL. */
 int rass_scan_topk_f32(const float* d_corpus, int64_t n_rows, int dim,
                        int64_t row_stride, const int32_t* d_row_tag,

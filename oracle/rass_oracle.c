@@ -118,6 +118,10 @@ static double score_f64(const float* x, const float* q, int dim) {
  * slices of 16*CH columns; inside a slice chunk j (16 columns), component i (0..3) and
  * lane group g (0..3) address column 16j + 4g + i, and one v_mfma_f32_16x16x4_f32 is the
  * fmaf chain over g = 0..3; the 8 slice partials are added in slice order. */
+/* The row stride the engine gives an index of `dim` columns (api.hip pad_stride): whole 128-column units up to 1 024
+ * columns, whole 256-column units above (the wide-row kernel walks a wave's slice in panels of whole chunks). */
+static int oracle_row_stride(int dim) { return dim <= 1024 ? (dim + 127) / 128 * 128 : (dim + 255) / 256 * 256; }
+
 static float score_f32_mfma(const float* x, const float* q, int dim, int stride) {
     const int ch = stride / 128;
     float part[8];
@@ -198,7 +202,7 @@ int rass_oracle_search(const float* X, int64_t n, int dim, int64_t x_stride, con
     nthreads = threads > 0 ? threads : omp_get_max_threads();
 #endif
     (void)threads;
-    const int stride_pad = (int)((dim + 127) / 128 * 128);
+    const int stride_pad = oracle_row_stride(dim);
     cand_t* lists = (cand_t*)malloc((size_t)nthreads * nq * k * sizeof(cand_t));
     int* lens = (int*)calloc((size_t)nthreads * nq, sizeof(int));
     if (!lists || !lens) {
@@ -263,7 +267,7 @@ int rass_oracle_search(const float* X, int64_t n, int dim, int64_t x_stride, con
 /* All nq x n scores of one kind (small cases: tie / near-tie analysis in the tests). */
 int rass_oracle_scores(const float* X, int64_t n, int dim, int64_t x_stride, const float* Q, int nq,
                        int64_t q_stride, int kind, double* out /* [nq][n] */) {
-    const int stride_pad = (int)((dim + 127) / 128 * 128);
+    const int stride_pad = oracle_row_stride(dim);
 #pragma omp parallel for schedule(static)
     for (int64_t r = 0; r < n; ++r) {
         const float* x = X + r * x_stride;

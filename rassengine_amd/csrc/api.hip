@@ -54,10 +54,15 @@ int fail(int code, const std::string& msg) {
 
 constexpr int kPrefilterMaxK = 16;     // prefilter keeps 32 bf16 candidates: only k <= 16 uses it, wider k scans fp32
 constexpr int kMaxGrid = 1024;        // upper bound on scan workgroups (sizing of scratch)
-constexpr int kMaxStride = 1024;      // dim_padded limit of the fused scan (CH <= 8)
+constexpr int kMaxStride = 2048;      // dim_padded limit of the fused scan (128 * {1..8}; wide rows: 256 * {5..8})
+constexpr int kNarrowStride = 1024;   // above it a row is "wide": flat fp32 scans of <= 16 queries per launch only
 constexpr int64_t kStageRows = 8192;  // host -> device staging granule for add()
 
 int64_t pad128(int64_t d) { return (d + 127) / 128 * 128; }
+// The row stride of an index of `dim` columns: whole 128-column units (8 waves x one 16-column chunk); above 1 024
+// columns whole 256-column units (the wide-row scan walks a wave's slice in an even number of chunks per panel).
+int64_t pad_stride(int64_t d) { return d <= kNarrowStride ? pad128(d) : (d + 255) / 256 * 256; }
+const char* kStrideMsg = "row_stride must be 128*{1..8} elements (dim <= 1024) or 256*{5..8} (dim <= 2048)";
 
 int device_cus(int device) {
     static std::mutex mu;
@@ -326,8 +331,29 @@ int scan_launch(const float* d_corpus, int64_t n_rows, int64_t stride, const int
     if (k < 1 || k > RASS_MAX_K) return fail(RASS_ERR_INVALID, "k must be in [1, RASS_MAX_K]");
     if (n_rows < 0 || n_rows > 0x7fffffc0LL) return fail(RASS_ERR_INVALID, "n_rows out of range for one scan");
     if (!rass::scan_supported_stride(stride) || stride > kMaxStride)
-        return fail(RASS_ERR_UNSUPPORTED, "row_stride must be 128*{1..8} elements (dim <= 1024)");
+        return fail(RASS_ERR_UNSUPPORTED, kStrideMsg);
     if (q_dim > stride) return fail(RASS_ERR_INVALID, "dim exceeds row_stride");
+    if (stride > kNarrowStride) {
+        if (plan) return fail(RASS_ERR_UNSUPPORTED, "IVF needs dim <= 1024");
+        if (nq > 16) {
+            // the wide-row kernel answers 16 queries per launch (its query fragments fill the registers): two launches,
+            // one after the other on the stream (they share the workspace)
+            ScanExt lo, hi;
+            if (ext) {
+                lo = *ext;
+                hi.d_q_mask = ext->d_q_mask ? ext->d_q_mask + 16 : nullptr;
+                hi.d_after_s = ext->d_after_s ? ext->d_after_s + 16 : nullptr;
+                hi.d_after_i = ext->d_after_i ? ext->d_after_i + 16 : nullptr;
+            }
+            int rc = scan_launch(d_corpus, n_rows, stride, d_row_tag, d_queries, q_dim, q_stride, 16, d_q_filter, k, id_base,
+                                 d_out_scores, d_out_ids, ws, ws_bytes, n_cus, st, timing, nullptr, id_map, ext ? &lo : nullptr);
+            if (rc != RASS_OK) return rc;
+            return scan_launch(d_corpus, n_rows, stride, d_row_tag, d_queries + 16 * q_stride, q_dim, q_stride, nq - 16,
+                               d_q_filter ? d_q_filter + 16 : nullptr, k, id_base, d_out_scores + (int64_t)16 * k,
+                               d_out_ids + (int64_t)16 * k, ws, ws_bytes, n_cus, st, timing, nullptr, id_map,
+                               ext ? &hi : nullptr);
+        }
+    }
     const ScratchLayout L = scratch_layout(nq, k);
     if (ws == nullptr || ws_bytes < L.total) return fail(RASS_ERR_INVALID, "scan workspace too small");
     if ((reinterpret_cast<uintptr_t>(d_corpus) & 15) != 0) return fail(RASS_ERR_INVALID, "corpus not 16-B aligned");
@@ -530,8 +556,8 @@ int rass_device_count(void) {
 int rass_engine_create(int device, int dim, rass_engine_t** out) {
     if (out == nullptr) return fail(RASS_ERR_INVALID, "out is NULL");
     *out = nullptr;
-    if (dim < 1 || pad128(dim) > kMaxStride)
-        return fail(RASS_ERR_UNSUPPORTED, "dim must be in [1, 1024] for the fused scan");
+    if (dim < 1 || pad_stride(dim) > kMaxStride)
+        return fail(RASS_ERR_UNSUPPORTED, "dim must be in [1, 2048] for the fused scan");
     int n = 0;
     HIP_TRY(hipGetDeviceCount(&n));
     if (device < 0 || device >= n) return fail(RASS_ERR_INVALID, "no such HIP device");
@@ -661,6 +687,8 @@ int rass_index_open(rass_engine_t* eng, const char* name, rass_dtype dtype, int6
     if (dtype != RASS_F32 && dtype != RASS_BF16) return fail(RASS_ERR_INVALID, "unknown corpus dtype");
     if (dtype == RASS_BF16 && pad128(eng->dim) % 256 != 0)
         return fail(RASS_ERR_UNSUPPORTED, "a bf16 corpus needs dim padded to a multiple of 256 (the bf16 scan's K split)");
+    if (dtype == RASS_BF16 && eng->dim > kNarrowStride)
+        return fail(RASS_ERR_UNSUPPORTED, "a bf16 corpus needs dim <= 1024 (wide rows are served by the fp32 scan only)");
     std::lock_guard<std::mutex> lk(eng->mu);
     auto it = eng->indices.find(name);
     if (it != eng->indices.end()) {
@@ -676,7 +704,7 @@ int rass_index_open(rass_engine_t* eng, const char* name, rass_dtype dtype, int6
     idx->name = name;
     idx->dtype = dtype;
     idx->dim = eng->dim;
-    idx->stride = pad128(eng->dim);
+    idx->stride = pad_stride(eng->dim);
     if (initial_capacity_rows > 0) {
         rc = index_reserve(idx, initial_capacity_rows);
         if (rc != RASS_OK) {
@@ -734,6 +762,7 @@ int rass_index_set_prefilter(rass_index_t* idx, int enable) {
     if (idx->dtype == RASS_BF16) return fail(RASS_ERR_UNSUPPORTED, "a bf16 corpus IS the bf16 scan: no prefilter mode");
     if (idx->prefilter) return RASS_OK;
     if (idx->stride % 256 != 0) return fail(RASS_ERR_UNSUPPORTED, "prefilter needs dim padded to a multiple of 256");
+    if (idx->stride > kNarrowStride) return fail(RASS_ERR_UNSUPPORTED, "prefilter needs dim <= 1024 (wide rows: fp32 flat scan only)");
     if (idx->capacity > 0) {
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&idx->d_rows_bf16), (size_t)idx->capacity * idx->stride * 2));
         HIP_TRY(hipMemsetAsync(idx->d_rows_bf16, 0, (size_t)idx->capacity * idx->stride * 2, st));
@@ -985,8 +1014,23 @@ int scan_launch_batch(rass_index* idx, const float* d_queries, int nq, int k, co
     if (k < 1 || k > RASS_MAX_K) return fail(RASS_ERR_INVALID, "k must be in [1, RASS_MAX_K]");
     if (rows < 0 || rows > 0x7fffffc0LL) return fail(RASS_ERR_INVALID, "n_rows out of range for one scan");
     if (!rass::scan_supported_stride(stride) || stride > kMaxStride)
-        return fail(RASS_ERR_UNSUPPORTED, "row_stride must be 128*{1..8} elements (dim <= 1024)");
+        return fail(RASS_ERR_UNSUPPORTED, kStrideMsg);
     const int groups = (nq + RASS_MAX_QBATCH - 1) / RASS_MAX_QBATCH;
+    if (stride > kNarrowStride) {
+        // wide rows: group by group through scan_launch (16 queries per kernel launch; no fused normalise / merge)
+        for (int g = 0; g < groups; ++g) {
+            const int b = std::min(RASS_MAX_QBATCH, nq - g * RASS_MAX_QBATCH);
+            const int64_t so = out_scores_group_stride > 0 ? out_scores_group_stride : (int64_t)RASS_MAX_QBATCH * k;
+            const int64_t io = out_ids_group_stride > 0 ? out_ids_group_stride : (int64_t)RASS_MAX_QBATCH * k;
+            int rc = scan_launch(idx->d_rows ? idx->d_rows : reinterpret_cast<const float*>(eng->d_scratch), rows, stride,
+                                 need_tags ? idx->d_tags : nullptr, d_queries + (int64_t)g * RASS_MAX_QBATCH * idx->dim, idx->dim,
+                                 idx->dim, b, d_q_filter ? d_q_filter + g * RASS_MAX_QBATCH : nullptr, k, gid ? 0 : id_base,
+                                 d_out_scores + g * so, d_out_ids + g * io, eng->d_scratch, eng->scratch_bytes, eng->n_cus, st,
+                                 eng, nullptr, gid ? idx->d_gid : nullptr, nullptr);
+            if (rc != RASS_OK) return rc;
+        }
+        return RASS_OK;
+    }
     const int64_t n_tiles = (rows + 31) / 32;
     int grid = (int)std::min<int64_t>(std::max<int64_t>(n_tiles, 1), std::min(eng->n_cus, kMaxGrid));
     if ((int64_t)grid * k > rass::kMergeMaxCandidates) grid = rass::kMergeMaxCandidates / k;
@@ -1257,6 +1301,8 @@ int rass_index_search_multi(rass_index_t* const* idxs, const float* queries, int
         if (idxs[q]->dtype != RASS_F32) return fail(RASS_ERR_UNSUPPORTED, "cross-index batches are fp32-only");
         if (idxs[q]->has_gid.load()) return fail(RASS_ERR_UNSUPPORTED, "cross-index batches need plain row ids");
     }
+    if (eng && eng->dim > kNarrowStride)
+        return fail(RASS_ERR_UNSUPPORTED, "cross-index batches need dim <= 1024: search wide-row indices one by one");
     int rc = set_device(eng);
     if (rc != RASS_OK) return rc;
     const int dim = eng->dim;
@@ -1327,7 +1373,7 @@ int rass_index_search_multi(rass_index_t* const* idxs, const float* queries, int
             }
             if (q_filter_mask) HIP_TRY(hipMemcpyAsync(eng->d_qmask, sl->h_mask, (size_t)b * 4, hipMemcpyHostToDevice, st));
             // launch: normalise -> MULTI scan over the work list -> merge (ids are rows of each query's own index)
-            const int64_t stride = pad128(dim);
+            const int64_t stride = pad_stride(dim);
             const ScratchLayout L = scratch_layout(b, k);
             unsigned char* ws = eng->d_scratch;
             float* q_padded = reinterpret_cast<float*>(ws + L.q_padded);
@@ -1789,6 +1835,7 @@ int rass_ivf_build(rass_index_t* src, const float* centroids, int nlist, const i
     *out = nullptr;
     if (nlist < 1 || nlist > 32768) return fail(RASS_ERR_INVALID, "nlist must be in [1, 32768]");
     if (src->dtype != RASS_F32) return fail(RASS_ERR_UNSUPPORTED, "the IVF build needs an fp32 source index");
+    if (src->stride > kNarrowStride) return fail(RASS_ERR_UNSUPPORTED, "IVF needs dim <= 1024 (wide rows: flat scan only)");
     rass_engine* eng = src->eng;
     std::lock_guard<std::mutex> lk(src->mu);
     int rc = set_device(eng);
@@ -2164,6 +2211,7 @@ int rass_kmeans_assign(rass_index_t* idx, int64_t first_block, int64_t block_ste
     if (!idx || !d_centroids_tile16 || !d_assign) return fail(RASS_ERR_INVALID, "NULL argument");
     if (nlist < 1 || nlist > 65536) return fail(RASS_ERR_INVALID, "nlist must be in [1, 65536]");
     if (idx->dtype != RASS_F32) return fail(RASS_ERR_UNSUPPORTED, "k-means needs an fp32 index");
+    if (idx->stride > kNarrowStride) return fail(RASS_ERR_UNSUPPORTED, "k-means needs dim <= 1024 (wide rows: flat scan only)");
     std::lock_guard<std::mutex> lk(idx->mu);
     if (!kmeans_range_ok(idx, first_block, block_step, n_blocks) || n_blocks > 0x7fffffff)
         return fail(RASS_ERR_INVALID, "block range outside the index");
@@ -2191,6 +2239,7 @@ int rass_kmeans_accumulate(rass_index_t* idx, int64_t first_block, int64_t block
     if (!idx || !d_assign || !d_sums || !d_counts) return fail(RASS_ERR_INVALID, "NULL argument");
     if (nlist < 1) return fail(RASS_ERR_INVALID, "nlist < 1");
     if (idx->dtype != RASS_F32) return fail(RASS_ERR_UNSUPPORTED, "k-means needs an fp32 index");
+    if (idx->stride > kNarrowStride) return fail(RASS_ERR_UNSUPPORTED, "k-means needs dim <= 1024 (wide rows: flat scan only)");
     std::lock_guard<std::mutex> lk(idx->mu);
     if (!kmeans_range_ok(idx, first_block, block_step, n_blocks) || n_blocks > 0x7fffffff)
         return fail(RASS_ERR_INVALID, "block range outside the index");
@@ -2261,9 +2310,14 @@ int rass_peer_wait(const void* d_flags, int n, int flag_stride_bytes, uint64_t s
 
 const char* rass_scan_kernel_name(int dim, int nq) {
     static thread_local char buf[64];
-    const int64_t stride = pad128(dim);
+    const int64_t stride = pad_stride(dim);
     if (dim < 1 || !rass::scan_supported_stride(stride) || stride > kMaxStride || nq < 1 || nq > RASS_MAX_QBATCH)
         return "";
+    if (stride > kNarrowStride) {
+        const int ch = (int)(stride / 128);
+        snprintf(buf, sizeof(buf), "scan_topk_f32_wide_kernel<%d, %d, false>", ch == 16 ? 4 : ch / 2, ch == 16 ? 4 : 2);
+        return buf;
+    }
     snprintf(buf, sizeof(buf), "scan_topk_f32_kernel<%d, %d, 0, false>", (int)(stride / 128), nq <= 16 ? 1 : 2);
     return buf;
 }

@@ -87,14 +87,16 @@ __device__ __forceinline__ int load_tag(const TileDesc& d) {
     return (int)__builtin_amdgcn_raw_buffer_load_b32(d.tags, (lane_id() & 31) * 4, 0, 0);
 }
 
-// Prologue: all of a tile's loads, in the order multiply_and_refill consumes them.
+// Prologue: all of a tile's loads, in the order multiply_and_refill consumes them.  `soff0`: byte offset of the K
+// panel these registers hold (0 unless the wave's K slice is walked in two panels: the wide-row kernel, dim > 1024).
 template <int CH, bool TAGS = true>
-__device__ __forceinline__ void issue_tile_loads(TileRegs<CH>& r, const TileDesc& d, int voff_lane, int mt_step) {
+__device__ __forceinline__ void issue_tile_loads(TileRegs<CH>& r, const TileDesc& d, int voff_lane, int mt_step,
+                                                 int soff0 = 0) {
     if (TAGS) r.tag = load_tag(d);
 #pragma unroll
     for (int j = 0; j < CH; ++j)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) r.a[mt][j] = load_chunk(d, voff_lane, mt * mt_step + j * 1024);
+        for (int mt = 0; mt < 2; ++mt) r.a[mt][j] = load_chunk(d, voff_lane, soff0 + mt * mt_step + j * 1024);
 }
 
 // Multiply the resident tile and, chunk by chunk, re-issue each consumed register's load
@@ -108,14 +110,19 @@ __device__ __forceinline__ void issue_tile_loads(TileRegs<CH>& r, const TileDesc
 // MFMAs execute on the matrix pipe (a v_mfma_f32_16x16x4_f32 occupies the pipe for 32 cycles but takes only a
 // few to issue).  Ranked in a phase of its own behind the barrier — as the first version did — it left the
 // matrix pipe idle while all 8 waves ranked in lockstep: 72 us of a 690 us launch at B = 32.
-template <int CH, int NT, bool TAGS = true, typename Between>
+//
+// ZERO = false continues the accumulators of the previous call (the second K panel of a wide row: the fmaf chain of a
+// wave's slice runs on in k order); `soff0` is the panel's byte offset for the refill loads.
+template <int CH, int NT, bool TAGS = true, bool ZERO = true, typename Between>
 __device__ __forceinline__ void multiply_and_refill(TileRegs<CH>& r, const f32x4 (&qf)[NT][CH],
                                                     f32x4 (&acc)[2][NT], const TileDesc& next, int voff_lane,
-                                                    int mt_step, Between&& between) {
+                                                    int mt_step, Between&& between, int soff0 = 0) {
+    if (ZERO) {
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     if (TAGS) r.tag = load_tag(next);  // the k-means kernel streams centroids: no row tags
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
@@ -135,8 +142,8 @@ __device__ __forceinline__ void multiply_and_refill(TileRegs<CH>& r, const f32x4
         RASS_KSTEP(z)
         RASS_KSTEP(w)
 #undef RASS_KSTEP
-        r.a[0][j] = load_chunk(next, voff_lane, j * 1024);
-        r.a[1][j] = load_chunk(next, voff_lane, mt_step + j * 1024);
+        r.a[0][j] = load_chunk(next, voff_lane, soff0 + j * 1024);
+        r.a[1][j] = load_chunk(next, voff_lane, soff0 + mt_step + j * 1024);
         __builtin_amdgcn_sched_barrier(0);
         between(j);
         __builtin_amdgcn_sched_barrier(0);

@@ -381,6 +381,178 @@ __global__ __launch_bounds__(kThreads, 2) void scan_topk_f32_kernel(ScanArgs p) 
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Wide rows: 1 024 < dim <= 2 048 (row_stride = 256 * {5..8}).  EMBED_DIM is an environment knob of the reference
+// (app/main.py:80) and the encoder serves hidden sizes up to 2 048, so the index must take what the encoder emits.
+// A wave's K slice (row_stride / 8 columns) no longer fits its registers as one tile image, so it is walked in P
+// PANELS of CHP chunks (P = 2 up to 1 792 columns, P = 4 x 4 chunks at 2 048): the two register images R0 / R1 hold
+// panels pn and pn + 1 of the current tile; a panel's MFMAs continue the accumulators of the panel before it (the
+// fmaf chain of the slice runs on in k order: a score is the same fixed sequence the oracle's emulation restates for
+// this stride), and each consumed register is refilled with the panel TWO steps ahead in the (tile, panel) sequence.
+// The query fragments of all panels stay in registers (row_stride / 32 VGPRs): that is what limits this kernel to 16
+// queries per launch (NT = 1; a 32-query group runs as two launches, api.hip).  Flat scans only (no IVF plan, no
+// cross-index work list, no sample floor: with <= 16 queries the scan is HBM-bound and the ranking hides under it).
+// Everything else — descriptors, XCD-aware item order, LDS images, one barrier per tile pair, ranking of the previous
+// pair between the MFMA chunks, register-only insertion, EXT filters / continuation bound — is the kernel above.
+template <int PN, int P, int CHP, typename Rank>
+__device__ __forceinline__ void wide_panels(TileRegs<CHP>& R0, TileRegs<CHP>& R1, const f32x4 (&qf)[P][1][CHP],
+                                            f32x4 (&acc)[2][1], const TileDesc& dcur, const TileDesc& dnext,
+                                            int voff_lane, int mt_step, Rank&& rank) {
+    if constexpr (PN < P) {
+        constexpr bool to_next = PN + 2 >= P;                      // the refill target lies in the next tile
+        constexpr int target = to_next ? PN + 2 - P : PN + 2;      // ... and is this panel of it
+        multiply_and_refill<CHP, 1, to_next && target == 0, PN == 0>(
+            (PN & 1) ? R1 : R0, qf[PN], acc, to_next ? dnext : dcur, voff_lane, mt_step,
+            [&](int j) { if (PN == P - 1 && j == CHP - 1) rank(); }, target * CHP * 1024);
+        wide_panels<PN + 1, P, CHP>(R0, R1, qf, acc, dcur, dnext, voff_lane, mt_step, rank);
+    }
+}
+
+template <int CHP, int P, bool EXT>
+__global__ __launch_bounds__(kThreads, 2) void scan_topk_f32_wide_kernel(ScanArgs p) {
+    static_assert(P == 2 || P == 4, "R0 holds the even panels, R1 the odd ones");
+    constexpr int NQ = 16, CHT = P * CHP;
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // [4][kWaves][NQ][kPitch]
+    const int lane = lane_id();
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m = lane & 15, g = lane >> 4;
+    const int n_tiles = (p.n_rows + kTileRows - 1) / kTileRows;
+    const int G = gridDim.x;
+
+    f32x4 qf[P][1][CHP];  // [panel]: lane (n = m, g) holds Qn[n][slice + 16 (panel CHP + j) + 4g .. +3]
+    {
+        const float* qbase = p.q_padded + (int64_t)m * p.row_stride + wid * 16 * CHT + 4 * g;
+#pragma unroll
+        for (int pn = 0; pn < P; ++pn)
+#pragma unroll
+            for (int j = 0; j < CHP; ++j) qf[pn][0][j] = *reinterpret_cast<const f32x4*>(qbase + 16 * (pn * CHP + j));
+    }
+    const int voff_lane = wid * CHT * 1024 + lane * 16;
+
+    TopList L;
+    L.s = -INFINITY;
+    L.i = 0x7fffffff;
+    float tau = -INFINITY;
+    __shared__ int sh_qfilt[16];
+    __shared__ int sh_tags[4][32];
+    __shared__ int sh_qmask[16];
+    __shared__ float sh_after_s[16];
+    __shared__ int64_t sh_after_i[16];
+    if (threadIdx.x < 16) {
+        const int q = threadIdx.x;
+        const bool live = q < p.nq;
+        sh_qfilt[q] = (p.q_filter != nullptr && live) ? p.q_filter[q] : -1;
+        if (EXT) {
+            sh_qmask[q] = (p.q_filter_mask != nullptr && live) ? p.q_filter_mask[q] : -1;
+            sh_after_s[q] = (p.q_after_score != nullptr && live) ? p.q_after_score[q] : INFINITY;
+            sh_after_i[q] = (p.q_after_id != nullptr && live) ? p.q_after_id[q] : (int64_t)-1;
+        }
+    }
+    __syncthreads();
+
+    const int mt_step = 16 * (int)p.row_stride * 4;
+    TileRegs<CHP> R0, R1;
+    ItemSeq seq((int)blockIdx.x, G, (G & 1) ? 0 : p.xcd_skew);
+    int t = seq.next();
+    WorkItem W0 = get_work<kFlat>(p, t, n_tiles);
+    TileDesc D0 = make_tile_desc(p.corpus, p.row_stride, p.row_tag, W0);
+    issue_tile_loads<CHP, true>(R0, D0, voff_lane, mt_step, 0);
+    issue_tile_loads<CHP, false>(R1, D0, voff_lane, mt_step, CHP * 1024);
+    __builtin_amdgcn_sched_barrier(0);
+
+    auto dump_tile = [&](const f32x4 (&acc)[2][1], int buf) {
+        float* P_ = lds + buf * (kWaves * NQ * kPitch);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) *reinterpret_cast<f32x4*>(P_ + (wid * NQ + m) * kPitch + mt * 16 + 4 * g) = acc[mt][0];
+    };
+    // wave wid ranks queries wid and 8 + wid (the two halves of the wave) of a dumped tile
+    auto rank_tile = [&](const WorkItem& w, int buf) {
+        const float* P_ = lds + buf * (kWaves * NQ * kPitch);
+        const int r = lane & 31;
+        const int row = w.tile * kTileRows + r;
+        const int tag = sh_tags[buf][r];
+        const bool row_ok = (r < w.rows) && (tag != -1);
+        const int q = (lane >> 5) * 8 + wid;
+        const int qf1 = sh_qfilt[q];
+        const float* src = P_ + q * kPitch + r;
+        float s = src[0];
+#pragma unroll
+        for (int wv = 1; wv < kWaves; ++wv) s += src[wv * NQ * kPitch];
+        bool ok;
+        if (EXT) {
+            ok = row_ok && (qf1 < 0 || qf1 == (tag & sh_qmask[q]));
+            const float as = sh_after_s[q];
+            ok = ok && (s < as || (s == as && (p.id_base + (int64_t)row) > sh_after_i[q]));
+        } else {
+            ok = row_ok && (qf1 < 0 || qf1 == tag);
+        }
+        s = ok ? s : -INFINITY;
+        insert_candidates(L, tau, s, row, p.k);
+    };
+
+    WorkItem Pa{0, 0, 0u}, Pb{0, 0, 0u};
+    int pair = 0;
+    while (t < n_tiles) {
+        f32x4 acc[2][1];
+        // ---- tile A = W0 (its first two panels resident); the registers run on into tile B
+        if (wid == 0 && lane < 32) sh_tags[pair][lane] = R0.tag;
+        const WorkItem Wa = W0;
+        const int tb = seq.next();
+        const WorkItem Wb = get_work<kFlat>(p, tb, n_tiles);
+        const TileDesc Db = make_tile_desc(p.corpus, p.row_stride, p.row_tag, Wb);
+        wide_panels<0, P, CHP>(R0, R1, qf, acc, D0, Db, voff_lane, mt_step, [&]() { rank_tile(Pa, pair ^ 2); });
+        dump_tile(acc, pair);
+        // ---- tile B; the registers run on into tile C
+        if (wid == 0 && lane < 32) sh_tags[pair + 1][lane] = R0.tag;
+        t = seq.next();
+        const WorkItem Wc = get_work<kFlat>(p, t, n_tiles);
+        D0 = make_tile_desc(p.corpus, p.row_stride, p.row_tag, Wc);
+        wide_panels<0, P, CHP>(R0, R1, qf, acc, Db, D0, voff_lane, mt_step, [&]() { rank_tile(Pb, (pair ^ 2) + 1); });
+        dump_tile(acc, pair + 1);
+        W0 = Wc;
+        Pa = Wa;
+        Pb = Wb;
+        __syncthreads();
+        pair ^= 2;
+    }
+    rank_tile(Pa, pair ^ 2);
+    rank_tile(Pb, (pair ^ 2) + 1);
+
+    const int lpos = lane & 31;
+    const int q = (lane >> 5) * 8 + wid;
+    if (q < p.nq && lpos < p.k) {
+        const int64_t o = ((int64_t)blockIdx.x * p.nq + q) * p.k + lpos;
+        const bool filled = L.i != 0x7fffffff;
+        p.part_scores[o] = filled ? L.s : -INFINITY;
+        p.part_ids[o] = filled ? (p.id_base + (int64_t)L.i) : (int64_t)-1;
+    }
+}
+
+template <int CHP, int P, bool EXT>
+static hipError_t launch_wide_variant(const ScanArgs& a, int grid, hipStream_t stream) {
+    constexpr size_t lds_bytes = (size_t)4 * kWaves * 16 * kPitch * sizeof(float);  // 72 KiB
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_topk_f32_wide_kernel<CHP, P, EXT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((scan_topk_f32_wide_kernel<CHP, P, EXT>), dim3(grid), dim3(kThreads), lds_bytes, stream, a);
+    return hipGetLastError();
+}
+
+template <bool EXT>
+static hipError_t launch_wide(int ch_total, const ScanArgs& a, int grid, hipStream_t stream) {
+    switch (ch_total) {
+        case 10: return launch_wide_variant<5, 2, EXT>(a, grid, stream);
+        case 12: return launch_wide_variant<6, 2, EXT>(a, grid, stream);
+        case 14: return launch_wide_variant<7, 2, EXT>(a, grid, stream);
+        case 16: return launch_wide_variant<4, 4, EXT>(a, grid, stream);   // 2 x 8 chunks spill (256 VGPRs at 2 waves per SIMD)
+        default: return hipErrorInvalidValue;
+    }
+}
+
 template <int CH, int NT, int MODE, bool EXT>
 static hipError_t launch_variant(const ScanArgs& a, int grid, hipStream_t stream) {
     constexpr size_t lds_bytes = (size_t)4 * kWaves * NT * 16 * kPitch * sizeof(float);  // 144 KiB at NT = 2
@@ -413,13 +585,19 @@ static hipError_t launch_ch(int ch, const ScanArgs& a, int grid, hipStream_t str
 bool scan_supported_stride(int64_t row_stride) {
     if (row_stride % 128 != 0) return false;
     const int64_t ch = row_stride / 128;
-    return ch >= 1 && ch <= 8;
+    return (ch >= 1 && ch <= 8) || (ch >= 10 && ch <= 16 && ch % 2 == 0);  // wide rows: whole 256-column units
 }
 
 hipError_t launch_scan_topk_f32(const ScanArgs& a, int grid, hipStream_t stream) {
     if (!scan_supported_stride(a.row_stride)) return hipErrorInvalidValue;
     const int ch = (int)(a.row_stride / 128);
     const bool ext = a.q_filter_mask || a.q_after_score || a.q_after_id;
+    if (ch > 8) {  // wide rows: flat scans of <= 16 queries (the caller splits larger groups)
+        if (a.sample_pass || a.sample_best || a.work_base || a.work_tile || a.nq > 16) return hipErrorInvalidValue;
+        if ((a.q_after_score == nullptr) != (a.q_after_id == nullptr)) return hipErrorInvalidValue;
+        if (a.q_filter_mask != nullptr && a.q_filter == nullptr) return hipErrorInvalidValue;
+        return ext ? launch_wide<true>(ch, a, grid, stream) : launch_wide<false>(ch, a, grid, stream);
+    }
     if (a.sample_pass) {  // the score-floor sample of a flat scan with > 16 queries
         if (a.work_base != nullptr || a.work_tile != nullptr || a.nq <= 16) return hipErrorInvalidValue;
         if ((a.q_after_score == nullptr) != (a.q_after_id == nullptr)) return hipErrorInvalidValue;

@@ -174,7 +174,7 @@ class FlatIndex:
     def multi_tiles(self) -> int:
         """Tiles this index would take of a cross-index batch's budget; 0 = it cannot join one (bf16 corpus,
         caller-assigned ids, or too large on its own): search it through its own batcher."""
-        if self.dtype != "f32" or self.has_global_ids:
+        if self.dtype != "f32" or self.has_global_ids or self.row_stride > 1024:
             return 0
         tiles = (self.rows + 31) // 32
         return tiles if tiles <= self.MULTI_MAX_TILES // 2 else 0

@@ -55,7 +55,8 @@ def pack_rows(x: torch.Tensor, normalize: bool = False, row_stride: Optional[int
     scan streams; see include/rass_engine.h).  ``normalize`` applies the reference formula."""
     _req(x, torch.float32, "x")
     n, d = x.shape
-    stride = (d + 127) // 128 * 128 if row_stride is None else int(row_stride)
+    # whole 128-column units up to 1 024 columns, whole 256-column units above (the wide-row scan's panels)
+    stride = ((d + 127) // 128 * 128 if d <= 1024 else (d + 255) // 256 * 256) if row_stride is None else int(row_stride)
     packed = torch.zeros(((n + 15) // 16 * 16, stride), dtype=torch.float32, device=x.device)
     N.check("rass_pack_rows_f32",
             N.lib().rass_pack_rows_f32(ctypes.c_void_p(x.data_ptr()), d, ctypes.c_void_p(packed.data_ptr()), stride,

@@ -1,9 +1,11 @@
-// gemm_phases.hip — where does a 256x256 tile of the ring GEMM spend its time?  Includes the
-// product kernel as source (RASS_GEMM_CLOCKS adds four wall-clock stamps per block: start, after
-// the pipeline prologue, after the K loop, after the epilogue stores have drained) and prints the
-// mean phase lengths.  Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -o gemm_phases.bin gemm_phases.hip
+// gemm_phases.hip — where does a 256x256 tile of the ring GEMM spend its time?  Includes the ring kernels as
+// source (round 1's kernels, retired from the product in round 3: gemm_retired_kernels.hip; RASS_GEMM_CLOCKS adds four
+// wall-clock stamps per block: start, after the pipeline prologue, after the K loop, after the epilogue stores have
+// drained) and prints the mean phase lengths.  RASS_GEMM_VARIANT=ring | pring (default pring) picks the kernel.
+// Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -o gemm_phases.bin gemm_phases.hip ../../rassengine_amd/csrc/encoder_misc.hip
 #define RASS_GEMM_CLOCKS 1
-#include "../../rassengine_amd/csrc/encoder_gemm.hip"
+#define RASS_RETIRED_NO_MAIN 1
+#include "gemm_retired_kernels.hip"
 
 #include <cstdio>
 #include <vector>
@@ -38,7 +40,7 @@ int main(int argc, char**) {
         float ms = 0;
         for (int r = 0; r < 4; ++r) {
             CK(hipEventRecord(e0, 0));
-            CK(rass::launch_gemm_bf16(X, W, b, R, Y, M, M, N, K, epi, 0));
+            CK(rass::launch_retired(getenv("RASS_GEMM_VARIANT") ? getenv("RASS_GEMM_VARIANT") : "pring", X, W, b, R, Y, M, M, N, K, epi, 0));
             CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
             CK(hipEventElapsedTime(&ms, e0, e1));
         }

@@ -91,10 +91,72 @@ def kmeans_accumulate(index: FlatIndex, assign: torch.Tensor, nlist: int, first_
     return sums, counts
 
 
+def _sample_row(j, step: int):
+    """Global row of entry j of the strided sample (every ``step``-th 32-row block)."""
+    return (j // BLOCK_ROWS) * step * BLOCK_ROWS + (j % BLOCK_ROWS)
+
+
+def _gather_rows(index: FlatIndex, rows, dev) -> torch.Tensor:
+    one = torch.empty((1, index.dim), dtype=torch.float32, device=dev)
+    out = torch.empty((len(rows), index.dim), dtype=torch.float32, device=dev)
+    for i, r in enumerate(rows):
+        out[i] = _rows_chunk(index, int(r), 1, one)[0]
+    return out
+
+
+def _repair(index: FlatIndex, cent: torch.Tensor, counts: torch.Tensor, best: torch.Tensor, step: int, n_blocks: int,
+            g: torch.Generator, dev, dup_cos: float = 0.8) -> Tuple[torch.Tensor, int]:
+    """One repair of a set of list means between two Lloyd iterations: lists whose means nearly coincide (cosine above
+    ``dup_cos``: two seeds fell into ONE cluster and split it) are merged — the smaller list of each such pair gives up its
+    centroid — and the freed centroids are re-seeded at sample rows that no mean is close to, drawn with probability
+    proportional to (1 - best cosine)^2.  Means, not rows, are compared: at sigma = 2 two rows of one cluster have cosine
+    0.2 but the means of two lists that split a cluster 0.97, and a row's cosine to its cluster's mean is 0.45 against
+    ~0.1 for a row whose cluster has no list.  The nearest-other-mean search is the engine's own flat scan over a scratch
+    index holding the nlist means (k = 2).  Returns (centroids, number re-seeded)."""
+    n, nlist = index.rows, cent.shape[0]
+    eng = index.engine
+    name = f"__kmeans_repair_{id(cent)}"
+    scratch = eng.open_index(name, capacity_rows=nlist)
+    try:
+        scratch.add_device(cent.contiguous().data_ptr(), nlist, normalize=True)
+        out_s = torch.empty((nlist, 2), dtype=torch.float32, device=dev)
+        out_i = torch.empty((nlist, 2), dtype=torch.int64, device=dev)
+        for a0 in range(0, nlist, 32):
+            b0 = min(32, nlist - a0)
+            scratch.search_device(cent[a0:a0 + b0].contiguous().data_ptr(), b0, 2, out_s[a0:a0 + b0].data_ptr(),
+                                  out_i[a0:a0 + b0].data_ptr())
+        torch.cuda.current_stream(dev).synchronize()
+    finally:
+        eng.drop_index(name)
+    me = torch.arange(nlist, device=dev)
+    other_is_second = out_i[:, 0] == me
+    nn_i = torch.where(other_is_second, out_i[:, 1], out_i[:, 0])
+    nn_s = torch.where(other_is_second, out_s[:, 1], out_s[:, 0])
+    cnt = counts.to(dev)
+    # list i yields to its near-duplicate j when it is the smaller of the two (ties: the higher index yields)
+    yields = (nn_s > dup_cos) & (nn_i >= 0) & ((cnt < cnt[nn_i.clamp(min=0)]) | ((cnt == cnt[nn_i.clamp(min=0)]) & (me > nn_i)))
+    freed = torch.nonzero(yields).flatten()
+    if freed.numel() == 0:
+        return cent, 0
+    m_sample = min(n_blocks * BLOCK_ROWS, n, 1 << 24)
+    rows_global = _sample_row(torch.arange(m_sample, device=dev), step)
+    w = torch.clamp(1.0 - best[:m_sample].float(), min=0.0) ** 2
+    w = torch.where(rows_global < n, w, torch.zeros_like(w))
+    idx = torch.multinomial(w.cpu().double(), int(freed.numel()), replacement=False, generator=g)
+    cent = cent.clone()
+    cent[freed] = _gather_rows(index, torch.clamp(_sample_row(idx, step), max=n - 1).tolist(), dev)
+    return cent, int(freed.numel())
+
+
 def train_centroids(index: FlatIndex, nlist: int, train_rows: int = 0, iters: int = 20, seed: int = 0,
-                    group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
+                    group: Optional[dist.ProcessGroup] = None, seeding: str = "repair") -> torch.Tensor:
     """Spherical k-means over a strided sample of the index's 32-row blocks (every ``step``-th block, about
-    ``train_rows`` rows; 0 = all); returns unit centroids [nlist, dim] on the GPU, identical on every rank."""
+    ``train_rows`` rows; 0 = all); returns unit centroids [nlist, dim] on the GPU, identical on every rank.
+    Seeds are nlist distinct sample rows.  ``seeding``: "random" = nothing else (rounds 1-2); "repair" = in the first
+    two thirds of the iterations every other one is followed by ``_repair``: near-duplicate list means are merged and
+    the freed centroids re-seeded where no mean is close (what k-means++ aims at, done on means instead of rows)."""
+    if seeding not in ("random", "repair"):
+        raise ValueError("seeding must be 'random' or 'repair'")
     dev = torch.device("cuda", index.engine.device)
     n = index.rows
     total_blocks = -(-n // BLOCK_ROWS)
@@ -104,20 +166,18 @@ def train_centroids(index: FlatIndex, nlist: int, train_rows: int = 0, iters: in
     step = max(1, total_blocks // max(1, -(-m // BLOCK_ROWS)))
     n_blocks = -(-total_blocks // step)
     world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
     g = torch.Generator(device="cpu")
     g.manual_seed(seed)
+    repair = seeding == "repair" and nlist >= 8 and min(n_blocks * BLOCK_ROWS, n) >= 2 * nlist
     with _engine_on_torch_stream(index):
+        one = torch.empty((1, index.dim), dtype=torch.float32, device=dev)
         # seeds: nlist distinct sample rows (deterministic for a seed); every rank starts from rank 0's
         pick = torch.randperm(min(n_blocks * BLOCK_ROWS, n - 0), generator=g)[:nlist]
-        rows = (pick // BLOCK_ROWS) * step * BLOCK_ROWS + (pick % BLOCK_ROWS)
-        rows = torch.clamp(rows, max=n - 1)
-        cent = torch.empty((nlist, index.dim), dtype=torch.float32, device=dev)
-        one = torch.empty((1, index.dim), dtype=torch.float32, device=dev)
-        for i, r in enumerate(rows.tolist()):
-            cent[i] = _rows_chunk(index, int(r), 1, one)[0]
+        cent = _gather_rows(index, torch.clamp(_sample_row(pick, step), max=n - 1).tolist(), dev)
         if world > 1:
             dist.broadcast(cent, src=0, group=group)
-        for _ in range(iters):
+        for it in range(iters):
             assign, _slab = kmeans_assign(index, cent, 0, step, n_blocks)
             sums, counts = kmeans_accumulate(index, assign, nlist, 0, step, n_blocks)
             if world > 1:
@@ -133,6 +193,13 @@ def train_centroids(index: FlatIndex, nlist: int, train_rows: int = 0, iters: in
                 if world > 1:
                     dist.broadcast(new, src=0, group=group)
             cent = new
+            if repair and it % 2 == 1 and it < (2 * iters) // 3:
+                # rank 0's sample decides what is merged and where the freed centroids go; everyone gets its result
+                if rank == 0:
+                    _a, best, _slab = kmeans_assign(index, cent, 0, step, n_blocks, with_best=True)
+                    cent, _n_fixed = _repair(index, cent, counts, best, step, n_blocks, g, dev)
+                if world > 1:
+                    dist.broadcast(cent, src=0, group=group)
     return cent
 
 

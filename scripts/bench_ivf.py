@@ -19,6 +19,7 @@ ap.add_argument("--queries", type=int, default=1024)
 ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--k", type=int, default=10)
 ap.add_argument("--iid", action="store_true", help="worst case: iid Gaussian rows instead of clusters")
+ap.add_argument("--seeding", default=None, help="train_centroids(seeding=...): 'random' | 'repair' (default: the library's)")
 a = ap.parse_args()
 
 dim = 1024
@@ -42,7 +43,12 @@ for lo in range(0, a.rows, chunk):
     eng.synchronize()
 gen_s = time.perf_counter() - t0
 t0 = time.perf_counter()
-ivf = IvfIndex.build(flat, nlist=a.nlist, train_rows=a.train_rows, iters=a.iters, seed=1)
+from rassengine_amd.ivf import train_centroids
+kw = {"seeding": a.seeding} if a.seeding else {}
+cent = train_centroids(flat, a.nlist, train_rows=a.train_rows, iters=a.iters, seed=1, **kw)
+torch.cuda.synchronize()
+train_s = time.perf_counter() - t0
+ivf = IvfIndex.build(flat, nlist=a.nlist, centroids=cent)
 build_s = time.perf_counter() - t0
 sizes = ivf.list_sizes
 if a.iid:
@@ -65,7 +71,8 @@ tm.stop(stream)
 flat_ms = tm.elapsed_ms()
 truth_h = truth.cpu().numpy()
 res = {"workload": f"IVF-{a.nlist} over {a.rows} x {dim} {'iid' if a.iid else 'clustered'} rows, top-{k}, batch {B}",
-       "gen_s": round(gen_s, 1), "build_s": round(build_s, 1), "list_len_mean": float(sizes.mean()),
+       "gen_s": round(gen_s, 1), "build_s": round(build_s, 1), "train_s": round(train_s, 1), "sigma": a.sigma,
+       "list_len_mean": float(sizes.mean()),
        "list_len_max": int(sizes.max()), "empty_lists": int((sizes == 0).sum()),
        "flat_qps": round(a.queries / flat_ms * 1e3, 1), "sweep": []}
 got = torch.empty((a.queries, k), dtype=torch.int64, device=dev)
@@ -80,6 +87,14 @@ for nprobe in (1, 2, 4, 8, 16, 32, 64, 128):
     ms = tm.elapsed_ms()
     got_h = got.cpu().numpy()
     recall = float(np.mean([len(set(got_h[r]) & set(truth_h[r])) / k for r in range(a.queries)]))
+    # rows the fine scans touch (the union of a batch's probed lists): the host API reports it; 8 batches sampled
+    q_h = q[:8 * B].cpu().numpy()
+    _, _, scanned = ivf.search(q_h, k, nprobe)
+    scanned_per_batch = scanned / 8
+    us_per_batch = ms / (a.queries / B) * 1e3
+    probed_bytes = scanned_per_batch * dim * 4 + a.nlist * dim * 4          # fine scans + the coarse scan over the centroids
     res["sweep"].append({"nprobe": nprobe, "recall_at_10": round(recall, 4), "qps": round(a.queries / ms * 1e3, 1),
-                         "us_per_batch": round(ms / (a.queries / B) * 1e3, 1)})
+                         "us_per_batch": round(us_per_batch, 1), "scanned_rows_per_batch": round(scanned_per_batch),
+                         "scanned_fraction": round(scanned_per_batch / a.rows, 5),
+                         "probed_TBps": round(probed_bytes / (us_per_batch * 1e-6) / 1e12, 3)})
 print(json.dumps(res))

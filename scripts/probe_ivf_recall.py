@@ -46,10 +46,12 @@ _, truth = flat.search(q, 10)
 same_cluster = float(np.mean(lab[truth] == qlab[:, None]))
 out = {"workload": f"{a.rows} rows, {a.centres} centres, sigma {a.sigma}, IVF-{a.nlist}",
        "true_top10_in_query_cluster": round(same_cluster, 4), "variants": []}
-for name, train_rows, iters in (("r01 budget: 1M-row sample, 10 iterations", 1_000_000, 10),
-                                ("all rows, 10 iterations", 0, 10), ("all rows, 30 iterations", 0, 30)):
+for name, train_rows, iters, seeding in (("random seeds, 1M-row sample, 10 iterations (rounds 1-2)", 1_000_000, 10, "random"),
+                                         ("repair, 1M-row sample, 10 iterations", 1_000_000, 10, "repair"),
+                                         ("random seeds, all rows, 30 iterations", 0, 30, "random"),
+                                         ("repair, all rows, 30 iterations", 0, 30, "repair")):
     t0 = time.perf_counter()
-    cent = train_centroids(flat, a.nlist, train_rows=train_rows, iters=iters, seed=1)
+    cent = train_centroids(flat, a.nlist, train_rows=train_rows, iters=iters, seed=1, seeding=seeding)
     ivf = IvfIndex.build(flat, nlist=a.nlist, centroids=cent)
     build_s = time.perf_counter() - t0
     assign = ivf.assign

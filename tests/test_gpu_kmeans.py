@@ -73,8 +73,8 @@ def test_train_centroids_is_a_lloyd_iteration_and_reseeds_empty_lists(gpu):
     try:
         idx = eng.open_index("km-train")
         idx.add(x, normalize=True)
-        c0 = ivf.train_centroids(idx, nlist=20, iters=0, seed=3)              # the seeds
-        c1 = ivf.train_centroids(idx, nlist=20, iters=1, seed=3)
+        c0 = ivf.train_centroids(idx, nlist=20, iters=0, seed=3, seeding="random")   # the seeds
+        c1 = ivf.train_centroids(idx, nlist=20, iters=1, seed=3, seeding="random")
         xn = torch.nn.functional.normalize(torch.from_numpy(x), dim=1)
         lab = (xn @ c0.cpu().T).argmax(dim=1)
         sums = torch.zeros((20, 256)).index_add_(0, lab, xn)
@@ -82,7 +82,7 @@ def test_train_centroids_is_a_lloyd_iteration_and_reseeds_empty_lists(gpu):
         live = torch.bincount(lab, minlength=20) > 0
         assert torch.allclose(c1.cpu()[live], ref[live], atol=1e-5)
         assert torch.allclose(c1.norm(dim=1).cpu(), torch.ones(20), atol=1e-5)    # re-seeded rows are unit too
-        c8 = ivf.train_centroids(idx, nlist=20, iters=8, seed=3)
+        c8 = ivf.train_centroids(idx, nlist=20, iters=8, seed=3, seeding="random")
         assign = ivf.assign_rows(idx, c8)
         assert assign.shape == (6000,) and assign.dtype == np.int32
         # k-means found the 20 planted clusters: every list is (almost) pure
@@ -93,5 +93,48 @@ def test_train_centroids_is_a_lloyd_iteration_and_reseeds_empty_lists(gpu):
         # a strided sample (every 4th block) trains too and more lists than clusters leaves no NaN behind
         c_s = ivf.train_centroids(idx, nlist=64, train_rows=1500, iters=3, seed=1)
         assert bool(torch.isfinite(c_s).all()) and torch.allclose(c_s.norm(dim=1).cpu(), torch.ones(64), atol=1e-5)
+    finally:
+        eng.close()
+
+
+def test_repair_merges_split_clusters_and_covers_missed_ones(gpu):
+    """train_centroids(seeding="repair"): with as many lists as planted clusters, random seeds leave ~1/e of the clusters
+    without a seed of their own and put two or more into others (which Lloyd then splits for good: it cannot move a
+    centre out of a cluster it shares); merging near-duplicate means and re-seeding the freed centroids where no mean is
+    close gives (almost) every cluster a list of its own."""
+    torch = gpu
+    from rassengine_amd import ivf
+    from rassengine_amd.engine import Engine
+    rng = np.random.default_rng(4)
+    n_clusters, dim = 128, 256
+    centres = rng.standard_normal((n_clusters, dim)).astype(np.float32)
+    lab = rng.integers(0, n_clusters, size=40000)
+    x = (centres[lab] + 0.5 * rng.standard_normal((40000, dim))).astype(np.float32)
+    eng = Engine(0, dim)
+    try:
+        idx = eng.open_index("km-seed")
+        idx.add(x, normalize=True)
+        cn = torch.nn.functional.normalize(torch.from_numpy(centres), dim=1)
+
+        def covered(cent):
+            """planted clusters that are the nearest planted centre of at least one trained centroid"""
+            owner = (torch.nn.functional.normalize(cent.cpu(), dim=1) @ cn.T).argmax(dim=1)
+            return len(set(owner.tolist())) / n_clusters
+
+        def cohesion(cent):
+            a = ivf.assign_rows(idx, cent)
+            return float(np.mean([np.bincount(a[lab == c]).max() / max(1, (lab == c).sum()) for c in range(n_clusters)]))
+
+        c_rand = ivf.train_centroids(idx, nlist=n_clusters, iters=9, seed=2, seeding="random")
+        c_rep = ivf.train_centroids(idx, nlist=n_clusters, iters=9, seed=2, seeding="repair")
+        assert c_rep.shape == (n_clusters, dim) and torch.allclose(c_rep.norm(dim=1).cpu(), torch.ones(n_clusters), atol=1e-5)
+        cov_r, cov_p = covered(c_rand), covered(c_rep)
+        coh_r, coh_p = cohesion(c_rand), cohesion(c_rep)
+        print(f"clusters with a centroid of their own: random seeds {cov_r:.3f}, with repair {cov_p:.3f}; "
+              f"cluster cohesion {coh_r:.3f} -> {coh_p:.3f}")
+        assert cov_p >= 0.97 and cov_p > cov_r and coh_p > coh_r
+        assert len(eng._indices) == 1                  # the scratch index of the repair is gone
+        with pytest.raises(ValueError):
+            ivf.train_centroids(idx, nlist=16, iters=1, seeding="kmeans++")
     finally:
         eng.close()

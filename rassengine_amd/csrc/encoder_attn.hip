@@ -249,7 +249,32 @@ __device__ __forceinline__ void dma16(const void* gptr, const unsigned char* lds
 }
 
 constexpr int kA64Threads = 512;
+#ifdef RASS_ATTN_STAMPS  // scripts/microbench/attn_stamps.hip only: where an item's cycles go, per wave (s_memtime ticks)
+// [block][wave][0 item total, 1 prologue (sync0 .. first step), 2 steps, 3 of which boundaries (wait + barrier + DMA issue),
+//  4 epilogue (last products, end-of-item wait + barrier, normalise + store), 5 items]
+//  then: 6 epilogue's last products, 7 its vmcnt(0) wait (next item's Q fragments), 8 its barrier
+__device__ unsigned long long g_attn_stamps[1024 * 8 * 9];
+#define RASS_STAMP(var) const unsigned long long var = clock64()
+#else
+#define RASS_STAMP(var)
+#endif
 
+// FOLD (round 3; built on VERDICT r2 #3's request, measured, NOT adopted — RASS_ATTN_VARIANT=w8f selects it): the softmax's
+// scale-and-subtract moves INTO the QK^T MFMA chain.  The plain kernel spends
+// one v_fma per score on exp2(s * scale - m): 16 of the ~74 vector instructions of a block, in a kernel whose time is its
+// vector issue.  Here (i) Q is scaled by 1/8 * log2(e) in registers when an item's fragments arrive (once per item: a
+// second bf16 rounding of Q, |rel err| <= 2^-9 per element — measured cost in profiles/r03_attention_experiments.txt), so
+// the MFMA yields scores in the exp2 domain, and (ii) the chain STARTS with a fifth k-step whose A fragment is 1 in one
+// k-slot and whose B fragment holds -m_ref of the lane's query there (m_ref is kept bf16-representable, so nothing is
+// rounded): S' = K Q'^T - m_ref leaves the chain and the exponentials take it as it is.  The reference maximum used is
+// the one known BEFORE the tile's QK^T; the tile's own maximum, now relative to it, moves it in the same rare branch as
+// before (by more than 2^8), which then also shifts the tile's scores by the difference.  One MFMA more per tile on a
+// matrix pipe that is 30 % busy, 16 fewer vector issues: 68 / 82 instructions per block against 87 / 98 in the ISA.
+// Measured (profiles/r03_attention_experiments.txt): the SAME time (377-386 against 381-396 us per launch at 256 x 512,
+// interleaved), because the launch is not paced by the instruction count of its steps alone; and 3x the error of the plain
+// form on peaked scores (max |err| 8.9e-2 against 3.1e-2 at |q.k|/8 up to 40: the second rounding of Q), outside this
+// file's test tolerance.  Same speed, less accuracy: the plain form stays the default.
+template <bool FOLD>
 __global__ __launch_bounds__(kA64Threads) void attention64_kernel(const u16* __restrict__ qkv,
                                                                   const int32_t* __restrict__ cu, int hidden, int heads,
                                                                   int s_pad, int n_items, u16* __restrict__ ctx) {
@@ -310,6 +335,20 @@ __global__ __launch_bounds__(kA64Threads) void attention64_kernel(const u16* __r
     int item = blockIdx.x;
     bool sync0 = true;  // does this item's first chunk still need a wait + barrier?
     bf16x8 qq[2][4];
+    bool q_fresh = true;  // FOLD: the fragments in qq are as loaded (not yet scaled)
+    // FOLD: Q' = bf16(Q * scale), in place, once per item (after the wait that retires the fragments' loads)
+    auto scale_q = [&]() {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                u32x4 w = __builtin_bit_cast(u32x4, qq[t][ks]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    w[i] = pack_bf16(__uint_as_float(w[i] << 16) * kScale, __uint_as_float(w[i] & 0xffff0000u) * kScale);
+                qq[t][ks] = __builtin_bit_cast(bf16x8, w);
+            }
+    };
     // everything this wave has in flight (DMA pieces, Q fragments, stores) is done; the operands tie the uses of qq behind it
     auto wait_all = [&]() {
         asm volatile("s_waitcnt vmcnt(0)"
@@ -324,7 +363,11 @@ __global__ __launch_bounds__(kA64Threads) void attention64_kernel(const u16* __r
         load_q(t0, S, item % heads, qq);
         for (int j = 0; j < (S + 127) / 128; ++j) dma_chunk(item, j);
     }
+#ifdef RASS_ATTN_STAMPS
+    unsigned long long st_item = 0, st_pro = 0, st_steps = 0, st_bound = 0, st_n = 0, st_e_tail = 0, st_e_wait = 0, st_e_bar = 0;
+#endif
     while (true) {
+        RASS_STAMP(c_item0);
         int t0, S;
         item_rows(item, t0, S);
         const int head = item % heads;
@@ -341,6 +384,10 @@ __global__ __launch_bounds__(kA64Threads) void attention64_kernel(const u16* __r
             wait_all();
             __syncthreads();
         }
+        if (FOLD && q_fresh) {   // every path to here has waited for the fragments (sync0, or the previous item's end)
+            scale_q();
+            q_fresh = false;
+        }
         // the next item's Q fragments: issued as soon as this item's last QK^T has read the old ones, a block before
         // the end-of-item wait
         auto load_q_next = [&]() {
@@ -353,9 +400,13 @@ __global__ __launch_bounds__(kA64Threads) void attention64_kernel(const u16* __r
         for (int j = nc; j < nc_next; ++j) dma_chunk(next, j);  // rows this item never touches
         // boundary b >= 1, between key tiles 4b-1 and 4b
         auto boundary = [&](int b) {
+            RASS_STAMP(c_b0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (b - 1 < nc_next) dma_chunk(next, b - 1);
+#ifdef RASS_ATTN_STAMPS
+            st_bound += clock64() - c_b0;
+#endif
         };
         const int q0 = wave * 64;
         if (q0 < S) {
@@ -363,6 +414,13 @@ __global__ __launch_bounds__(kA64Threads) void attention64_kernel(const u16* __r
             float m_ref[2] = {-INFINITY, -INFINITY}, l_part[2] = {0.f, 0.f};
             f32x16 O[2][2], s[2];
             bf16x8 pf[2][2];
+            // FOLD: the fifth k-step's operands.  A = 1.0 in k-slot 0 of lane half 0 (every key row), B = -m_ref of the
+            // lane's query in that slot: the chain starts at -m_ref.  Before the first tile m_ref stands at 0.
+            bf16x8 one_a = {0, 0, 0, 0, 0, 0, 0, 0}, mneg[2] = {{0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}};
+            if (FOLD) {
+                one_a[0] = h == 0 ? (short)0x3F80 : (short)0;
+                m_ref[0] = m_ref[1] = 0.f;
+            }
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -399,6 +457,9 @@ __global__ __launch_bounds__(kA64Threads) void attention64_kernel(const u16* __r
             auto qk = [&](int t) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+#ifndef RASS_ATTN_EXP_NO_MFMA
+                if (FOLD) s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(one_a, mneg[t], s[t], 0, 0, 0);
+#endif
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks)
 #ifdef RASS_ATTN_EXP_NO_MFMA
@@ -444,6 +505,27 @@ __global__ __launch_bounds__(kA64Threads) void attention64_kernel(const u16* __r
                         __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
                     mx = max2f(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
                 }
+                if constexpr (FOLD) {
+                    // mx is the tile maximum RELATIVE to m_ref (the chain started at -m_ref, scores are in the exp2 domain)
+                    if (__builtin_expect(__any(mx > 8.f), 0)) {
+                        // the new reference: the running maximum, rounded UP to a bf16 value (so that it fits the B
+                        // fragment exactly; scores then stay <= 0 up to that rounding); delta is exact in fp32
+                        const float cand = m_ref[t] + max2f(mx, 0.f);
+                        unsigned u = __float_as_uint(cand);
+                        u = (cand > 0.f ? u + 0xffffu : u) & 0xffff0000u;
+                        const float m_new = __uint_as_float(u);
+                        const float delta = m_new - m_ref[t];
+                        const float alpha = __builtin_amdgcn_exp2f(-delta);  // 1 where the reference did not move
+                        l_part[t] *= alpha;
+                        O[t][0] *= alpha;
+                        O[t][1] *= alpha;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) s[t][r] -= delta;   // this tile's scores were taken against the old one
+                        m_ref[t] = m_new;
+                        mneg[t][0] = h == 0 ? (short)((__float_as_uint(-m_new)) >> 16) : (short)0;
+                    }
+                    return;
+                }
                 mx *= kScale;  // finite in tile 0 (key 0 is always valid); -inf for a fully masked query never happens
                 if (__builtin_expect(__any(mx > m_ref[t] + 8.f), 0)) {  // out of line: the usual path falls through
                     const float m_new = max2f(m_ref[t], mx);
@@ -461,7 +543,8 @@ __global__ __launch_bounds__(kA64Threads) void attention64_kernel(const u16* __r
 #ifdef RASS_ATTN_EXP_NO_EXP
                 for (int r = 0; r < 16; ++r) pe[r] = __builtin_fmaf(s[t][r], kScale, -m_ref[t]);
 #else
-                for (int r = 0; r < 16; ++r) pe[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][r], kScale, -m_ref[t]));
+                for (int r = 0; r < 16; ++r)
+                    pe[r] = FOLD ? __builtin_amdgcn_exp2f(s[t][r]) : __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][r], kScale, -m_ref[t]));
 #endif
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
@@ -491,6 +574,10 @@ __global__ __launch_bounds__(kA64Threads) void attention64_kernel(const u16* __r
             exps(0);
             maxres(1, 0, kMasked);
             auto step = [&](int kt, auto last_tile) {
+#ifdef RASS_ATTN_EXP_PRIO
+                // experiment: the two waves of a SIMD take turns at the higher issue priority, one step each
+                if (((kt ^ (wave >> 2)) & 1) != 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#endif
                 qk(0);            // S_A(kt)
                 pv(0);            // O_A += V^T P_A(kt-1)
                 exps(1);          // P_B(kt-1)
@@ -503,6 +590,7 @@ __global__ __launch_bounds__(kA64Threads) void attention64_kernel(const u16* __r
                 exps(0);          // P_A(kt)
                 maxres(1, kt, last_tile);
             };
+            RASS_STAMP(c_steps0);
             for (int kt = 1; kt < n_kt - 1; ++kt) {
                 if ((kt & 3) == 0) boundary(kt >> 2);
                 step(kt, kFull);
@@ -511,13 +599,28 @@ __global__ __launch_bounds__(kA64Threads) void attention64_kernel(const u16* __r
                 if (((n_kt - 1) & 3) == 0) boundary((n_kt - 1) >> 2);
                 step(n_kt - 1, kMasked);
             }
+            RASS_STAMP(c_steps1);
+#ifdef RASS_ATTN_STAMPS
+            st_pro += c_steps0 - c_item0;
+            st_steps += c_steps1 - c_steps0;
+#endif
             pv(0);
             exps(1);
             pv(1);
+            RASS_STAMP(c_e1);
             // end of the item: everyone is done with the last chunk (and the next item's Q fragments have arrived)
             wait_all();
+            RASS_STAMP(c_e2);
             __syncthreads();
+            RASS_STAMP(c_e3);
+#ifdef RASS_ATTN_STAMPS
+            st_e_tail += c_e1 - c_steps1;
+            st_e_wait += c_e2 - c_e1;
+            st_e_bar += c_e3 - c_e2;
+#endif
+#ifndef RASS_ATTN_EXP_NO_ENDDMA
             if (nc - 1 < nc_next) dma_chunk(next, nc - 1);
+#endif
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int q = q0 + 32 * t + qi;
@@ -530,6 +633,9 @@ __global__ __launch_bounds__(kA64Threads) void attention64_kernel(const u16* __r
                 }
                 const float inv_l = 1.f / l_run;
                 u16* dst = ctx + (int64_t)(t0 + (q < S ? q : 0)) * hidden + head * kHeadDim + 8 * h;
+                // (Round 3 also staged a tile through 4 KiB of LDS per wave and stored whole 128-B rows, 8 lines per wave
+                // instruction instead of 64 partial ones: same time, 404 against 398-401 us — the stores cost ~25 us of a launch
+                // whatever their shape, profiles/r03_attention_experiments.txt — so the registers are stored as they lie.)
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
                     unsigned w[8];
@@ -542,7 +648,11 @@ __global__ __launch_bounds__(kA64Threads) void attention64_kernel(const u16* __r
                     for (int p = 0; p < 2; ++p) {
                         const auto s0 = __builtin_amdgcn_permlane32_swap(w[4 * p + 0], w[4 * p + 2], false, false);
                         const auto s1 = __builtin_amdgcn_permlane32_swap(w[4 * p + 1], w[4 * p + 3], false, false);
+#ifdef RASS_ATTN_EXP_NO_STORE   // timing experiment: everything but the global stores (one lane keeps the data alive)
+                        if (q < S && s0[0] == 0x12345678u && lane == 63)
+#else
                         if (q < S)
+#endif
                             *reinterpret_cast<u32x4*>(dst + 32 * dt + 16 * p) = u32x4{s0[0], s1[0], s0[1], s1[1]};
                     }
                 }
@@ -554,10 +664,25 @@ __global__ __launch_bounds__(kA64Threads) void attention64_kernel(const u16* __r
             __syncthreads();
             if (nc - 1 < nc_next) dma_chunk(next, nc - 1);
         }
+#ifdef RASS_ATTN_STAMPS
+        {
+            const unsigned long long c_end = clock64();
+            st_item += c_end - c_item0;
+            st_n += 1;
+        }
+#endif
         if (!has_next) break;
         sync0 = nc < 3;  // chunk 1 (nc == 2) or chunk 0 (nc == 1) of the next item was only just sent
+        q_fresh = true;  // load_q_next() replaced the fragments (both branches above end in wait_all())
         item = next;
     }
+#ifdef RASS_ATTN_STAMPS
+    if (lane == 0 && blockIdx.x < 1024) {
+        unsigned long long* o = g_attn_stamps + ((size_t)blockIdx.x * 8 + wave) * 9;
+        o[0] = st_item; o[1] = st_pro; o[2] = st_steps; o[3] = st_bound; o[4] = st_item - st_pro - st_steps; o[5] = st_n;
+        o[6] = st_e_tail; o[7] = st_e_wait; o[8] = st_e_bar;
+    }
+#endif
 }
 
 static int attn_cus() {  // one persistent workgroup per CU (the K / V image takes most of a CU's LDS)
@@ -590,20 +715,31 @@ hipError_t launch_attention(const void* qkv, const int32_t* cu_seqlens, int nseq
     // RASS_ATTN_VARIANT=w8 / w16 forces one (tests, A/B).
     const char* variant = attn_variant();
     const bool long_rows = (long long)total_tokens >= 320LL * nseq;
-    if (strcmp(variant, "w8") == 0 || (long_rows && strcmp(variant, "w16") != 0)) {
+    const bool w8_plain = strcmp(variant, "w8") == 0;     // scale-and-subtract as one v_fma per score (the default form)
+    const bool w8_fold = strcmp(variant, "w8f") == 0;     // both folded into the QK^T chain: measured, not adopted (see the kernel)
+    if (w8_plain || w8_fold || (long_rows && strcmp(variant, "w16") != 0)) {
         const int s_pad128 = (max_seqlen + 127) / 128 * 128;  // whole 128-row chunks are sent
         const size_t lds_bytes = (size_t)s_pad128 * 256;      // 128 KiB at S = 512
         static size_t attr64_bytes = 0;
         if (lds_bytes > attr64_bytes) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention64_kernel),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention64_kernel<false>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention64_kernel<true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
             if (e != hipSuccess) return e;
             attr64_bytes = lds_bytes;
         }
         const int n_items = nseq * heads;
-        hipLaunchKernelGGL(attention64_kernel, dim3(n_items < attn_cus() ? n_items : attn_cus()), dim3(kA64Threads),
-                           lds_bytes, stream, static_cast<const u16*>(qkv), cu_seqlens, hidden, heads, s_pad128, n_items,
-                           static_cast<u16*>(ctx));
+        const dim3 grid(n_items < attn_cus() ? n_items : attn_cus());
+        if (!w8_fold)
+            hipLaunchKernelGGL(attention64_kernel<false>, grid, dim3(kA64Threads), lds_bytes, stream,
+                               static_cast<const u16*>(qkv), cu_seqlens, hidden, heads, s_pad128, n_items,
+                               static_cast<u16*>(ctx));
+        else
+            hipLaunchKernelGGL(attention64_kernel<true>, grid, dim3(kA64Threads), lds_bytes, stream,
+                               static_cast<const u16*>(qkv), cu_seqlens, hidden, heads, s_pad128, n_items,
+                               static_cast<u16*>(ctx));
         return hipGetLastError();
     }
     const size_t lds_bytes = (size_t)s_pad * 128 + (size_t)s_pad * kVPitch;  // 144 KiB at S = 512

@@ -5,7 +5,12 @@ Tolerance: the kernel rounds the exponentiated scores to bf16 before the second 
 the bound follows sum_j p_j |v_j|, not the possibly cancelled result) and the output to bf16:
 |err| <= 2^-8 (sum_j p_j |v_j|) + 2^-8 |ref| + 2e-3 per element.  Both kernels are held to it on every case: the
 32x32-tile persistent kernel (RASS_ATTN_VARIANT=w8; the default for batches of mostly-long sequences) and the 16x16-tile
-kernel (w16; the default otherwise); the variable is read per launch."""
+kernel (w16; the default otherwise); the variable is read per launch.
+
+w8f is round 3's experiment: the 32x32 kernel with the scale and the reference maximum folded into the
+QK^T MFMA chain, which re-rounds Q to bf16 after scaling (2^-9 per element -> an error in the exponent that grows with
+|q.k|).  It runs every case here; on the peaked-scores case it is held to 8x the tolerance (measured: 3x the plain
+kernel's error there) — the accuracy cost that, at equal speed, keeps it from being the default."""
 import ctypes
 import os
 
@@ -47,7 +52,7 @@ def _run(torch, qkv, lens, heads, max_seqlen=None):
     return ctx[:qkv.shape[0]].float()
 
 
-def _check(torch, lens, heads, scale, seed, max_seqlen=None):
+def _check(torch, lens, heads, scale, seed, max_seqlen=None, slack=1.0):
     g = torch.Generator(device="cuda")
     g.manual_seed(seed)
     total = int(sum(lens))
@@ -55,12 +60,12 @@ def _check(torch, lens, heads, scale, seed, max_seqlen=None):
     ref, mag = _reference(torch, qkv, lens, heads)
     got = _run(torch, qkv, lens, heads, max_seqlen)
     err = (got - ref).abs()
-    tol = 2.0 ** -8 * mag + 2.0 ** -8 * ref.abs() + 2e-3
+    tol = slack * (2.0 ** -8 * mag + 2.0 ** -8 * ref.abs() + 2e-3)
     assert bool(torch.isfinite(got).all())
-    assert bool((err <= tol).all()), (float((err - tol).max()), int((err > tol).sum()))
+    assert bool((err <= tol).all()), (float((err - tol).max()), int((err > tol).sum()), float((err / tol).max()))
 
 
-@pytest.fixture(params=["w8", "w16", ""])
+@pytest.fixture(params=["w8f", "w8", "w16", ""])
 def variant(request):
     old = os.environ.get("RASS_ATTN_VARIANT")
     if request.param:
@@ -82,7 +87,7 @@ def test_attention_every_length_class(gpu, variant):
 def test_attention_peaked_scores_and_moving_maximum(gpu, variant):
     """|q.k| / 8 up to ~40: the running maximum moves in most key blocks (the rescale path), probabilities span
     2^-100 .. 1."""
-    _check(gpu, [512, 77, 300, 64], heads=2, scale=2.5, seed=2)
+    _check(gpu, [512, 77, 300, 64], heads=2, scale=2.5, seed=2, slack=8.0 if variant == "w8f" else 1.0)
 
 
 def test_attention_large_shape_and_padded_launch(gpu, variant):
@@ -113,9 +118,14 @@ def test_attention_variants_agree_closely(gpu):
         a = _run(torch, qkv, lens, 4)
         os.environ["RASS_ATTN_VARIANT"] = "w16"
         b = _run(torch, qkv, lens, 4)
+        os.environ["RASS_ATTN_VARIANT"] = "w8f"
+        c = _run(torch, qkv, lens, 4)
     finally:
         os.environ.pop("RASS_ATTN_VARIANT", None)
         if old is not None:
             os.environ["RASS_ATTN_VARIANT"] = old
     assert float((a - b).abs().max()) <= 2.0 ** -7 * float(a.abs().max())
     assert float(((a - b).abs() > 2.0 ** -8 * a.abs() + 1e-3).float().mean()) < 0.01
+    # the folded form re-rounds Q after scaling (2^-9 per element): a few more elements differ by an ulp, none by more than two
+    assert float((c - b).abs().max()) <= 2.0 ** -6 * float(b.abs().max())
+    assert float(((c - b).abs() > 2.0 ** -8 * b.abs() + 1e-3).float().mean()) < 0.05

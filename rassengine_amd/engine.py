@@ -176,7 +176,7 @@ class FlatIndex:
         caller-assigned ids, or too large on its own): search it through its own batcher."""
         if self.dtype != "f32" or self.has_global_ids or self.row_stride > 1024:
             return 0
-        tiles = (self.rows + 31) // 32
+        tiles = max(1, (self.rows + 31) // 32)        # an empty index may join too (it answers with padding)
         return tiles if tiles <= self.MULTI_MAX_TILES // 2 else 0
 
     @property

@@ -128,3 +128,47 @@ def topk_merge(list_scores: torch.Tensor, list_ids: torch.Tensor) -> Tuple[torch
                                     n_lists, nq, k, ctypes.c_void_p(out_s.data_ptr()),
                                     ctypes.c_void_p(out_i.data_ptr()), ctypes.c_void_p(_stream_ptr())))
     return out_s, out_i
+
+
+# ------------------------------------------------------------------------------------------- torch.library custom ops
+# BASELINE.json's north_star asks for the kernels "under PyTorch-ROCm custom ops": the three stateless launchers above are
+# registered as torch.library ops (namespace ``rass``), so they can be called as ``torch.ops.rass.*``, traced / exported with
+# their shapes known (the fake implementations below), and composed with torch code on the current stream.  They are thin:
+# the arithmetic is the C ABI's (``rass_scan_topk_f32``, ``rass_topk_merge``, ``rass_normalize_rows_f32``), device tensors are
+# pointer carriers.  The product's host layer (engine.py, indexer.py) keeps calling the C ABI directly.
+def _register_torch_ops() -> None:
+    lib = torch.library
+
+    @lib.custom_op("rass::scan_topk_packed", mutates_args=())
+    def _scan(packed: torch.Tensor, n_rows: int, queries: torch.Tensor, k: int, row_tag: Optional[torch.Tensor] = None,
+              q_filter: Optional[torch.Tensor] = None, id_base: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
+        return scan_topk_packed(packed, n_rows, queries, k, row_tag=row_tag, q_filter=q_filter, id_base=id_base)
+
+    @_scan.register_fake
+    def _(packed, n_rows, queries, k, row_tag=None, q_filter=None, id_base=0):
+        nq = queries.shape[0]
+        return (queries.new_empty((nq, k), dtype=torch.float32), queries.new_empty((nq, k), dtype=torch.int64))
+
+    @lib.custom_op("rass::topk_merge", mutates_args=())
+    def _merge(list_scores: torch.Tensor, list_ids: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        return topk_merge(list_scores, list_ids)
+
+    @_merge.register_fake
+    def _(list_scores, list_ids):
+        _n, nq, k = list_scores.shape
+        return (list_scores.new_empty((nq, k)), list_ids.new_empty((nq, k)))
+
+    @lib.custom_op("rass::normalize_rows", mutates_args=())
+    def _norm(x: torch.Tensor, out_stride: int = 0) -> torch.Tensor:
+        return normalize_rows(x, out_stride or None)
+
+    @_norm.register_fake
+    def _(x, out_stride=0):
+        return x.new_empty((x.shape[0], out_stride or x.shape[1]))
+
+
+try:
+    _register_torch_ops()
+except Exception as _e:  # pragma: no cover - an older torch without torch.library.custom_op: the plain functions remain
+    import warnings
+    warnings.warn(f"rassengine_amd: torch.library registration skipped ({_e})")

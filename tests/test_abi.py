@@ -78,3 +78,22 @@ def test_product_never_imports_the_oracle():
             if fn.endswith((".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, fn), encoding="utf-8").read()
                 assert "rass_oracle_" not in src and not re.search(r"#include\s*[\"<].*oracle", src), fn
+
+
+def test_torch_library_ops_are_registered_and_refuse_cpu_tensors():
+    """north_star: the kernels "under PyTorch-ROCm custom ops" — the three stateless launchers are torch.library ops
+    (namespace rass) with shape-inferring fake implementations; like everything else they have no CPU path."""
+    import pytest
+    import torch
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    from rassengine_amd import ops  # noqa: F401  (registers)
+    for name in ("scan_topk_packed", "topk_merge", "normalize_rows"):
+        assert hasattr(torch.ops.rass, name)
+    with FakeTensorMode():
+        s, i = torch.ops.rass.scan_topk_packed(torch.empty((64, 1024)), 60, torch.empty((5, 1024)), 10)
+        assert s.shape == (5, 10) and i.dtype == torch.int64
+        ms, mi = torch.ops.rass.topk_merge(torch.empty((8, 5, 10)), torch.empty((8, 5, 10), dtype=torch.int64))
+        assert ms.shape == (5, 10) and mi.shape == (5, 10)
+        assert torch.ops.rass.normalize_rows(torch.empty((3, 1000)), 1024).shape == (3, 1024)
+    with pytest.raises(ValueError, match="no CPU path"):
+        torch.ops.rass.normalize_rows(torch.zeros((2, 8)))

@@ -222,7 +222,7 @@ class _FakeIndex:
     def multi_tiles(self):
         if self.dtype != "f32" or self.has_global_ids:
             return 0
-        t = (self.rows + 31) // 32
+        t = max(1, (self.rows + 31) // 32)
         return t if t <= 65536 // 2 else 0
 
     def search(self, qs, k, f=None, m=None):

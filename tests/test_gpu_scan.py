@@ -308,6 +308,25 @@ def test_strided_merge_of_packed_records(gpu, oracle):
     assert np.array_equal(out_s.cpu().numpy(), rs.astype(np.float32))
 
 
+def test_torch_library_ops_equal_the_plain_launchers(gpu, oracle):
+    """torch.ops.rass.* (rassengine_amd/ops.py) run the same C-ABI launchers: same bits."""
+    torch = gpu
+    from rassengine_amd import ops
+    rng = np.random.default_rng(3)
+    xn = oracle.normalize_ref(rng.standard_normal((700, 384), dtype=np.float32)).astype(np.float32)
+    q = torch.from_numpy(rng.standard_normal((9, 384), dtype=np.float32)).cuda()
+    packed = ops.pack_rows(torch.from_numpy(xn).cuda())
+    s0, i0 = ops.scan_topk_packed(packed, 700, q, 7)
+    s1, i1 = torch.ops.rass.scan_topk_packed(packed, 700, q, 7)
+    assert torch.equal(s0, s1) and torch.equal(i0, i1)
+    assert torch.equal(torch.ops.rass.normalize_rows(q, 512), ops.normalize_rows(q, 512))
+    ls = torch.stack([s0, s0 - 0.5]).contiguous()
+    li = torch.stack([i0, i0 + 1000]).contiguous()
+    a, b = torch.ops.rass.topk_merge(ls, li)
+    c, d = ops.topk_merge(ls, li)
+    assert torch.equal(a, c) and torch.equal(b, d) and torch.equal(b, i0)
+
+
 def test_wide_index_end_to_end(gpu, oracle):
     """An index of 1 536-d rows (EMBED_DIM is an env knob of the reference, app/main.py:80; the encoder serves hidden sizes
     up to 2 048) through the product path: add (normalised on the GPU), tombstone, patient filter, 39 queries in one call

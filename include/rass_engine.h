@@ -274,6 +274,11 @@ int rass_pack_rows_f32(const float* d_in, int64_t in_stride, float* d_packed,
 int rass_unpack_rows_f32(const float* d_packed, int64_t row_stride,
                          int64_t first_row, int64_t n, int dim, float* d_out,
                          int64_t out_stride, void* stream);
+/* d_out[i] (row-major, out_stride) <- row d_row_ids[i] of a tile16 slab holding n_rows rows, i < n (device arrays): the
+ * scattered form of rass_unpack_rows_f32 (k-means seeds are nlist sample rows all over the slab). */
+int rass_gather_rows_f32(const float* d_packed, int64_t row_stride, int64_t n_rows,
+                         const int64_t* d_row_ids, int64_t n, int dim, float* d_out,
+                         int64_t out_stride, void* stream);
 
 /* K1+K2: fused flat cosine scan + per-workgroup top-k + merge over a tile16
  * fp32 corpus slab in HBM.  Rows must already be normalised (rass_pack_rows_f32

@@ -99,6 +99,8 @@ SIGNATURES = {
                                           ctypes.c_void_p]),
     "rass_unpack_rows_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
                                             ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
+    "rass_gather_rows_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
+                                            ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
     "rass_topk_merge": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "rass_topk_merge_strided": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,

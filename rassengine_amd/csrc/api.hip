@@ -326,7 +326,7 @@ int scan_launch(const float* d_corpus, int64_t n_rows, int64_t stride, const int
                 const float* d_queries, int q_dim, int64_t q_stride, int nq, const int32_t* d_q_filter, int k,
                 int64_t id_base, float* d_out_scores, int64_t* d_out_ids, unsigned char* ws, size_t ws_bytes,
                 int n_cus, hipStream_t st, rass_engine* timing = nullptr, const IvfPlan* plan = nullptr,
-                const int64_t* id_map = nullptr, const ScanExt* ext = nullptr) {
+                const int64_t* id_map = nullptr, const ScanExt* ext = nullptr, bool queries_prepared = false) {
     if (nq < 1 || nq > RASS_MAX_QBATCH) return fail(RASS_ERR_INVALID, "nq must be in [1, RASS_MAX_QBATCH]");
     if (k < 1 || k > RASS_MAX_K) return fail(RASS_ERR_INVALID, "k must be in [1, RASS_MAX_K]");
     if (n_rows < 0 || n_rows > 0x7fffffc0LL) return fail(RASS_ERR_INVALID, "n_rows out of range for one scan");
@@ -363,8 +363,10 @@ int scan_launch(const float* d_corpus, int64_t n_rows, int64_t stride, const int
     int64_t* part_ids = reinterpret_cast<int64_t*>(ws + L.part_ids);
     const int nq_pad = nq <= 16 ? 16 : 32;
 
-    // a4 on the query side (reference app/main.py:1536-1537), written zero-padded.
-    HIP_TRY(rass::launch_normalize_rows_f32(d_queries, q_stride, q_padded, stride, nq, q_dim, st, nq_pad));
+    // a4 on the query side (reference app/main.py:1536-1537), written zero-padded.  (`queries_prepared`: the workspace
+    // already holds these very queries normalised at this stride — the fine scan of an IVF probe right after its coarse scan.)
+    if (!queries_prepared)
+        HIP_TRY(rass::launch_normalize_rows_f32(d_queries, q_stride, q_padded, stride, nq, q_dim, st, nq_pad));
 
     // IVF: the number of work tiles is only known on the device; size the grid by the slab
     const int64_t n_tiles = plan ? plan->max_tiles : (n_rows + 31) / 32;
@@ -1681,6 +1683,16 @@ int rass_unpack_rows_f32(const float* d_packed, int64_t row_stride, int64_t firs
     return RASS_OK;
 }
 
+int rass_gather_rows_f32(const float* d_packed, int64_t row_stride, int64_t n_rows, const int64_t* d_row_ids, int64_t n,
+                         int dim, float* d_out, int64_t out_stride, void* stream) {
+    if (n < 0 || n_rows < 0 || dim < 1 || out_stride < dim || row_stride < dim || row_stride % 128 != 0)
+        return fail(RASS_ERR_INVALID, "bad shape");
+    if (n > 0 && (!d_out || !d_packed || !d_row_ids)) return fail(RASS_ERR_INVALID, "NULL argument");
+    HIP_TRY(rass::launch_gather_rows_tile16(d_packed, row_stride, d_row_ids, n, n_rows, dim, d_out, out_stride,
+                                            reinterpret_cast<hipStream_t>(stream)));
+    return RASS_OK;
+}
+
 int rass_topk_merge(const float* d_scores, const int64_t* d_ids, int n_lists, int nq, int k, float* d_out_scores,
                     int64_t* d_out_ids, void* stream) {
     if (!d_scores || !d_ids || !d_out_scores || !d_out_ids) return fail(RASS_ERR_INVALID, "NULL argument");
@@ -2147,9 +2159,10 @@ static int ivf_search_locked(rass_ivf_t* v, const float* d_queries, int nq, int 
     // (iii) fine: the same fused scan over the planned tiles; slab positions -> source ids in the merge
     IvfPlan plan{v->d_work_tile, v->d_work_rows, v->d_work_mask, v->d_n_work, v->total_tiles};
     const bool need_tags = v->any_tags || d_q_filter != nullptr;
+    // (both branches above left the batch's normalised queries at the head of the engine scratch, at this stride)
     return scan_launch(v->d_slab, v->slab_rows, v->stride, need_tags ? v->d_tags : nullptr, d_queries, v->dim, v->dim,
                        nq, d_q_filter, k, 0, d_out_scores, d_out_ids, eng->d_scratch, eng->scratch_bytes, eng->n_cus,
-                       st, eng, &plan, v->d_ids);
+                       st, eng, &plan, v->d_ids, nullptr, /*queries_prepared=*/true);
 }
 
 int rass_ivf_search_device(rass_ivf_t* v, const float* d_queries, int nq, int k, int nprobe,

@@ -169,6 +169,9 @@ hipError_t launch_pack_rows_tile16(const float* in, int64_t in_stride, float* pa
 // out[0..n) row-major <- packed rows [first_row, first_row+n).
 hipError_t launch_unpack_rows_tile16(const float* packed, int64_t stride, int64_t first_row, int64_t n, int dim,
                                      float* out, int64_t out_stride, hipStream_t stream);
+// out[i] <- row row_ids[i] (device array) of the packed slab; ids outside [0, n_rows) leave their output row untouched
+hipError_t launch_gather_rows_tile16(const float* packed, int64_t stride, const int64_t* row_ids, int64_t n, int64_t n_rows,
+                                     int dim, float* out, int64_t out_stride, hipStream_t stream);
 
 // Synthetic corpus: packed rows [first_row, first_row+n) get iid N(0,1) from Philox4x32-10
 // keyed by (seed, row_id_base + row, col/4), L2-normalised; padding columns zero.

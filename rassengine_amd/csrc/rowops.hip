@@ -294,6 +294,38 @@ hipError_t launch_unpack_rows_tile16(const float* packed, int64_t stride, int64_
     return hipGetLastError();
 }
 
+// out[i] (row-major, out_stride) <- row row_ids[i] of the packed slab, i < n: one workgroup per row, a thread per
+// (16-column chunk, 4-column group).  The k-means seeding picks nlist scattered sample rows: as single-row unpack launches
+// that was 38 us per row (one wave walking 64 chunks), 0.16 s of a 1.4-s training at 4 096 lists.
+__global__ __launch_bounds__(kRowThreads) void gather_rows_tile16_kernel(const float* __restrict__ packed, int64_t stride,
+                                                                         const int64_t* __restrict__ row_ids, int64_t n_rows,
+                                                                         int dim, float* __restrict__ out, int64_t out_stride) {
+    const int64_t i = blockIdx.x;
+    const int64_t row = row_ids[i];
+    if (row < 0 || row >= n_rows) return;   // (the caller clamps; an out-of-range id leaves its output row untouched)
+    const int nchunks = (int)(stride >> 4);
+    const float* src = packed + (row >> 4) * 16 * stride + (row & 15) * 4;
+    float* dst = out + i * out_stride;
+    for (int t = threadIdx.x; t < nchunks * 4; t += kRowThreads) {
+        const int j = t >> 2, g = t & 3;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + (int64_t)j * 256 + g * 64);
+        const int c = 16 * j + 4 * g;
+        if (c < dim) dst[c] = v.x;
+        if (c + 1 < dim) dst[c + 1] = v.y;
+        if (c + 2 < dim) dst[c + 2] = v.z;
+        if (c + 3 < dim) dst[c + 3] = v.w;
+    }
+}
+
+hipError_t launch_gather_rows_tile16(const float* packed, int64_t stride, const int64_t* row_ids, int64_t n, int64_t n_rows,
+                                     int dim, float* out, int64_t out_stride, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    if (n > 0x7fffffff) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gather_rows_tile16_kernel, dim3((unsigned)n), dim3(kRowThreads), 0, stream, packed, stride, row_ids,
+                       n_rows, dim, out, out_stride);
+    return hipGetLastError();
+}
+
 // Synthetic unit rows [first_row, first_row + n) written straight into the packed slab.
 __global__ __launch_bounds__(kRowThreads) void fill_synthetic_kernel(float* __restrict__ packed, int64_t stride,
                                                                      int64_t first_row, int64_t n, int dim,

@@ -97,10 +97,14 @@ def _sample_row(j, step: int):
 
 
 def _gather_rows(index: FlatIndex, rows, dev) -> torch.Tensor:
-    one = torch.empty((1, index.dim), dtype=torch.float32, device=dev)
-    out = torch.empty((len(rows), index.dim), dtype=torch.float32, device=dev)
-    for i, r in enumerate(rows):
-        out[i] = _rows_chunk(index, int(r), 1, one)[0]
+    """Row-major fp32 copies of the given (scattered) rows of the index's slab: one ``rass_gather_rows_f32`` launch."""
+    ids = torch.as_tensor(list(rows), dtype=torch.int64).to(dev)
+    out = torch.zeros((ids.numel(), index.dim), dtype=torch.float32, device=dev)
+    N.check("rass_gather_rows_f32",
+            N.lib().rass_gather_rows_f32(ctypes.c_void_p(index.device_rows_ptr), index.row_stride, int(index.rows),
+                                         ctypes.c_void_p(ids.data_ptr()), int(ids.numel()), index.dim,
+                                         ctypes.c_void_p(out.data_ptr()), index.dim,
+                                         ctypes.c_void_p(int(torch.cuda.current_stream().cuda_stream))))
     return out
 
 

@@ -243,6 +243,27 @@ def test_pack_unpack_roundtrip(gpu, n, dim, first):
         assert np.all(before == 7.0)
 
 
+def test_gather_rows_equals_unpack(gpu):
+    """rass_gather_rows_f32: scattered rows of a tile16 slab (k-means seeds) == the rows rass_unpack_rows_f32 returns; ids out
+    of range leave their output row untouched."""
+    import ctypes
+    from rassengine_amd import _native as N_
+    from rassengine_amd import ops
+    torch = gpu
+    rng = np.random.default_rng(9)
+    for n, dim in ((1000, 1024), (77, 100), (300, 1536)):
+        x = torch.from_numpy(rng.standard_normal((n, dim), dtype=np.float32)).cuda()
+        packed = ops.pack_rows(x)
+        ids = torch.from_numpy(np.concatenate([rng.integers(0, n, size=50), [0, n - 1, n, -1]]).astype(np.int64)).cuda()
+        out = torch.full((ids.numel(), dim + 3), 7.0, device="cuda")
+        N_.check("g", N_.lib().rass_gather_rows_f32(ctypes.c_void_p(packed.data_ptr()), packed.shape[1], n,
+                                                    ctypes.c_void_p(ids.data_ptr()), ids.numel(), dim,
+                                                    ctypes.c_void_p(out.data_ptr()), dim + 3,
+                                                    ctypes.c_void_p(int(torch.cuda.current_stream().cuda_stream))))
+        torch.cuda.synchronize()
+        assert torch.equal(out[:52, :dim], x[ids[:52]]) and bool((out[:, dim:] == 7.0).all()) and bool((out[52:] == 7.0).all())
+
+
 def test_merge_matches_oracle(gpu, oracle):
     from rassengine_amd import ops
     rng = np.random.default_rng(9)

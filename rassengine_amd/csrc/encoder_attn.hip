@@ -249,6 +249,12 @@ __device__ __forceinline__ void dma16(const void* gptr, const unsigned char* lds
 }
 
 constexpr int kA64Threads = 512;
+#ifndef RASS_ATTN_CHUNK
+#define RASS_ATTN_CHUNK 128   // rows of the K / V image replaced per boundary (experiment: 256 = two barriers per item instead of four)
+#endif
+constexpr int kChunk = RASS_ATTN_CHUNK;
+constexpr int kChunkTiles = kChunk / 32;
+static_assert(kChunk == 128 || kChunk == 256, "chunk = 16 or 32 DMA pieces of 8 rows, two or four per wave");
 #ifdef RASS_ATTN_STAMPS  // scripts/microbench/attn_stamps.hip only: where an item's cycles go, per wave (s_memtime ticks)
 // [block][wave][0 item total, 1 prologue (sync0 .. first step), 2 steps, 3 of which boundaries (wait + barrier + DMA issue),
 //  4 epilogue (last products, end-of-item wait + barrier, normalise + store), 5 items]
@@ -305,8 +311,8 @@ __global__ __launch_bounds__(kA64Threads) void attention64_kernel(const u16* __r
         item_rows(it, t0, S);
         const u16* base = qkv + (it % heads) * kHeadDim + hidden;
 #pragma unroll
-        for (int pp = 0; pp < 2; ++pp) {
-            const int row0 = 128 * j + 8 * (wave + 8 * pp);
+        for (int pp = 0; pp < kChunk / 64; ++pp) {
+            const int row0 = kChunk * j + 8 * (wave + 8 * pp);
             const int row = row0 + (lane >> 3);
             const int tok = clamp_tok(t0 + (row < S ? row : S - 1));
             const int ck = (lane & 7) ^ ((row >> 1) & 7);
@@ -361,7 +367,7 @@ __global__ __launch_bounds__(kA64Threads) void attention64_kernel(const u16* __r
         int t0, S;
         item_rows(item, t0, S);
         load_q(t0, S, item % heads, qq);
-        for (int j = 0; j < (S + 127) / 128; ++j) dma_chunk(item, j);
+        for (int j = 0; j < (S + kChunk - 1) / kChunk; ++j) dma_chunk(item, j);
     }
 #ifdef RASS_ATTN_STAMPS
     unsigned long long st_item = 0, st_pro = 0, st_steps = 0, st_bound = 0, st_n = 0, st_e_tail = 0, st_e_wait = 0, st_e_bar = 0;
@@ -371,14 +377,14 @@ __global__ __launch_bounds__(kA64Threads) void attention64_kernel(const u16* __r
         int t0, S;
         item_rows(item, t0, S);
         const int head = item % heads;
-        const int n_kt = (S + 31) / 32, nc = (S + 127) / 128;
+        const int n_kt = (S + 31) / 32, nc = (S + kChunk - 1) / kChunk;
         const int next = item + gridDim.x;
         const bool has_next = next < n_items;
         int nc_next = 0;
         if (has_next) {
             int nt0, nS;
             item_rows(next, nt0, nS);
-            nc_next = (nS + 127) / 128;
+            nc_next = (nS + kChunk - 1) / kChunk;
         }
         if (sync0) {
             wait_all();
@@ -592,11 +598,11 @@ __global__ __launch_bounds__(kA64Threads) void attention64_kernel(const u16* __r
             };
             RASS_STAMP(c_steps0);
             for (int kt = 1; kt < n_kt - 1; ++kt) {
-                if ((kt & 3) == 0) boundary(kt >> 2);
+                if ((kt % kChunkTiles) == 0) boundary(kt / kChunkTiles);
                 step(kt, kFull);
             }
             if (n_kt > 1) {
-                if (((n_kt - 1) & 3) == 0) boundary((n_kt - 1) >> 2);
+                if (((n_kt - 1) % kChunkTiles) == 0) boundary((n_kt - 1) / kChunkTiles);
                 step(n_kt - 1, kMasked);
             }
             RASS_STAMP(c_steps1);
@@ -718,7 +724,7 @@ hipError_t launch_attention(const void* qkv, const int32_t* cu_seqlens, int nseq
     const bool w8_plain = strcmp(variant, "w8") == 0;     // scale-and-subtract as one v_fma per score (the default form)
     const bool w8_fold = strcmp(variant, "w8f") == 0;     // both folded into the QK^T chain: measured, not adopted (see the kernel)
     if (w8_plain || w8_fold || (long_rows && strcmp(variant, "w16") != 0)) {
-        const int s_pad128 = (max_seqlen + 127) / 128 * 128;  // whole 128-row chunks are sent
+        const int s_pad128 = (max_seqlen + kChunk - 1) / kChunk * kChunk;  // whole chunks are sent
         const size_t lds_bytes = (size_t)s_pad128 * 256;      // 128 KiB at S = 512
         static size_t attr64_bytes = 0;
         if (lds_bytes > attr64_bytes) {

@@ -498,10 +498,19 @@ __global__ __launch_bounds__(256) void gemm_bf16_lnin_kernel(const u16* __restri
 }
 
 // tokens <= 64; K = whole 256-deep trips per wave: 4 waves per workgroup (K <= 3072), 16 for whole multiples of 4096
+// RASS_GEMM_FEWROWS_MAX=<rows> (A/B; read per launch): the one-launch kernel up to that many rows where its partial tiles fit
+// (4 waves: K <= 3072); default 128 (r03: 96 tokens 1.405 -> 1.337 ms per forward, 128 tokens 1.539 -> 1.495)
+static int fewrows_max_rows() {
+    const char* v = getenv("RASS_GEMM_FEWROWS_MAX");
+    const int m = v ? atoi(v) : 128;
+    return m < 16 ? 16 : (m > 128 ? 128 : m);
+}
+
 static int fewrows_waves(int M, int N, int K) {
-    if (M < 1 || M > 64 || N % 16 != 0 || N < 1024) return 0;
+    if (M < 1 || N % 16 != 0 || N < 1024) return 0;
+    if (K % 1024 == 0 && K <= 3072) return M <= fewrows_max_rows() ? 4 : 0;
+    if (M > 64) return 0;                        // 16 waves x 8 row blocks of partial tiles would not fit the static LDS
     if (K % 4096 == 0 && K <= 8192) return 16;
-    if (K % 1024 == 0 && K <= 3072) return 4;
     return 0;
 }
 
@@ -525,7 +534,19 @@ static hipError_t launch_fewrows_w(const u16* x, const u16* w, const float* bias
         case 1: hipLaunchKernelGGL((gemm_bf16_fewrows_kernel<EPI, 1, WAVES>), grid, block, 0, stream, x, w, bias, r, y, M, N, K, partial, rows_pad); break;
         case 2: hipLaunchKernelGGL((gemm_bf16_fewrows_kernel<EPI, 2, WAVES>), grid, block, 0, stream, x, w, bias, r, y, M, N, K, partial, rows_pad); break;
         case 3: hipLaunchKernelGGL((gemm_bf16_fewrows_kernel<EPI, 3, WAVES>), grid, block, 0, stream, x, w, bias, r, y, M, N, K, partial, rows_pad); break;
-        default: hipLaunchKernelGGL((gemm_bf16_fewrows_kernel<EPI, 4, WAVES>), grid, block, 0, stream, x, w, bias, r, y, M, N, K, partial, rows_pad); break;
+        case 4: hipLaunchKernelGGL((gemm_bf16_fewrows_kernel<EPI, 4, WAVES>), grid, block, 0, stream, x, w, bias, r, y, M, N, K, partial, rows_pad); break;
+        default:
+            if constexpr (WAVES == 4) {   // 65 .. 128 rows: 4-wave workgroups only (fewrows_waves)
+                switch ((M + 15) / 16) {
+                    case 5: hipLaunchKernelGGL((gemm_bf16_fewrows_kernel<EPI, 5, 4>), grid, block, 0, stream, x, w, bias, r, y, M, N, K, partial, rows_pad); break;
+                    case 6: hipLaunchKernelGGL((gemm_bf16_fewrows_kernel<EPI, 6, 4>), grid, block, 0, stream, x, w, bias, r, y, M, N, K, partial, rows_pad); break;
+                    case 7: hipLaunchKernelGGL((gemm_bf16_fewrows_kernel<EPI, 7, 4>), grid, block, 0, stream, x, w, bias, r, y, M, N, K, partial, rows_pad); break;
+                    default: hipLaunchKernelGGL((gemm_bf16_fewrows_kernel<EPI, 8, 4>), grid, block, 0, stream, x, w, bias, r, y, M, N, K, partial, rows_pad); break;
+                }
+            } else {
+                return hipErrorInvalidValue;
+            }
+            break;
     }
     return hipGetLastError();
 }

@@ -147,10 +147,13 @@ def test_gemm_mid_size_split_k(gpu, M, N, K, epi, mid_s, monkeypatch):
                                        (1300, 1024, 1024, 1), (700, 1024, 4096, 0),
                                        # a few rows against a wide matrix: the one-launch kernel (one wave per 16 features)
                                        (1, 3072, 1024, 0), (64, 2048, 2048, 1), (49, 4096, 1024, 2), (17, 2048, 1024, 1),
-                                       (33, 1024, 4096, 1), (64, 1024, 8192, 0), (5, 1024, 3072, 2)])
+                                       (33, 1024, 4096, 1), (64, 1024, 8192, 0), (5, 1024, 3072, 2),
+                                       # 65 .. 128 rows: the same kernel with 5 .. 8 row blocks per wave (K <= 3072)
+                                       (65, 3072, 1024, 0), (96, 4096, 1024, 2), (100, 2048, 2048, 1), (128, 3072, 1024, 0),
+                                       (120, 1024, 3072, 1)])
 def test_gemm_split_k_for_few_rows(gpu, M, N, K, epi, fewrows, monkeypatch):
     """The query-time paths (rass_gemm_bf16_ws) against torch, bit-identical from run to run (no atomics): K split over
-    workgroups with the slices summed in fixed order, and — tokens <= 64, N >= 2048, K <= 2048 — the one-launch kernel
+    workgroups with the slices summed in fixed order, and — N >= 1024 and tokens <= 128 (K <= 3072) or <= 64 (K = 4096, 8192) — the one-launch kernel
     (RASS_GEMM_FEWROWS=0, read per launch, keeps the split-K pair for those shapes too)."""
     torch = gpu
     monkeypatch.setenv("RASS_GEMM_FEWROWS", fewrows)

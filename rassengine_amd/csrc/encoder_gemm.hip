@@ -899,7 +899,11 @@ static hipError_t launch_p5(const u16* X, const u16* W, const float* bias, const
             n_cus = 256;
     }
     const int tiles_total = (N / RBN) * (M_pad / RBM);
-    const int grid = tiles_total < n_cus ? tiles_total : n_cus;
+    int grid = tiles_total < n_cus ? tiles_total : n_cus;
+    if (const char* v = getenv("RASS_GEMM_GRID")) {   // experiment: fewer persistent workgroups than CUs (per-CU vs chip-wide limits)
+        const int g = atoi(v);
+        if (g >= 1 && g < grid) grid = g;
+    }
     hipLaunchKernelGGL((gemm_bf16_p5_kernel<EPI>), dim3(grid), dim3(kRingThreads), kP5LdsBytes, stream, X, W, bias,
                        residual, Y, M, N, K, tiles_total);
     return hipGetLastError();

@@ -142,6 +142,49 @@ __global__ __launch_bounds__(1024) void rates_kernel(int mode_a, int mode_b, int
     if (threadIdx.x == 0 && blockIdx.x == 0) clocks[gridDim.x * 8] = c1 - c0;   // s_memtime ticks of one wave, for the clock ratio
 }
 
+// Sustained MFMA-only streams with pseudo-random bf16 operands that differ per lane and per instruction (toggling operand
+// buses like a real GEMM does): which clock does the chip hold for each MFMA shape?  SHAPE 0: v_mfma_f32_16x16x32_bf16 on 16
+// accumulator tiles, SHAPE 1: v_mfma_f32_32x32x16_bf16 on 4 (the same flops per iteration: 16 x 16 384 = 8 x 32 768).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int SHAPE>
+__global__ __launch_bounds__(512) void mfma_power_kernel(int iters, float* sink) {
+    bf16x8 a[4], b[4];
+    unsigned h = threadIdx.x * 2654435761u + blockIdx.x * 40503u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+            a[i][j] = (__bf16)(((float)(h & 0xffff) - 32768.f) * (1.f / 32768.f));
+            b[i][j] = (__bf16)(((float)(h >> 16) - 32768.f) * (1.f / 32768.f));
+        }
+    float s = 0.f;
+    if constexpr (SHAPE == 0) {
+        f32x4 acc[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int it = 0; it < iters; ++it)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i & 3], b[i >> 2], acc[i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s += acc[i][0];
+    } else {
+        f32x16 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+        for (int it = 0; it < iters; ++it)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[(i + u) & 3], b[(i + 2 * u) & 3], acc[i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s += acc[i][0];
+    }
+    if (s == 123.456f) sink[0] = s;
+}
+
 static const char* kNames[] = {"v_fma_f32", "v_exp_f32", "v_pk_fma_f32", "v_cvt_pk_bf16_f32", "v_max_f32", "v_add_f32",
                                "v_pk_add_f32", "v_pk_mul_f32", "v_rcp_f32", "v_mfma_f32_32x32x16_bf16"};
 
@@ -207,6 +250,35 @@ int main() {
             printf("  %dw %6.2f", wps, per);
         }
         printf("\n");
+    }
+    {   // sustained, every CU: nothing but back-to-back MFMAs (two waves per SIMD) for ~0.3 s: what clock does the chip hold?
+        const int n = 40;
+        hipEventRecord(e0, 0);
+        for (int i = 0; i < n; ++i) hipLaunchKernelGGL(rates_kernel, dim3(blocks), dim3(512), 0, 0, 9, 9, iters, sink, d_clocks, d_all16);
+        hipEventRecord(e1, 0); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        const double mfmas = (double)n * blocks * 8 * 16.0 * iters;
+        const double tflops = mfmas * 32768.0 / (ms * 1e-3) / 1e12;
+        // a SIMD retires one 32x32x16 MFMA per 32 cycles: clock = MFMAs per SIMD / time * 32
+        const double ghz = (double)n * 2 * 16.0 * iters * 32.0 / (ms * 1e-3) / 1e9;
+        printf("sustained MFMA only, %d CUs x 8 waves, %.0f ms: %.0f TFLOP/s bf16 = a core clock of %.2f GHz (spec peak 2 500 TFLOP/s = 2.4 GHz)\n",
+               blocks, ms, tflops, ghz);
+    }
+    for (int shape = 0; shape < 2; ++shape) {
+        const int n = 40, it2 = 2 * iters;
+        for (int rep = 0; rep < 2; ++rep) {   // second pass is the one reported (first warms the power state)
+            hipEventRecord(e0, 0);
+            for (int i = 0; i < n; ++i) {
+                if (shape == 0) hipLaunchKernelGGL(mfma_power_kernel<0>, dim3(blocks), dim3(512), 0, 0, it2, sink);
+                else hipLaunchKernelGGL(mfma_power_kernel<1>, dim3(blocks), dim3(512), 0, 0, it2, sink);
+            }
+            hipEventRecord(e1, 0); hipEventSynchronize(e1);
+        }
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        const double flops = (double)n * blocks * 8 * (double)it2 * 16.0 * 16384.0;
+        printf("sustained %s, pseudo-random operands, %d CUs x 8 waves, %.0f ms: %.0f TFLOP/s = %.2f GHz\n",
+               shape == 0 ? "v_mfma_f32_16x16x32_bf16" : "v_mfma_f32_32x32x16_bf16", blocks, ms, flops / (ms * 1e-3) / 1e12,
+               flops / (ms * 1e-3) / 1e12 / 2500.0 * 2.4);
     }
     printf("one MFMA + NF v_fma_f32 + NE v_exp_f32 per group (asm order kept), cycles per GROUP; one wave per SIMD | two waves per SIMD (each)\n");
     const char* mixed_names[] = {"mfma", "mfma + 2 fma", "mfma + 4 fma", "mfma + 6 fma", "mfma + 8 fma", "mfma + 12 fma", "mfma + 6 fma + 2 exp",

@@ -6,10 +6,14 @@ from rassengine_amd import _native as N
 ap = argparse.ArgumentParser()
 ap.add_argument("--m", type=int, default=131072)
 ap.add_argument("--iters", type=int, default=5)
+ap.add_argument("--grid", type=int, default=0, help="RASS_GEMM_GRID: cap on the persistent kernel's workgroups; rows scale with it (same tiles per workgroup)")
 a = ap.parse_args()
 L = N.lib()
 g = torch.Generator(device="cuda"); g.manual_seed(0)
 M = a.m
+if a.grid:
+    os.environ["RASS_GEMM_GRID"] = str(a.grid); os.environ["RASS_GEMM_VARIANT"] = "p5"
+    M = a.m * a.grid // 256
 stream = ctypes.c_void_p(int(torch.cuda.current_stream().cuda_stream))
 for (Nn, K, epi) in [(3072, 1024, 0), (1024, 1024, 1), (4096, 1024, 2), (1024, 4096, 1)]:
     X = torch.randn((M, K), generator=g, device="cuda").bfloat16()

@@ -379,6 +379,13 @@ int rass_kmeans_accumulate(rass_index_t* idx, int64_t first_block, int64_t block
  * row ids.  The source index may be dropped afterwards. */
 int rass_ivf_build(rass_index_t* src, const float* centroids, int nlist,
                    const int32_t* assign, rass_ivf_t** out);
+/* The same with the IVF's list-ordered copy of the rows held as `slab_dtype`: RASS_F32 = rass_ivf_build;
+ * RASS_BF16 = the rows rounded to bf16 (half the HBM bytes per probed row; needs the row stride to be a multiple of
+ * 256): the fine scan is then the bf16 scan (queries rounded to bf16, fp32 accumulation) and a probe returns what a
+ * flat RASS_BF16 index over the same rows returns, restricted to the probed lists.  The source index is fp32 either
+ * way (k-means and the assignment read it) and may be dropped afterwards.  (SURVEY §8f-4's bf16 path for cfg 5.) */
+int rass_ivf_build_ex(rass_index_t* src, const float* centroids, int nlist,
+                      const int32_t* assign, rass_dtype slab_dtype, rass_ivf_t** out);
 void rass_ivf_destroy(rass_ivf_t* ivf);
 /* IVF persistence (SURVEY §8f-3 for the IVF shard): the whole device state — list table, slab ids, tags,
  * centroid slab, permuted row slab — so a load needs neither the flat index nor a re-training.  The file is
@@ -387,6 +394,7 @@ int rass_ivf_save(rass_ivf_t* ivf, const char* path);
 int rass_ivf_load(rass_engine_t* eng, const char* path, rass_ivf_t** out);
 int64_t rass_ivf_rows(const rass_ivf_t* ivf);
 int rass_ivf_nlist(const rass_ivf_t* ivf);
+int rass_ivf_dtype(const rass_ivf_t* ivf); /* rass_dtype of the row slab; -1 for NULL */
 /* Same contract as rass_index_search; nprobe >= 1 lists per query (capped at
  * nlist; nprobe > 32 selects by a per-query score threshold, ties may add lists).
  * *scanned_rows (may be NULL) receives the rows the fine scans touched. */

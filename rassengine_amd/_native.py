@@ -127,6 +127,9 @@ SIGNATURES = {
     "rass_ivf_load": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, c_void_pp]),
     "rass_ivf_build": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, c_void_pp]),
     "rass_ivf_destroy": (None, [ctypes.c_void_p]),
+    "rass_ivf_build_ex": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                         c_void_pp]),
+    "rass_ivf_dtype": (ctypes.c_int, [ctypes.c_void_p]),
     "rass_ivf_rows": (ctypes.c_int64, [ctypes.c_void_p]),
     "rass_ivf_nlist": (ctypes.c_int, [ctypes.c_void_p]),
     "rass_ivf_search": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,

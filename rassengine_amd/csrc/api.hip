@@ -525,7 +525,10 @@ struct rass_ivf {
     rass_engine* eng = nullptr;
     int dim = 0, nlist = 0;
     int64_t stride = 0, rows = 0, slab_rows = 0, total_tiles = 0;
+    int dtype = RASS_F32;           // RASS_F32: d_slab (tile16, 32-row tiles) | RASS_BF16: d_slab_b16 (tile16b, 64-row tiles)
+    int tile_rows = 32;             // rows per plan tile = the fine scan kernel's tile
     float* d_slab = nullptr;        // tile16, lists contiguous, each starting on a 32-row tile
+    unsigned short* d_slab_b16 = nullptr;  // bf16 slab: the rows rounded to bf16, lists starting on 64-row tiles
     int32_t* d_tags = nullptr;      // [slab_rows] permuted row tags (0 on padding)
     int64_t* d_ids = nullptr;       // [slab_rows] source row id, -1 on padding
     float* d_centroids = nullptr;   // tile16 slab of nlist normalised centroids
@@ -1834,7 +1837,7 @@ void* rass_index_device_tags(rass_index_t* idx) { return idx ? reinterpret_cast<
 
 static void ivf_free(rass_ivf* v) {
     if (!v) return;
-    for (void* p : {(void*)v->d_slab, (void*)v->d_tags, (void*)v->d_ids, (void*)v->d_centroids, (void*)v->d_list_tile0,
+    for (void* p : {(void*)v->d_slab, (void*)v->d_slab_b16, (void*)v->d_tags, (void*)v->d_ids, (void*)v->d_centroids, (void*)v->d_list_tile0,
                     (void*)v->d_list_len, (void*)v->d_work_tile, (void*)v->d_work_rows, (void*)v->d_n_work,
                     (void*)v->d_work_mask, (void*)v->d_scanned, (void*)v->d_probe_scores, (void*)v->d_probe_ids,
                     (void*)v->d_tau, (void*)v->d_list_mask})
@@ -1843,11 +1846,20 @@ static void ivf_free(rass_ivf* v) {
 }
 
 int rass_ivf_build(rass_index_t* src, const float* centroids, int nlist, const int32_t* assign, rass_ivf_t** out) {
+    return rass_ivf_build_ex(src, centroids, nlist, assign, RASS_F32, out);
+}
+
+int rass_ivf_build_ex(rass_index_t* src, const float* centroids, int nlist, const int32_t* assign, rass_dtype slab_dtype,
+                      rass_ivf_t** out) {
     if (!src || !centroids || !assign || !out) return fail(RASS_ERR_INVALID, "NULL argument");
     *out = nullptr;
     if (nlist < 1 || nlist > 32768) return fail(RASS_ERR_INVALID, "nlist must be in [1, 32768]");
     if (src->dtype != RASS_F32) return fail(RASS_ERR_UNSUPPORTED, "the IVF build needs an fp32 source index");
     if (src->stride > kNarrowStride) return fail(RASS_ERR_UNSUPPORTED, "IVF needs dim <= 1024 (wide rows: flat scan only)");
+    if (slab_dtype != RASS_F32 && slab_dtype != RASS_BF16) return fail(RASS_ERR_INVALID, "unknown slab dtype");
+    if (slab_dtype == RASS_BF16 && src->stride % 256 != 0)
+        return fail(RASS_ERR_UNSUPPORTED, "a bf16 slab needs dim padded to a multiple of 256 (the bf16 scan's K split)");
+    const int tile_rows = slab_dtype == RASS_BF16 ? 64 : 32;
     rass_engine* eng = src->eng;
     std::lock_guard<std::mutex> lk(src->mu);
     int rc = set_device(eng);
@@ -1864,20 +1876,22 @@ int rass_ivf_build(rass_index_t* src, const float* centroids, int nlist, const i
     int64_t tiles = 0;
     for (int l = 0; l < nlist; ++l) {
         tile0[(size_t)l] = (int32_t)tiles;
-        tiles += (len[(size_t)l] + 31) / 32;
+        tiles += (len[(size_t)l] + tile_rows - 1) / tile_rows;
     }
-    if (tiles * 32 > 0x7fffffc0LL) return fail(RASS_ERR_UNSUPPORTED, "slab too large for one IVF shard");
-    const int64_t slab_rows = std::max<int64_t>(tiles, 1) * 32;
+    if (tiles * tile_rows > 0x7fffffc0LL) return fail(RASS_ERR_UNSUPPORTED, "slab too large for one IVF shard");
+    const int64_t slab_rows = std::max<int64_t>(tiles, 1) * tile_rows;
     std::vector<int64_t> src_of((size_t)slab_rows, -1);
     std::vector<int32_t> fill((size_t)nlist, 0);
     for (int64_t r = 0; r < n; ++r) {  // ascending source id inside every list
         if (src->host_deleted[(size_t)(r >> 3)] & (1u << (r & 7))) continue;
         const int32_t l = assign[r];
-        src_of[(size_t)((int64_t)tile0[(size_t)l] * 32 + fill[(size_t)l]++)] = r;
+        src_of[(size_t)((int64_t)tile0[(size_t)l] * tile_rows + fill[(size_t)l]++)] = r;
     }
     rass_ivf* v = new (std::nothrow) rass_ivf();
     if (!v) return fail(RASS_ERR_OOM, "host allocation failed");
     v->eng = eng;
+    v->dtype = slab_dtype;
+    v->tile_rows = tile_rows;
     v->dim = src->dim;
     v->stride = src->stride;
     v->nlist = nlist;
@@ -1896,7 +1910,10 @@ int rass_ivf_build(rass_index_t* src, const float* centroids, int nlist, const i
                         std::string("ivf build: ") + #expr + ": " + hipGetErrorString(_e));                 \
         }                                                                                                   \
     } while (0)
-    IVF_TRY(hipMalloc(reinterpret_cast<void**>(&v->d_slab), (size_t)slab_rows * v->stride * 4));
+    if (slab_dtype == RASS_BF16)
+        IVF_TRY(hipMalloc(reinterpret_cast<void**>(&v->d_slab_b16), (size_t)slab_rows * v->stride * 2));
+    else
+        IVF_TRY(hipMalloc(reinterpret_cast<void**>(&v->d_slab), (size_t)slab_rows * v->stride * 4));
     IVF_TRY(hipMalloc(reinterpret_cast<void**>(&v->d_tags), (size_t)slab_rows * 4));
     IVF_TRY(hipMalloc(reinterpret_cast<void**>(&v->d_ids), (size_t)slab_rows * 8));
     IVF_TRY(hipMalloc(reinterpret_cast<void**>(&v->d_centroids), (size_t)cent_rows * v->stride * 4));
@@ -1914,7 +1931,10 @@ int rass_ivf_build(rass_index_t* src, const float* centroids, int nlist, const i
     IVF_TRY(hipMemcpyAsync(v->d_ids, src_of.data(), (size_t)slab_rows * 8, hipMemcpyHostToDevice, st));
     IVF_TRY(hipMemcpyAsync(v->d_list_tile0, tile0.data(), (size_t)nlist * 4, hipMemcpyHostToDevice, st));
     IVF_TRY(hipMemcpyAsync(v->d_list_len, len.data(), (size_t)nlist * 4, hipMemcpyHostToDevice, st));
-    IVF_TRY(rass::launch_permute_rows_tile16(src->d_rows, v->d_slab, v->stride, v->d_ids, slab_rows, st));
+    if (slab_dtype == RASS_BF16)
+        IVF_TRY(rass::launch_permute_rows_tile16_bf16(src->d_rows, v->d_slab_b16, v->stride, v->d_ids, slab_rows, st));
+    else
+        IVF_TRY(rass::launch_permute_rows_tile16(src->d_rows, v->d_slab, v->stride, v->d_ids, slab_rows, st));
     // tags: permuted on the host (small), padding rows get 0
     {
         std::vector<int32_t> tags((size_t)std::max<int64_t>(n, 1), 0), ptags((size_t)slab_rows, 0);
@@ -1994,7 +2014,7 @@ int rass_ivf_save(rass_ivf_t* v, const char* path) {
     IvfSaveHeader h;
     memset(&h, 0, sizeof(h));
     memcpy(h.magic, "RASSIVF1", 8);
-    h.version = 1;
+    h.version = v->dtype == RASS_BF16 ? 2 : 1;   // 2: the row slab is bf16 (tile16b) with lists on 64-row tiles
     h.dim = v->dim;
     h.nlist = v->nlist;
     h.any_tags = v->any_tags ? 1 : 0;
@@ -2010,7 +2030,8 @@ int rass_ivf_save(rass_ivf_t* v, const char* path) {
     ok = ok && dev_to_file(f, v->d_ids, (size_t)v->slab_rows * 8, st, buf);
     ok = ok && dev_to_file(f, v->d_tags, (size_t)v->slab_rows * 4, st, buf);
     ok = ok && dev_to_file(f, v->d_centroids, (size_t)h.cent_rows * v->stride * 4, st, buf);
-    ok = ok && dev_to_file(f, v->d_slab, (size_t)v->slab_rows * v->stride * 4, st, buf);
+    ok = ok && (v->dtype == RASS_BF16 ? dev_to_file(f, v->d_slab_b16, (size_t)v->slab_rows * v->stride * 2, st, buf)
+                                       : dev_to_file(f, v->d_slab, (size_t)v->slab_rows * v->stride * 4, st, buf));
     ok = ok && fflush(f) == 0 && fsync(fileno(f)) == 0;
     ok = (fclose(f) == 0) && ok;
     return ok ? RASS_OK : fail(RASS_ERR_IO, std::string("ivf save failed (short write or device read): ") + path);
@@ -2024,20 +2045,24 @@ int rass_ivf_load(rass_engine_t* eng, const char* path, rass_ivf_t** out) {
     FILE* f = fopen(path, "rb");
     if (!f) return fail(RASS_ERR_IO, std::string("cannot open for read: ") + path);
     IvfSaveHeader h;
-    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "RASSIVF1", 8) != 0 || h.version != 1) {
+    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "RASSIVF1", 8) != 0 || (h.version != 1 && h.version != 2)) {
         fclose(f);
         return fail(RASS_ERR_IO, "not a rass IVF file");
     }
+    const bool b16 = h.version == 2;
+    const int tile_rows = b16 ? 64 : 32;
+    const int64_t esize = b16 ? 2 : 4;
     const int64_t cent_rows = ((int64_t)h.nlist + 15) / 16 * 16;
     bool sane = h.dim == eng->dim && h.stride == pad128(h.dim) && h.nlist >= 1 && h.nlist <= 32768 && h.rows >= 0 &&
-                h.slab_rows >= 32 && h.slab_rows % 32 == 0 && h.slab_rows <= 0x7fffffc0LL &&
-                h.total_tiles == h.slab_rows / 32 && h.cent_rows == cent_rows && h.rows <= h.slab_rows;
+                h.slab_rows >= tile_rows && h.slab_rows % tile_rows == 0 && h.slab_rows <= 0x7fffffc0LL &&
+                h.total_tiles == h.slab_rows / tile_rows && h.cent_rows == cent_rows && h.rows <= h.slab_rows &&
+                (!b16 || h.stride % 256 == 0) && h.stride <= kNarrowStride;
     if (sane) {  // the header must agree with the file length before anything is allocated from it
         const long body = ftell(f);
         int64_t len = -1;
         if (body >= 0 && fseek(f, 0, SEEK_END) == 0) len = (int64_t)ftell(f);
-        const int64_t need = (int64_t)sizeof(h) + (int64_t)h.nlist * 8 + h.slab_rows * 12 +
-                             (cent_rows + h.slab_rows) * h.stride * 4;
+        const int64_t need = (int64_t)sizeof(h) + (int64_t)h.nlist * 8 + h.slab_rows * 12 + cent_rows * h.stride * 4 +
+                             h.slab_rows * h.stride * esize;
         sane = body >= 0 && len == need && fseek(f, body, SEEK_SET) == 0;
     }
     if (!sane) {
@@ -2057,10 +2082,14 @@ int rass_ivf_load(rass_engine_t* eng, const char* path, rass_ivf_t** out) {
     v->slab_rows = h.slab_rows;
     v->total_tiles = h.total_tiles;
     v->any_tags = h.any_tags != 0;
+    v->dtype = b16 ? RASS_BF16 : RASS_F32;
+    v->tile_rows = tile_rows;
     std::lock_guard<std::mutex> lk(eng->mu);
     hipStream_t st = eng->stream;
     auto alloc = [&](void** p, size_t bytes) { return hipMalloc(p, bytes) == hipSuccess; };
-    bool ok = alloc((void**)&v->d_slab, (size_t)h.slab_rows * h.stride * 4) && alloc((void**)&v->d_tags, (size_t)h.slab_rows * 4) &&
+    bool ok = (b16 ? alloc((void**)&v->d_slab_b16, (size_t)h.slab_rows * h.stride * 2)
+                   : alloc((void**)&v->d_slab, (size_t)h.slab_rows * h.stride * 4)) &&
+              alloc((void**)&v->d_tags, (size_t)h.slab_rows * 4) &&
               alloc((void**)&v->d_ids, (size_t)h.slab_rows * 8) && alloc((void**)&v->d_centroids, (size_t)cent_rows * h.stride * 4) &&
               alloc((void**)&v->d_list_tile0, (size_t)h.nlist * 4) && alloc((void**)&v->d_list_len, (size_t)h.nlist * 4) &&
               alloc((void**)&v->d_work_tile, (size_t)h.total_tiles * 4) && alloc((void**)&v->d_work_rows, (size_t)h.total_tiles * 4) &&
@@ -2077,7 +2106,8 @@ int rass_ivf_load(rass_engine_t* eng, const char* path, rass_ivf_t** out) {
     ok = file_to_dev(f, v->d_list_tile0, (size_t)h.nlist * 4, st, buf) && file_to_dev(f, v->d_list_len, (size_t)h.nlist * 4, st, buf) &&
          file_to_dev(f, v->d_ids, (size_t)h.slab_rows * 8, st, buf) && file_to_dev(f, v->d_tags, (size_t)h.slab_rows * 4, st, buf) &&
          file_to_dev(f, v->d_centroids, (size_t)cent_rows * h.stride * 4, st, buf) &&
-         file_to_dev(f, v->d_slab, (size_t)h.slab_rows * h.stride * 4, st, buf);
+         (b16 ? file_to_dev(f, v->d_slab_b16, (size_t)h.slab_rows * h.stride * 2, st, buf)
+              : file_to_dev(f, v->d_slab, (size_t)h.slab_rows * h.stride * 4, st, buf));
     fclose(f);
     if (!ok) {
         ivf_free(v);
@@ -2091,7 +2121,7 @@ int rass_ivf_load(rass_engine_t* eng, const char* path, rass_ivf_t** out) {
         int64_t tiles = 0;
         for (int l = 0; good && l < h.nlist; ++l) {
             good = len[(size_t)l] >= 0 && t0[(size_t)l] == tiles;
-            tiles += (len[(size_t)l] + 31) / 32;
+            tiles += (len[(size_t)l] + tile_rows - 1) / tile_rows;
         }
         if (!good || std::max<int64_t>(tiles, 1) != h.total_tiles) {
             ivf_free(v);
@@ -2104,6 +2134,7 @@ int rass_ivf_load(rass_engine_t* eng, const char* path, rass_ivf_t** out) {
 
 int64_t rass_ivf_rows(const rass_ivf_t* v) { return v ? v->rows : 0; }
 int rass_ivf_nlist(const rass_ivf_t* v) { return v ? v->nlist : 0; }
+int rass_ivf_dtype(const rass_ivf_t* v) { return v ? v->dtype : -1; }
 
 // Caller holds eng->mu (the probe scratch of the IVF object and the engine scratch are shared).
 static int ivf_search_locked(rass_ivf_t* v, const float* d_queries, int nq, int k, int nprobe,
@@ -2126,7 +2157,7 @@ static int ivf_search_locked(rass_ivf_t* v, const float* d_queries, int nq, int 
         // (ii) plan: union of probed lists -> work tiles with per-tile query masks
         HIP_TRY(rass::launch_plan_probe(v->d_probe_ids, nq, std::min(np, RASS_MAX_K), v->nlist, v->d_list_tile0,
                                         v->d_list_len, v->d_work_tile, v->d_work_rows, v->d_work_mask, v->d_n_work,
-                                        v->d_scanned, st));
+                                        v->d_scanned, st, nullptr, v->tile_rows));
     } else {
         // nprobe > 32: one workgroup per 32-centroid tile with k = 32 leaves EVERY centroid score in
         // the per-workgroup lists; radix-select the nprobe-th best per query, mask by threshold
@@ -2154,12 +2185,52 @@ static int ivf_search_locked(rass_ivf_t* v, const float* d_queries, int nq, int 
         HIP_TRY(rass::launch_ivf_mask_from_scores(part_scores, part_ids, n_ctiles, nq, v->nlist, v->d_tau,
                                                   v->d_list_mask, st));
         HIP_TRY(rass::launch_plan_probe(v->d_probe_ids, nq, 1, v->nlist, v->d_list_tile0, v->d_list_len, v->d_work_tile,
-                                        v->d_work_rows, v->d_work_mask, v->d_n_work, v->d_scanned, st, v->d_list_mask));
+                                        v->d_work_rows, v->d_work_mask, v->d_n_work, v->d_scanned, st, v->d_list_mask,
+                                        v->tile_rows));
     }
     // (iii) fine: the same fused scan over the planned tiles; slab positions -> source ids in the merge
     IvfPlan plan{v->d_work_tile, v->d_work_rows, v->d_work_mask, v->d_n_work, v->total_tiles};
     const bool need_tags = v->any_tags || d_q_filter != nullptr;
     // (both branches above left the batch's normalised queries at the head of the engine scratch, at this stride)
+    if (v->dtype == RASS_BF16) {
+        // the bf16 scan over the planned 64-row tiles: queries rounded to bf16, fp32 accumulation, slab positions -> source
+        // ids in the merge.  Scores are those of a flat bf16 index holding the same rows.
+        const ScratchLayout L = scratch_layout(RASS_MAX_QBATCH, RASS_MAX_K);
+        unsigned char* ws = eng->d_scratch;
+        const float* q_padded = reinterpret_cast<const float*>(ws + L.q_padded);
+        float* part_scores = reinterpret_cast<float*>(ws + L.part_scores);
+        int64_t* part_ids = reinterpret_cast<int64_t*>(ws + L.part_ids);
+        unsigned short* q_bf16 = reinterpret_cast<unsigned short*>(ws + L.q_bf16);
+        const int nq_pad = nq <= 16 ? 16 : 32;
+        HIP_TRY(rass::launch_queries_to_bf16(q_padded, q_bf16, (int64_t)nq_pad * v->stride, st));
+        int grid = (int)std::min<int64_t>(std::max<int64_t>(v->total_tiles, 1), std::min(eng->n_cus, kMaxGrid));
+        if ((int64_t)grid * k > rass::kMergeMaxCandidates) grid = rass::kMergeMaxCandidates / k;
+        rass::ScanBf16Args a;
+        a.corpus = v->d_slab_b16;
+        a.row_tag = need_tags ? v->d_tags : nullptr;
+        a.q_bf16 = q_bf16;
+        a.q_filter = d_q_filter;
+        a.part_scores = part_scores;
+        a.part_ids = part_ids;
+        a.row_stride = v->stride;
+        a.n_rows = (int)v->slab_rows;
+        a.nq = nq;
+        a.k = k;
+        a.id_base = 0;
+        a.work_tile = v->d_work_tile;
+        a.work_rows = v->d_work_rows;
+        a.work_mask = v->d_work_mask;
+        a.n_work = v->d_n_work;
+        const bool timed = eng->ev_on && (size_t)(2 * eng->ev_used + 1) < eng->ev_pool.size();
+        if (timed) HIP_TRY(hipEventRecord(eng->ev_pool[2 * eng->ev_used], st));
+        HIP_TRY(rass::launch_scan_bf16_topk(a, grid, st));
+        if (timed) {
+            HIP_TRY(hipEventRecord(eng->ev_pool[2 * eng->ev_used + 1], st));
+            eng->ev_used += 1;
+        }
+        HIP_TRY(rass::launch_merge_topk(part_scores, part_ids, grid, nq, k, d_out_scores, d_out_ids, st, v->d_ids));
+        return RASS_OK;
+    }
     return scan_launch(v->d_slab, v->slab_rows, v->stride, need_tags ? v->d_tags : nullptr, d_queries, v->dim, v->dim,
                        nq, d_q_filter, k, 0, d_out_scores, d_out_ids, eng->d_scratch, eng->scratch_bytes, eng->n_cus,
                        st, eng, &plan, v->d_ids, nullptr, /*queries_prepared=*/true);

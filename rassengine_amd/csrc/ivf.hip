@@ -11,6 +11,7 @@
 // scan_topk.hip).  A tile is fetched once per batch however many queries probe it.
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
 #include <stdint.h>
 
 #include "kernels.h"
@@ -31,7 +32,8 @@ __global__ __launch_bounds__(kPlanThreads) void plan_probe_kernel(const int64_t*
                                                                   uint32_t* __restrict__ work_mask,
                                                                   int32_t* __restrict__ n_work,
                                                                   int64_t* __restrict__ scanned_rows,
-                                                                  const uint32_t* __restrict__ preset_mask) {
+                                                                  const uint32_t* __restrict__ preset_mask,
+                                                                  int tile_rows) {
     extern __shared__ uint32_t sh[];   // [nlist] query masks, then [kPlanThreads] scan scratch
     uint32_t* mask = sh;
     uint32_t* part = sh + nlist;
@@ -52,7 +54,7 @@ __global__ __launch_bounds__(kPlanThreads) void plan_probe_kernel(const int64_t*
     uint32_t rows = 0;
     for (int l = l0; l < l1; ++l)
         if (mask[l]) {
-            cnt += (uint32_t)((list_len[l] + 31) / 32);
+            cnt += (uint32_t)((list_len[l] + tile_rows - 1) / tile_rows);
             rows += (uint32_t)list_len[l];
         }
     part[tid] = cnt;
@@ -83,13 +85,13 @@ __global__ __launch_bounds__(kPlanThreads) void plan_probe_kernel(const int64_t*
             mk = mask[l];
             if (!mk) continue;
             len = list_len[l];
-            const uint32_t nt = (uint32_t)((len + 31) / 32);
+            const uint32_t nt = (uint32_t)((len + tile_rows - 1) / tile_rows);
             if (i - base < nt) break;
             base += nt;
         }
         const int t = (int)(i - base);
         work_tile[i] = list_tile0[l] + t;
-        work_rows[i] = min(32, len - 32 * t);
+        work_rows[i] = min(tile_rows, len - tile_rows * t);
         work_mask[i] = mk;
     }
     if (tid == kPlanThreads - 1) *n_work = (int32_t)part[tid];
@@ -106,8 +108,10 @@ __global__ __launch_bounds__(kPlanThreads) void plan_probe_kernel(const int64_t*
 
 hipError_t launch_plan_probe(const int64_t* probe_ids, int nq, int nprobe, int nlist, const int32_t* list_tile0,
                              const int32_t* list_len, int32_t* work_tile, int32_t* work_rows, uint32_t* work_mask,
-                             int32_t* n_work, int64_t* scanned_rows, hipStream_t stream, const uint32_t* preset_mask) {
+                             int32_t* n_work, int64_t* scanned_rows, hipStream_t stream, const uint32_t* preset_mask,
+                             int tile_rows) {
     if (nq < 1 || nq > 32 || nprobe < 1 || nlist < 1 || nlist > 32768) return hipErrorInvalidValue;
+    if (tile_rows != 32 && tile_rows != 64) return hipErrorInvalidValue;   // the fp32 scan's tile / the bf16 scan's
     const size_t lds = ((size_t)nlist + kPlanThreads) * sizeof(uint32_t);
     static size_t attr = 0;
     if (lds > attr && lds > 48 * 1024) {
@@ -117,7 +121,7 @@ hipError_t launch_plan_probe(const int64_t* probe_ids, int nq, int nprobe, int n
         attr = lds;
     }
     hipLaunchKernelGGL(plan_probe_kernel, dim3(1), dim3(kPlanThreads), lds, stream, probe_ids, nq, nprobe, nlist,
-                       list_tile0, list_len, work_tile, work_rows, work_mask, n_work, scanned_rows, preset_mask);
+                       list_tile0, list_len, work_tile, work_rows, work_mask, n_work, scanned_rows, preset_mask, tile_rows);
     return hipGetLastError();
 }
 
@@ -233,6 +237,52 @@ hipError_t launch_permute_rows_tile16(const float* src, float* dst, int64_t stri
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(permute_rows_tile16_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, src, dst, stride,
                        src_of, dst_rows);
+    return hipGetLastError();
+}
+
+// The same permutation into a bf16 tile16b slab (scan_bf16.hip's layout: lane (m, g) of 32-column chunk jb holds
+// X[16b + m][32jb + 8g .. +7]), rounding to bf16 on the way (round to nearest even, as convert_tile16_bf16_kernel): the
+// IVF over a bf16 slab is built from the fp32 index without an fp32 list-ordered copy in between.
+__global__ __launch_bounds__(256) void permute_rows_tile16_bf16_kernel(const float* __restrict__ src,
+                                                                       unsigned short* __restrict__ dst, int64_t stride,
+                                                                       const int64_t* __restrict__ src_of,
+                                                                       int64_t dst_rows) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int m = lane & 15, g = lane >> 4;
+    const int nchb = (int)(stride >> 5);
+    const int64_t nblk = dst_rows >> 4;
+    auto bf = [](float f) -> unsigned {   // the conversion convert_tile16_bf16_kernel uses: the two slabs hold the same bits
+        __hip_bfloat16 h = __float2bfloat16(f);
+        return (unsigned)*reinterpret_cast<unsigned short*>(&h);
+    };
+    for (int64_t b = (int64_t)blockIdx.x * 4 + wave; b < nblk; b += (int64_t)gridDim.x * 4) {
+        const int64_t s = src_of[b * 16 + m];
+        const float* sp = s >= 0 ? src + (s >> 4) * 16 * stride + (int64_t)(g >> 1) * 256 + ((2 * (g & 1)) * 16 + (s & 15)) * 4 : nullptr;
+        unsigned short* dp = dst + b * 16 * stride + lane * 8;
+        for (int jb = 0; jb < nchb; ++jb) {
+            uint4 o = uint4{0u, 0u, 0u, 0u};
+            if (sp) {
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp + (int64_t)jb * 512);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(sp + (int64_t)jb * 512 + 64);
+                o.x = bf(v0.x) | (bf(v0.y) << 16);
+                o.y = bf(v0.z) | (bf(v0.w) << 16);
+                o.z = bf(v1.x) | (bf(v1.y) << 16);
+                o.w = bf(v1.z) | (bf(v1.w) << 16);
+            }
+            *reinterpret_cast<uint4*>(dp + (int64_t)jb * 512) = o;
+        }
+    }
+}
+
+hipError_t launch_permute_rows_tile16_bf16(const float* src, void* dst, int64_t stride, const int64_t* src_of,
+                                           int64_t dst_rows, hipStream_t stream) {
+    if (dst_rows <= 0) return hipSuccess;
+    if (dst_rows % 16 != 0 || stride % 32 != 0) return hipErrorInvalidValue;
+    int64_t blocks = (dst_rows / 16 + 3) / 4;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(permute_rows_tile16_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, src,
+                       static_cast<unsigned short*>(dst), stride, src_of, dst_rows);
     return hipGetLastError();
 }
 

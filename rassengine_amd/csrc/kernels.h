@@ -94,6 +94,12 @@ struct ScanBf16Args {
     const int32_t* q_filter_mask = nullptr;
     const float* q_after_score = nullptr;
     const int64_t* q_after_id = nullptr;
+    // IVF probe plan over a bf16 slab (all nullptr for the flat scan; as ScanArgs, in 64-row tiles): work item i = slab
+    // tile work_tile[i] with work_rows[i] valid rows, visible to the queries whose bit is set in work_mask[i]
+    const int32_t* work_tile = nullptr;
+    const int32_t* work_rows = nullptr;
+    const uint32_t* work_mask = nullptr;
+    const int32_t* n_work = nullptr;
 };
 hipError_t launch_scan_bf16_topk(const ScanBf16Args& a, int grid, hipStream_t stream);
 // fp32 tile16 blocks -> bf16 tile16b blocks [block0, block1) of dst.  src_block0 (default = block0): the source
@@ -137,13 +143,16 @@ hipError_t launch_kmeans_accumulate(const float* rows, int64_t stride, int64_t f
 hipError_t launch_plan_probe(const int64_t* probe_ids, int nq, int nprobe, int nlist, const int32_t* list_tile0,
                              const int32_t* list_len, int32_t* work_tile, int32_t* work_rows, uint32_t* work_mask,
                              int32_t* n_work, int64_t* scanned_rows, hipStream_t stream,
-                             const uint32_t* preset_mask = nullptr);
+                             const uint32_t* preset_mask = nullptr, int tile_rows = 32);
 hipError_t launch_ivf_threshold(const float* part_scores, const int64_t* part_ids, int n_ctiles, int nq, int nprobe,
                                 uint32_t* tau_key, hipStream_t stream);
 hipError_t launch_ivf_mask_from_scores(const float* part_scores, const int64_t* part_ids, int n_ctiles, int nq,
                                        int nlist, const uint32_t* tau_key, uint32_t* mask, hipStream_t stream);
 hipError_t launch_permute_rows_tile16(const float* src, float* dst, int64_t stride, const int64_t* src_of,
                                       int64_t dst_rows, hipStream_t stream);
+// the same rows rounded to bf16 into a tile16b slab (the IVF over a bf16 slab)
+hipError_t launch_permute_rows_tile16_bf16(const float* src, void* dst, int64_t stride, const int64_t* src_of,
+                                           int64_t dst_rows, hipStream_t stream);
 
 // out[r][0..dim) = in[r] / (||in[r]|| + 1e-9); out[r][dim..out_stride) = 0 for r < n;
 // rows [n, n_total) of out are zero-filled (query padding), all in one launch.

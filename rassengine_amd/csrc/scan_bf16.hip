@@ -44,12 +44,35 @@ struct BDesc {
     __amdgpu_buffer_rsrc_t tags;
 };
 
+// a work item: 64-row tile `tile` of the slab with `rows` valid rows, visible to the queries whose bit is set in `mask`
+struct BWork {
+    int tile, rows;
+    unsigned mask;
+};
+
+// item i of the launch: tile i of the slab (flat) or entry i of the probe plan (IVF); past the end: zero rows of tile 0
+template <bool IVF>
+__device__ __forceinline__ BWork get_bwork(const ScanBf16Args& p, int i, int n_items) {
+    BWork w;
+    const bool ok = i < n_items;
+    if (IVF) {
+        w.tile = ok ? p.work_tile[i] : 0;
+        w.rows = ok ? p.work_rows[i] : 0;
+        w.mask = ok ? p.work_mask[i] : 0u;
+    } else {
+        int rows = p.n_rows - i * kBTileRows;
+        rows = rows < 0 ? 0 : (rows > kBTileRows ? kBTileRows : rows);
+        w.tile = ok ? i : 0;
+        w.rows = ok ? rows : 0;
+        w.mask = 0xffffffffu;
+    }
+    return w;
+}
+
 __device__ __forceinline__ BDesc make_bdesc(const u16* __restrict__ X, int64_t stride, const int32_t* __restrict__ tag,
-                                            int tile, int n_tiles, int n_rows) {
-    int rows_here = n_rows - tile * kBTileRows;
-    rows_here = rows_here < 0 ? 0 : (rows_here > kBTileRows ? kBTileRows : rows_here);
-    if (tile >= n_tiles) rows_here = 0;
-    const int64_t base_row = tile < n_tiles ? (int64_t)tile * kBTileRows : 0;
+                                            const BWork& w) {
+    const int rows_here = w.rows;
+    const int64_t base_row = (int64_t)w.tile * kBTileRows;
     const uint64_t bu = reinterpret_cast<uint64_t>(X + base_row * stride);
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)bu), hi = __builtin_amdgcn_readfirstlane((uint32_t)(bu >> 32));
     const unsigned blocks = (unsigned)(rows_here + 15) >> 4;
@@ -70,14 +93,16 @@ struct BTile {
     int tag;  // tag of row lane (0..63) of the tile
 };
 
-template <int CHB, int NT, bool EXT>
+template <int CHB, int NT, bool EXT, bool IVF>
 __global__ __launch_bounds__(kBThreads, 2) void scan_bf16_topk_kernel(ScanBf16Args p) {
     constexpr int NQ = NT * 16;
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [2][kBWaves][NQ][kBPitch]
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int m = lane & 15, g = lane >> 4;
-    const int n_tiles = (p.n_rows + kBTileRows - 1) / kBTileRows;
+    // number of work items: tiles of the slab (flat) or entries of the probe plan (IVF: written by plan_probe_kernel earlier
+    // on this stream)
+    const int n_tiles = IVF ? __builtin_amdgcn_readfirstlane(*p.n_work) : (p.n_rows + kBTileRows - 1) / kBTileRows;
     const int G = gridDim.x;
 
     bf16x8 qf[NT][CHB];
@@ -142,7 +167,7 @@ __global__ __launch_bounds__(kBThreads, 2) void scan_bf16_topk_kernel(ScanBf16Ar
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    auto finish = [&](const f32x4 (&acc)[4][NT], int tile, int tag, int buf) {
+    auto finish = [&](const f32x4 (&acc)[4][NT], const BWork& w, int tag, int buf) {
         float* P = lds + buf * (kBWaves * NQ * kBPitch);
 #pragma unroll
         for (int b = 0; b < 4; ++b)
@@ -153,9 +178,9 @@ __global__ __launch_bounds__(kBThreads, 2) void scan_bf16_topk_kernel(ScanBf16Ar
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const int r = (lane & 31) + 32 * half;
-            const int row = tile * kBTileRows + r;
+            const int row = w.tile * kBTileRows + r;
             const int rtag = __shfl(tag, r, 64);
-            const bool row_ok = (tile < n_tiles) && (row < p.n_rows) && (rtag != -1);
+            const bool row_ok = (r < w.rows) && (rtag != -1);
 #pragma unroll
             for (int pq = 0; pq < NT; ++pq) {
                 const int q = pq * 16 + (lane >> 5) * 8 + wid;
@@ -170,6 +195,7 @@ __global__ __launch_bounds__(kBThreads, 2) void scan_bf16_topk_kernel(ScanBf16Ar
                 } else {
                     ok = row_ok && (qfilt[pq] < 0 || qfilt[pq] == rtag);
                 }
+                if (IVF) ok = ok && ((w.mask >> q) & 1u) != 0;   // only the queries that probe this tile's list
                 insert_candidates(L[pq], tau[pq], ok ? s : -INFINITY, row, p.k);
             }
         }
@@ -177,17 +203,22 @@ __global__ __launch_bounds__(kBThreads, 2) void scan_bf16_topk_kernel(ScanBf16Ar
 
     BTile<CHB> R0, R1;
     int t = blockIdx.x;
-    issue(R0, make_bdesc(p.corpus, p.row_stride, p.row_tag, t, n_tiles, p.n_rows));
-    issue(R1, make_bdesc(p.corpus, p.row_stride, p.row_tag, t + G, n_tiles, p.n_rows));
+    BWork w0 = get_bwork<IVF>(p, t, n_tiles), w1 = get_bwork<IVF>(p, t + G, n_tiles);
+    issue(R0, make_bdesc(p.corpus, p.row_stride, p.row_tag, w0));
+    issue(R1, make_bdesc(p.corpus, p.row_stride, p.row_tag, w1));
     __builtin_amdgcn_sched_barrier(0);
     for (; t < n_tiles; t += 2 * G) {
         f32x4 acc[4][NT];
         int tag = R0.tag;
-        mul_refill(R0, acc, make_bdesc(p.corpus, p.row_stride, p.row_tag, t + 2 * G, n_tiles, p.n_rows));
-        finish(acc, t, tag, 0);
+        const BWork w2 = get_bwork<IVF>(p, t + 2 * G, n_tiles);
+        mul_refill(R0, acc, make_bdesc(p.corpus, p.row_stride, p.row_tag, w2));
+        finish(acc, w0, tag, 0);
         tag = R1.tag;
-        mul_refill(R1, acc, make_bdesc(p.corpus, p.row_stride, p.row_tag, t + 3 * G, n_tiles, p.n_rows));
-        finish(acc, t + G, tag, 1);
+        const BWork w3 = get_bwork<IVF>(p, t + 3 * G, n_tiles);
+        mul_refill(R1, acc, make_bdesc(p.corpus, p.row_stride, p.row_tag, w3));
+        finish(acc, w1, tag, 1);
+        w0 = w2;
+        w1 = w3;
     }
     const int lpos = lane & 31;
 #pragma unroll
@@ -203,17 +234,17 @@ __global__ __launch_bounds__(kBThreads, 2) void scan_bf16_topk_kernel(ScanBf16Ar
     }
 }
 
-template <int CHB, int NT, bool EXT>
+template <int CHB, int NT, bool EXT, bool IVF = false>
 static hipError_t launch_bvariant(const ScanBf16Args& a, int grid, hipStream_t stream) {
     constexpr size_t lds_bytes = (size_t)2 * kBWaves * NT * 16 * kBPitch * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_bf16_topk_kernel<CHB, NT, EXT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_bf16_topk_kernel<CHB, NT, EXT, IVF>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((scan_bf16_topk_kernel<CHB, NT, EXT>), dim3(grid), dim3(kBThreads), lds_bytes, stream, a);
+    hipLaunchKernelGGL((scan_bf16_topk_kernel<CHB, NT, EXT, IVF>), dim3(grid), dim3(kBThreads), lds_bytes, stream, a);
     return hipGetLastError();
 }
 
@@ -226,8 +257,11 @@ hipError_t launch_scan_bf16_topk(const ScanBf16Args& a, int grid, hipStream_t st
         if ((a.q_after_score == nullptr) != (a.q_after_id == nullptr)) return hipErrorInvalidValue;
         if (a.q_filter_mask != nullptr && a.q_filter == nullptr) return hipErrorInvalidValue;
     }
+    const bool ivf = a.work_tile != nullptr;
+    if (ivf && (ext || !a.work_rows || !a.work_mask || !a.n_work)) return hipErrorInvalidValue;   // IVF probe: plain filters only
 #define RASS_BF16_CASE(C)                                                                                     \
     case C:                                                                                                   \
+        if (ivf) return two ? launch_bvariant<C, 2, false, true>(a, grid, stream) : launch_bvariant<C, 1, false, true>(a, grid, stream); \
         if (ext) return two ? launch_bvariant<C, 2, true>(a, grid, stream) : launch_bvariant<C, 1, true>(a, grid, stream); \
         return two ? launch_bvariant<C, 2, false>(a, grid, stream) : launch_bvariant<C, 1, false>(a, grid, stream);
     switch (chb) {

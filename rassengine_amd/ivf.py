@@ -235,14 +235,20 @@ class IvfIndex:
 
     @classmethod
     def build(cls, index: FlatIndex, nlist: int = 4096, train_rows: int = 0, iters: int = 20, seed: int = 0,
-              group: Optional[dist.ProcessGroup] = None, centroids: Optional[torch.Tensor] = None) -> "IvfIndex":
+              group: Optional[dist.ProcessGroup] = None, centroids: Optional[torch.Tensor] = None,
+              dtype: str = "f32") -> "IvfIndex":
+        """``dtype="bf16"``: the IVF keeps its list-ordered copy of the rows in bf16 (``rass_ivf_build_ex``): half the bytes
+        per probed row, the scores of a flat bf16 index over the same rows.  The source index stays fp32."""
+        if dtype not in ("f32", "bf16"):
+            raise ValueError(f"dtype must be 'f32' or 'bf16', got {dtype!r}")
         if centroids is None:
             centroids = train_centroids(index, nlist, train_rows, iters, seed, group)
         assign = assign_rows(index, centroids)
         c_host = np.ascontiguousarray(centroids.cpu().numpy(), dtype=np.float32)
         h = ctypes.c_void_p()
-        N.check("rass_ivf_build", N.lib().rass_ivf_build(index._h, c_host.ctypes.data_as(ctypes.c_void_p), int(nlist),
-                                                        assign.ctypes.data_as(ctypes.c_void_p), ctypes.byref(h)))
+        N.check("rass_ivf_build_ex",
+                N.lib().rass_ivf_build_ex(index._h, c_host.ctypes.data_as(ctypes.c_void_p), int(nlist),
+                                          assign.ctypes.data_as(ctypes.c_void_p), 1 if dtype == "bf16" else 0, ctypes.byref(h)))
         ivf = cls(h, index.engine, index.dim)
         ivf.assign = assign                                   # list id of every source row (host int32)
         ivf.list_sizes = np.bincount(assign, minlength=nlist)
@@ -269,6 +275,10 @@ class IvfIndex:
     @property
     def nlist(self) -> int:
         return int(self._L.rass_ivf_nlist(self._h))
+
+    @property
+    def dtype(self) -> str:
+        return "bf16" if int(self._L.rass_ivf_dtype(self._h)) == 1 else "f32"
 
     def close(self) -> None:
         if self._h:

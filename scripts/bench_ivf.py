@@ -19,6 +19,7 @@ ap.add_argument("--queries", type=int, default=1024)
 ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--k", type=int, default=10)
 ap.add_argument("--iid", action="store_true", help="worst case: iid Gaussian rows instead of clusters")
+ap.add_argument("--slab", default="f32", help="the IVF's list-ordered copy of the rows: 'f32' | 'bf16' (rass_ivf_build_ex)")
 ap.add_argument("--seeding", default=None, help="train_centroids(seeding=...): 'random' | 'repair' (default: the library's)")
 a = ap.parse_args()
 
@@ -48,7 +49,7 @@ kw = {"seeding": a.seeding} if a.seeding else {}
 cent = train_centroids(flat, a.nlist, train_rows=a.train_rows, iters=a.iters, seed=1, **kw)
 torch.cuda.synchronize()
 train_s = time.perf_counter() - t0
-ivf = IvfIndex.build(flat, nlist=a.nlist, centroids=cent)
+ivf = IvfIndex.build(flat, nlist=a.nlist, centroids=cent, dtype=a.slab)
 build_s = time.perf_counter() - t0
 sizes = ivf.list_sizes
 if a.iid:
@@ -70,7 +71,8 @@ for b in range(0, a.queries, B):
 tm.stop(stream)
 flat_ms = tm.elapsed_ms()
 truth_h = truth.cpu().numpy()
-res = {"workload": f"IVF-{a.nlist} over {a.rows} x {dim} {'iid' if a.iid else 'clustered'} rows, top-{k}, batch {B}",
+esize = 2 if a.slab == "bf16" else 4
+res = {"workload": f"IVF-{a.nlist} over {a.rows} x {dim} {'iid' if a.iid else 'clustered'} rows, {a.slab} slab, top-{k}, batch {B}",
        "gen_s": round(gen_s, 1), "build_s": round(build_s, 1), "train_s": round(train_s, 1), "sigma": a.sigma,
        "list_len_mean": float(sizes.mean()),
        "list_len_max": int(sizes.max()), "empty_lists": int((sizes == 0).sum()),
@@ -92,7 +94,7 @@ for nprobe in (1, 2, 4, 8, 16, 32, 64, 128):
     _, _, scanned = ivf.search(q_h, k, nprobe)
     scanned_per_batch = scanned / 8
     us_per_batch = ms / (a.queries / B) * 1e3
-    probed_bytes = scanned_per_batch * dim * 4 + a.nlist * dim * 4          # fine scans + the coarse scan over the centroids
+    probed_bytes = scanned_per_batch * dim * esize + a.nlist * dim * 4          # fine scans + the coarse scan over the centroids
     res["sweep"].append({"nprobe": nprobe, "recall_at_10": round(recall, 4), "qps": round(a.queries / ms * 1e3, 1),
                          "us_per_batch": round(us_per_batch, 1), "scanned_rows_per_batch": round(scanned_per_batch),
                          "scanned_fraction": round(scanned_per_batch / a.rows, 5),

@@ -641,7 +641,9 @@ __global__ __launch_bounds__(kA64Threads) void attention64_kernel(const u16* __r
                 u16* dst = ctx + (int64_t)(t0 + (q < S ? q : 0)) * hidden + head * kHeadDim + 8 * h;
                 // (Round 3 also staged a tile through 4 KiB of LDS per wave and stored whole 128-B rows, 8 lines per wave
                 // instruction instead of 64 partial ones: same time, 404 against 398-401 us — the stores cost ~25 us of a launch
-                // whatever their shape, profiles/r03_attention_experiments.txt — so the registers are stored as they lie.)
+                // whatever their shape, profiles/r03_attention_experiments.txt — so the registers are stored as they lie.
+                // Nontemporal stores, which win 3 % in the GEMM epilogue's whole-line stores, LOSE here: 430-512 us per launch
+                // against 396-405 — these are 16-B pieces of a line, and without L2 to combine them every piece is a partial write.)
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
                     unsigned w[8];

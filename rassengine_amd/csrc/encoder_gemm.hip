@@ -625,7 +625,12 @@ constexpr int kPStageTokens = 32;         // tokens per epilogue staging chunk (
 constexpr int kP5HalfBytes = 32768;
 constexpr int kP5LdsBytes = 5 * kP5HalfBytes;
 
-template <int EPI>
+// POL = cache policy of the three streams, one decimal digit each (x w y): operand loads 0 = default, 2 = nt (streaming), 1 = sc0,
+// 3 = sc0 nt (the aux bits of global_load_lds); output stores 0 = default, 1 = nontemporal.  Measured in round 3
+// (profiles/r03_gemm_power_limit.txt §6, RASS_P5_POLICY): nt on either operand stream costs 1-8 %, nontemporal OUTPUT stores
+// win 3 % on the wide-output shapes (QKV 790 -> 763 us, FFN-up 1 115 -> 1 080; the 0.8-1.1 GB of output no longer push the
+// operands out of L2) and nothing on the N = 1024 ones: POL = 1 is the default, RASS_P5_POLICY=0 the A/B.
+template <int EPI, int POL = 1>
 __global__ __launch_bounds__(kRingThreads, 2) void gemm_bf16_p5_kernel(const u16* __restrict__ X,
                                                                       const u16* __restrict__ W,
                                                                       const float* __restrict__ bias,
@@ -683,13 +688,14 @@ __global__ __launch_bounds__(kRingThreads, 2) void gemm_bf16_p5_kernel(const u16
         for (int p = 0; p < 2; ++p) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)srcX[h][p],
                                              (__attribute__((address_space(3))) void*)(base + 16384 + (wave + 8 * p) * 1024),
-                                             16, 0, 0);
+                                             16, 0, (POL / 100) % 10);
             srcX[h][p] += 64;
         }
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)srcW[h][p],
-                                             (__attribute__((address_space(3))) void*)(base + (wave + 8 * p) * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(base + (wave + 8 * p) * 1024), 16, 0,
+                                             (POL / 10) % 10);
             srcW[h][p] += 64;
         }
     };
@@ -820,8 +826,15 @@ __global__ __launch_bounds__(kRingThreads, 2) void gemm_bf16_p5_kernel(const u16
 #pragma unroll
                         for (int pass = 0; pass < kPStageTokens / 8; ++pass) {
                             const int m = m0 + wm * 64 + jc * kPStageTokens + pass * 8 + tl;
-                            res[pass] = m < M ? *reinterpret_cast<const uint4*>(residual + (int64_t)m * N + nbase)
-                                              : uint4{0u, 0u, 0u, 0u};
+                            if constexpr (POL % 10 == 1) {   // read once, like the output: keep it out of the operands' way
+                                typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+                                u32x4_t rv = u32x4_t{0u, 0u, 0u, 0u};
+                                if (m < M) rv = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(residual + (int64_t)m * N + nbase));
+                                res[pass] = uint4{rv[0], rv[1], rv[2], rv[3]};
+                            } else {
+                                res[pass] = m < M ? *reinterpret_cast<const uint4*>(residual + (int64_t)m * N + nbase)
+                                                  : uint4{0u, 0u, 0u, 0u};
+                            }
                         }
                     }
 #pragma unroll
@@ -866,7 +879,12 @@ __global__ __launch_bounds__(kRingThreads, 2) void gemm_bf16_p5_kernel(const u16
                             o.y = (unsigned)f32_to_bf16(v0.z) | ((unsigned)f32_to_bf16(v0.w) << 16);
                             o.z = (unsigned)f32_to_bf16(v1.x) | ((unsigned)f32_to_bf16(v1.y) << 16);
                             o.w = (unsigned)f32_to_bf16(v1.z) | ((unsigned)f32_to_bf16(v1.w) << 16);
-                            *reinterpret_cast<uint4*>(Y + (int64_t)m * N + nbase) = o;
+                            if constexpr (POL % 10 == 1) {
+                                typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+                                __builtin_nontemporal_store(u32x4_t{o.x, o.y, o.z, o.w}, reinterpret_cast<u32x4_t*>(Y + (int64_t)m * N + nbase));
+                            } else {
+                                *reinterpret_cast<uint4*>(Y + (int64_t)m * N + nbase) = o;
+                            }
                         }
                     }
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -881,16 +899,24 @@ __global__ __launch_bounds__(kRingThreads, 2) void gemm_bf16_p5_kernel(const u16
     }
 }
 
-template <int EPI>
-static hipError_t launch_p5(const u16* X, const u16* W, const float* bias, const u16* residual, u16* Y, int M,
-                            int M_pad, int N, int K, hipStream_t stream) {
+template <int EPI, int POL>
+static hipError_t launch_p5_pol(const u16* X, const u16* W, const float* bias, const u16* residual, u16* Y, int M, int N,
+                                int K, int tiles_total, int grid, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_p5_kernel<EPI>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_p5_kernel<EPI, POL>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kP5LdsBytes);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
+    hipLaunchKernelGGL((gemm_bf16_p5_kernel<EPI, POL>), dim3(grid), dim3(kRingThreads), kP5LdsBytes, stream, X, W, bias,
+                       residual, Y, M, N, K, tiles_total);
+    return hipGetLastError();
+}
+
+template <int EPI>
+static hipError_t launch_p5(const u16* X, const u16* W, const float* bias, const u16* residual, u16* Y, int M,
+                            int M_pad, int N, int K, hipStream_t stream) {
     static int n_cus = 0;
     if (n_cus == 0) {
         int dev = 0;
@@ -904,9 +930,9 @@ static hipError_t launch_p5(const u16* X, const u16* W, const float* bias, const
         const int g = atoi(v);
         if (g >= 1 && g < grid) grid = g;
     }
-    hipLaunchKernelGGL((gemm_bf16_p5_kernel<EPI>), dim3(grid), dim3(kRingThreads), kP5LdsBytes, stream, X, W, bias,
-                       residual, Y, M, N, K, tiles_total);
-    return hipGetLastError();
+    if (const char* v = getenv("RASS_P5_POLICY"))   // A/B: 0 = plain output stores (read per launch)
+        if (atoi(v) == 0) return launch_p5_pol<EPI, 0>(X, W, bias, residual, Y, M, N, K, tiles_total, grid, stream);
+    return launch_p5_pol<EPI, 1>(X, W, bias, residual, Y, M, N, K, tiles_total, grid, stream);
 }
 
 template <int EPI>

@@ -245,7 +245,13 @@ __device__ __forceinline__ void dma16(const void* gptr, const unsigned char* lds
     const unsigned dst = __builtin_amdgcn_readfirstlane(
         (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)lds_piece);
     // M0 = the piece's LDS address (nothing else in these kernels uses M0)
+    // nt: every K / V row is read once per (sequence, head); kept out of L2's way the 16-B pieces of the output stores combine a
+    // little better (r03: 409.8 -> 405.1 us per launch at 256 x 512, three A/B pairs; -DRASS_ATTN_DMA_PLAIN = the A/B build)
+#ifdef RASS_ATTN_DMA_PLAIN
     asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(gptr) : "memory");
+#else
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off nt" ::"s"(dst), "v"(gptr) : "memory");
+#endif
 }
 
 constexpr int kA64Threads = 512;

@@ -118,6 +118,13 @@ def _ivf_worker(rank, world, port, n_local, out_dir):
             torch.cuda.synchronize()
             out[f"s{nprobe}"] = s.cpu().numpy()
             out[f"i{nprobe}"] = i.cpu().numpy()
+        # the same lists over a bf16 slab (rass_ivf_build_ex): every list probed, merged over the ranks
+        ivf_b = IvfIndex.build(idx, nlist=64, centroids=cent, dtype="bf16")
+        s, i = ShardedSearch(IvfShard(ivf_b, id_base=rank * n_local, nprobe=64)).search(q, 10)
+        torch.cuda.synchronize()
+        out["sb"] = s.cpu().numpy()
+        out["ib"] = i.cpu().numpy()
+        ivf_b.close()
         out["q"] = q.cpu().numpy()
         np.savez(os.path.join(out_dir, f"ivf_rank{rank}.npz"), **out)
         ivf.close()
@@ -150,6 +157,18 @@ def test_two_rank_ivf_shards_share_centroids_and_match_flat(gpu, tmp_path):
     finally:
         eng.close()
     assert np.array_equal(r0["i64"], i) and np.array_equal(r0["s64"], s)
+    # bf16 slabs on both ranks == ONE flat bf16 index over all rows (same rows rounded to bf16, same kernel arithmetic)
+    assert np.array_equal(r0["ib"], r1["ib"]) and np.array_equal(r0["sb"], r1["sb"])
+    eng = Engine(0, 1024)
+    try:
+        whole_b = eng.open_index("whole-b", capacity_rows=world * n_local, dtype="bf16")
+        whole_b.fill_synthetic(world * n_local, seed=78, row_id_base=0)
+        whole_b.delete(3)
+        whole_b.delete(n_local + 3)
+        sb, ib = whole_b.search(r0["q"], 10)
+    finally:
+        eng.close()
+    assert np.array_equal(r0["ib"], ib) and np.array_equal(r0["sb"], sb)
     truth = {(qq, int(a)): float(b) for qq in range(i.shape[0]) for a, b in zip(i[qq], s[qq])}
     hits = 0
     for qq in range(i.shape[0]):

@@ -152,13 +152,94 @@ def _repair(index: FlatIndex, cent: torch.Tensor, counts: torch.Tensor, best: to
     return cent, int(freed.numel())
 
 
+def _lloyd(index: FlatIndex, cent: torch.Tensor, iters: int, step: int, n_blocks: int, g: torch.Generator, repair: bool,
+           group: Optional[dist.ProcessGroup]) -> Tuple[torch.Tensor, torch.Tensor]:
+    """``iters`` spherical Lloyd iterations over the strided sample, starting from ``cent``; returns (unit means, the sizes
+    their lists had in the last assignment), identical on every rank.  Called inside ``_engine_on_torch_stream``."""
+    dev = cent.device
+    n, nlist = index.rows, cent.shape[0]
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    one = torch.empty((1, index.dim), dtype=torch.float32, device=dev)
+    counts = torch.zeros((nlist,), dtype=torch.float32, device=dev)
+    for it in range(iters):
+        assign, _slab = kmeans_assign(index, cent, 0, step, n_blocks)
+        sums, counts = kmeans_accumulate(index, assign, nlist, 0, step, n_blocks)
+        if world > 1:
+            dist.all_reduce(sums, group=group)
+            dist.all_reduce(counts, group=group)
+        new = ops.normalize_rows(sums)                      # sums / (||sums|| + 1e-9)
+        empty = counts == 0
+        if bool(empty.any()):  # re-seed empty lists from (deterministic) sample rows; rank 0's win
+            idx = torch.nonzero(empty).flatten()
+            for li in idx.tolist():
+                r = min(n - 1, ((li * 7919 + 13) % n_blocks) * step * BLOCK_ROWS + (li % BLOCK_ROWS))
+                new[li] = _rows_chunk(index, int(r), 1, one)[0]
+            if world > 1:
+                dist.broadcast(new, src=0, group=group)
+        cent = new
+        if repair and it % 2 == 1 and it < (2 * iters) // 3:
+            # rank 0's sample decides what is merged and where the freed centroids go; everyone gets its result
+            if rank == 0:
+                _a, best, _slab = kmeans_assign(index, cent, 0, step, n_blocks, with_best=True)
+                cent, _n_fixed = _repair(index, cent, counts, best, step, n_blocks, g, dev)
+            if world > 1:
+                dist.broadcast(cent, src=0, group=group)
+    return cent, counts
+
+
+def _group_means(fine: torch.Tensor, counts: torch.Tensor, nlist: int, seed: int, iters: int = 15) -> torch.Tensor:
+    """The second level of two-level training: spherical k-means over the K' FINE list means, each weighted by its list's
+    size, into ``nlist`` groups; returns the groups' unit means (= the means of their rows, up to the fine lists' own
+    spread).  Seeds by D^2 sampling over the fine means (k-means++ — affordable and effective HERE: K' points, and means are
+    sharp where rows are not: two fine means of one cluster have cosine ~0.97, of two clusters ~0), so that fine lists of
+    one cluster meet in one group and every group starts in a cluster of its own.  K' x nlist x dim flops per iteration:
+    nothing next to one assignment of the rows."""
+    K, dev = fine.shape[0], fine.device
+    g = torch.Generator(device=dev)
+    g.manual_seed(int(seed) + 7919)
+    w = counts.clamp(min=0).float().to(dev)
+    w = torch.where(w > 0, w, torch.zeros_like(w))
+    first = int(torch.multinomial(w + 1e-9, 1, generator=g))
+    picks = [first]
+    d = (1.0 - fine @ fine[first]).clamp(min=0.0)
+    for _ in range(1, nlist):
+        p = w * d * d
+        if float(p.sum()) <= 0:          # fewer distinct means than groups: any unused mean will do
+            p = torch.ones_like(p)
+            p[torch.tensor(picks, device=dev)] = 0
+        nxt = int(torch.multinomial(p, 1, generator=g))
+        picks.append(nxt)
+        d = torch.minimum(d, (1.0 - fine @ fine[nxt]).clamp(min=0.0))
+    cent = fine[torch.tensor(picks, device=dev)].clone()
+    for it in range(iters + 1):
+        grp = (fine @ cent.T).argmax(dim=1)
+        sums = torch.zeros_like(cent).index_add_(0, grp, fine * w[:, None])
+        norm = sums.norm(dim=1)
+        ok = norm > 0                     # a group that lost its members keeps its mean
+        cent[ok] = sums[ok] / norm[ok][:, None]
+    return cent
+
+
 def train_centroids(index: FlatIndex, nlist: int, train_rows: int = 0, iters: int = 20, seed: int = 0,
-                    group: Optional[dist.ProcessGroup] = None, seeding: str = "repair") -> torch.Tensor:
+                    group: Optional[dist.ProcessGroup] = None, seeding: str = "repair", fine_factor: int = 4) -> torch.Tensor:
     """Spherical k-means over a strided sample of the index's 32-row blocks (every ``step``-th block, about
     ``train_rows`` rows; 0 = all); returns unit centroids [nlist, dim] on the GPU, identical on every rank.
-    Seeds are nlist distinct sample rows.  ``seeding``: "random" = nothing else (rounds 1-2); "repair" = in the first
-    two thirds of the iterations every other one is followed by ``_repair``: near-duplicate list means are merged and
-    the freed centroids re-seeded where no mean is close (what k-means++ aims at, done on means instead of rows)."""
+
+    ``fine_factor`` > 1 (default 4) trains in TWO LEVELS: K' = fine_factor x nlist fine lists from K' random sample rows
+    (plain Lloyd, ``iters`` iterations), then the fine means — each weighted by its list's size — are grouped into nlist
+    groups by a k-means of their own, and the groups' means are the centroids.  Why: with more natural clusters than lists
+    (SURVEY §8d's corpus has 8 192 for IVF-4096) Lloyd from nlist seeds leaves the clusters without a seed scattered over
+    all lists and cannot gather them however long it runs (sigma = 2: recall@10 0.69 after 10 iterations, 0.79 after 300);
+    over-clustered, nearly every cluster has a fine list or two of its own, and whole fine lists — not rows — are then
+    dealt to the coarse lists (sigma = 2: 0.994 at nprobe 1, 1.0 from nprobe 4, for 2.6 s instead of 1.5;
+    profiles/r03_ivf4096_2M_sigma2_two_level.json.txt).  K' is capped at 65 536 (the assign kernel's limit) and at a
+    sixteenth of the sample; below 2 x nlist the training falls back to one level.
+
+    One level (``fine_factor`` <= 1): seeds are nlist distinct sample rows; ``seeding`` "random" = nothing else (rounds
+    1-2), "repair" = in the first two thirds of the iterations every other one is followed by ``_repair``: near-duplicate
+    list means are merged and the freed centroids re-seeded where no mean is close (what k-means++ aims at, done on means
+    instead of rows)."""
     if seeding not in ("random", "repair"):
         raise ValueError("seeding must be 'random' or 'repair'")
     dev = torch.device("cuda", index.engine.device)
@@ -173,37 +254,24 @@ def train_centroids(index: FlatIndex, nlist: int, train_rows: int = 0, iters: in
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     g = torch.Generator(device="cpu")
     g.manual_seed(seed)
-    repair = seeding == "repair" and nlist >= 8 and min(n_blocks * BLOCK_ROWS, n) >= 2 * nlist
+    sample = min(n_blocks * BLOCK_ROWS, n)
+    k_fine = min(int(fine_factor) * nlist, 65536, sample // 16) if fine_factor and fine_factor > 1 else 0
+    two_level = k_fine >= 2 * nlist
+    k_first = k_fine if two_level else nlist
+    repair = (not two_level) and seeding == "repair" and nlist >= 8 and sample >= 2 * nlist
     with _engine_on_torch_stream(index):
-        one = torch.empty((1, index.dim), dtype=torch.float32, device=dev)
-        # seeds: nlist distinct sample rows (deterministic for a seed); every rank starts from rank 0's
-        pick = torch.randperm(min(n_blocks * BLOCK_ROWS, n - 0), generator=g)[:nlist]
+        # seeds: distinct sample rows (deterministic for a seed); every rank starts from rank 0's
+        pick = torch.randperm(sample, generator=g)[:k_first]
         cent = _gather_rows(index, torch.clamp(_sample_row(pick, step), max=n - 1).tolist(), dev)
         if world > 1:
             dist.broadcast(cent, src=0, group=group)
-        for it in range(iters):
-            assign, _slab = kmeans_assign(index, cent, 0, step, n_blocks)
-            sums, counts = kmeans_accumulate(index, assign, nlist, 0, step, n_blocks)
+        cent, counts = _lloyd(index, cent, iters, step, n_blocks, g, repair, group)
+        if two_level:
+            # rank 0 groups the fine means (float atomics in the weighted sums: one rank decides, everyone gets its result)
+            coarse = _group_means(cent, counts, nlist, seed) if rank == 0 else torch.empty((nlist, index.dim), dtype=torch.float32, device=dev)
             if world > 1:
-                dist.all_reduce(sums, group=group)
-                dist.all_reduce(counts, group=group)
-            new = ops.normalize_rows(sums)                      # sums / (||sums|| + 1e-9)
-            empty = counts == 0
-            if bool(empty.any()):  # re-seed empty lists from (deterministic) sample rows; rank 0's win
-                idx = torch.nonzero(empty).flatten()
-                for li in idx.tolist():
-                    r = min(n - 1, ((li * 7919 + 13) % n_blocks) * step * BLOCK_ROWS + (li % BLOCK_ROWS))
-                    new[li] = _rows_chunk(index, int(r), 1, one)[0]
-                if world > 1:
-                    dist.broadcast(new, src=0, group=group)
-            cent = new
-            if repair and it % 2 == 1 and it < (2 * iters) // 3:
-                # rank 0's sample decides what is merged and where the freed centroids go; everyone gets its result
-                if rank == 0:
-                    _a, best, _slab = kmeans_assign(index, cent, 0, step, n_blocks, with_best=True)
-                    cent, _n_fixed = _repair(index, cent, counts, best, step, n_blocks, g, dev)
-                if world > 1:
-                    dist.broadcast(cent, src=0, group=group)
+                dist.broadcast(coarse, src=0, group=group)
+            cent = coarse
     return cent
 
 
@@ -236,14 +304,19 @@ class IvfIndex:
     @classmethod
     def build(cls, index: FlatIndex, nlist: int = 4096, train_rows: int = 0, iters: int = 20, seed: int = 0,
               group: Optional[dist.ProcessGroup] = None, centroids: Optional[torch.Tensor] = None,
-              dtype: str = "f32") -> "IvfIndex":
+              dtype: str = "f32", assign: Optional[np.ndarray] = None) -> "IvfIndex":
         """``dtype="bf16"``: the IVF keeps its list-ordered copy of the rows in bf16 (``rass_ivf_build_ex``): half the bytes
         per probed row, the scores of a flat bf16 index over the same rows.  The source index stays fp32."""
         if dtype not in ("f32", "bf16"):
             raise ValueError(f"dtype must be 'f32' or 'bf16', got {dtype!r}")
         if centroids is None:
             centroids = train_centroids(index, nlist, train_rows, iters, seed, group)
-        assign = assign_rows(index, centroids)
+        if assign is None:
+            assign = assign_rows(index, centroids)
+        else:   # the caller's lists (e.g. two-level training: a row follows its fine list's group)
+            assign = np.ascontiguousarray(assign, dtype=np.int32)
+            if assign.shape != (index.rows,):
+                raise ValueError(f"assign must hold one list id per row ({index.rows}), got {assign.shape}")
         c_host = np.ascontiguousarray(centroids.cpu().numpy(), dtype=np.float32)
         h = ctypes.c_void_p()
         N.check("rass_ivf_build_ex",

@@ -20,6 +20,7 @@ ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--k", type=int, default=10)
 ap.add_argument("--iid", action="store_true", help="worst case: iid Gaussian rows instead of clusters")
 ap.add_argument("--slab", default="f32", help="the IVF's list-ordered copy of the rows: 'f32' | 'bf16' (rass_ivf_build_ex)")
+ap.add_argument("--fine-factor", type=int, default=None, help="train_centroids(fine_factor=...): 1 = one level (rounds 1-3a), default: the library's (4)")
 ap.add_argument("--seeding", default=None, help="train_centroids(seeding=...): 'random' | 'repair' (default: the library's)")
 a = ap.parse_args()
 
@@ -46,6 +47,8 @@ gen_s = time.perf_counter() - t0
 t0 = time.perf_counter()
 from rassengine_amd.ivf import train_centroids
 kw = {"seeding": a.seeding} if a.seeding else {}
+if a.fine_factor is not None:
+    kw["fine_factor"] = a.fine_factor
 cent = train_centroids(flat, a.nlist, train_rows=a.train_rows, iters=a.iters, seed=1, **kw)
 torch.cuda.synchronize()
 train_s = time.perf_counter() - t0

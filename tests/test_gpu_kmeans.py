@@ -73,8 +73,8 @@ def test_train_centroids_is_a_lloyd_iteration_and_reseeds_empty_lists(gpu):
     try:
         idx = eng.open_index("km-train")
         idx.add(x, normalize=True)
-        c0 = ivf.train_centroids(idx, nlist=20, iters=0, seed=3, seeding="random")   # the seeds
-        c1 = ivf.train_centroids(idx, nlist=20, iters=1, seed=3, seeding="random")
+        c0 = ivf.train_centroids(idx, nlist=20, iters=0, seed=3, seeding="random", fine_factor=1)   # the seeds
+        c1 = ivf.train_centroids(idx, nlist=20, iters=1, seed=3, seeding="random", fine_factor=1)
         xn = torch.nn.functional.normalize(torch.from_numpy(x), dim=1)
         lab = (xn @ c0.cpu().T).argmax(dim=1)
         sums = torch.zeros((20, 256)).index_add_(0, lab, xn)
@@ -82,7 +82,7 @@ def test_train_centroids_is_a_lloyd_iteration_and_reseeds_empty_lists(gpu):
         live = torch.bincount(lab, minlength=20) > 0
         assert torch.allclose(c1.cpu()[live], ref[live], atol=1e-5)
         assert torch.allclose(c1.norm(dim=1).cpu(), torch.ones(20), atol=1e-5)    # re-seeded rows are unit too
-        c8 = ivf.train_centroids(idx, nlist=20, iters=8, seed=3, seeding="random")
+        c8 = ivf.train_centroids(idx, nlist=20, iters=8, seed=3, seeding="random", fine_factor=1)
         assign = ivf.assign_rows(idx, c8)
         assert assign.shape == (6000,) and assign.dtype == np.int32
         # k-means found the 20 planted clusters: every list is (almost) pure
@@ -125,8 +125,8 @@ def test_repair_merges_split_clusters_and_covers_missed_ones(gpu):
             a = ivf.assign_rows(idx, cent)
             return float(np.mean([np.bincount(a[lab == c]).max() / max(1, (lab == c).sum()) for c in range(n_clusters)]))
 
-        c_rand = ivf.train_centroids(idx, nlist=n_clusters, iters=9, seed=2, seeding="random")
-        c_rep = ivf.train_centroids(idx, nlist=n_clusters, iters=9, seed=2, seeding="repair")
+        c_rand = ivf.train_centroids(idx, nlist=n_clusters, iters=9, seed=2, seeding="random", fine_factor=1)
+        c_rep = ivf.train_centroids(idx, nlist=n_clusters, iters=9, seed=2, seeding="repair", fine_factor=1)
         assert c_rep.shape == (n_clusters, dim) and torch.allclose(c_rep.norm(dim=1).cpu(), torch.ones(n_clusters), atol=1e-5)
         cov_r, cov_p = covered(c_rand), covered(c_rep)
         coh_r, coh_p = cohesion(c_rand), cohesion(c_rep)
@@ -134,7 +134,65 @@ def test_repair_merges_split_clusters_and_covers_missed_ones(gpu):
               f"cluster cohesion {coh_r:.3f} -> {coh_p:.3f}")
         assert cov_p >= 0.97 and cov_p > cov_r and coh_p > coh_r
         assert len(eng._indices) == 1                  # the scratch index of the repair is gone
+        # the default (two levels: 4 x nlist fine lists grouped into nlist) keeps these tight clusters whole as well
+        c_two = ivf.train_centroids(idx, nlist=n_clusters, iters=9, seed=2)
+        assert c_two.shape == (n_clusters, dim) and torch.allclose(c_two.norm(dim=1).cpu(), torch.ones(n_clusters), atol=1e-5)
+        coh_t = cohesion(c_two)
+        print(f"two-level default: clusters with a centroid of their own {covered(c_two):.3f}, cohesion {coh_t:.3f}")
+        assert coh_t >= 0.97
         with pytest.raises(ValueError):
             ivf.train_centroids(idx, nlist=16, iters=1, seeding="kmeans++")
+    finally:
+        eng.close()
+
+
+def test_two_level_training_keeps_clusters_whole_when_there_are_more_clusters_than_lists(gpu):
+    """The corpus shape of SURVEY §8d in small: twice as many planted clusters as lists, noisy rows (a row's cosine to its
+    cluster's centre 0.45, two rows of one cluster 0.2).  One-level Lloyd from nlist seeds scatters the clusters that got no
+    seed over all lists and stalls; the two-level default (fine_factor = 4) deals whole fine lists to the coarse lists: a
+    cluster's rows end up together, and the 10 nearest neighbours of a query are found in its best list."""
+    torch = gpu
+    from rassengine_amd import ivf
+    from rassengine_amd.engine import Engine
+    g = torch.Generator(device="cuda")
+    g.manual_seed(11)
+    n_clusters, nlist, dim, n = 4096, 2048, 1024, 1_000_000
+    centres = torch.nn.functional.normalize(torch.randn((n_clusters, dim), generator=g, device="cuda"), dim=1)
+    lab = torch.randint(0, n_clusters, (n,), generator=g, device="cuda")
+    qlab = torch.randint(0, n_clusters, (64,), generator=g, device="cuda")
+    q = (centres[qlab] + 2.0 * torch.randn((64, dim), generator=g, device="cuda") / dim ** 0.5).cpu().numpy()
+    lab_h = lab.cpu().numpy()
+    eng = Engine(0, dim)
+    try:
+        idx = eng.open_index("km-two-level", capacity_rows=n)
+        for lo in range(0, n, 250_000):           # 1 M rows x 1024 = 4 GB in the index; generated a quarter at a time
+            x = centres[lab[lo:lo + 250_000]] + 2.0 * torch.randn((250_000, dim), generator=g, device="cuda") / dim ** 0.5
+            torch.cuda.synchronize()
+            idx.add_device(x.data_ptr(), 250_000, normalize=True)
+            eng.synchronize()
+        del x
+        _, truth = idx.search(q, 10)
+
+        def measure(cent):
+            iv = ivf.IvfIndex.build(idx, nlist=nlist, centroids=cent)
+            try:
+                a = iv.assign
+                key = lab_h.astype(np.int64) * nlist + a          # (cluster, list) pairs: the majority list's share per cluster
+                uniq, cnt = np.unique(key, return_counts=True)
+                best = np.zeros(n_clusters)
+                np.maximum.at(best, uniq // nlist, cnt)
+                coh = float(np.mean(best / np.maximum(1, np.bincount(lab_h, minlength=n_clusters))))
+                _, got, _ = iv.search(q, 10, nprobe=1)
+                rec = float(np.mean([len(set(got[r]) & set(truth[r])) / 10 for r in range(64)]))
+                return coh, rec, int(iv.list_sizes.max())
+            finally:
+                iv.close()
+
+        one = measure(ivf.train_centroids(idx, nlist=nlist, train_rows=500_000, iters=8, seed=1, fine_factor=1))
+        two = measure(ivf.train_centroids(idx, nlist=nlist, train_rows=500_000, iters=8, seed=1))
+        print(f"cohesion / recall@10 at nprobe 1 / longest list: one level {one}, two levels {two}")
+        assert two[0] >= 0.9 and two[1] >= 0.9
+        assert two[0] > one[0] + 0.05 and two[1] > one[1] + 0.05
+        assert two[2] <= 8 * n // nlist
     finally:
         eng.close()

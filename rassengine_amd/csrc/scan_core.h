@@ -205,6 +205,11 @@ __device__ __forceinline__ void insert_candidates(TopList& L, float& tau, float 
         L.s = take ? cs : (shift ? us : L.s);
         L.i = take ? ci : (shift ? ui : L.i);
         tau = bcast_kth(L.s, k);
+        // candidates the raised threshold has just ruled out leave the queue (they would rank behind the k kept: same lists).
+        // A workgroup's FIRST tile meets empty lists — all 64 lanes queue up — and on a small slab (an IVF's coarse scan, a
+        // fine scan at nprobe 1, a 10 k-row index) that tile is the whole launch: 64 serial steps per part cost 5.5 us of a
+        // 15 us launch however small k was (r03, scripts/microbench/scan_small.hip).
+        mask &= __ballot(s > tau);
     }
 }
 

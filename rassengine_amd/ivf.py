@@ -224,7 +224,8 @@ def _group_means(fine: torch.Tensor, counts: torch.Tensor, nlist: int, seed: int
 def train_centroids(index: FlatIndex, nlist: int, train_rows: int = 0, iters: int = 20, seed: int = 0,
                     group: Optional[dist.ProcessGroup] = None, seeding: str = "repair", fine_factor: int = 4) -> torch.Tensor:
     """Spherical k-means over a strided sample of the index's 32-row blocks (every ``step``-th block, about
-    ``train_rows`` rows; 0 = all); returns unit centroids [nlist, dim] on the GPU, identical on every rank.
+    ``train_rows`` rows; 0 = all rows for one level, 64 rows per fine list for two); returns unit centroids [nlist, dim] on
+    the GPU, identical on every rank.
 
     ``fine_factor`` > 1 (default 4) trains in TWO LEVELS: K' = fine_factor x nlist fine lists from K' random sample rows
     (plain Lloyd, ``iters`` iterations), then the fine means — each weighted by its list's size — are grouped into nlist
@@ -246,6 +247,10 @@ def train_centroids(index: FlatIndex, nlist: int, train_rows: int = 0, iters: in
     n = index.rows
     total_blocks = -(-n // BLOCK_ROWS)
     m = n if train_rows <= 0 else min(n, int(train_rows))
+    if train_rows <= 0 and fine_factor and fine_factor > 1:
+        # "all rows" with two levels means a strided sample of 64 rows per fine list (1 M rows for IVF-4096: what the
+        # profiles were measured on): the fine assignment costs K' x dim x 2 flops per row and iteration
+        m = min(n, 64 * min(int(fine_factor) * nlist, 65536))
     if m < nlist:
         raise ValueError(f"need at least nlist={nlist} training rows, have {m}")
     step = max(1, total_blocks // max(1, -(-m // BLOCK_ROWS)))

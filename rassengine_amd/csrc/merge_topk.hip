@@ -7,7 +7,8 @@
 // OpenSearch's shard -> coordinator top-k merge (reference SHARD_COUNT, app/main.py:89).
 //
 // Wavefront bitonic top-k: one workgroup per query, 16 waves.  A wave pulls 64 candidates
-// at a time, sorts them in registers with a 21-stage shuffle network (no LDS, no barrier),
+// at a time, sorts them in registers with a 21-stage exchange network (DPP inside a row of 16 lanes, v_permlane16/32_swap
+// across rows: no LDS, no barrier; round 3: 16.9 -> 13.9 us per launch against the ds_bpermute form),
 // and folds them into its running best-32 with a 6-stage bitonic merge (running list in
 // lanes 0..31, the new group's best 32 reversed into lanes 32..63).  The 16 per-wave lists
 // meet once in LDS and wave 0 folds them the same way.  k <= 32.
@@ -32,55 +33,95 @@ __device__ __forceinline__ bool cand_better(const Cand& a, const Cand& b) {
     return (a.s > b.s) || (a.s == b.s && a.id < b.id);
 }
 
-__device__ __forceinline__ Cand shfl_xor_cand(const Cand& c, int mask) {
+// One dword of lane (lane ^ STRIDE), in registers: DPP moves inside a row of 16 lanes (quad permutes for 1 and 2; 4 and 8 as a
+// mirror of a mirror: half_mirror(i) = i ^ 7, quad_reverse(i) = i ^ 3, row_mirror(i) = i ^ 15), v_permlane16_swap /
+// v_permlane32_swap across rows (swap(x, x) leaves the even rows / the lower half of x in every row of the first result and
+// the odd rows / the upper half in the second: a lane's partner value is in the result its own row does not name).  Round 3:
+// the 34 compare-exchange stages of a merge were 102 ds_bpermute round trips through the LDS crossbar.
+template <int STRIDE>
+__device__ __forceinline__ int xor_lane(int v, int lane) {
+    static_assert(STRIDE == 1 || STRIDE == 2 || STRIDE == 4 || STRIDE == 8 || STRIDE == 16 || STRIDE == 32, "stride");
+    if constexpr (STRIDE == 1) return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, true);          // quad_perm [1,0,3,2]
+    if constexpr (STRIDE == 2) return __builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, true);          // quad_perm [2,3,0,1]
+    if constexpr (STRIDE == 4)
+        return __builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp(v, 0x1B, 0xf, 0xf, true), 0x141, 0xf, 0xf, true);
+    if constexpr (STRIDE == 8)
+        return __builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp(v, 0x141, 0xf, 0xf, true), 0x140, 0xf, 0xf, true);
+    if constexpr (STRIDE == 16) {
+        const auto sw = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+        return (int)((lane & 16) ? sw[0] : sw[1]);
+    }
+    if constexpr (STRIDE == 32) {
+        const auto sw = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+        return (int)((lane & 32) ? sw[0] : sw[1]);
+    }
+    return v;
+}
+
+template <int STRIDE>
+__device__ __forceinline__ Cand xor_cand(const Cand& c, int lane) {
     Cand o;
-    o.s = __shfl_xor(c.s, mask, 64);
-    const int lo = __shfl_xor((int)(c.id & 0xffffffffLL), mask, 64);
-    const int hi = __shfl_xor((int)(c.id >> 32), mask, 64);
+    o.s = __int_as_float(xor_lane<STRIDE>(__float_as_int(c.s), lane));
+    const int lo = xor_lane<STRIDE>((int)(c.id & 0xffffffffLL), lane);
+    const int hi = xor_lane<STRIDE>((int)(c.id >> 32), lane);
     o.id = ((int64_t)hi << 32) | (uint32_t)lo;
     return o;
 }
 
-__device__ __forceinline__ Cand shfl_cand(const Cand& c, int src) {
-    Cand o;
-    o.s = __shfl(c.s, src, 64);
-    const int lo = __shfl((int)(c.id & 0xffffffffLL), src, 64);
-    const int hi = __shfl((int)(c.id >> 32), src, 64);
+// lane (63 - lane) = lane ^ 63: across the halves, across the rows, mirrored inside the row
+__device__ __forceinline__ Cand reverse_cand(const Cand& c, int lane) {
+    Cand o = xor_cand<32>(c, lane);
+    o = xor_cand<16>(o, lane);
+    o.s = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(o.s), 0x140, 0xf, 0xf, true));
+    const int lo = __builtin_amdgcn_mov_dpp((int)(o.id & 0xffffffffLL), 0x140, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp((int)(o.id >> 32), 0x140, 0xf, 0xf, true);
     o.id = ((int64_t)hi << 32) | (uint32_t)lo;
     return o;
 }
 
-// compare-exchange with lane ^ stride; keep the better one when keep_better
-__device__ __forceinline__ void cmpx(Cand& c, int stride, bool keep_better) {
-    const Cand o = shfl_xor_cand(c, stride);
+// compare-exchange with lane ^ STRIDE; keep the better one when keep_better
+template <int STRIDE>
+__device__ __forceinline__ void cmpx(Cand& c, int lane, bool keep_better) {
+    const Cand o = xor_cand<STRIDE>(c, lane);
     const bool mine_better = cand_better(c, o);
     if (mine_better != keep_better) c = o;
 }
 
+template <int SIZE, int STRIDE>
+__device__ __forceinline__ void sort_steps(Cand& c, int lane) {
+    if constexpr (STRIDE > 0) {
+        const bool best_first = (lane & SIZE) == 0;  // SIZE == 64: always true
+        const bool lower = (lane & STRIDE) == 0;
+        cmpx<STRIDE>(c, lane, best_first == lower);
+        sort_steps<SIZE, STRIDE / 2>(c, lane);
+    }
+}
+
 // full bitonic sort of the wave's 64 candidates, best first
 __device__ __forceinline__ void wave_sort64(Cand& c, int lane) {
-#pragma unroll
-    for (int size = 2; size <= 64; size <<= 1) {
-#pragma unroll
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            const bool best_first = (lane & size) == 0;  // size == 64: always true
-            const bool lower = (lane & stride) == 0;
-            cmpx(c, stride, best_first == lower);
-        }
-    }
+    sort_steps<2, 1>(c, lane);
+    sort_steps<4, 2>(c, lane);
+    sort_steps<8, 4>(c, lane);
+    sort_steps<16, 8>(c, lane);
+    sort_steps<32, 16>(c, lane);
+    sort_steps<64, 32>(c, lane);
 }
 
 // lanes 0..31 sorted best-first, lanes 32..63 sorted worst-first (a bitonic sequence)
 // -> whole wave sorted best-first
-__device__ __forceinline__ void wave_bitonic_merge64(Cand& c, int lane) {
-#pragma unroll
-    for (int stride = 32; stride > 0; stride >>= 1) cmpx(c, stride, (lane & stride) == 0);
+template <int STRIDE>
+__device__ __forceinline__ void merge_steps(Cand& c, int lane) {
+    if constexpr (STRIDE > 0) {
+        cmpx<STRIDE>(c, lane, (lane & STRIDE) == 0);
+        merge_steps<STRIDE / 2>(c, lane);
+    }
 }
+__device__ __forceinline__ void wave_bitonic_merge64(Cand& c, int lane) { merge_steps<32>(c, lane); }
 
 // fold a sorted-best-first 64 group (only its best 32 matter) into the running list
 __device__ __forceinline__ void fold_group(Cand& run, const Cand& grp_sorted, int lane) {
     // lane 32+i takes the group's element 31-i (reversed), lanes 0..31 keep the running list
-    const Cand rev = shfl_cand(grp_sorted, 63 - lane);
+    const Cand rev = reverse_cand(grp_sorted, lane);
     Cand c = (lane < 32) ? run : rev;
     wave_bitonic_merge64(c, lane);
     run = c;
@@ -117,7 +158,9 @@ __global__ __launch_bounds__(kMergeThreads) void merge_topk_kernel(const float* 
     Cand run;
     run.s = -INFINITY;
     run.id = kWorstId;
-    // groups of 64 consecutive candidates, dealt round-robin to the waves
+    // groups of 64 consecutive candidates, dealt round-robin to the waves.  (Issuing a group's scattered loads a group ahead of
+    // its sort changed nothing, 14.3 against 13.9 us per launch: with the exchanges in registers the kernel is paced by the
+    // vector issue of its sixteen waves on one CU, ~1 900 instructions each.)
     for (int base = wave * 64; base < n; base += kMergeWaves * 64) {
         const int e = base + lane;
         Cand c;

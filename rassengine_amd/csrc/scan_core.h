@@ -80,7 +80,10 @@ __device__ __forceinline__ TileDesc make_tile_desc(const float* __restrict__ X, 
 // part (M-tile and chunk), which goes into the instruction's SGPR / immediate offset fields.  Folding it into
 // per-load VGPR offsets, as the first version did, cost ~10 VGPRs the main loop does not have.
 __device__ __forceinline__ f32x4 load_chunk(const TileDesc& d, int voff, int soff) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(d.rows, voff, soff, /*aux: nt*/ 2));
+#ifndef RASS_SCAN_AUX      // cache policy of the corpus stream: 2 = nt (read once); the micro-benchmarks sweep it (-DRASS_SCAN_AUX=<bits>)
+#define RASS_SCAN_AUX 2
+#endif
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(d.rows, voff, soff, RASS_SCAN_AUX));
 }
 
 __device__ __forceinline__ int load_tag(const TileDesc& d) {

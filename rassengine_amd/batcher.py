@@ -3,8 +3,8 @@
 The reference answers one ``/ask`` at a time with one k-NN request each
 (app/main.py:2878-2885 -> 1552).  The fused scan costs the same HBM pass for 1 or 32
 queries, so concurrent requests are coalesced: callers ``await batcher.search(...)``; a
-single drain task collects up to ``max_batch`` (<= 32) pending queries — waiting at most
-``max_delay_ms`` after the first one — and issues ONE scan for all of them.  Requests with
+single drain task collects up to ``max_batch`` (<= 32) pending queries — everything queued
+when it runs; optionally lingering ``max_delay_ms`` — and issues ONE scan for all of them.  Requests with
 different ``k`` share a scan at the largest ``k`` and are sliced afterwards (a prefix of a
 top-k list under a total order is the top-k' list).
 """
@@ -16,8 +16,34 @@ from typing import List, Optional, Tuple
 import numpy as np
 
 
+async def _collect(q: "asyncio.Queue", max_batch: int, max_delay: float) -> List[tuple]:
+    """The next batch of a drain task: the first entry, then whatever else is ALREADY queued or becomes queued by
+    tasks that are runnable right now (one ``sleep(0)``: requests that left one encoder forward together wake in the
+    same loop iteration and all enqueue before the scan is issued).  No timer by default — while a scan runs, arrivals
+    pile up and form the next batch; asyncio timers on the selector loop round up to whole milliseconds, which is
+    longer than a 1 M-row scan.  ``max_delay`` > 0 additionally lingers that long for a batch that is not full."""
+    batch = [await q.get()]
+    await asyncio.sleep(0)
+    while len(batch) < max_batch and not q.empty():
+        batch.append(q.get_nowait())
+    if max_delay > 0 and len(batch) < max_batch:
+        loop = asyncio.get_running_loop()
+        deadline = loop.time() + max_delay
+        while len(batch) < max_batch:
+            timeout = deadline - loop.time()
+            if timeout <= 0:
+                break
+            try:
+                batch.append(await asyncio.wait_for(q.get(), timeout))
+            except asyncio.TimeoutError:
+                break
+            while len(batch) < max_batch and not q.empty():
+                batch.append(q.get_nowait())
+    return batch
+
+
 class QueryBatcher:
-    def __init__(self, index, max_batch: int = 32, max_delay_ms: float = 0.25):
+    def __init__(self, index, max_batch: int = 32, max_delay_ms: float = 0.0):
         if not 1 <= max_batch <= 32:
             raise ValueError("max_batch must be in [1, 32] (one scan launch)")
         self.index = index                  # FlatIndex-like: search(queries, k, q_filter)
@@ -47,18 +73,7 @@ class QueryBatcher:
     async def _drain(self) -> None:
         q = self._queue
         while True:
-            first = await q.get()
-            batch = [first]
-            loop = asyncio.get_running_loop()
-            deadline = loop.time() + self.max_delay
-            while len(batch) < self.max_batch:
-                timeout = deadline - loop.time()
-                if timeout <= 0:
-                    break
-                try:
-                    batch.append(await asyncio.wait_for(q.get(), timeout))
-                except asyncio.TimeoutError:
-                    break
+            batch = await _collect(q, self.max_batch, self.max_delay)
             await self._run(batch)
 
     async def _run(self, batch: List[tuple]) -> None:
@@ -101,7 +116,7 @@ class CrossIndexBatcher:
     answered by ONE cross-index scan (``Engine.search_multi`` -> ``rass_index_search_multi``): every distinct index
     of the batch is streamed once, in the same launch as the others."""
 
-    def __init__(self, engine, max_batch: int = 32, max_delay_ms: float = 0.25):
+    def __init__(self, engine, max_batch: int = 32, max_delay_ms: float = 0.0):
         if not 1 <= max_batch <= 32:
             raise ValueError("max_batch must be in [1, 32] (one scan launch)")
         self.engine = engine
@@ -129,17 +144,7 @@ class CrossIndexBatcher:
     async def _drain(self) -> None:
         q = self._queue
         while True:
-            batch = [await q.get()]
-            loop = asyncio.get_running_loop()
-            deadline = loop.time() + self.max_delay
-            while len(batch) < self.max_batch:
-                timeout = deadline - loop.time()
-                if timeout <= 0:
-                    break
-                try:
-                    batch.append(await asyncio.wait_for(q.get(), timeout))
-                except asyncio.TimeoutError:
-                    break
+            batch = await _collect(q, self.max_batch, self.max_delay)
             await self._run(batch)
 
     MAX_TILES = 65536     # rass_index_search_multi's budget: 32-row tiles over the distinct indices of one call
@@ -178,7 +183,15 @@ class CrossIndexBatcher:
             cur_seen[id(ix)] = True
         if cur:
             multi.append(cur)
-        return multi, list(solo.values())
+        # a group whose entries all name ONE index gains nothing from the work-list launch: that index's own search
+        # is the tuned path (sample floor, no per-call tile list) and answers bit-identically
+        kept = []
+        for group in multi:
+            if len({id(e[0]) for e in group}) == 1:
+                solo.setdefault(id(group[0][0]), []).extend(group)
+            else:
+                kept.append(group)
+        return kept, list(solo.values())
 
     @staticmethod
     def _answer(entries, scores, ids) -> None:
@@ -241,8 +254,9 @@ class EmbedBatcher:
     """Coalesces concurrent EMBED requests into one varlen encoder forward.
 
     The reference keeps up to ``MAX_EMBED_CONCURRENCY`` = 5 embed requests in flight, one text each
-    (app/main.py:250-260), and every ``/ask`` awaits ``embed_query`` (app/main.py:2800) — the one place where an
-    unmodified ``ask()`` yields the event loop, i.e. the only place where requests of different users can meet.
+    (app/main.py:250-260), and every ``/ask`` awaits ``embed_query`` (app/main.py:2800) — the first place where an
+    unmodified ``ask()`` yields the event loop on this path, i.e. where the EMBEDS of different users can meet (their
+    k-NN scans meet at the next await, ``ensure_index_exists``: prefetch.py).
     A forward of 32 short queries costs about as much as a forward of one (the few-rows GEMMs stream the same
     weights), so callers enqueue their texts and ONE worker thread — which owns every encoder call of the
     process — takes whatever has arrived, up to ``max_seqs`` sequences, and runs one ``encode`` for all of it;
@@ -252,8 +266,10 @@ class EmbedBatcher:
     the previous forward had company (more than one entry) the worker also lingers until the queue has been quiet
     for ``quiet_us`` (default 50 us), never longer than ``max_delay_ms`` (default 0.2 ms) after the first arrival;
     a lone caller in a quiet process — the previous forward served one entry — is not held back at all.  (The linger
-    is a ``threading.Condition`` wait: asyncio timers on the selector loop round up to whole milliseconds.)  Entries of more than ``max_seqs`` texts — upload slices — run on their own, behind any
-    waiting small entries, so a query never queues behind more than one upload slice.
+    is a ``threading.Condition`` wait: asyncio timers on the selector loop round up to whole milliseconds.)  Entries of
+    more than ``max_seqs`` texts — upload slices — run on their own, behind any waiting small entries, so a query never
+    queues behind more than one upload slice; a waiting slice is served after at most ``big_after`` (8) small batches
+    in a row, so queries cannot starve an upload either.
 
     Errors are per entry, as the reference's are per text: if a coalesced forward fails, every entry is retried
     on its own and only the ones that fail again see the exception.
@@ -278,6 +294,8 @@ class EmbedBatcher:
         self.served = 0                     # entries answered
         self.retries = 0                    # entries re-run alone after a failed batch
         self._company = False               # the previous forward served more than one entry
+        self.big_after = 8                  # small batches served in a row while an upload slice waits
+        self._small_streak = 0
 
     # ------------------------------------------------------------------ caller side (any event loop)
     async def embed(self, texts: List[str]) -> np.ndarray:
@@ -301,15 +319,19 @@ class EmbedBatcher:
 
     # ------------------------------------------------------------------ worker side
     def _take(self):
-        """Called with the lock held and at least one entry queued: the entries of the next forward."""
-        if self._small:
-            batch, total = [], 0
-            while self._small and total + len(self._small[0][0]) <= self.max_seqs:
-                e = self._small.popleft()
-                batch.append(e)
-                total += len(e[0])
-            return batch
-        return [self._big.popleft()]
+        """Called with the lock held and at least one entry queued: the entries of the next forward.  Small entries
+        (queries) go first, but a waiting upload slice is served after at most ``big_after`` consecutive small
+        batches: sustained query traffic cannot starve an upload."""
+        if self._big and (not self._small or self._small_streak >= self.big_after):
+            self._small_streak = 0
+            return [self._big.popleft()]
+        self._small_streak = self._small_streak + 1 if self._big else 0
+        batch, total = [], 0
+        while self._small and total + len(self._small[0][0]) <= self.max_seqs:
+            e = self._small.popleft()
+            batch.append(e)
+            total += len(e[0])
+        return batch
 
     def _worker(self) -> None:
         import time

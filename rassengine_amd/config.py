@@ -31,6 +31,8 @@ try:
     RASS_EMBED_BATCH_QUIET_US = float(os.getenv("RASS_EMBED_BATCH_QUIET_US", "50"))
 except ValueError:
     RASS_EMBED_BATCH_DELAY_MS, RASS_EMBED_BATCH_QUIET_US = 0.2, 50.0
+# k-NN prefetch at ask()'s `await ensure_index_exists` (prefetch.py): 0 = off, 1 = when other requests are in flight, 2 = always
+RASS_KNN_PREFETCH = _int("RASS_KNN_PREFETCH", 1)
 
 
 def get_index_name(user_id: str) -> str:

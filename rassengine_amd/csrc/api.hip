@@ -1407,7 +1407,14 @@ int rass_index_search_multi(rass_index_t* const* idxs, const float* queries, int
             a.n_work = eng->d_mw_n;
             a.work_base = eng->d_mw_base;
             a.work_tags = eng->d_mw_tags;
+            // counted by rass_engine_kernel_timing_* like every other scan launch
+            const bool timed = eng->ev_on && (size_t)(2 * eng->ev_used + 1) < eng->ev_pool.size();
+            if (timed) HIP_TRY(hipEventRecord(eng->ev_pool[2 * eng->ev_used], st));
             HIP_TRY(rass::launch_scan_topk_f32(a, grid, st));
+            if (timed) {
+                HIP_TRY(hipEventRecord(eng->ev_pool[2 * eng->ev_used + 1], st));
+                eng->ev_used += 1;
+            }
             HIP_TRY(rass::launch_merge_topk(part_scores, part_ids, grid, b, k, eng->d_out_scores, eng->d_out_ids, st));
             HIP_TRY(hipMemcpyAsync(sl->h_out_s, eng->d_out_scores, (size_t)b * k * sizeof(float), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipMemcpyAsync(sl->h_out_i, eng->d_out_ids, (size_t)b * k * sizeof(int64_t), hipMemcpyDeviceToHost, st));

@@ -36,7 +36,7 @@ from typing import List, Optional, Protocol
 
 import numpy as np
 
-from . import config
+from . import config, prefetch
 
 BATCH_SIZE = config.BATCH_SIZE
 EMBED_DIM = config.EMBED_DIM
@@ -149,8 +149,15 @@ async def embed_query(query: str) -> np.ndarray:
         return np.array([])
     # the reference builds np.array([emb_list], dtype=np.float32) from ollama_embed_text's list of Python floats; the
     # encoder's fp32 row IS that array (float32 -> float -> float32 is exact), without 1 024 boxed floats per query
-    vec = await _encode_nonblank([query])
-    return np.ascontiguousarray(vec[:1], dtype=np.float32)
+    prefetch.embed_enter()
+    try:
+        vec = await _encode_nonblank([query])
+    finally:
+        prefetch.embed_exit()
+    out = np.ascontiguousarray(vec[:1], dtype=np.float32)
+    # ask() awaits ensure_index_exists next (app/main.py:2801): the k-NN scans of concurrent requests are shared there
+    prefetch.remember(out)
+    return out
 
 
 # ------------------------------------------------------------------ app/embedding_gen.py:152-192

@@ -45,7 +45,7 @@ from typing import Any, Callable, Dict, List, Optional, Tuple
 
 import numpy as np
 
-from . import config
+from . import config, prefetch
 from .docstore import REGISTRY, IndexState
 
 logger = logging.getLogger("rassengine_amd")
@@ -234,6 +234,9 @@ class HipIndexer:
         if prep is None:
             return []
         q, k_eff, (fval, fmask) = prep
+        parked = prefetch.take(st, q, k_eff, fval, fmask)
+        if parked is not None:      # this request's scan was shared with the other requests in flight
+            return self._hits(st, parked[0], parked[1], boost, score_mode)
         if fmask:
             scores, ids = st.index.search(q, k_eff, q_filter=np.array([fval], dtype=np.int32),
                                           q_filter_mask=np.array([fmask], dtype=np.int32))
@@ -307,8 +310,9 @@ async def ensure_index_exists(client: Any, index_name: str) -> None:
     """app/main.py:350-579: create the per-user cosine index when absent; errors are printed
     and swallowed (578-579).  When a text engine is kept (``client`` given and the module's original
     function was recorded by ``install``) its index — the ~90 text fields — is ensured as well."""
+    st = None
     try:
-        REGISTRY.get(index_name, create=True)
+        st = REGISTRY.get(index_name, create=True)
     except Exception as e:
         print(f"[Error] OpenSearch Index could not be created: {e}")
     orig = _originals_for().get("ensure_index_exists")
@@ -317,6 +321,9 @@ async def ensure_index_exists(client: Any, index_name: str) -> None:
             await orig(client, index_name)
         except Exception as e:
             print(f"[Error] OpenSearch Index could not be created: {e}")
+    # ask() awaits this right after embed_query and right before its synchronous search (app/main.py:2800-2802):
+    # the one place where the k-NN scans of concurrent requests can share a launch (prefetch.py)
+    await prefetch.run(st)
 
 
 def add_documents(index_name: str, docs: List[Dict], embeddings: Optional[np.ndarray],

@@ -620,6 +620,11 @@ class ShardedIndex:
             live, _rows = s.execute(s.post([OP_COUNT, self.code]))
             return live
 
+    @property
+    def epoch(self) -> Tuple[int, int]:
+        """(ids ever given out, rows tombstoned) from rank 0's own bookkeeping — no collective (``prefetch.index_epoch``)."""
+        return self._rows, len(self._deleted)
+
     def _owner(self, gid: int) -> int:
         """The rank that holds global row ``gid``; -1 for a HOLE: an id an append consumed before it failed."""
         e = bisect.bisect_right(self._owner_gid, gid) - 1

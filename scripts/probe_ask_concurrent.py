@@ -1,10 +1,12 @@
 """Latency of /ask-shaped requests under CONCURRENT users, through the drop-in boundary (one GPU).
 
 Every simulated user is a coroutine on ONE event loop (uvicorn's model) that repeats what ``ask()`` does on this
-path (app/main.py:2800-2885): ``query_emb = await embed_query(text)`` — the only await, hence the only place requests
-of different users can meet — then the SYNCHRONOUS ``OpenSearchIndexer(client, index).semantic_search(query_emb, k)``
-inline on the loop.  Reported per user count: p50 / p99 of one request, requests/s, and how many encoder forwards the
-embeds became (``rass_encoder_stats``), with the embed micro-batcher on and off (``RASS_EMBED_BATCH_MAX=0``).
+path (app/main.py:2800-2885): ``query_emb = await embed_query(text)`` (the embed micro-batcher coalesces here),
+``await ensure_index_exists(client, index)`` (the k-NN prefetch shares scan launches here, rassengine_amd/prefetch.py),
+then the SYNCHRONOUS ``OpenSearchIndexer(client, index).semantic_search(query_emb=, k=, query=)`` inline on the loop.
+Reported per user count: p50 / p99 of one request, requests/s, how many encoder forwards the embeds became
+(``rass_encoder_stats``) and how many scan launches the searches became (``rass_engine_kernel_timing_*``), with both
+coalescers on, with the k-NN prefetch off (``RASS_KNN_PREFETCH=0``: round 3) and with both off (round 2).
 BERT-large-class seeded random weights (no real weights offline), real C++ tokeniser on synthetic text."""
 import argparse
 import asyncio
@@ -16,7 +18,7 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 
-from rassengine_amd import config, embedding, indexer
+from rassengine_amd import config, embedding, indexer, prefetch
 from rassengine_amd.docstore import REGISTRY
 from rassengine_amd.encoder import EncoderConfig, HipSentenceEncoder, write_random_model_dir
 from rassengine_amd.engine import Engine
@@ -32,8 +34,9 @@ def make_queries(n, rng, words=10):
 async def user(name, queries, k, lat):
     for q in queries:
         t0 = time.perf_counter()
-        emb = await embedding.embed_query(q)
-        hits = indexer.HipIndexer(None, name).semantic_search(emb, k=k)
+        emb = await embedding.embed_query(q)                      # app/main.py:2800
+        await indexer.ensure_index_exists(None, name)              # 2801: the k-NN prefetch shares scans here
+        hits = indexer.HipIndexer(None, name).semantic_search(query_emb=emb, k=k, query=q)     # 2802, 2878-2885: sync
         lat.append(time.perf_counter() - t0)
         assert len(hits) == k
 
@@ -69,19 +72,25 @@ def main():
         st.row_doc = [{"doc_id": f"doc-{i}"} for i in range(n)]
         st.doc_row = {f"doc-{i}": i for i in range(n)}
         eng.synchronize()
-        for batch_max in (64, 0):
+        for label, batch_max, knn in (("embed+knn shared", 64, 1), ("embed shared (r3) ", 64, 0), ("nothing shared (r2)", 0, 0)):
             config.RASS_EMBED_BATCH_MAX = batch_max
+            config.RASS_KNN_PREFETCH = knn
             embedding.reset_batcher()
             for u in args.users:
                 per_user = max(20, args.requests // u)
                 asyncio.run(run_users(name, u, 20, args.k, rng))          # warm-up
                 s0 = enc.stats()
+                prefetch.reset_stats()
+                eng.kernel_timing_begin(u * per_user + 64)
                 lat, wall = asyncio.run(run_users(name, u, per_user, args.k, rng))
+                _, scans = eng.kernel_timing_end()
                 s1 = enc.stats()
                 fw = s1["forwards"] - s0["forwards"]
-                print(f"rows {n:8d}  coalescing {'on ' if batch_max else 'off'}  users {u:3d}: p50 {np.percentile(lat, 50):6.3f} ms  "
+                print(f"rows {n:8d}  {label}  users {u:3d}: p50 {np.percentile(lat, 50):6.3f} ms  "
                       f"p99 {np.percentile(lat, 99):6.3f} ms  {len(lat) / wall:8.0f} requests/s  "
-                      f"{len(lat)} embeds in {fw} forwards ({len(lat) / fw:.1f} per forward)", flush=True)
+                      f"{len(lat)} embeds in {fw} forwards ({len(lat) / fw:.1f} per forward), searches in {scans} scan "
+                      f"launches ({len(lat) / max(scans, 1):.1f} per launch; answered from a shared scan: "
+                      f"{prefetch.stats['answered']})", flush=True)
         REGISTRY.drop(name)
         eng.drop_index(name)
     embedding.reset_batcher()

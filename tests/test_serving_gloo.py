@@ -140,6 +140,36 @@ def _scenario(indexer, embedding, REGISTRY, config, name):
     return out
 
 
+def _prefetch_scenario(indexer, embedding, config, name):
+    """12 concurrent ask()-shaped coroutines (embed_query -> ensure_index_exists -> a synchronous search,
+    app/main.py:2800-2885): their k-NN scans are shared at the second await (rassengine_amd/prefetch.py) — over a
+    sharded index through its QueryBatcher, one OP_SEARCH of 12 queries — and must equal the serial answers."""
+    import asyncio
+    from rassengine_amd import prefetch
+    reqs = [(f"chunk number {i} about topic{i % 7} and drug{i % 4}", 6, None if i % 3 else f"p{i % 3}") for i in range(12)]
+
+    async def ask(q, k, pid):
+        emb = await embedding.embed_query(q)
+        await indexer.ensure_index_exists(None, name)
+        return indexer.HipIndexer(None, name).semantic_search(query_emb=emb, k=k, patient_id=pid, query=q)
+
+    async def burst():
+        return await asyncio.gather(*[ask(*r) for r in reqs])
+
+    mode0 = config.RASS_KNN_PREFETCH
+    try:
+        config.RASS_KNN_PREFETCH = 0
+        serial = asyncio.run(burst())
+        config.RASS_KNN_PREFETCH = 1
+        prefetch.reset_stats()
+        shared = asyncio.run(burst())
+    finally:
+        config.RASS_KNN_PREFETCH = mode0
+    assert [[(d["doc_id"], s) for d, s in h] for h in shared] == [[(d["doc_id"], s) for d, s in h] for h in serial]
+    assert prefetch.stats["answered"] >= 10, prefetch.stats
+    return {"pf_ids": [d["doc_id"] for h in shared for d, _ in h], "pf_scores": [float(s) for h in shared for _, s in h]}
+
+
 def _worker(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -157,6 +187,7 @@ def _worker(rank, world, port, out_dir):
             return
         embedding.set_embedder(HashEmbedder(1024))
         sharded = _scenario(indexer, embedding, REGISTRY, config, "rass-idx-user1")
+        sharded.update(_prefetch_scenario(indexer, embedding, config, "rass-idx-user1"))
         # round-robin by batch really spread the rows: every rank holds some
         idx = REGISTRY.get("rass-idx-user1").index
         assert isinstance(idx, serving.ShardedIndex)
@@ -190,6 +221,7 @@ def _worker(rank, world, port, out_dir):
         REGISTRY.clear()
         REGISTRY.set_index_factory(lambda name: OracleIndex(1024))
         single = _scenario(indexer, embedding, REGISTRY, config, "rass-idx-user1")
+        single.update(_prefetch_scenario(indexer, embedding, config, "rass-idx-user1"))
         np.savez(os.path.join(out_dir, "rank0.npz"), **{"sharded_" + k: np.asarray(v) for k, v in sharded.items()},
                  **{"single_" + k: np.asarray(v) for k, v in single.items()})
     finally:

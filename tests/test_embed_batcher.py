@@ -187,6 +187,30 @@ def test_coalescing_can_be_switched_off(emb, monkeypatch):
     assert embedding.get_batcher() is None and len(emb.calls) == 6 and all(g.shape == (1, 1024) for g in got)
 
 
+def test_sustained_queries_cannot_starve_an_upload_slice():
+    """small entries go first, but a waiting upload slice is served after at most ``big_after`` small
+    batches in a row."""
+    order = []
+
+    def enc(texts):
+        order.append(len(texts))
+        time.sleep(0.002)
+        return np.zeros((len(texts), 8), dtype=np.float32)
+
+    b = EmbedBatcher(enc, max_seqs=1, max_delay_ms=0.0)        # one query per forward: 40 queued queries = 40 small batches
+
+    async def go():
+        qs = [asyncio.ensure_future(b.embed([f"q{i}"])) for i in range(40)]
+        up = asyncio.ensure_future(b.embed([f"chunk{i}" for i in range(5)]))     # > max_seqs: an upload slice
+        await asyncio.gather(up, *qs)
+
+    asyncio.run(go())
+    b.close()
+    assert sorted(order) == [1] * 40 + [5]
+    assert order.index(5) <= b.big_after + 1, order            # not behind all 40 queries
+    assert order.index(5) >= 1                                 # but queries do go first
+
+
 def test_batcher_caps_and_close():
     calls = []
 

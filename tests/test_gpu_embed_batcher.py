@@ -57,7 +57,9 @@ def test_32_concurrent_embed_queries_become_one_or_two_forwards(hip_embedder):
         t_single.append(time.perf_counter() - t0)
     single = float(np.median(t_single))
 
-    # five bursts, the fastest one judged: a host hiccup (another process on the box, a page fault) must not fail the criterion
+    # five bursts: the forward count is judged on EVERY burst (<= 4) and on the median (<= 2: the worker wakes at the first
+    # submit and normally finds all 32 queued, or runs one short forward first and the rest in a second one); only the
+    # wall-time criterion takes the fastest burst (a host hiccup — another process on the box, a page fault — must not fail it)
     trials = []
     for _ in range(5):
         s0 = enc.stats()
@@ -68,8 +70,8 @@ def test_32_concurrent_embed_queries_become_one_or_two_forwards(hip_embedder):
         assert s1["sequences"] - s0["sequences"] == 32
         trials.append((wall_t, s1["forwards"] - s0["forwards"], got_t))
     assert all(1 <= f <= 4 for _, f, _ in trials), [f for _, f, _ in trials]
+    assert float(np.median([f for _, f, _ in trials])) <= 2, [f for _, f, _ in trials]
     wall, forwards, got = min(trials, key=lambda t: t[0])
-    assert 1 <= forwards <= 2, [f for _, f, _ in trials]
     worst = 1.0
     for g, l in zip(got, lone):
         assert g.shape == (1, 1024) and g.dtype == np.float32 and np.all(np.isfinite(g))

@@ -405,6 +405,38 @@ int rass_ivf_search_device(rass_ivf_t* ivf, const float* d_queries, int nq,
                            int k, int nprobe, const int32_t* d_q_filter,
                            float* d_out_scores, int64_t* d_out_ids);
 
+/* ---- IVF + flat delta: the approximate index that stays incrementally insertable.
+ * Replaces what the reference gets from OpenSearch's knn_vector field: an approximate (HNSW) index
+ * (app/main.py:563-572) that takes bulk inserts of 64 docs at any time (app/main.py:1253-1282) and honours
+ * `_id` overwrites / deletes.  Here: the IVF is a snapshot of source rows [0, covered); rows the source index
+ * takes afterwards (the DELTA) are scanned exactly from its own slab in the same call and merged with the
+ * probe's list by the same merge kernel; tombstones are honoured on both sides.
+ *
+ * rass_ivf_build_prefix: rass_ivf_build_ex over the first `n_rows` source rows only (-1 = all).  An IVF that
+ * is to be searched with a delta must cover a multiple of 32 rows (the scan's tile), or every row.
+ * rass_ivf_delete: tombstone source row `src_row` inside the IVF's slab (a no-op for rows it does not cover or
+ * that are already gone) — call it next to rass_index_delete on the source index.
+ * rass_ivf_search_delta[_device]: per query the exact top-k over (the rows of its nprobe best lists) U (source
+ * rows >= covered), ties (score desc, source ordinal asc); ids = source ordinals, or the source index's
+ * caller-assigned ids (rass_index_add_ex).  `q_filter` / `q_filter_mask` as rass_index_search_ex.  With
+ * nprobe >= nlist the result equals rass_index_search_ex on the source index bit for bit (fp32 slab).
+ * nq <= RASS_MAX_QBATCH for the device variant; k <= RASS_MAX_K (deeper lists: search the source index).
+ * IVF files written since round 4 (versions 3 / 4) carry `covered`; older files load with covered = the
+ * largest slab id + 1. */
+int rass_ivf_build_prefix(rass_index_t* src, const float* centroids, int nlist,
+                          const int32_t* assign, rass_dtype slab_dtype,
+                          int64_t n_rows, rass_ivf_t** out);
+int64_t rass_ivf_covered_rows(const rass_ivf_t* ivf);
+int rass_ivf_delete(rass_ivf_t* ivf, int64_t src_row);
+int rass_ivf_search_delta(rass_ivf_t* ivf, rass_index_t* src, const float* queries,
+                          int nq, int k, int nprobe, const int32_t* q_filter,
+                          const int32_t* q_filter_mask, float* out_scores,
+                          int64_t* out_ids, int64_t* scanned_rows);
+int rass_ivf_search_delta_device(rass_ivf_t* ivf, rass_index_t* src,
+                                 const float* d_queries, int nq, int k, int nprobe,
+                                 const int32_t* d_q_filter, const int32_t* d_q_filter_mask,
+                                 float* d_out_scores, int64_t* d_out_ids);
+
 /* ---------------------------------------------------------------- encoder
  * Replaces ollama_embed_text / embed_texts_in_batches / embed_query's HTTP hop
  * to Ollama (app/main.py:225-274): a BERT-class post-LN sentence encoder

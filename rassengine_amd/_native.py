@@ -136,6 +136,16 @@ SIGNATURES = {
                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_i64_p]),
     "rass_ivf_search_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                               ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "rass_ivf_build_prefix": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                             ctypes.c_int64, c_void_pp]),
+    "rass_ivf_covered_rows": (ctypes.c_int64, [ctypes.c_void_p]),
+    "rass_ivf_delete": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64]),
+    "rass_ivf_search_delta": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                             ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                             ctypes.c_void_p, c_i64_p]),
+    "rass_ivf_search_delta_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                                    ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                                    ctypes.c_void_p, ctypes.c_void_p]),
     "rass_encoder_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, c_void_pp]),
     "rass_encoder_destroy": (None, [ctypes.c_void_p]),
     "rass_encoder_hidden": (ctypes.c_int, [ctypes.c_void_p]),

@@ -33,6 +33,17 @@ except ValueError:
     RASS_EMBED_BATCH_DELAY_MS, RASS_EMBED_BATCH_QUIET_US = 0.2, 50.0
 # k-NN prefetch at ask()'s `await ensure_index_exists` (prefetch.py): 0 = off, 1 = when other requests are in flight, 2 = always
 RASS_KNN_PREFETCH = _int("RASS_KNN_PREFETCH", 1)
+# IVF behind the boundary (ivf.IvfPolicy): 0 = every index stays flat (exact; the default).  > 0: an index of at least
+# RASS_IVF_MIN_ROWS rows gets an IVF-<nlist> (probed with RASS_IVF_NPROBE lists per query) + a flat delta for the rows
+# appended since; the IVF is rebuilt once the delta exceeds RASS_IVF_REBUILD_FRACTION of the rows it covers
+RASS_IVF_NLIST = _int("RASS_IVF_NLIST", 0)
+RASS_IVF_NPROBE = _int("RASS_IVF_NPROBE", 8)
+RASS_IVF_MIN_ROWS = _int("RASS_IVF_MIN_ROWS", 262144)
+RASS_IVF_DTYPE = os.getenv("RASS_IVF_DTYPE", "f32")            # the IVF's own copy of the rows: "f32" | "bf16"
+try:
+    RASS_IVF_REBUILD_FRACTION = float(os.getenv("RASS_IVF_REBUILD_FRACTION", "0.25"))
+except ValueError:
+    RASS_IVF_REBUILD_FRACTION = 0.25
 
 
 def get_index_name(user_id: str) -> str:

@@ -541,6 +541,12 @@ struct rass_ivf {
     uint32_t* d_tau = nullptr;        // [32] nprobe > 32: per-query threshold keys
     uint32_t* d_list_mask = nullptr;  // [nlist] nprobe > 32: probe masks from the score matrix
     bool any_tags = false;
+    // IVF + flat delta (rass_ivf_search_delta*): the IVF covers source rows [0, src_rows); rows the source index took
+    // afterwards are scanned exactly from its own slab and merged with the probe's list
+    int64_t src_rows = 0;
+    std::vector<int32_t> pos_of;      // host: slab position of source row r (< src_rows), -1 = not in the slab (tombstoned)
+    float* d_pair_scores = nullptr;   // [2][32][32] the probe's list and the delta scan's list of one launch group
+    int64_t* d_pair_ids = nullptr;
 };
 
 extern "C" void rassint_set_last_error(const char* msg) { g_err = msg ? msg : ""; }
@@ -1847,7 +1853,7 @@ static void ivf_free(rass_ivf* v) {
     for (void* p : {(void*)v->d_slab, (void*)v->d_slab_b16, (void*)v->d_tags, (void*)v->d_ids, (void*)v->d_centroids, (void*)v->d_list_tile0,
                     (void*)v->d_list_len, (void*)v->d_work_tile, (void*)v->d_work_rows, (void*)v->d_n_work,
                     (void*)v->d_work_mask, (void*)v->d_scanned, (void*)v->d_probe_scores, (void*)v->d_probe_ids,
-                    (void*)v->d_tau, (void*)v->d_list_mask})
+                    (void*)v->d_tau, (void*)v->d_list_mask, (void*)v->d_pair_scores, (void*)v->d_pair_ids})
         if (p) (void)hipFree(p);
     delete v;
 }
@@ -1858,6 +1864,11 @@ int rass_ivf_build(rass_index_t* src, const float* centroids, int nlist, const i
 
 int rass_ivf_build_ex(rass_index_t* src, const float* centroids, int nlist, const int32_t* assign, rass_dtype slab_dtype,
                       rass_ivf_t** out) {
+    return rass_ivf_build_prefix(src, centroids, nlist, assign, slab_dtype, -1, out);
+}
+
+int rass_ivf_build_prefix(rass_index_t* src, const float* centroids, int nlist, const int32_t* assign,
+                          rass_dtype slab_dtype, int64_t n_rows, rass_ivf_t** out) {
     if (!src || !centroids || !assign || !out) return fail(RASS_ERR_INVALID, "NULL argument");
     *out = nullptr;
     if (nlist < 1 || nlist > 32768) return fail(RASS_ERR_INVALID, "nlist must be in [1, 32768]");
@@ -1871,7 +1882,8 @@ int rass_ivf_build_ex(rass_index_t* src, const float* centroids, int nlist, cons
     std::lock_guard<std::mutex> lk(src->mu);
     int rc = set_device(eng);
     if (rc != RASS_OK) return rc;
-    const int64_t n = src->rows;
+    if (n_rows > src->rows) return fail(RASS_ERR_INVALID, "n_rows exceeds the rows of the source index");
+    const int64_t n = n_rows < 0 ? src->rows.load() : n_rows;
     // list lengths over live rows, tile-aligned offsets
     std::vector<int32_t> len((size_t)nlist, 0), tile0((size_t)nlist, 0);
     for (int64_t r = 0; r < n; ++r) {
@@ -1902,7 +1914,12 @@ int rass_ivf_build_ex(rass_index_t* src, const float* centroids, int nlist, cons
     v->dim = src->dim;
     v->stride = src->stride;
     v->nlist = nlist;
-    v->rows = n - src->deleted;
+    v->rows = 0;
+    for (int l = 0; l < nlist; ++l) v->rows += len[(size_t)l];
+    v->src_rows = n;
+    v->pos_of.assign((size_t)n, -1);
+    for (int64_t d = 0; d < slab_rows; ++d)
+        if (src_of[(size_t)d] >= 0) v->pos_of[(size_t)src_of[(size_t)d]] = (int32_t)d;
     v->slab_rows = slab_rows;
     v->total_tiles = std::max<int64_t>(tiles, 1);
     v->any_tags = src->has_tags;
@@ -1935,6 +1952,8 @@ int rass_ivf_build_ex(rass_index_t* src, const float* centroids, int nlist, cons
     IVF_TRY(hipMalloc(reinterpret_cast<void**>(&v->d_probe_ids), RASS_MAX_QBATCH * RASS_MAX_K * 8));
     IVF_TRY(hipMalloc(reinterpret_cast<void**>(&v->d_tau), RASS_MAX_QBATCH * 4));
     IVF_TRY(hipMalloc(reinterpret_cast<void**>(&v->d_list_mask), (size_t)nlist * 4));
+    IVF_TRY(hipMalloc(reinterpret_cast<void**>(&v->d_pair_scores), 2 * RASS_MAX_QBATCH * RASS_MAX_K * 4));
+    IVF_TRY(hipMalloc(reinterpret_cast<void**>(&v->d_pair_ids), 2 * RASS_MAX_QBATCH * RASS_MAX_K * 8));
     IVF_TRY(hipMemcpyAsync(v->d_ids, src_of.data(), (size_t)slab_rows * 8, hipMemcpyHostToDevice, st));
     IVF_TRY(hipMemcpyAsync(v->d_list_tile0, tile0.data(), (size_t)nlist * 4, hipMemcpyHostToDevice, st));
     IVF_TRY(hipMemcpyAsync(v->d_list_len, len.data(), (size_t)nlist * 4, hipMemcpyHostToDevice, st));
@@ -2021,7 +2040,9 @@ int rass_ivf_save(rass_ivf_t* v, const char* path) {
     IvfSaveHeader h;
     memset(&h, 0, sizeof(h));
     memcpy(h.magic, "RASSIVF1", 8);
-    h.version = v->dtype == RASS_BF16 ? 2 : 1;   // 2: the row slab is bf16 (tile16b) with lists on 64-row tiles
+    // 3 / 4 (since round 4) = 1 / 2 followed by one int64: the source rows the IVF covers (rass_ivf_covered_rows).
+    // 2, 4: the row slab is bf16 (tile16b) with lists on 64-row tiles
+    h.version = v->dtype == RASS_BF16 ? 4 : 3;
     h.dim = v->dim;
     h.nlist = v->nlist;
     h.any_tags = v->any_tags ? 1 : 0;
@@ -2032,6 +2053,7 @@ int rass_ivf_save(rass_ivf_t* v, const char* path) {
     h.cent_rows = ((int64_t)v->nlist + 15) / 16 * 16;
     std::vector<unsigned char> buf((size_t)32 << 20);
     bool ok = fwrite(&h, sizeof(h), 1, f) == 1;
+    ok = ok && fwrite(&v->src_rows, sizeof(int64_t), 1, f) == 1;
     ok = ok && dev_to_file(f, v->d_list_tile0, (size_t)v->nlist * 4, st, buf);
     ok = ok && dev_to_file(f, v->d_list_len, (size_t)v->nlist * 4, st, buf);
     ok = ok && dev_to_file(f, v->d_ids, (size_t)v->slab_rows * 8, st, buf);
@@ -2052,11 +2074,17 @@ int rass_ivf_load(rass_engine_t* eng, const char* path, rass_ivf_t** out) {
     FILE* f = fopen(path, "rb");
     if (!f) return fail(RASS_ERR_IO, std::string("cannot open for read: ") + path);
     IvfSaveHeader h;
-    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "RASSIVF1", 8) != 0 || (h.version != 1 && h.version != 2)) {
+    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "RASSIVF1", 8) != 0 || h.version < 1 || h.version > 4) {
         fclose(f);
         return fail(RASS_ERR_IO, "not a rass IVF file");
     }
-    const bool b16 = h.version == 2;
+    int64_t src_rows = -1;   // versions 1 / 2 do not carry it: taken from the slab's ids below
+    const int64_t extra = h.version >= 3 ? (int64_t)sizeof(int64_t) : 0;
+    if (extra && (fread(&src_rows, sizeof(int64_t), 1, f) != 1 || src_rows < 0)) {
+        fclose(f);
+        return fail(RASS_ERR_IO, "IVF file is truncated / corrupt");
+    }
+    const bool b16 = h.version == 2 || h.version == 4;
     const int tile_rows = b16 ? 64 : 32;
     const int64_t esize = b16 ? 2 : 4;
     const int64_t cent_rows = ((int64_t)h.nlist + 15) / 16 * 16;
@@ -2068,7 +2096,7 @@ int rass_ivf_load(rass_engine_t* eng, const char* path, rass_ivf_t** out) {
         const long body = ftell(f);
         int64_t len = -1;
         if (body >= 0 && fseek(f, 0, SEEK_END) == 0) len = (int64_t)ftell(f);
-        const int64_t need = (int64_t)sizeof(h) + (int64_t)h.nlist * 8 + h.slab_rows * 12 + cent_rows * h.stride * 4 +
+        const int64_t need = (int64_t)sizeof(h) + extra + (int64_t)h.nlist * 8 + h.slab_rows * 12 + cent_rows * h.stride * 4 +
                              h.slab_rows * h.stride * esize;
         sane = body >= 0 && len == need && fseek(f, body, SEEK_SET) == 0;
     }
@@ -2103,7 +2131,9 @@ int rass_ivf_load(rass_engine_t* eng, const char* path, rass_ivf_t** out) {
               alloc((void**)&v->d_work_mask, (size_t)h.total_tiles * 4) && alloc((void**)&v->d_n_work, 4) &&
               alloc((void**)&v->d_scanned, 8) && alloc((void**)&v->d_probe_scores, RASS_MAX_QBATCH * RASS_MAX_K * 4) &&
               alloc((void**)&v->d_probe_ids, RASS_MAX_QBATCH * RASS_MAX_K * 8) && alloc((void**)&v->d_tau, RASS_MAX_QBATCH * 4) &&
-              alloc((void**)&v->d_list_mask, (size_t)h.nlist * 4);
+              alloc((void**)&v->d_list_mask, (size_t)h.nlist * 4) &&
+              alloc((void**)&v->d_pair_scores, 2 * RASS_MAX_QBATCH * RASS_MAX_K * 4) &&
+              alloc((void**)&v->d_pair_ids, 2 * RASS_MAX_QBATCH * RASS_MAX_K * 8);
     if (!ok) {
         fclose(f);
         ivf_free(v);
@@ -2135,6 +2165,27 @@ int rass_ivf_load(rass_engine_t* eng, const char* path, rass_ivf_t** out) {
             return fail(RASS_ERR_IO, "ivf load: inconsistent list table");
         }
     }
+    // source row -> slab position (rass_ivf_delete), from the slab's ids and tags (-1 tag = tombstoned after the build)
+    {
+        std::vector<int64_t> ids((size_t)h.slab_rows);
+        std::vector<int32_t> tags((size_t)h.slab_rows);
+        if (hipMemcpy(ids.data(), v->d_ids, (size_t)h.slab_rows * 8, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(tags.data(), v->d_tags, (size_t)h.slab_rows * 4, hipMemcpyDeviceToHost) != hipSuccess) {
+            ivf_free(v);
+            return fail(RASS_ERR_HIP, "ivf load: reading back the slab ids failed");
+        }
+        int64_t max_id = -1;
+        for (int64_t d = 0; d < h.slab_rows; ++d) max_id = std::max(max_id, ids[(size_t)d]);
+        if (src_rows < 0) src_rows = max_id + 1;
+        if (max_id >= src_rows) {
+            ivf_free(v);
+            return fail(RASS_ERR_IO, "ivf load: a slab id lies outside the covered source rows");
+        }
+        v->src_rows = src_rows;
+        v->pos_of.assign((size_t)src_rows, -1);
+        for (int64_t d = 0; d < h.slab_rows; ++d)
+            if (ids[(size_t)d] >= 0 && tags[(size_t)d] != -1) v->pos_of[(size_t)ids[(size_t)d]] = (int32_t)d;
+    }
     *out = v;
     return RASS_OK;
 }
@@ -2142,10 +2193,32 @@ int rass_ivf_load(rass_engine_t* eng, const char* path, rass_ivf_t** out) {
 int64_t rass_ivf_rows(const rass_ivf_t* v) { return v ? v->rows : 0; }
 int rass_ivf_nlist(const rass_ivf_t* v) { return v ? v->nlist : 0; }
 int rass_ivf_dtype(const rass_ivf_t* v) { return v ? v->dtype : -1; }
+int64_t rass_ivf_covered_rows(const rass_ivf_t* v) { return v ? v->src_rows : 0; }
+
+int rass_ivf_delete(rass_ivf_t* v, int64_t src_row) {
+    if (!v) return fail(RASS_ERR_INVALID, "NULL argument");
+    rass_engine* eng = v->eng;
+    int rc = set_device(eng);
+    if (rc != RASS_OK) return rc;
+    // the engine mutex: a search holds it for its whole enqueue sequence, so the fill cannot land between a probe's
+    // plan and its fine scan (as rass_index_delete)
+    std::lock_guard<std::mutex> lk(eng->mu);
+    if (src_row < 0 || src_row >= v->src_rows) return RASS_OK;   // not covered: the row lives in the flat delta only
+    const int32_t pos = v->pos_of[(size_t)src_row];
+    if (pos < 0) return RASS_OK;                                  // already gone
+    const int32_t dead = -1;
+    HIP_TRY(hipMemcpyAsync(v->d_tags + pos, &dead, 4, hipMemcpyHostToDevice, eng->stream));
+    HIP_TRY(hipStreamSynchronize(eng->stream));                   // `dead` is a stack variable
+    v->pos_of[(size_t)src_row] = -1;
+    v->any_tags = true;
+    v->rows -= 1;
+    return RASS_OK;
+}
 
 // Caller holds eng->mu (the probe scratch of the IVF object and the engine scratch are shared).
 static int ivf_search_locked(rass_ivf_t* v, const float* d_queries, int nq, int k, int nprobe,
-                             const int32_t* d_q_filter, float* d_out_scores, int64_t* d_out_ids) {
+                             const int32_t* d_q_filter, float* d_out_scores, int64_t* d_out_ids,
+                             const int32_t* d_q_filter_mask = nullptr) {
     if (!v || !d_queries || !d_out_scores || !d_out_ids) return fail(RASS_ERR_INVALID, "NULL argument");
     if (nprobe < 1) return fail(RASS_ERR_INVALID, "nprobe must be >= 1");
     if (nq < 1 || nq > RASS_MAX_QBATCH) return fail(RASS_ERR_INVALID, "nq must be in [1, RASS_MAX_QBATCH]");
@@ -2228,6 +2301,7 @@ static int ivf_search_locked(rass_ivf_t* v, const float* d_queries, int nq, int 
         a.work_rows = v->d_work_rows;
         a.work_mask = v->d_work_mask;
         a.n_work = v->d_n_work;
+        a.q_filter_mask = d_q_filter_mask;
         const bool timed = eng->ev_on && (size_t)(2 * eng->ev_used + 1) < eng->ev_pool.size();
         if (timed) HIP_TRY(hipEventRecord(eng->ev_pool[2 * eng->ev_used], st));
         HIP_TRY(rass::launch_scan_bf16_topk(a, grid, st));
@@ -2238,9 +2312,104 @@ static int ivf_search_locked(rass_ivf_t* v, const float* d_queries, int nq, int 
         HIP_TRY(rass::launch_merge_topk(part_scores, part_ids, grid, nq, k, d_out_scores, d_out_ids, st, v->d_ids));
         return RASS_OK;
     }
+    ScanExt ext;
+    ext.d_q_mask = d_q_filter_mask;
     return scan_launch(v->d_slab, v->slab_rows, v->stride, need_tags ? v->d_tags : nullptr, d_queries, v->dim, v->dim,
                        nq, d_q_filter, k, 0, d_out_scores, d_out_ids, eng->d_scratch, eng->scratch_bytes, eng->n_cus,
-                       st, eng, &plan, v->d_ids, nullptr, /*queries_prepared=*/true);
+                       st, eng, &plan, v->d_ids, d_q_filter_mask ? &ext : nullptr, /*queries_prepared=*/true);
+}
+
+// One launch group of an IVF + delta search; the caller holds eng->mu.  List 0 = the probe (source ordinals through the
+// slab's id map), list 1 = the exact scan of the source rows the IVF does not cover (ordinals through id_base); the
+// final merge orders them by (score desc, ordinal asc) and maps ordinals to the source's caller-assigned ids, if any.
+static int ivf_delta_group_locked(rass_ivf_t* v, rass_index* flat, const float* d_queries, int nq, int k, int nprobe,
+                                  const int32_t* d_q_filter, const int32_t* d_q_filter_mask, float* d_out_scores,
+                                  int64_t* d_out_ids) {
+    rass_engine* eng = v->eng;
+    if (!flat || flat->eng != eng) return fail(RASS_ERR_INVALID, "the delta index must live on the IVF's engine");
+    if (flat->dtype != RASS_F32 || flat->stride != v->stride || flat->dim != v->dim)
+        return fail(RASS_ERR_UNSUPPORTED, "the delta index must be the fp32 index the IVF was built from");
+    if (k < 1 || k > RASS_MAX_K) return fail(RASS_ERR_INVALID, "k must be in [1, RASS_MAX_K]");
+    if (d_q_filter_mask && !d_q_filter) return fail(RASS_ERR_INVALID, "q_filter_mask without q_filter");
+    const int64_t rows = flat->rows.load(std::memory_order_acquire);
+    const int64_t covered = v->src_rows;
+    if (covered > rows) return fail(RASS_ERR_INVALID, "the IVF covers more rows than the delta index holds");
+    const int64_t delta = rows - covered;
+    if (delta > 0 && covered % 32 != 0)
+        return fail(RASS_ERR_UNSUPPORTED, "an IVF with a delta must cover a multiple of 32 source rows (rass_ivf_build_prefix)");
+    const bool gid = flat->has_gid.load(std::memory_order_acquire);
+    hipStream_t st = eng->stream;
+    float* ps = v->d_pair_scores;
+    int64_t* pi = v->d_pair_ids;
+    int rc = ivf_search_locked(v, d_queries, nq, k, nprobe, d_q_filter, ps, pi, d_q_filter_mask);
+    if (rc != RASS_OK) return rc;
+    int n_lists = 1;
+    if (delta > 0) {
+        const bool need_tags = (flat->deleted.load(std::memory_order_acquire) > 0) || (d_q_filter != nullptr);
+        ScanExt ext;
+        ext.d_q_mask = d_q_filter_mask;
+        rc = scan_launch(flat->d_rows + covered * flat->stride, delta, flat->stride,
+                         need_tags ? flat->d_tags + covered : nullptr, d_queries, flat->dim, flat->dim, nq, d_q_filter, k,
+                         covered, ps + (int64_t)nq * k, pi + (int64_t)nq * k, eng->d_scratch, eng->scratch_bytes,
+                         eng->n_cus, st, eng, nullptr, nullptr, d_q_filter_mask ? &ext : nullptr);
+        if (rc != RASS_OK) return rc;
+        n_lists = 2;
+    }
+    HIP_TRY(rass::launch_merge_topk(ps, pi, n_lists, nq, k, d_out_scores, d_out_ids, st, gid ? flat->d_gid : nullptr));
+    return RASS_OK;
+}
+
+int rass_ivf_search_delta_device(rass_ivf_t* v, rass_index_t* flat, const float* d_queries, int nq, int k, int nprobe,
+                                 const int32_t* d_q_filter, const int32_t* d_q_filter_mask, float* d_out_scores,
+                                 int64_t* d_out_ids) {
+    if (!v || !flat || !d_queries || !d_out_scores || !d_out_ids) return fail(RASS_ERR_INVALID, "NULL argument");
+    if (nq < 1 || nq > RASS_MAX_QBATCH) return fail(RASS_ERR_INVALID, "nq must be in [1, RASS_MAX_QBATCH]");
+    int rc = set_device(v->eng);
+    if (rc != RASS_OK) return rc;
+    std::lock_guard<std::mutex> lk(v->eng->mu);
+    return ivf_delta_group_locked(v, flat, d_queries, nq, k, nprobe, d_q_filter, d_q_filter_mask, d_out_scores, d_out_ids);
+}
+
+int rass_ivf_search_delta(rass_ivf_t* v, rass_index_t* flat, const float* queries, int nq, int k, int nprobe,
+                          const int32_t* q_filter, const int32_t* q_filter_mask, float* out_scores, int64_t* out_ids,
+                          int64_t* scanned_rows) {
+    if (!v || !flat || !out_scores || !out_ids) return fail(RASS_ERR_INVALID, "NULL argument");
+    if (nq < 0 || (nq > 0 && !queries)) return fail(RASS_ERR_INVALID, "bad queries / nq");
+    if (k < 1 || k > RASS_MAX_K) return fail(RASS_ERR_INVALID, "k must be in [1, RASS_MAX_K]");
+    if (q_filter_mask && !q_filter) return fail(RASS_ERR_INVALID, "q_filter_mask without q_filter");
+    rass_engine* eng = v->eng;
+    int rc = set_device(eng);
+    if (rc != RASS_OK) return rc;
+    int64_t scanned_total = 0;
+    SlotGuard guard(eng);
+    HostSlot* sl = guard.sl;
+    for (int done = 0; done < nq;) {
+        const int b = std::min(RASS_MAX_QBATCH, nq - done);
+        memcpy(sl->h_q, queries + (int64_t)done * v->dim, (size_t)b * v->dim * 4);
+        if (q_filter) memcpy(sl->h_filter, q_filter + done, (size_t)b * 4);
+        if (q_filter_mask) memcpy(sl->h_mask, q_filter_mask + done, (size_t)b * 4);
+        {
+            std::lock_guard<std::mutex> lk(eng->mu);
+            hipStream_t st = eng->stream;
+            HIP_TRY(hipMemcpyAsync(eng->d_qraw, sl->h_q, (size_t)b * v->dim * 4, hipMemcpyHostToDevice, st));
+            if (q_filter) HIP_TRY(hipMemcpyAsync(eng->d_qfilter, sl->h_filter, (size_t)b * 4, hipMemcpyHostToDevice, st));
+            if (q_filter_mask) HIP_TRY(hipMemcpyAsync(eng->d_qmask, sl->h_mask, (size_t)b * 4, hipMemcpyHostToDevice, st));
+            rc = ivf_delta_group_locked(v, flat, eng->d_qraw, b, k, nprobe, q_filter ? eng->d_qfilter : nullptr,
+                                        q_filter_mask ? eng->d_qmask : nullptr, eng->d_out_scores, eng->d_out_ids);
+            if (rc != RASS_OK) return rc;
+            HIP_TRY(hipMemcpyAsync(sl->h_out_s, eng->d_out_scores, (size_t)b * k * 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(sl->h_out_i, eng->d_out_ids, (size_t)b * k * 8, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(sl->h_scanned, v->d_scanned, 8, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipEventRecord(sl->done, st));
+        }
+        HIP_TRY(hipEventSynchronize(sl->done));
+        memcpy(out_scores + (int64_t)done * k, sl->h_out_s, (size_t)b * k * 4);
+        memcpy(out_ids + (int64_t)done * k, sl->h_out_i, (size_t)b * k * 8);
+        scanned_total += *sl->h_scanned + std::max<int64_t>(0, flat->rows.load() - v->src_rows);
+        done += b;
+    }
+    if (scanned_rows) *scanned_rows = scanned_total;
+    return RASS_OK;
 }
 
 int rass_ivf_search_device(rass_ivf_t* v, const float* d_queries, int nq, int k, int nprobe,

@@ -258,9 +258,11 @@ hipError_t launch_scan_bf16_topk(const ScanBf16Args& a, int grid, hipStream_t st
         if (a.q_filter_mask != nullptr && a.q_filter == nullptr) return hipErrorInvalidValue;
     }
     const bool ivf = a.work_tile != nullptr;
-    if (ivf && (ext || !a.work_rows || !a.work_mask || !a.n_work)) return hipErrorInvalidValue;   // IVF probe: plain filters only
+    // IVF probe: plain or masked filters; no continuation bound (the ids it compares would be slab positions)
+    if (ivf && (a.q_after_score || a.q_after_id || !a.work_rows || !a.work_mask || !a.n_work)) return hipErrorInvalidValue;
 #define RASS_BF16_CASE(C)                                                                                     \
     case C:                                                                                                   \
+        if (ivf && ext) return two ? launch_bvariant<C, 2, true, true>(a, grid, stream) : launch_bvariant<C, 1, true, true>(a, grid, stream); \
         if (ivf) return two ? launch_bvariant<C, 2, false, true>(a, grid, stream) : launch_bvariant<C, 1, false, true>(a, grid, stream); \
         if (ext) return two ? launch_bvariant<C, 2, true>(a, grid, stream) : launch_bvariant<C, 1, true>(a, grid, stream); \
         return two ? launch_bvariant<C, 2, false>(a, grid, stream) : launch_bvariant<C, 1, false>(a, grid, stream);

@@ -611,8 +611,14 @@ hipError_t launch_scan_topk_f32(const ScanArgs& a, int grid, hipStream_t stream)
         if (a.nq <= 16) return launch_ch<1, kMulti, true>(ch, a, grid, stream);
         return launch_ch<2, kMulti, true>(ch, a, grid, stream);
     }
-    if (ext) {  // masked filters / continuation bound: flat scan only
-        if (a.work_tile != nullptr) return hipErrorInvalidValue;
+    if (ext && a.work_tile != nullptr) {  // IVF probe with masked filters (no continuation bound: ids are slab positions)
+        if (!a.work_rows || !a.work_mask || !a.n_work) return hipErrorInvalidValue;
+        if (a.q_after_score || a.q_after_id) return hipErrorInvalidValue;
+        if (a.q_filter_mask != nullptr && a.q_filter == nullptr) return hipErrorInvalidValue;
+        if (a.nq <= 16) return launch_ch<1, kIvf, true>(ch, a, grid, stream);
+        return launch_ch<2, kIvf, true>(ch, a, grid, stream);
+    }
+    if (ext) {  // masked filters / continuation bound of a flat scan
         if ((a.q_after_score == nullptr) != (a.q_after_id == nullptr)) return hipErrorInvalidValue;
         if (a.q_filter_mask != nullptr && a.q_filter == nullptr) return hipErrorInvalidValue;
         if (a.nq <= 16) return launch_ch<1, kFlat, true>(ch, a, grid, stream);

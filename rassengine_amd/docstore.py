@@ -223,7 +223,11 @@ class Registry:
     def _default_factory(self, name: str):
         from . import config
         from .engine import Engine
-        return Engine.get(config.RASS_DEVICE, config.EMBED_DIM).open_index(name)
+        eng = Engine.get(config.RASS_DEVICE, config.EMBED_DIM)
+        if config.RASS_IVF_NLIST > 0:       # approximate index + flat delta for later inserts (ivf.IvfBackedIndex)
+            from .ivf import open_backed_index
+            return open_backed_index(eng, name)
+        return eng.open_index(name)
 
     def get(self, name: str, create: bool = True) -> Optional[IndexState]:
         with self._lock:

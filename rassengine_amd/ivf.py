@@ -251,19 +251,29 @@ def train_centroids(index: FlatIndex, nlist: int, train_rows: int = 0, iters: in
         # "all rows" with two levels means a strided sample of 64 rows per fine list (1 M rows for IVF-4096: what the
         # profiles were measured on): the fine assignment costs K' x dim x 2 flops per row and iteration
         m = min(n, 64 * min(int(fine_factor) * nlist, 65536))
-    if m < nlist:
-        raise ValueError(f"need at least nlist={nlist} training rows, have {m}")
-    step = max(1, total_blocks // max(1, -(-m // BLOCK_ROWS)))
-    n_blocks = -(-total_blocks // step)
     world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if m < nlist and world == 1:
+        raise ValueError(f"need at least nlist={nlist} training rows, have {m}")
+    step = max(1, total_blocks // max(1, -(-max(m, 1) // BLOCK_ROWS)))
+    n_blocks = -(-total_blocks // step)
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     g = torch.Generator(device="cpu")
     g.manual_seed(seed)
     sample = min(n_blocks * BLOCK_ROWS, n)
-    k_fine = min(int(fine_factor) * nlist, 65536, sample // 16) if fine_factor and fine_factor > 1 else 0
+    # every rank must train the SAME number of first-level lists in the same mode (the broadcast of the seeds and the
+    # all-reduce of sums / counts carry [k_first, dim] tensors): size them from the SMALLEST rank's sample, not from the
+    # rank-local row count (shards hold unequal rows)
+    sample_all = sample
+    if world > 1:
+        t = torch.tensor([sample], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+        sample_all = int(t.item())
+    if sample_all < nlist:
+        raise ValueError(f"need at least nlist={nlist} training rows on every rank, the smallest sample has {sample_all}")
+    k_fine = min(int(fine_factor) * nlist, 65536, sample_all // 16) if fine_factor and fine_factor > 1 else 0
     two_level = k_fine >= 2 * nlist
     k_first = k_fine if two_level else nlist
-    repair = (not two_level) and seeding == "repair" and nlist >= 8 and sample >= 2 * nlist
+    repair = (not two_level) and seeding == "repair" and nlist >= 8 and sample_all >= 2 * nlist
     with _engine_on_torch_stream(index):
         # seeds: distinct sample rows (deterministic for a seed); every rank starts from rank 0's
         pick = torch.randperm(sample, generator=g)[:k_first]
@@ -309,7 +319,7 @@ class IvfIndex:
     @classmethod
     def build(cls, index: FlatIndex, nlist: int = 4096, train_rows: int = 0, iters: int = 20, seed: int = 0,
               group: Optional[dist.ProcessGroup] = None, centroids: Optional[torch.Tensor] = None,
-              dtype: str = "f32", assign: Optional[np.ndarray] = None) -> "IvfIndex":
+              dtype: str = "f32", assign: Optional[np.ndarray] = None, n_rows: int = -1) -> "IvfIndex":
         """``dtype="bf16"``: the IVF keeps its list-ordered copy of the rows in bf16 (``rass_ivf_build_ex``): half the bytes
         per probed row, the scores of a flat bf16 index over the same rows.  The source index stays fp32."""
         if dtype not in ("f32", "bf16"):
@@ -320,16 +330,19 @@ class IvfIndex:
             assign = assign_rows(index, centroids)
         else:   # the caller's lists (e.g. two-level training: a row follows its fine list's group)
             assign = np.ascontiguousarray(assign, dtype=np.int32)
-            if assign.shape != (index.rows,):
+            if assign.ndim != 1 or assign.shape[0] < (index.rows if n_rows < 0 else n_rows):
                 raise ValueError(f"assign must hold one list id per row ({index.rows}), got {assign.shape}")
         c_host = np.ascontiguousarray(centroids.cpu().numpy(), dtype=np.float32)
         h = ctypes.c_void_p()
-        N.check("rass_ivf_build_ex",
-                N.lib().rass_ivf_build_ex(index._h, c_host.ctypes.data_as(ctypes.c_void_p), int(nlist),
-                                          assign.ctypes.data_as(ctypes.c_void_p), 1 if dtype == "bf16" else 0, ctypes.byref(h)))
+        # n_rows >= 0: an IVF over the first n_rows source rows only (the rest is the flat delta of an IvfBackedIndex)
+        N.check("rass_ivf_build_prefix",
+                N.lib().rass_ivf_build_prefix(index._h, c_host.ctypes.data_as(ctypes.c_void_p), int(nlist),
+                                              assign.ctypes.data_as(ctypes.c_void_p), 1 if dtype == "bf16" else 0,
+                                              int(n_rows), ctypes.byref(h)))
         ivf = cls(h, index.engine, index.dim)
-        ivf.assign = assign                                   # list id of every source row (host int32)
-        ivf.list_sizes = np.bincount(assign, minlength=nlist)
+        ivf.assign = assign[:ivf.covered_rows]                # list id of every covered source row (host int32)
+        ivf.centroids = centroids                             # [nlist, dim] (device) as trained, before the engine's normalise
+        ivf.list_sizes = np.bincount(ivf.assign, minlength=nlist)
         return ivf
 
     def save(self, path: str) -> None:
@@ -353,6 +366,45 @@ class IvfIndex:
     @property
     def nlist(self) -> int:
         return int(self._L.rass_ivf_nlist(self._h))
+
+    @property
+    def covered_rows(self) -> int:
+        """Source rows [0, covered) are in the IVF (live or tombstoned); later rows are somebody's flat delta."""
+        return int(self._L.rass_ivf_covered_rows(self._h))
+
+    def delete(self, src_row: int) -> None:
+        """Tombstone a source row inside the IVF's slab (no-op when it is not covered)."""
+        N.check("rass_ivf_delete", self._L.rass_ivf_delete(self._h, int(src_row)))
+
+    def search_delta(self, flat: FlatIndex, queries: np.ndarray, k: int, nprobe: int, q_filter: Optional[np.ndarray] = None,
+                     q_filter_mask: Optional[np.ndarray] = None) -> Tuple[np.ndarray, np.ndarray, int]:
+        """``rass_ivf_search_delta``: the probe of this IVF + the exact scan of ``flat``'s rows behind ``covered_rows``,
+        merged.  (scores, ids, rows touched)."""
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        if q.ndim != 2 or q.shape[1] != self.dim:
+            raise ValueError(f"expected [nq, {self.dim}] queries, got {q.shape}")
+        f = None if q_filter is None else np.ascontiguousarray(q_filter, dtype=np.int32)
+        m = None if q_filter_mask is None else np.ascontiguousarray(q_filter_mask, dtype=np.int32)
+        if (f is not None and f.shape != (q.shape[0],)) or (m is not None and (f is None or m.shape != (q.shape[0],))):
+            raise ValueError("q_filter / q_filter_mask must be one int32 per query (mask needs filter)")
+        out_s = np.empty((q.shape[0], int(k)), dtype=np.float32)
+        out_i = np.empty((q.shape[0], int(k)), dtype=np.int64)
+        scanned = ctypes.c_int64(0)
+        N.check("rass_ivf_search_delta",
+                self._L.rass_ivf_search_delta(self._h, flat._h, q.ctypes.data_as(ctypes.c_void_p), q.shape[0], int(k),
+                                              int(nprobe), None if f is None else f.ctypes.data_as(ctypes.c_void_p),
+                                              None if m is None else m.ctypes.data_as(ctypes.c_void_p),
+                                              out_s.ctypes.data_as(ctypes.c_void_p), out_i.ctypes.data_as(ctypes.c_void_p),
+                                              ctypes.byref(scanned)))
+        return out_s, out_i, int(scanned.value)
+
+    def search_delta_device(self, flat: FlatIndex, d_queries_ptr: int, nq: int, k: int, nprobe: int, d_out_scores_ptr: int,
+                            d_out_ids_ptr: int, d_q_filter_ptr: int = 0, d_q_filter_mask_ptr: int = 0) -> None:
+        N.check("rass_ivf_search_delta_device",
+                self._L.rass_ivf_search_delta_device(self._h, flat._h, ctypes.c_void_p(d_queries_ptr), int(nq), int(k),
+                                                     int(nprobe), ctypes.c_void_p(d_q_filter_ptr or 0),
+                                                     ctypes.c_void_p(d_q_filter_mask_ptr or 0),
+                                                     ctypes.c_void_p(d_out_scores_ptr), ctypes.c_void_p(d_out_ids_ptr)))
 
     @property
     def dtype(self) -> str:
@@ -412,3 +464,183 @@ class IvfShard:
     def merge(self, list_scores: torch.Tensor, list_ids: torch.Tensor):
         from . import ops
         return ops.topk_merge(list_scores, list_ids)
+
+
+# ------------------------------------------------------------------------------------ IVF behind the boundary
+class IvfPolicy:
+    """When an index gets an IVF and when that IVF is rebuilt (``RASS_IVF_*``, config.py).
+
+    The reference's index is approximate (HNSW, app/main.py:563-572) AND takes inserts at any time (bulk per 64 docs,
+    app/main.py:1253-1282).  Here an index below ``min_rows`` stays flat (an exact scan of 262 144 rows is 0.16 ms);
+    above it an IVF-``nlist`` is built over the rows it holds; rows appended afterwards form a flat DELTA that every
+    search scans exactly next to the probe (``rass_ivf_search_delta``), and once the delta exceeds ``rebuild_fraction``
+    of the covered rows the IVF is rebuilt over everything (2.4-3.7 s per 12.5 M rows, inside the ``add`` that crossed
+    the threshold — an ingest-path cost; searches keep being served from the old IVF + delta until the swap)."""
+
+    def __init__(self, nlist: int = 0, nprobe: int = 8, min_rows: int = 262144, rebuild_fraction: float = 0.25,
+                 dtype: str = "f32", train_rows: int = 0, iters: int = 10, seed: int = 0):
+        self.nlist, self.nprobe, self.min_rows = int(nlist), max(1, int(nprobe)), int(min_rows)
+        self.rebuild_fraction, self.dtype = float(rebuild_fraction), dtype
+        self.train_rows, self.iters, self.seed = int(train_rows), int(iters), int(seed)
+
+    @classmethod
+    def from_config(cls) -> "IvfPolicy":
+        from . import config
+        return cls(config.RASS_IVF_NLIST, config.RASS_IVF_NPROBE, config.RASS_IVF_MIN_ROWS,
+                   config.RASS_IVF_REBUILD_FRACTION, config.RASS_IVF_DTYPE)
+
+    @classmethod
+    def manual(cls, nprobe: int = 8) -> "IvfPolicy":
+        """No automatic builds (a shard of a multi-GPU index: rank 0 decides for all ranks, ``OP_IVF_BUILD``)."""
+        return cls(0, nprobe)
+
+    def due(self, rows: int, covered: int) -> bool:
+        if self.nlist <= 0 or rows < max(self.min_rows, self.nlist):
+            return False
+        if covered <= 0:
+            return True
+        return rows - covered > self.rebuild_fraction * covered
+
+
+class IvfBackedIndex(FlatIndex):
+    """A ``FlatIndex`` (same handle, same surface: what ``IndexState.index`` / ``HipServingShard`` talk to) whose
+    searches go through an IVF over its first ``covered`` rows + an exact scan of the rows appended since, merged by
+    the engine's merge kernel; tombstones are applied to both.  The flat index stays authoritative: k > 32, continuation
+    passes, ``get_row``, rebuilds and every search before the first build are served from it exactly."""
+
+    def __init__(self, flat: FlatIndex, policy: Optional[IvfPolicy] = None):
+        super().__init__(flat.engine, flat.name, flat._h)
+        import threading
+        self.policy = policy or IvfPolicy.from_config()
+        self.ivf: Optional[IvfIndex] = None
+        self.builds = 0                      # bumped by every swap (part of ``epoch``)
+        self._ivf_lock = threading.RLock()   # deletes and the build's final phase exclude each other
+
+    # ---- bookkeeping
+    @property
+    def covered(self) -> int:
+        ivf = self.ivf
+        return ivf.covered_rows if ivf is not None else 0
+
+    @property
+    def epoch(self) -> Tuple[int, int, int]:
+        rows = self.rows
+        return rows, rows - self.count, self.builds
+
+    @property
+    def multi_tiles(self) -> int:
+        """An index with an IVF answers through its own search (it cannot join a cross-index work-list launch)."""
+        return 0 if self.ivf is not None else super().multi_tiles
+
+    # ---- build / rebuild
+    def build_ivf(self, nlist: Optional[int] = None, group: Optional[dist.ProcessGroup] = None,
+                  centroids: Optional[torch.Tensor] = None, dtype: Optional[str] = None) -> Optional[IvfIndex]:
+        """Train (all ranks of ``group`` together: shared centroids), assign, and build the IVF over the first
+        ``rows // 32 * 32`` rows (the scan's tile: the delta must start on a tile); the remaining <= 31 rows and
+        everything appended later are the delta.  Swaps the new IVF in and frees the old one."""
+        p = self.policy
+        nlist = int(nlist or p.nlist)
+        if nlist <= 0:
+            raise ValueError("build_ivf needs nlist > 0 (RASS_IVF_NLIST)")
+        if centroids is None:
+            centroids = train_centroids(self, nlist, p.train_rows, p.iters, p.seed, group)
+        rows = self.rows
+        assign = assign_rows(self, centroids)
+        with self._ivf_lock:
+            new = IvfIndex.build(self, nlist=nlist, centroids=centroids, dtype=dtype or p.dtype, assign=assign,
+                                 n_rows=min(rows, len(assign)) // 32 * 32)
+            old, self.ivf = self.ivf, new
+            self.builds += 1
+        if old is not None:
+            old.close()
+        return new
+
+    def maybe_rebuild(self) -> bool:
+        if self.policy.due(self.rows, self.covered):
+            self.build_ivf()
+            return True
+        return False
+
+    def drop_ivf(self) -> None:
+        with self._ivf_lock:
+            old, self.ivf = self.ivf, None
+            self.builds += 1
+        if old is not None:
+            old.close()
+
+    # ---- write path
+    def add(self, vecs, tags=None, normalize: bool = True, first_global_id: int = -1) -> int:
+        first = super().add(vecs, tags=tags, normalize=normalize, first_global_id=first_global_id)
+        self.maybe_rebuild()
+        return first
+
+    def add_device(self, d_vecs_ptr: int, n: int, d_tags_ptr: int = 0, normalize: bool = True) -> int:
+        first = super().add_device(d_vecs_ptr, n, d_tags_ptr, normalize)
+        self.maybe_rebuild()
+        return first
+
+    def delete(self, row: int) -> None:
+        with self._ivf_lock:
+            super().delete(row)
+            if self.ivf is not None:
+                self.ivf.delete(row)
+
+    # ---- persistence: `<path>` = the flat index (authoritative), `<path minus .tmp>.ivf` = the IVF's device state
+    @staticmethod
+    def _ivf_path(path: str) -> str:
+        return (path[:-4] if path.endswith(".tmp") else path) + ".ivf"
+
+    def save(self, path: str) -> None:
+        with self._ivf_lock:
+            if self.ivf is not None:
+                self.ivf.save(self._ivf_path(path))
+            super().save(path)
+
+    def saved_files(self, path: str):
+        """Files of a saved generation besides ``path`` itself (``IndexState.save`` removes the previous one's)."""
+        return [self._ivf_path(path)]
+
+    @classmethod
+    def load(cls, engine, name: str, path: str, policy: Optional[IvfPolicy] = None) -> "IvfBackedIndex":
+        import os
+        idx = cls(engine.load_index(name, path), policy)
+        f = cls._ivf_path(path)
+        if os.path.exists(f):
+            try:
+                ivf = IvfIndex.load(engine, f)
+                if ivf.covered_rows <= idx.rows and (ivf.covered_rows % 32 == 0 or ivf.covered_rows == idx.rows):
+                    idx.ivf = ivf
+                else:
+                    ivf.close()
+            except Exception:       # a missing / torn IVF file costs a rebuild, never the index
+                idx.ivf = None
+        return idx
+
+    # ---- read path
+    def _use_ivf(self, k: int) -> Optional[IvfIndex]:
+        ivf = self.ivf
+        return ivf if (ivf is not None and 1 <= int(k) <= 32) else None
+
+    def search(self, queries: np.ndarray, k: int, q_filter: Optional[np.ndarray] = None,
+               q_filter_mask: Optional[np.ndarray] = None, exact: bool = False, nprobe: Optional[int] = None
+               ) -> Tuple[np.ndarray, np.ndarray]:
+        ivf = None if exact else self._use_ivf(k)
+        if ivf is None:
+            return super().search(queries, k, q_filter, q_filter_mask)
+        s, i, _ = ivf.search_delta(self, queries, int(k), int(nprobe or self.policy.nprobe), q_filter, q_filter_mask)
+        return s, i
+
+    def search_device(self, d_queries_ptr: int, nq: int, k: int, d_out_scores_ptr: int, d_out_ids_ptr: int,
+                      id_base: int = 0, d_q_filter_ptr: int = 0, d_q_filter_mask_ptr: int = 0, exact: bool = False,
+                      nprobe: Optional[int] = None) -> None:
+        ivf = None if (exact or id_base) else self._use_ivf(k)
+        if ivf is None:
+            return super().search_device(d_queries_ptr, nq, k, d_out_scores_ptr, d_out_ids_ptr, id_base, d_q_filter_ptr,
+                                         d_q_filter_mask_ptr)
+        ivf.search_delta_device(self, d_queries_ptr, nq, k, int(nprobe or self.policy.nprobe), d_out_scores_ptr,
+                                d_out_ids_ptr, d_q_filter_ptr, d_q_filter_mask_ptr)
+
+
+def open_backed_index(engine, name: str, policy: Optional[IvfPolicy] = None) -> IvfBackedIndex:
+    """``docstore.REGISTRY``'s index factory when ``RASS_IVF_NLIST`` > 0."""
+    return IvfBackedIndex(engine.open_index(name), policy)

@@ -25,6 +25,9 @@ rank then executes the same operation on its shard, so the collectives line up b
             batches dealt to it with its own encoder straight into its shard (no embedding crosses ranks)
     SAVE    every rank writes its shard file, an all-reduce tells rank 0 that all are durable, rank 0 writes the
             manifest (world size, run table, tombstones); LOAD is the inverse and rebuilds the ranks' extent tables
+    IVF_BUILD every rank trains the SAME centroids together (k-means sums / counts all-reduced over the data group),
+            assigns its own rows and builds an IVF over its shard; later SEARCHes probe it (+ an exact scan of the rows
+            the shard took since: the flat delta) unless they carry the EXACT flag (k > 32 passes)
     SHUTDOWN workers leave the loop; every rank then meets in a barrier (a clean collective exit: the workers
             are ordinary processes that return, nothing is re-exec'ed or killed)
 
@@ -55,7 +58,8 @@ import torch.distributed as dist
 
 logger = logging.getLogger("rassengine_amd.serving")
 
-OP_SHUTDOWN, OP_OPEN, OP_SEARCH, OP_ADD, OP_DELETE, OP_COUNT, OP_GETROW, OP_DROP, OP_ENCODE, OP_SAVE, OP_LOAD = range(11)
+OP_SHUTDOWN, OP_OPEN, OP_SEARCH, OP_ADD, OP_DELETE, OP_COUNT, OP_GETROW, OP_DROP, OP_ENCODE, OP_SAVE, OP_LOAD, OP_IVF_BUILD = range(12)
+SEARCH_FILTER, SEARCH_MASK, SEARCH_AFTER, SEARCH_EXACT = 1, 2, 4, 8     # flag bits of OP_SEARCH
 ENC_BATCH_SEQS = 256          # sequences per encoder batch = the unit dealt to a rank (BASELINE configs[2]: batch 256)
 HDR_WORDS = 16
 MAX_Q = 32
@@ -147,11 +151,19 @@ class HipServingShard:
 
     strided_records = True     # search_packed(out=...) writes in place, merge_packed(stride_bytes=...) reads records with tails
 
+    def build_ivf(self, nlist: int, nprobe: int, dtype: str = "f32", group=None) -> None:
+        """This rank's part of OP_IVF_BUILD: shared centroids (trained by all ranks of ``group`` together), an IVF over
+        this shard's rows.  The shard's index must be an ``ivf.IvfBackedIndex`` (``hip_shard_factory`` makes one)."""
+        self.index.policy.nprobe = max(1, int(nprobe))
+        self.index.build_ivf(nlist=int(nlist), group=group, dtype=dtype)
+
     def search_packed(self, queries: torch.Tensor, k: int, filt: Optional[torch.Tensor], mask: Optional[torch.Tensor],
-                      after: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, out: Optional[torch.Tensor] = None
-                      ) -> torch.Tensor:
+                      after: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, out: Optional[torch.Tensor] = None,
+                      exact: bool = False, nprobe: int = 0) -> torch.Tensor:
         """``after`` = (scores f32 [nq], LOCAL row ordinals i64 [nq]): rank only the rows strictly behind them.
-        ``out``: a caller-owned buffer of at least the record size (8-byte aligned) to write the record into."""
+        ``out``: a caller-owned buffer of at least the record size (8-byte aligned) to write the record into.
+        ``exact``: scan the flat shard even when it has an IVF (the passes of a k > 32 search); ``nprobe``: lists per
+        query of an IVF probe (0 = the shard's own default) — a query-time parameter, so it travels with the command."""
         nq = queries.shape[0]
         ids_off, size = self.record_bytes(nq, k)
         rec = torch.empty((size,), dtype=torch.uint8, device=self.device) if out is None else out
@@ -163,9 +175,12 @@ class HipServingShard:
                                            d_q_filter_mask_ptr=mask.data_ptr() if mask is not None else 0)
             self._keep = (a_s, a_r)      # alive until the stream has consumed them
             return rec
+        kw = {}
+        if hasattr(self.index, "build_ivf"):
+            kw = {"exact": bool(exact), "nprobe": int(nprobe) or None}
         self.index.search_device(queries.data_ptr(), nq, k, rec.data_ptr(), rec.data_ptr() + ids_off, id_base=0,
                                  d_q_filter_ptr=filt.data_ptr() if filt is not None else 0,
-                                 d_q_filter_mask_ptr=mask.data_ptr() if mask is not None else 0)
+                                 d_q_filter_mask_ptr=mask.data_ptr() if mask is not None else 0, **kw)
         return rec
 
     def merge_packed(self, gathered: torch.Tensor, world: int, nq: int, k: int, stride_bytes: int = 0
@@ -385,10 +400,12 @@ class ShardServer:
                     ext = self.extents[code]
                     a_r = torch.tensor([ext.ordinal_upto(int(g)) for g in a_g], dtype=torch.int64)
                     after = (a_s.clone(), a_r)
+                ivf_kw = {"exact": bool(flags & SEARCH_EXACT), "nprobe": int(hdr[5])} if hasattr(shard, "build_ivf") else {}
                 if getattr(shard, "strided_records", False):
-                    shard.search_packed(q, k, filt, mask, after, out=buf)
+                    shard.search_packed(q, k, filt, mask, after, out=buf, **ivf_kw)
                 else:
-                    rec = shard.search_packed(q, k, filt, mask, after) if after is not None else shard.search_packed(q, k, filt, mask)
+                    rec = shard.search_packed(q, k, filt, mask, after, **ivf_kw) if (after is not None or ivf_kw) \
+                        else shard.search_packed(q, k, filt, mask)
                     buf[:size].copy_(rec)
             except Exception as e:
                 ok = failed("search", e)
@@ -455,6 +472,22 @@ class ShardServer:
             except Exception as e:
                 ok = failed("encode", e)
             self._verdict(ok, "encode")
+            return None
+        if op == OP_IVF_BUILD:
+            nlist, nprobe, dtype = int(hdr[2]), int(hdr[3]), "bf16" if int(hdr[4]) == 1 else "f32"
+            # the training is itself collective (all-reduce of the k-means sums over the data group): a rank that cannot
+            # even start must not leave the others waiting in it, so every rank first says whether it can
+            try:
+                if not hasattr(shard, "build_ivf"):
+                    raise RuntimeError("this shard type has no IVF")
+            except Exception as e:
+                ok = failed("ivf build", e)
+            self._verdict(ok, "ivf build (precondition)")
+            try:
+                shard.build_ivf(nlist, nprobe, dtype, group=self.group if self.world > 1 else None)
+            except Exception as e:
+                ok = failed("ivf build", e)
+            self._verdict(ok, "ivf build")
             return None
         if op == OP_DELETE:
             try:
@@ -579,6 +612,8 @@ class ShardedFront:
                     idx._owner_gid.append(int(g))
                     idx._owner_rank.append(int(r))
             idx._runs = [[int(g), int(r), int(n)] for g, r, n in man["runs"]]
+            ivf = man.get("ivf") or {}
+            idx._ivf_covered, idx._nprobe = int(ivf.get("covered", 0)), int(ivf.get("nprobe", 0))
             return idx
 
     def shutdown(self) -> None:
@@ -606,6 +641,9 @@ class ShardedIndex:
         self._owner_rank: List[int] = []    # ... and the rank that holds each run
         self._runs: List[List[int]] = []    # every appended run (gid base, rank, rows): what a saved manifest keeps
         self._deleted = set()
+        self._ivf_covered = 0               # global rows the shards' IVFs were built over (0 = no IVF)
+        self._ivf_builds = 0
+        self._nprobe = 0                    # lists per query and shard of an IVF probe (0 = the shards' default)
 
     # ---- bookkeeping
     @property
@@ -623,7 +661,37 @@ class ShardedIndex:
     @property
     def epoch(self) -> Tuple[int, int]:
         """(ids ever given out, rows tombstoned) from rank 0's own bookkeeping — no collective (``prefetch.index_epoch``)."""
-        return self._rows, len(self._deleted)
+        return self._rows, len(self._deleted), self._ivf_builds
+
+    # ---- IVF (every shard builds its own over shared centroids; ivf.IvfPolicy decides when)
+    def build_ivf(self, nlist: Optional[int] = None, nprobe: Optional[int] = None, dtype: Optional[str] = None) -> None:
+        """Collective build of an IVF-``nlist`` on every shard (``OP_IVF_BUILD``); searches of k <= 32 then probe
+        ``nprobe`` lists per shard + the rows appended since, and equal the flat result at nprobe = nlist."""
+        from . import config
+        nlist = int(nlist or config.RASS_IVF_NLIST)
+        if nlist <= 0:
+            raise ValueError("build_ivf needs nlist > 0 (RASS_IVF_NLIST)")
+        code = 1 if (dtype or config.RASS_IVF_DTYPE) == "bf16" else 0
+        with self.front.lock:
+            s = self.front.server
+            self._nprobe = max(1, int(nprobe or config.RASS_IVF_NPROBE))
+            s.execute(s.post([OP_IVF_BUILD, self.code, nlist, self._nprobe, code]))
+            self._ivf_covered = self._rows
+            self._ivf_builds += 1
+
+    def _maybe_rebuild(self) -> None:
+        """After an append: ``IvfPolicy`` on the GLOBAL row count (rank 0 decides for all shards)."""
+        from . import config
+        if config.RASS_IVF_NLIST <= 0:
+            return
+        from .ivf import IvfPolicy
+        p = IvfPolicy.from_config()
+        p.min_rows = max(p.min_rows, p.nlist * self.front.server.world)      # every shard needs nlist training rows
+        if p.due(self._rows, self._ivf_covered):
+            try:
+                self.build_ivf()
+            except Exception as e:      # the rows are in; searches stay exact (or on the old IVF + delta)
+                logger.error(f"IVF (re)build of {self.name!r} failed: {e}")
 
     def _owner(self, gid: int) -> int:
         """The rank that holds global row ``gid``; -1 for a HOLE: an id an append consumed before it failed."""
@@ -685,6 +753,7 @@ class ShardedIndex:
                     raise
                 committed.append((self._rows, m))
                 self._commit_run(owner, m)           # only after the verdict
+            self._maybe_rebuild()
             return first
 
     @property
@@ -746,6 +815,7 @@ class ShardedIndex:
                 if failed_ranks is not None:
                     self._rollback(committed)
                     raise failure
+            self._maybe_rebuild()
             return first
 
     # ---- persistence (docstore.IndexState.save / load call these through the FlatIndex surface)
@@ -761,7 +831,8 @@ class ShardedIndex:
                 raise ValueError("path too long")
             s.execute(s.post([OP_SAVE, self.code, raw.size], raw))
             man = {"format": "rass-sharded-1", "world": s.world, "base": os.path.basename(base), "rows": self._rows,
-                   "batches": self._batches, "runs": self._runs, "deleted": sorted(self._deleted)}
+                   "batches": self._batches, "runs": self._runs, "deleted": sorted(self._deleted),
+                   "ivf": {"covered": self._ivf_covered, "nprobe": self._nprobe}}
             with open(path, "w", encoding="utf-8") as f:
                 json.dump(man, f)
                 f.flush()
@@ -773,7 +844,8 @@ class ShardedIndex:
             with open(manifest_path, encoding="utf-8") as f:
                 man = json.load(f)
             d = os.path.dirname(manifest_path) or "."
-            return [ShardServer.shard_file(os.path.join(d, man["base"]), r, int(man["world"])) for r in range(int(man["world"]))]
+            files = [ShardServer.shard_file(os.path.join(d, man["base"]), r, int(man["world"])) for r in range(int(man["world"]))]
+            return files + [f + ".ivf" for f in files]      # a shard with an IVF saves it next to its rows
         except (OSError, ValueError, KeyError):
             return []
 
@@ -825,6 +897,8 @@ class ShardedIndex:
             # k > 32: passes of <= 32; pass p asks every shard for its best rows strictly behind pass p-1's last
             # global hit (score desc, id asc) — the single-index multipass of rass_index_search_ex, across shards
             done = 0
+            if k > MAX_K:
+                flags |= SEARCH_EXACT                    # every pass of a deep search scans the flat shards
             while done < k:
                 kk = min(MAX_K, k - done)
                 pf = flags
@@ -838,7 +912,7 @@ class ShardedIndex:
                     payload[off + 3 * MAX_Q * 4:off + 3 * MAX_Q * 4 + b * 8] = last_i.view(np.uint8)
                 with self.front.lock:
                     # an unfiltered first pass moves only its queries; filters / continuation bounds sit behind them
-                    sc, ids = s.execute(s.post([OP_SEARCH, self.code, b, kk, pf], payload,
+                    sc, ids = s.execute(s.post([OP_SEARCH, self.code, b, kk, pf, self._nprobe], payload,
                                                payload_len=b * self.dim * 4 if pf == 0 else None))
                 out_s[a:a + b, done:done + kk] = sc
                 out_i[a:a + b, done:done + kk] = ids
@@ -882,7 +956,10 @@ def hip_shard_loader(device_index: int, dim: int) -> Callable[[str, str], "HipSe
     from .engine import Engine
 
     def load(name: str, path: str) -> HipServingShard:
-        return HipServingShard(Engine.get(device_index, dim).load_index(name, path))
+        from .ivf import IvfBackedIndex, IvfPolicy
+        from . import config
+        return HipServingShard(IvfBackedIndex.load(Engine.get(device_index, dim), name, path,
+                                                   IvfPolicy.manual(config.RASS_IVF_NPROBE)))
     return load
 
 
@@ -891,5 +968,9 @@ def hip_shard_factory(device_index: int, dim: int) -> Callable[[str], HipServing
     from .engine import Engine
 
     def make(name: str) -> HipServingShard:
-        return HipServingShard(Engine.get(device_index, dim).open_index(name))
+        # an IvfBackedIndex with no policy of its own: it is a plain flat shard until rank 0 posts OP_IVF_BUILD
+        from .ivf import IvfBackedIndex, IvfPolicy
+        from . import config
+        return HipServingShard(IvfBackedIndex(Engine.get(device_index, dim).open_index(name),
+                                              IvfPolicy.manual(config.RASS_IVF_NPROBE)))
     return make

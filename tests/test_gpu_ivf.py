@@ -168,7 +168,7 @@ def test_ivf_save_load_roundtrip(built, tmp_path):
         IvfIndex.load(eng, bad2)
     # a list table that points outside the slab is refused too (it would send the probe out of bounds)
     import struct
-    hdr = 8 + 4 * 4 + 8 * 5
+    hdr = 8 + 4 * 4 + 8 * 5 + 8            # header + (file versions 3 / 4) the covered source rows
     tampered = bytearray(raw)
     tampered[hdr:hdr + 4] = struct.pack("<i", 5)            # list 0 no longer starts at tile 0
     bad3 = str(tmp_path / "tampered.ivf")

@@ -51,6 +51,14 @@ def main():
     ap.add_argument("--weak", action="store_true",
                     help="N > 1: weak scaling instead (every GPU holds --rows-per-gpu rows, corpus = N x that)")
     ap.add_argument("--no-ingest", action="store_true", help="skip the encoder (configs[2]) leg of the N = 1 line")
+    ap.add_argument("--no-ivf", action="store_true", help="skip the IVF (configs[4] per-GPU share) leg of the N = 1 line")
+    ap.add_argument("--mode", choices=["flat", "ivf"], default="flat",
+                    help="ivf (N >= 1): BASELINE configs[4] — IVF-4096 over --ivf-rows clustered rows PER GPU (12.5 M = the "
+                         "100 M-row corpus / 8), shared centroids, per-shard probes, one all-gather of per-shard top-k")
+    ap.add_argument("--ivf-rows", type=int, default=12_500_000, help="rows per GPU of the IVF leg / mode")
+    ap.add_argument("--ivf-nlist", type=int, default=4096)
+    ap.add_argument("--ivf-nprobe", type=int, default=8, help="lists probed per query and shard in --mode ivf's timed region")
+    ap.add_argument("--ivf-queries", type=int, default=1024, help="queries of the IVF leg's recall / rate sweep")
     ap.add_argument("--ingest-batches", type=int, default=4, help="timed 256 x 512-token forwards of the ingest leg")
     ap.add_argument("--dim", type=int, default=1024)
     ap.add_argument("--batch", type=int, default=32, help="queries per scan launch (<= 32)")
@@ -101,6 +109,15 @@ def main():
 
     from rassengine_amd.dist import HipShard, PeerMergeSearch, ShardedSearch, shard_bounds
     from rassengine_amd.engine import Engine, scan_kernel_name
+
+    if args.mode == "ivf":
+        result = ivf_mode(np, torch, dist, args, world, rank, local_rank, dev, coll)
+        if rank == 0:
+            print(json.dumps(result), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     dim, B, k = args.dim, args.batch, args.k
     if args.rows_global < 0:
@@ -306,6 +323,16 @@ def main():
         eng.synchronize()
         result["ingest"] = ingest_leg(np, torch, local_rank, args.ingest_batches)
 
+    if rank == 0 and world == 1 and not args.no_ivf and not bf16 and not args.prefilter and dim == 1024:
+        # BASELINE configs[4] at one GPU's share (12.5 M of the 100 M rows), outside the timed region: the search index is
+        # dropped first (the IVF leg holds 51 GB of rows + the IVF's own 51 GB copy)
+        eng.synchronize()
+        eng.drop_index("bench")
+        try:
+            result["ivf"] = ivf_leg(np, torch, local_rank, args)
+        except Exception as e:      # the headline must not die with an auxiliary leg
+            result["ivf"] = {"error": f"{type(e).__name__}: {e}"}
+
     if rank == 0:
         print(json.dumps(result), flush=True)
     if isinstance(search, PeerMergeSearch):
@@ -428,6 +455,238 @@ def ingest_leg(np, torch, device, timed_batches):
     finally:
         eng2.close()
         enc.close()
+
+
+IVF_CENTRES, IVF_SIGMA, IVF_SEED = 8192, 1.0, 7       # SURVEY 8d cfg 5: 8 192 Gaussian centres (seed 7) + sigma-noise, normalised
+
+
+def _ivf_fill(torch, flat, eng, rows, dev, iid, seed, centres):
+    """`rows` synthetic rows straight into the flat index's slab (device-resident, 262 144 per add)."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    dim = centres.shape[1]
+    for lo in range(0, rows, 262144):
+        n = min(262144, rows - lo)
+        if iid:
+            x = torch.randn((n, dim), generator=g, device=dev)
+        else:
+            lab = torch.randint(0, centres.shape[0], (n,), generator=g, device=dev)
+            x = centres[lab] + IVF_SIGMA * torch.randn((n, dim), generator=g, device=dev) / dim ** 0.5
+        torch.cuda.synchronize()
+        flat.add_device(x.data_ptr(), n, normalize=True)
+        eng.synchronize()
+
+
+def _ivf_queries(torch, n, dev, iid, centres, seed=4321):
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    dim = centres.shape[1]
+    if iid:
+        return torch.randn((n, dim), generator=g, device=dev).contiguous()
+    lab = torch.randint(0, centres.shape[0], (n,), generator=g, device=dev)
+    return (centres[lab] + IVF_SIGMA * torch.randn((n, dim), generator=g, device=dev) / dim ** 0.5).contiguous()
+
+
+def _ivf_centres(torch, dev, dim):
+    g = torch.Generator(device=dev)
+    g.manual_seed(IVF_SEED)
+    c = torch.randn((IVF_CENTRES, dim), generator=g, device=dev)
+    return c / c.norm(dim=1, keepdim=True)
+
+
+def _ivf_one_corpus(np, torch, eng, dev, rows, nlist, nq, k, iid, nprobes):
+    """Generate, build (two-level k-means + assignment + list-ordered copy), then per nprobe: queries/s over `nq` queries in
+    32-query launch groups (hipEvents on the engine stream), recall@k against the flat scan of the SAME shard, the rows the
+    fine scans touch (host API, 4 groups sampled) and probed bytes / time against the 8 TB/s HBM peak."""
+    from rassengine_amd.engine import HipTimer
+    from rassengine_amd.ivf import IvfIndex, train_centroids
+    dim, B = 1024, 32
+    centres = _ivf_centres(torch, dev, dim)
+    name = "bench-ivf-iid" if iid else "bench-ivf"
+    flat = eng.open_index(name, capacity_rows=rows)
+    t0 = time.perf_counter()
+    _ivf_fill(torch, flat, eng, rows, dev, iid, IVF_SEED + 1, centres)
+    gen_s = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    cent = train_centroids(flat, nlist, train_rows=0, iters=10, seed=1)
+    torch.cuda.synchronize()
+    train_s = time.perf_counter() - t0
+    ivf = IvfIndex.build(flat, nlist=nlist, centroids=cent)
+    build_s = time.perf_counter() - t0
+    try:
+        q = _ivf_queries(torch, nq, dev, iid, centres)
+        out_s = torch.empty((B, k), device=dev)
+        truth = torch.empty((nq, k), dtype=torch.int64, device=dev)
+        stream = eng.stream
+        tm = HipTimer()
+        tm.start(stream)
+        for b in range(0, nq, B):
+            flat.search_device(q[b:b + B].data_ptr(), B, k, out_s.data_ptr(), truth[b:b + B].data_ptr())
+        tm.stop(stream)
+        flat_ms = tm.elapsed_ms()
+        truth_h = truth.cpu().numpy()
+        got = torch.empty((nq, k), dtype=torch.int64, device=dev)
+        sweep = []
+        stride = flat.row_stride
+        for nprobe in nprobes:
+            for b in range(0, min(nq, 4 * B), B):
+                ivf.search_device(q[b:b + B].data_ptr(), B, k, nprobe, out_s.data_ptr(), got[b:b + B].data_ptr())
+            eng.synchronize()
+            tm.start(stream)
+            for b in range(0, nq, B):
+                ivf.search_device(q[b:b + B].data_ptr(), B, k, nprobe, out_s.data_ptr(), got[b:b + B].data_ptr())
+            tm.stop(stream)
+            ms = tm.elapsed_ms()
+            got_h = got.cpu().numpy()
+            recall = float(np.mean([len(set(got_h[r]) & set(truth_h[r])) / k for r in range(nq)]))
+            _, _, scanned = ivf.search(q[:4 * B].cpu().numpy(), k, nprobe)
+            per_batch = scanned / 4
+            us = ms / (nq / B) * 1e3
+            probed = per_batch * stride * 4 + nlist * stride * 4          # SURVEY 8d: fine scans + the coarse scan per batch
+            gbps = probed / (us * 1e-6) / 1e9
+            sweep.append({"nprobe": nprobe, "queries_per_s": round(nq / ms * 1e3, 1), "recall_at_10": round(recall, 4),
+                          "us_per_batch": round(us, 1), "scanned_rows_per_batch": round(per_batch),
+                          "scanned_fraction": round(per_batch / rows, 5),
+                          "roofline": {"bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                       "frac": round(gbps / HBM_PEAK_GBPS, 4), "bytes_per_batch": int(probed)}})
+        sizes = ivf.list_sizes
+        return {"rows": rows, "data": "iid N(0,1) rows (the flagged WORST case: no cluster structure to find)" if iid else
+                f"{IVF_CENTRES} Gaussian centres (seed {IVF_SEED}) + sigma {IVF_SIGMA} noise, normalised",
+                "gen_s": round(gen_s, 1), "train_s": round(train_s, 1), "build_s": round(build_s, 1),
+                "list_len_mean": round(float(sizes.mean()), 1), "list_len_max": int(sizes.max()),
+                "empty_lists": int((sizes == 0).sum()), "flat_queries_per_s_same_shard": round(nq / flat_ms * 1e3, 1),
+                "sweep": sweep}
+    finally:
+        ivf.close()
+        eng.drop_index(name)
+
+
+def ivf_leg(np, torch, device, args):
+    """BASELINE configs[4] / SURVEY 8d cfg 5 at ONE GPU's share: IVF-4096 (two-level k-means) over 12.5 M x 1024 fp32 rows,
+    nprobe sweep with recall@10 against the flat scan of the same shard; iid rows of the same size as the worst case."""
+    from rassengine_amd.engine import Engine
+    dev = torch.device("cuda", device)
+    eng = Engine(device=device, dim=1024)
+    nprobes = (1, 2, 8, 32, 128)
+    t0 = time.perf_counter()
+    try:
+        out = {"workload": f"BASELINE configs[4] per-GPU share: IVF-{args.ivf_nlist} over {args.ivf_rows} x 1024-d fp32 rows "
+                           f"(100 M / 8), top-{args.k}, 32 queries per launch group, {args.ivf_queries} queries per point; "
+                           "recall_at_10 = overlap with the exact flat scan of the same shard",
+               "nlist": args.ivf_nlist, "training": "two-level spherical k-means (4 x nlist fine lists), 10 iterations, 1 M-row sample",
+               "clustered": _ivf_one_corpus(np, torch, eng, dev, args.ivf_rows, args.ivf_nlist, args.ivf_queries, args.k,
+                                            False, nprobes)}
+        out["iid_worst_case"] = _ivf_one_corpus(np, torch, eng, dev, args.ivf_rows, args.ivf_nlist, args.ivf_queries,
+                                                args.k, True, nprobes)
+        out["leg_s"] = round(time.perf_counter() - t0, 1)
+        return out
+    finally:
+        eng.close()
+
+
+def ivf_mode(np, torch, dist, args, world, rank, local_rank, dev, coll):
+    """`--mode ivf`: BASELINE configs[4] — every GPU holds --ivf-rows clustered rows (12.5 M = 100 M / 8: at N = 8 this IS the
+    100 M-row corpus; at smaller N the corpus is N x 12.5 M, because a 50 M-row shard plus its IVF copy does not fit one
+    GPU), centroids trained by all ranks together (k-means sums all-reduced), every rank probes its own lists, ONE
+    all-gather of per-shard top-k + merge.  A step = 1 024 queries in 32 launch groups.  Outside the timed region: recall@10
+    against the FLAT sharded search of the same shards, the N > 1 self-proof, the per-batch probed bytes."""
+    from rassengine_amd.dist import HipShard, ShardedSearch
+    from rassengine_amd.engine import Engine
+    from rassengine_amd.ivf import IvfIndex, IvfShard, train_centroids
+    dim, B, k, nlist, nprobe = 1024, 32, args.k, args.ivf_nlist, args.ivf_nprobe
+    rows = args.ivf_rows
+    row_lo = rank * rows
+    eng = Engine(device=local_rank, dim=dim)
+    centres = _ivf_centres(torch, dev, dim)
+    flat = eng.open_index("bench-ivf-shard", capacity_rows=rows)
+    _ivf_fill(torch, flat, eng, rows, dev, False, IVF_SEED + 1 + rank, centres)
+    t0 = time.perf_counter()
+    cent = train_centroids(flat, nlist, train_rows=0, iters=10, seed=1)        # collective: shared centroids
+    ivf = IvfIndex.build(flat, nlist=nlist, centroids=cent)
+    torch.cuda.synchronize()
+    build_s = time.perf_counter() - t0
+    shard = IvfShard(ivf, id_base=row_lo, nprobe=nprobe)        # switches the engine to torch's current stream
+    search = ShardedSearch(shard)
+    LPS = args.launches_per_step
+    pool = _ivf_queries(torch, args.query_pool, dev, False, centres)           # same on every rank (same seed)
+    n_batches = args.query_pool // B
+    q_buf = torch.empty((B, dim), device=dev)
+
+    def step(i):
+        out = None
+        for j in range(LPS):
+            g = (i * LPS + j) % n_batches
+            if rank == 0:
+                q_buf.copy_(pool[g * B:(g + 1) * B])
+            out = search.search(q_buf, k)
+        return out
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    eng.kernel_timing_begin(args.steps * LPS)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    scan_ms, scan_launches = eng.kernel_timing_end()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    qps = B * LPS * args.steps / elapsed
+    # probed rows per launch group on THIS shard (host API reports them), 8 groups sampled
+    _, _, scanned = ivf.search(pool[:8 * B].cpu().numpy(), k, nprobe)
+    per_batch = scanned / 8
+    stride = flat.row_stride
+    fine_bytes = per_batch * stride * 4
+    achieved = fine_bytes * scan_launches / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+    rows_global = rows * world
+    result = {
+        "metric": "queries/sec, IVF cosine top-10 over N x 1024-d fp32 corpus in HBM (BASELINE configs[4])",
+        "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "row_queries_per_s": round(qps * rows_global, 1), "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{rows_global} x {dim}-d IVF-{nlist} cosine top-{k}, {world} x MI355X, nprobe {nprobe} "
+                               f"(BASELINE configs[4]: {rows} rows per GPU = 100 M / 8; the full 100 M at 8 GPUs)",
+                   "rows_per_gpu": rows, "rows_global": rows_global, "dim": dim, "k": k, "query_batch": B, "nlist": nlist,
+                   "nprobe": nprobe, "queries_per_step": B * LPS, "launch_groups_per_step": LPS,
+                   "data": f"{IVF_CENTRES} Gaussian centres (seed {IVF_SEED}) + sigma {IVF_SIGMA} noise, normalised",
+                   "cross_shard_exchange": f"{coll} all-gather" if world > 1 else None,
+                   "sharding": f"row-sharded x{world}, shared centroids, {coll} all-gather merge" if world > 1 else "single shard",
+                   "train_and_build_s": round(build_s, 1)},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                     "kernel": "scan_topk_f32_kernel<8, 2, 2, false> (the IVF fine scan over the batch's probed lists)",
+                     "bytes_per_launch": int(fine_bytes), "scanned_rows_per_batch": round(per_batch),
+                     "avg_launch_us": round(scan_ms / max(scan_launches, 1) * 1e3, 2), "launches": scan_launches},
+    }
+    # recall@10 against the exact FLAT sharded search of the same shards (all ranks take part), 256 queries
+    flat_search = ShardedSearch(HipShard(flat, id_base=row_lo))
+    hits = total = 0
+    for b in range(0, 256, B):
+        qb = pool[b:b + B].contiguous().clone()
+        _, ti = flat_search.search(qb, k)
+        _, gi = search.search(qb, k)
+        torch.cuda.synchronize()
+        th, gh = ti.cpu().numpy(), gi.cpu().numpy()
+        hits += sum(len(set(gh[r]) & set(th[r])) for r in range(B))
+        total += B * k
+    result["recall_at_10_vs_flat_shards"] = round(hits / total, 4)
+    if world > 1:
+        shard.ivf.engine.set_stream(int(torch.cuda.current_stream(dev).cuda_stream))
+        result.update(multi_gpu_proof(np, torch, dist, search, shard, pool, dev, rank, world, local_rank, row_lo, rows, k, B,
+                                      scan_ms, scan_launches, int(fine_bytes), True))
+    ivf.close()
+    eng.close()
+    return result
 
 
 def pmc_traffic(kernel: str, bytes_per_launch: int):

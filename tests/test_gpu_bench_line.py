@@ -26,7 +26,8 @@ def _line(cmd, env=None, timeout=900):
 
 def test_single_gpu_line_has_roofline_cpu_baseline_and_ingest(gpu):
     j = _line([sys.executable, "bench.py", "--steps", "3", "--warmup", "2", "--cpu-sample-rows", "50000",
-               "--cpu-hnsw-rows", "2000", "--ingest-batches", "2"])
+               "--cpu-hnsw-rows", "2000", "--ingest-batches", "2", "--ivf-rows", "400000", "--ivf-nlist", "256",
+               "--ivf-queries", "256"])
     assert j["n_gpus"] == 1 and j["scaling"] == "weak" and j["dtype"] == "f32" and j["vs_baseline"] is None
     assert "configs[1]" in j["config"]["workload"] and j["config"]["rows_global"] == 1_000_000
     rf = j["roofline"]
@@ -38,6 +39,23 @@ def test_single_gpu_line_has_roofline_cpu_baseline_and_ingest(gpu):
     assert ing["last_batch_rows_finite_and_unit_norm"] is True and ing["rows_in_index"] == 4 * 256
     assert ing["chunks_per_s"] > 1500 and 0.2 < ing["roofline"]["frac"] < 1.0
     assert abs(ing["tflops"] - ing["flop_per_batch"] / (ing["ms_per_batch"] * 1e-3) / 1e12) < 1.0
+    # the IVF leg (BASELINE configs[4] at one GPU's share; a small share here): nprobe sweep with recall against the flat
+    # scan of the same shard and probed bytes / time against the HBM peak, clustered rows + iid rows as the worst case
+    ivf = j["ivf"]
+    assert "error" not in ivf and ivf["nlist"] == 256
+    for key in ("clustered", "iid_worst_case"):
+        c = ivf[key]
+        assert c["rows"] == 400000 and [p["nprobe"] for p in c["sweep"]] == [1, 2, 8, 32, 128]
+        for p in c["sweep"]:
+            rf = p["roofline"]
+            assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and 0 < rf["frac"] < 1.0 and p["queries_per_s"] > 0
+            assert abs(rf["bytes_per_batch"] - (p["scanned_rows_per_batch"] * 4096 + 256 * 4096)) <= 4096     # (rounded mean)
+        rec = [p["recall_at_10"] for p in c["sweep"]]
+        assert all(b >= a - 0.02 for a, b in zip(rec, rec[1:])), rec
+        assert rec[-1] >= (0.95 if key == "clustered" else 0.3), rec        # iid rows have no lists worth probing: the worst case
+    # cluster structure is what an IVF finds: at every nprobe the clustered corpus recalls more than the iid one
+    assert all(c["recall_at_10"] > w["recall_at_10"] for c, w in zip(ivf["clustered"]["sweep"], ivf["iid_worst_case"]["sweep"]))
+    assert ivf["clustered"]["sweep"][0]["queries_per_s"] > ivf["clustered"]["flat_queries_per_s_same_shard"]
 
 
 def test_two_rank_line_defaults_to_configs3_and_proves_itself(gpu):
@@ -53,3 +71,22 @@ def test_two_rank_line_defaults_to_configs3_and_proves_itself(gpu):
     assert j["sharded_equals_merge_of_shards"] is True
     assert j["roofline_per_rank"]["avg_launch_us_min"] > 0
     assert "ingest" not in j and "cpu_baseline" not in j                # rank 0 at N = 1 only
+
+
+def test_two_rank_ivf_mode_line(gpu):
+    """`--mode ivf` (BASELINE configs[4]): shared centroids trained by both ranks, per-shard probes, one all-gather; the line
+    proves who took part, that the merged result is the merge of the shards' lists, and reports recall against the FLAT
+    sharded search of the same shards."""
+    port = 29900 + os.getpid() % 90
+    j = _line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2", "--mode", "ivf", "--steps", "2",
+               "--warmup", "1", "--ivf-rows", "300000", "--ivf-nlist", "128", "--ivf-nprobe", "128", "--launches-per-step", "8"],
+              env={"RASS_BENCH_SHARE_GPU": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and "configs[4]" in j["config"]["workload"]
+    assert j["config"]["rows_global"] == 600000 and j["config"]["nlist"] == 128 and j["config"]["nprobe"] == 128
+    assert j["ranks_seen"] == 2 and [r["rank"] for r in j["ranks"]] == [0, 1] and j["ranks"][1]["row_lo"] == 300000
+    assert j["sharded_equals_merge_of_shards"] is True
+    assert j["recall_at_10_vs_flat_shards"] == 1.0       # every list probed on every shard == the flat sharded search
+    rf = j["roofline"]
+    assert rf["bound"] == "hbm" and rf["launches"] == 2 * 8 and 0 < rf["frac"] < 1.0
+    assert abs(rf["bytes_per_launch"] - rf["scanned_rows_per_batch"] * 4096) <= 4096

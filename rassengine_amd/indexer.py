@@ -218,8 +218,14 @@ class HipIndexer:
         if q.ndim == 1:
             q = q[None, :]
         q = np.ascontiguousarray(q[:1])  # the reference searches row 0 only: (…)[0].tolist(), 1537
-        pid = patient_id if patient_id else _term_from_filter(filter_clause, "patientId")
-        dtype = doc_type if doc_type else _term_from_filter(filter_clause, "doc_type")
+        # the reference ANDs its filter list (filter_clause, then term: patientId, then — hybrid_structured_search — term:
+        # doc_type, 1543-1550 / 1760-1765): two different values for one field match nothing
+        f_pid, f_dtype = _term_from_filter(filter_clause, "patientId"), _term_from_filter(filter_clause, "doc_type")
+        if (patient_id and f_pid is not None and str(f_pid) != str(patient_id)) or \
+                (doc_type and f_dtype is not None and str(f_dtype) != str(doc_type)):
+            return None
+        pid = patient_id if patient_id else f_pid
+        dtype = doc_type if doc_type else f_dtype
         flt = st.filter_for(pid, dtype)
         if flt is None:
             return None  # term filter on a value that was never indexed

@@ -350,6 +350,15 @@ class ShardServer:
                 f = self.shard_file(base, self.rank, self.world)
                 self.shards[code].save(f + ".tmp")
                 os.replace(f + ".tmp", f)
+                # this rank's extent table travels with its shard file: an append that failed half-way may have left
+                # (tombstoned) rows in the shard that no run of the manifest accounts for, so ordinals are NOT the
+                # cumulative sum of the rank's runs in general
+                ext = self.extents[code]
+                with open(f + ".ext.tmp", "w", encoding="utf-8") as fh:
+                    json.dump({"gid": ext.gid, "ordinal": ext.ordinal, "n": ext.n, "rows": int(self.shards[code].rows)}, fh)
+                    fh.flush()
+                    os.fsync(fh.fileno())
+                os.replace(f + ".ext.tmp", f + ".ext")
             except Exception as e:       # reported through the verdict: the ranks must stay in step
                 ok = failed("shard save", e)
             self._verdict(ok, "shard save")
@@ -362,15 +371,31 @@ class ShardServer:
                 name = bytes(self._payload(nlen, plen).cpu().numpy()).decode("utf-8")
                 if self.loader is None:
                     raise RuntimeError("serving.start() was given no shard_loader")
-                shard = self.loader(name, self.shard_file(base, self.rank, self.world))
+                sf = self.shard_file(base, self.rank, self.world)
+                shard = self.loader(name, sf)
                 ext = Extents()
-                ordinal = 0
-                for gid, owner, n in runs:      # this rank's runs, in the order it appended them
-                    if int(owner) == self.rank:
-                        ext.append(int(gid), ordinal, int(n))
-                        ordinal += int(n)
-                if ordinal != int(shard.rows):
-                    raise RuntimeError(f"shard file holds {int(shard.rows)} rows, the manifest gives this rank {ordinal}")
+                mine = [(int(gid), int(n)) for gid, owner, n in runs if int(owner) == self.rank]
+                if os.path.exists(sf + ".ext"):
+                    # the table this rank saved: ordinals as they really are (rows a failed append left behind included)
+                    with open(sf + ".ext", encoding="utf-8") as fh:
+                        tab = json.load(fh)
+                    for g, o, n in zip(tab["gid"], tab["ordinal"], tab["n"]):
+                        ext.append(int(g), int(o), int(n))
+                    covered = sorted((g, n) for g, n in zip(ext.gid, ext.n))
+                    merged = Extents()
+                    for g, n in mine:           # the manifest's runs of this rank, coalesced the same way
+                        merged.append(g, merged.ordinal[-1] + merged.n[-1] if merged.gid else 0, n)
+                    if int(tab.get("rows", -1)) != int(shard.rows) or sum(n for _, n in covered) != sum(n for _, n in mine) or \
+                            any(ext.ordinal_of(g) is None or ext.ordinal_of(g + n - 1) is None for g, n in mine) or \
+                            (ext.gid and max(o + n for o, n in zip(ext.ordinal, ext.n)) > int(shard.rows)):
+                        raise RuntimeError("the shard's extent table disagrees with the manifest's runs or the shard file")
+                else:                           # saved before round 4: ordinals = the cumulative sum of the rank's runs
+                    ordinal = 0
+                    for gid, n in mine:
+                        ext.append(gid, ordinal, n)
+                        ordinal += n
+                    if ordinal != int(shard.rows):
+                        raise RuntimeError(f"shard file holds {int(shard.rows)} rows, the manifest gives this rank {ordinal}")
                 self.shards[code], self.extents[code] = shard, ext
             except Exception as e:
                 ok = failed("shard load", e)
@@ -845,7 +870,7 @@ class ShardedIndex:
                 man = json.load(f)
             d = os.path.dirname(manifest_path) or "."
             files = [ShardServer.shard_file(os.path.join(d, man["base"]), r, int(man["world"])) for r in range(int(man["world"]))]
-            return files + [f + ".ivf" for f in files]      # a shard with an IVF saves it next to its rows
+            return files + [f + ".ivf" for f in files] + [f + ".ext" for f in files]   # IVF + extent table next to the rows
         except (OSError, ValueError, KeyError):
             return []
 

@@ -200,7 +200,7 @@ def _worker(rank, world, port, out_dir):
         prefix = os.path.join(out_dir, "saved-user1")
         st.save(prefix)
         gen1 = sorted(f for f in os.listdir(out_dir) if ".g000001." in f)
-        assert len(gen1) == 1 + world, gen1                     # manifest + one shard file per rank
+        assert len(gen1) == 1 + 2 * world, gen1                 # manifest + per rank: the shard file and its extent table
         st.save(prefix)
         assert not [f for f in os.listdir(out_dir) if ".g000001." in f]
         st2 = IndexState.load("rass-idx-restored", prefix, front.load_index)
@@ -653,3 +653,72 @@ def _ivf_worker(rank, world, port, out_dir):
 def test_ivf_build_op_delta_and_exact_flag_on_two_ranks(tmp_path):
     mp.spawn(_ivf_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     assert os.path.exists(os.path.join(str(tmp_path), "ivf0.done")) and os.path.exists(os.path.join(str(tmp_path), "ivf1.done"))
+
+
+# ------------------------------------------------------------------ a PARTIAL append, then save / load
+def _partial_append_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from rassengine_amd import serving
+        D = 32
+
+        class PartialShard(OracleServingShard):
+            """An append that stores PART of its batch and then fails (a slab growth that ran out of memory half-way)."""
+
+            def add(self, vecs, tags, normalize, first_global_id):
+                if (tags.numpy() == 999).any():
+                    super().add(vecs[:3], torch.ones(3, dtype=torch.int32), normalize, first_global_id)
+                    raise MemoryError("slab growth failed after 3 rows")
+                return super().add(vecs, tags, normalize, first_global_id)
+
+        front = serving.start(lambda name: PartialShard(D), D, torch.device("cpu"), install_registry=False,
+                              shard_loader=lambda name, path: PartialShard.load(D, path))
+        if rank != 0:
+            open(os.path.join(out_dir, f"partial{rank}.done"), "w").write("ok")
+            return
+        rng = np.random.default_rng(5)
+        ix = front.open_index("partial")
+
+        def batch(n, tag=1):
+            return rng.standard_normal((n, D)).astype(np.float32), np.full(n, tag, dtype=np.int32)
+        va, ta = batch(20)
+        ix.add(va, ta)                                             # batch 0 -> rank 0
+        vb, tb = batch(20)
+        ix.add(vb, tb)                                             # batch 1 -> rank 1
+        vc, tc = batch(10)
+        ix.add(vc, tc)                                             # batch 2 -> rank 0
+        bad_v, bad_t = batch(7, tag=999)
+        with pytest.raises(serving.CollectiveFailure):
+            ix.add(bad_v, bad_t)                                   # batch 3 -> rank 1: stores 3 rows, then raises
+        assert ix.rows == 57 and ix.count == 50                    # the 7 ids are burnt, the 3 stored rows are tombstones
+        vd, td = batch(15)
+        ix.add(vd, td)                                             # batch 4 -> rank 0
+        ve, te = batch(12)
+        assert ix.add(ve, te) == 72                                # batch 5 -> rank 1: its ordinals start BEHIND the 3 dead rows
+        q = np.concatenate([ve[4:5] * 2.0, vb[7:8], bad_v[1:2], rng.standard_normal((3, D)).astype(np.float32)])
+        before = ix.search(q, 6)
+        assert int(before[1][0, 0]) == 72 + 4 and int(before[1][1, 0]) == 20 + 7
+        assert int(before[1][2, 0]) not in range(50, 57)           # a row of the failed batch is never a hit
+        row_e = ix.get_row(72 + 4)
+        man = os.path.join(out_dir, "partial.manifest")
+        ix.save(man)
+        assert os.path.exists(os.path.join(out_dir, "partial.manifest.shard1of2.ext"))
+        back = front.load_index("partial-restored", man)           # refused before round 4: 35 rows in the file, 32 in the runs
+        after = back.search(q, 6)
+        assert np.array_equal(before[1], after[1]) and np.array_equal(before[0], after[0])
+        assert np.array_equal(back.get_row(72 + 4), row_e) and back.rows == ix.rows and back.count == ix.count
+        back.delete(72 + 4)                                        # the restored extent table finds the right ordinal
+        assert int(back.search(q[:1], 1)[1][0, 0]) != 72 + 4
+        assert back.add(*batch(5)) == 84
+        front.shutdown()
+        open(os.path.join(out_dir, "partial0.done"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_partial_append_then_save_and_load(tmp_path):
+    mp.spawn(_partial_append_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(os.path.join(str(tmp_path), "partial0.done")) and os.path.exists(os.path.join(str(tmp_path), "partial1.done"))

@@ -316,6 +316,11 @@ def main():
             result["recall_at_k_note"] = "recall_at_k / max_abs_cosine_err above are the fp32 parity path's on the sample"
     elif rank == 0 and world == 1 and not args.no_cpu_baseline:
         result.update(cpu_baseline_and_recall(np, torch, eng, idx, pool, args, n_local, dim, B, k))
+        if not batched and not args.prefilter:
+            # the TIMED path's own output: the last launch group of the timed loop (32 queries over ALL rows of the shard)
+            # against the oracle's fp64 ranking of the same rows — not a separate launch over a prefix
+            g_last = ((args.warmup + args.steps - 1) * LPS + LPS - 1) % n_batches
+            result.update(timed_path_check(np, idx, pool[g_last * B:(g_last + 1) * B], out, n_local, k))
 
     if rank == 0 and world == 1 and not args.no_ingest and not bf16 and not args.prefilter and dim == 1024:
         # BASELINE configs[2]'s larger half (the "embedding" of "embedding + ANN"): after the timed search region and
@@ -708,6 +713,24 @@ def pmc_traffic(kernel: str, bytes_per_launch: int):
                 best = {"bytes": round(b + e.get("hbm_write_bytes_per_launch", 0.0)),
                         "source": os.path.relpath(path, ROOT)}
     return best
+
+
+def timed_path_check(np, idx, q_dev, out, n_local, k):
+    """`out` = (scores, ids) the LAST search of the timed region returned for `q_dev`; checked against the oracle's fp64
+    exact cosine over every row the GPU scanned (the rows are read back from the slab, 4 GB at 1 M rows)."""
+    from oracle import oracle as O
+    t0 = time.perf_counter()
+    x = idx.get_rows(0, n_local)
+    qn = O.normalize_ref(q_dev.cpu().numpy()).astype(np.float32)
+    s64, i64 = O.search(x, qn, k, kind=O.KIND_F64, threads=O.usable_cpus())
+    s_gpu, i_gpu = out[0].cpu().numpy(), out[1].cpu().numpy()
+    nq = qn.shape[0]
+    recall = float(np.mean([len(set(i_gpu[q]) & set(i64[q])) / k for q in range(nq)]))
+    return {"recall_at_k_timed_path": recall,
+            "timed_path_check": {"queries": nq, "rows": n_local, "ids_identical": bool(np.array_equal(i_gpu, i64)),
+                                 "max_abs_cosine_err": float(np.abs(s_gpu.astype(np.float64) - s64).max()),
+                                 "what": "the last launch group of the timed loop vs oracle fp64 exact cosine over all rows",
+                                 "seconds": round(time.perf_counter() - t0, 1)}}
 
 
 def cpu_baseline_and_recall(np, torch, eng, idx, pool, args, n_local, dim, B, k):

@@ -730,7 +730,12 @@ hipError_t launch_attention(const void* qkv, const int32_t* cu_seqlens, int nseq
     const char* variant = attn_variant();
     const bool long_rows = (long long)total_tokens >= 320LL * nseq;
     const bool w8_plain = strcmp(variant, "w8") == 0;     // scale-and-subtract as one v_fma per score (the default form)
+#ifdef RASS_ATTN_EXPERIMENTS
     const bool w8_fold = strcmp(variant, "w8f") == 0;     // both folded into the QK^T chain: measured, not adopted (see the kernel)
+#else
+    const bool w8_fold = false;   // the FOLD experiment (3x the error on peaked scores, no faster) is not instantiated in the
+                                  // product library: build with -DRASS_ATTN_EXPERIMENTS (make EXTRA=-DRASS_ATTN_EXPERIMENTS)
+#endif
     if (w8_plain || w8_fold || (long_rows && strcmp(variant, "w16") != 0)) {
         const int s_pad128 = (max_seqlen + kChunk - 1) / kChunk * kChunk;  // whole chunks are sent
         const size_t lds_bytes = (size_t)s_pad128 * 256;      // 128 KiB at S = 512
@@ -738,9 +743,11 @@ hipError_t launch_attention(const void* qkv, const int32_t* cu_seqlens, int nseq
         if (lds_bytes > attr64_bytes) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention64_kernel<false>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+#ifdef RASS_ATTN_EXPERIMENTS
             if (e == hipSuccess)
                 e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention64_kernel<true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+#endif
             if (e != hipSuccess) return e;
             attr64_bytes = lds_bytes;
         }
@@ -750,10 +757,12 @@ hipError_t launch_attention(const void* qkv, const int32_t* cu_seqlens, int nseq
             hipLaunchKernelGGL(attention64_kernel<false>, grid, dim3(kA64Threads), lds_bytes, stream,
                                static_cast<const u16*>(qkv), cu_seqlens, hidden, heads, s_pad128, n_items,
                                static_cast<u16*>(ctx));
+#ifdef RASS_ATTN_EXPERIMENTS
         else
             hipLaunchKernelGGL(attention64_kernel<true>, grid, dim3(kA64Threads), lds_bytes, stream,
                                static_cast<const u16*>(qkv), cu_seqlens, hidden, heads, s_pad128, n_items,
                                static_cast<u16*>(ctx));
+#endif
         return hipGetLastError();
     }
     const size_t lds_bytes = (size_t)s_pad * 128 + (size_t)s_pad * kVPitch;  // 144 KiB at S = 512

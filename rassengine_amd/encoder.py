@@ -367,6 +367,11 @@ class HipSentenceEncoder:
         run on.  Hand it to ``Engine.set_stream`` for the device-resident ingest hand-off."""
         return int(self._L.rass_encoder_get_stream(self._h) or 0)
 
+    @property
+    def handle(self) -> int:
+        """The ``rass_encoder_t*`` as an int (what ``torch.ops.rass.encode`` takes)."""
+        return int(self._h.value or 0)
+
     def stats(self) -> Dict[str, int]:
         """Forwards / sequences / tokens since the encoder was created (``rass_encoder_stats``)."""
         out = (ctypes.c_int64 * 3)()

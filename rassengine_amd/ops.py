@@ -130,8 +130,80 @@ def topk_merge(list_scores: torch.Tensor, list_ids: torch.Tensor) -> Tuple[torch
     return out_s, out_i
 
 
+# ------------------------------------------------------------------------------------------- the encoder's kernels
+def gemm_bf16(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, residual: Optional[torch.Tensor] = None,
+              epilogue: int = 0) -> torch.Tensor:
+    """``rass_gemm_bf16``: y = epi(x w^T + bias), bf16 operands, fp32 accumulation; epilogue 0 bias, 1 bias + residual,
+    2 bias + GELU(erf).  x [m, k], w [n, k] (the encoder's weight layout), bias fp32 [n]; n % 128 == 0, k % 64 == 0."""
+    _req(x, torch.bfloat16, "x")
+    _req(w, torch.bfloat16, "w")
+    _req(bias, torch.float32, "bias")
+    m, k = x.shape
+    n = w.shape[0]
+    if w.shape[1] != k or bias.shape != (n,) or n % 128 or k % 64:
+        raise ValueError(f"gemm_bf16: x [m, k], w [n, k], bias [n] with n % 128 == 0 and k % 64 == 0; got {tuple(x.shape)}, {tuple(w.shape)}")
+    if epilogue not in (0, 1, 2) or (epilogue == 1) != (residual is not None):
+        raise ValueError("gemm_bf16: epilogue 1 (and only it) takes a residual")
+    m_pad = (m + 255) // 256 * 256 if m >= 1024 else (m + 127) // 128 * 128     # whole tiles must be allocated
+    xin = x
+    if m_pad != m:
+        xin = torch.zeros((m_pad, k), dtype=torch.bfloat16, device=x.device)
+        xin[:m] = x
+    r = None
+    if residual is not None:
+        _req(residual, torch.bfloat16, "residual")
+        if residual.shape != (m, n):
+            raise ValueError("gemm_bf16: residual must be [m, n]")
+        r = residual
+        if m_pad != m:
+            r = torch.zeros((m_pad, n), dtype=torch.bfloat16, device=x.device)
+            r[:m] = residual
+    y = torch.empty((m_pad, n), dtype=torch.bfloat16, device=x.device)
+    N.check("rass_gemm_bf16",
+            N.lib().rass_gemm_bf16(ctypes.c_void_p(xin.data_ptr()), ctypes.c_void_p(w.data_ptr()), ctypes.c_void_p(bias.data_ptr()),
+                                   ctypes.c_void_p(r.data_ptr()) if r is not None else None, ctypes.c_void_p(y.data_ptr()),
+                                   int(m), int(m_pad), int(n), int(k), int(epilogue), ctypes.c_void_p(_stream_ptr())))
+    return y[:m]
+
+
+def attention_bf16(qkv: torch.Tensor, cu_seqlens: torch.Tensor, max_seqlen: int, heads: int) -> torch.Tensor:
+    """``rass_attention_bf16``: varlen multi-head self-attention, heads of 64, softmax(q k^T / 8) v in fp32.  qkv bf16
+    [tokens, 3 * hidden] (q | k | v per token), cu_seqlens int32 [nseq + 1] (device) -> ctx bf16 [tokens, hidden]."""
+    _req(qkv, torch.bfloat16, "qkv")
+    _req(cu_seqlens, torch.int32, "cu_seqlens")
+    tokens, three_h = qkv.shape
+    hidden = three_h // 3
+    if three_h != 3 * hidden or hidden != 64 * int(heads) or not 1 <= int(max_seqlen) <= 512:
+        raise ValueError("attention_bf16: qkv [tokens, 3 * 64 * heads], max_seqlen <= 512")
+    nseq = cu_seqlens.numel() - 1
+    ctx = torch.empty((tokens, hidden), dtype=torch.bfloat16, device=qkv.device)
+    N.check("rass_attention_bf16",
+            N.lib().rass_attention_bf16(ctypes.c_void_p(qkv.data_ptr()), ctypes.c_void_p(cu_seqlens.data_ptr()), int(nseq),
+                                        int(tokens), int(max_seqlen), int(hidden), int(heads), ctypes.c_void_p(ctx.data_ptr()),
+                                        ctypes.c_void_p(_stream_ptr())))
+    return ctx
+
+
+def encode(encoder_handle: int, token_ids: torch.Tensor, cu_seqlens: torch.Tensor, max_seqlen: int, hidden: int
+           ) -> torch.Tensor:
+    """``rass_encode_device`` on torch's current stream: the whole sentence-encoder forward (embeddings + LayerNorm, 24 x
+    (QKV, attention, attn-out + residual, LayerNorm, FFN-up + GELU, FFN-down + residual, LayerNorm), pooling) of the packed
+    sequences ``token_ids`` int32 [tokens] / ``cu_seqlens`` int32 [nseq + 1] -> fp32 [nseq, hidden] (not normalised).
+    ``encoder_handle``: the ``rass_encoder_t*`` of a loaded encoder as an int (``HipSentenceEncoder.handle``)."""
+    _req(token_ids, torch.int32, "token_ids")
+    _req(cu_seqlens, torch.int32, "cu_seqlens")
+    nseq = cu_seqlens.numel() - 1
+    out = torch.empty((nseq, int(hidden)), dtype=torch.float32, device=token_ids.device)
+    N.check("rass_encode_device",
+            N.lib().rass_encode_device(ctypes.c_void_p(int(encoder_handle)), ctypes.c_void_p(token_ids.data_ptr()),
+                                       ctypes.c_void_p(cu_seqlens.data_ptr()), int(nseq), int(token_ids.numel()),
+                                       int(max_seqlen), ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(_stream_ptr())))
+    return out
+
+
 # ------------------------------------------------------------------------------------------- torch.library custom ops
-# BASELINE.json's north_star asks for the kernels "under PyTorch-ROCm custom ops": the three stateless launchers above are
+# BASELINE.json's north_star asks for the kernels "under PyTorch-ROCm custom ops": the stateless launchers above — search
+# (scan_topk_packed, topk_merge, normalize_rows) and encoder (gemm_bf16, attention_bf16, encode) — are
 # registered as torch.library ops (namespace ``rass``), so they can be called as ``torch.ops.rass.*``, traced / exported with
 # their shapes known (the fake implementations below), and composed with torch code on the current stream.  They are thin:
 # the arithmetic is the C ABI's (``rass_scan_topk_f32``, ``rass_topk_merge``, ``rass_normalize_rows_f32``), device tensors are
@@ -165,6 +237,33 @@ def _register_torch_ops() -> None:
     @_norm.register_fake
     def _(x, out_stride=0):
         return x.new_empty((x.shape[0], out_stride or x.shape[1]))
+
+    # the encoder's kernels (north_star: "MFMA bf16 GEMMs for attention/MLP ... under PyTorch-ROCm custom ops")
+    @lib.custom_op("rass::gemm_bf16", mutates_args=())
+    def _gemm(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, residual: Optional[torch.Tensor] = None,
+              epilogue: int = 0) -> torch.Tensor:
+        return gemm_bf16(x, w, bias, residual, epilogue).clone()        # (a custom op may not return a view of its scratch)
+
+    @_gemm.register_fake
+    def _(x, w, bias, residual=None, epilogue=0):
+        return x.new_empty((x.shape[0], w.shape[0]))
+
+    @lib.custom_op("rass::attention_bf16", mutates_args=())
+    def _attn(qkv: torch.Tensor, cu_seqlens: torch.Tensor, max_seqlen: int, heads: int) -> torch.Tensor:
+        return attention_bf16(qkv, cu_seqlens, max_seqlen, heads)
+
+    @_attn.register_fake
+    def _(qkv, cu_seqlens, max_seqlen, heads):
+        return qkv.new_empty((qkv.shape[0], qkv.shape[1] // 3))
+
+    @lib.custom_op("rass::encode", mutates_args=())
+    def _encode(encoder_handle: int, token_ids: torch.Tensor, cu_seqlens: torch.Tensor, max_seqlen: int, hidden: int
+                ) -> torch.Tensor:
+        return encode(encoder_handle, token_ids, cu_seqlens, max_seqlen, hidden)
+
+    @_encode.register_fake
+    def _(encoder_handle, token_ids, cu_seqlens, max_seqlen, hidden):
+        return token_ids.new_empty((cu_seqlens.shape[0] - 1, hidden), dtype=torch.float32)
 
 
 try:

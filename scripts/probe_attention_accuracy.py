@@ -1,5 +1,6 @@
 """Accuracy of the attention kernels against a plain fp32 softmax(q k^T / 8) v on the same bf16 inputs, per variant
-(RASS_ATTN_VARIANT, read per launch): w8f = scale and reference maximum folded into the QK^T MFMA chain, Q re-rounded to
+(RASS_ATTN_VARIANT, read per launch; w8f needs a library built with `make EXTRA=-DRASS_ATTN_EXPERIMENTS`, otherwise it falls
+back to the default dispatch): w8f = scale and reference maximum folded into the QK^T MFMA chain, Q re-rounded to
 bf16 after scaling; w8 = round 2's form (one v_fma per score, Q as stored); w16 = the 16x16-tile kernel.
 Cases: unit-variance inputs (the encoder's regime), peaked scores (|q.k|/8 up to ~40: the running maximum moves in most
 key tiles), very peaked (scale 4)."""

@@ -7,10 +7,9 @@ the bound follows sum_j p_j |v_j|, not the possibly cancelled result) and the ou
 32x32-tile persistent kernel (RASS_ATTN_VARIANT=w8; the default for batches of mostly-long sequences) and the 16x16-tile
 kernel (w16; the default otherwise); the variable is read per launch.
 
-w8f is round 3's experiment: the 32x32 kernel with the scale and the reference maximum folded into the
-QK^T MFMA chain, which re-rounds Q to bf16 after scaling (2^-9 per element -> an error in the exponent that grows with
-|q.k|).  It runs every case here; on the peaked-scores case it is held to 8x the tolerance (measured: 3x the plain
-kernel's error there) — the accuracy cost that, at equal speed, keeps it from being the default."""
+(Round 3's w8f experiment — scale and reference maximum folded into the QK^T MFMA chain: no faster, 3x the error on peaked
+scores — is no longer instantiated in the product library: `make EXTRA=-DRASS_ATTN_EXPERIMENTS` builds it,
+scripts/probe_attention_accuracy.py measures it.)"""
 import ctypes
 import os
 
@@ -65,7 +64,7 @@ def _check(torch, lens, heads, scale, seed, max_seqlen=None, slack=1.0):
     assert bool((err <= tol).all()), (float((err - tol).max()), int((err > tol).sum()), float((err / tol).max()))
 
 
-@pytest.fixture(params=["w8f", "w8", "w16", ""])
+@pytest.fixture(params=["w8", "w16", ""])
 def variant(request):
     old = os.environ.get("RASS_ATTN_VARIANT")
     if request.param:
@@ -87,7 +86,7 @@ def test_attention_every_length_class(gpu, variant):
 def test_attention_peaked_scores_and_moving_maximum(gpu, variant):
     """|q.k| / 8 up to ~40: the running maximum moves in most key blocks (the rescale path), probabilities span
     2^-100 .. 1."""
-    _check(gpu, [512, 77, 300, 64], heads=2, scale=2.5, seed=2, slack=8.0 if variant == "w8f" else 1.0)
+    _check(gpu, [512, 77, 300, 64], heads=2, scale=2.5, seed=2)
 
 
 def test_attention_large_shape_and_padded_launch(gpu, variant):
@@ -118,14 +117,9 @@ def test_attention_variants_agree_closely(gpu):
         a = _run(torch, qkv, lens, 4)
         os.environ["RASS_ATTN_VARIANT"] = "w16"
         b = _run(torch, qkv, lens, 4)
-        os.environ["RASS_ATTN_VARIANT"] = "w8f"
-        c = _run(torch, qkv, lens, 4)
     finally:
         os.environ.pop("RASS_ATTN_VARIANT", None)
         if old is not None:
             os.environ["RASS_ATTN_VARIANT"] = old
     assert float((a - b).abs().max()) <= 2.0 ** -7 * float(a.abs().max())
     assert float(((a - b).abs() > 2.0 ** -8 * a.abs() + 1e-3).float().mean()) < 0.01
-    # the folded form re-rounds Q after scaling (2^-9 per element): a few more elements differ by an ulp, none by more than two
-    assert float((c - b).abs().max()) <= 2.0 ** -6 * float(b.abs().max())
-    assert float(((c - b).abs() > 2.0 ** -8 * b.abs() + 1e-3).float().mean()) < 0.05

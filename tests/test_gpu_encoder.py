@@ -320,3 +320,49 @@ def test_embedding_shim_over_hip_encoder(gpu, tiny_model):
     finally:
         embedding.set_embedder(None)
         enc.close()
+
+
+def test_encoder_kernels_as_torch_library_ops(gpu, tmp_path):
+    """north_star: the encoder's kernels "under PyTorch-ROCm custom ops" — torch.ops.rass.gemm_bf16 / attention_bf16 /
+    encode on torch's current stream equal the direct C-ABI calls (same kernels) and a plain fp32 torch reference."""
+    torch = gpu
+    from rassengine_amd import ops  # noqa: F401
+    from rassengine_amd.encoder import EncoderConfig, HipSentenceEncoder, write_random_model_dir
+    g = torch.Generator(device="cuda")
+    g.manual_seed(11)
+    M, N, K = 300, 512, 256
+    X = torch.randn((M, K), generator=g, device="cuda").bfloat16()
+    W = (torch.randn((N, K), generator=g, device="cuda") / K ** 0.5).bfloat16()
+    b = torch.randn((N,), generator=g, device="cuda") * 0.1
+    R = torch.randn((M, N), generator=g, device="cuda").bfloat16()
+    for epi, res in ((0, None), (1, R), (2, None)):
+        y = torch.ops.rass.gemm_bf16(X, W, b, res, epi)
+        ref = X.float() @ W.float().T + b
+        ref = ref + R.float() if epi == 1 else (torch.nn.functional.gelu(ref) if epi == 2 else ref)
+        assert y.shape == (M, N) and bool(((y.float() - ref).abs() <= 1.5 * 2.0 ** -8 * ref.abs() + 2e-3).all())
+    heads, lens = 4, [70, 33, 128]
+    qkv = (torch.randn((sum(lens), 3 * heads * 64), generator=g, device="cuda") * 0.7).bfloat16()
+    cu = torch.tensor([0, 70, 103, 231], dtype=torch.int32, device="cuda")
+    ctx = torch.ops.rass.attention_bf16(qkv, cu, 128, heads)
+    t = 0
+    for n in lens:
+        blk = qkv[t:t + n].float().view(n, 3, heads, 64)
+        q, k, v = blk[:, 0].transpose(0, 1), blk[:, 1].transpose(0, 1), blk[:, 2].transpose(0, 1)
+        ref = (torch.softmax(q @ k.transpose(1, 2) / 8.0, dim=-1) @ v).transpose(0, 1).reshape(n, heads * 64)
+        assert bool(((ctx[t:t + n].float() - ref).abs() <= 2.0 ** -7 * (ref.abs() + 1.0)).all())
+        t += n
+    d = str(tmp_path / "tiny")
+    write_random_model_dir(d, EncoderConfig(vocab_size=300, hidden=128, layers=2, heads=2, intermediate=512, max_positions=512,
+                                            pooling="mean"), seed=5)
+    enc = HipSentenceEncoder.from_dir(d, device=0)
+    try:
+        rng = np.random.default_rng(2)
+        seqs = [list(rng.integers(0, 300, size=n)) for n in (9, 64, 130)]
+        want = enc.encode_ids(seqs)
+        ids = torch.tensor([t_ for s in seqs for t_ in s], dtype=torch.int32, device="cuda")
+        cu2 = torch.tensor([0, 9, 73, 203], dtype=torch.int32, device="cuda")
+        got = torch.ops.rass.encode(enc.handle, ids, cu2, 130, 128)
+        torch.cuda.synchronize()
+        assert got.shape == (3, 128) and np.array_equal(got.cpu().numpy(), want)      # the same forward, bit for bit
+    finally:
+        enc.close()

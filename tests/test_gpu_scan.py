@@ -79,6 +79,9 @@ def _run_scan(torch, xn, q_raw, k, dim, stride, tags=None, qfilter=None, id_base
     (2000, 1100, 5, 5),    # padded to 1280: 2 x 5
     (1500, 1792, 20, 7),   # 2 x 7
     (33, 2048, 17, 32),
+    # the other two panel variants: stride 1 280 = <5, 2> and 1 792 = <7, 2> (the closest to the spill limit)
+    (3000, 1100, 16, 10), (2500, 1280, 32, 32), (777, 1250, 17, 5), (40000, 1280, 1, 10),
+    (3000, 1600, 16, 10), (2500, 1792, 32, 32), (777, 1700, 17, 5), (40000, 1792, 16, 32),
     (40000, 2048, 16, 10),  # full grid, XCD-skewed tile order, ragged last tile
     (1, 1536, 1, 1),
 ])

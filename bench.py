@@ -534,6 +534,7 @@ def _ivf_one_corpus(np, torch, eng, dev, rows, nlist, nq, k, iid, nprobes):
         sweep = []
         stride = flat.row_stride
         for nprobe in nprobes:
+            # group by group (one engine call per 32 queries: coarse scan, merge, plan, fine scan, merge = 5 launches each)
             for b in range(0, min(nq, 4 * B), B):
                 ivf.search_device(q[b:b + B].data_ptr(), B, k, nprobe, out_s.data_ptr(), got[b:b + B].data_ptr())
             eng.synchronize()
@@ -541,8 +542,22 @@ def _ivf_one_corpus(np, torch, eng, dev, rows, nlist, nq, k, iid, nprobes):
             for b in range(0, nq, B):
                 ivf.search_device(q[b:b + B].data_ptr(), B, k, nprobe, out_s.data_ptr(), got[b:b + B].data_ptr())
             tm.stop(stream)
+            ms_groups = tm.elapsed_ms()
+            by_group = got.cpu().numpy().copy()
+            # the whole 1 024-query step in ONE call (rass_ivf_search_device_batch: one grouped coarse scan, one plan launch,
+            # G fine scans, one grouped merge) — the rate reported; results must equal the group-by-group ones
+            step = min(nq, 1024)
+            all_s = torch.empty((nq, k), device=dev)
+            for b in range(0, nq, step):
+                ivf.search_device_batch(q[b:b + step].data_ptr(), min(step, nq - b), k, nprobe, all_s[b:].data_ptr(), got[b:].data_ptr())
+            eng.synchronize()
+            tm.start(stream)
+            for b in range(0, nq, step):
+                ivf.search_device_batch(q[b:b + step].data_ptr(), min(step, nq - b), k, nprobe, all_s[b:].data_ptr(), got[b:].data_ptr())
+            tm.stop(stream)
             ms = tm.elapsed_ms()
             got_h = got.cpu().numpy()
+            same = bool(np.array_equal(got_h, by_group))
             recall = float(np.mean([len(set(got_h[r]) & set(truth_h[r])) / k for r in range(nq)]))
             _, _, scanned = ivf.search(q[:4 * B].cpu().numpy(), k, nprobe)
             per_batch = scanned / 4
@@ -550,6 +565,7 @@ def _ivf_one_corpus(np, torch, eng, dev, rows, nlist, nq, k, iid, nprobes):
             probed = per_batch * stride * 4 + nlist * stride * 4          # fine scans + the coarse scan per batch
             gbps = probed / (us * 1e-6) / 1e9
             sweep.append({"nprobe": nprobe, "queries_per_s": round(nq / ms * 1e3, 1), "recall_at_10": round(recall, 4),
+                          "queries_per_s_group_by_group": round(nq / ms_groups * 1e3, 1), "batch_equals_group_by_group": same,
                           "us_per_batch": round(us, 1), "scanned_rows_per_batch": round(per_batch),
                           "scanned_fraction": round(per_batch / rows, 5),
                           "roofline": {"bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -617,14 +633,33 @@ def ivf_mode(np, torch, dist, args, world, rank, local_rank, dev, coll):
     n_batches = args.query_pool // B
     q_buf = torch.empty((B, dim), device=dev)
 
+    from rassengine_amd import ops
+    if LPS * B > 1024:
+        raise SystemExit("--mode ivf answers a step of <= 1 024 queries per engine call")
+    step_q = torch.empty((LPS * B, dim), device=dev)
+    loc_s = torch.empty((LPS * B, k), dtype=torch.float32, device=dev)
+    loc_i = torch.empty((LPS * B, k), dtype=torch.int64, device=dev)
+    scanned_dev = torch.zeros((LPS,), dtype=torch.int64, device=dev)
+
     def step(i):
-        out = None
-        for j in range(LPS):
-            g = (i * LPS + j) % n_batches
-            if rank == 0:
-                q_buf.copy_(pool[g * B:(g + 1) * B])
-            out = search.search(q_buf, k)
-        return out
+        # the step's 1 024 queries in ONE engine call per rank (rass_ivf_search_device_batch: one grouped coarse scan, one
+        # plan launch, one fine-scan launch over every group's probed lists, one grouped merge), one broadcast, one
+        # all-gather of (scores, ids) and one cross-shard merge
+        if rank == 0:
+            for j in range(LPS):
+                g = (i * LPS + j) % n_batches
+                step_q[j * B:(j + 1) * B].copy_(pool[g * B:(g + 1) * B])
+        if world > 1:
+            dist.broadcast(step_q, src=0)
+        ivf.search_device_batch(step_q.data_ptr(), LPS * B, k, nprobe, loc_s.data_ptr(), loc_i.data_ptr(), 0, scanned_dev.data_ptr())
+        ids = torch.where(loc_i >= 0, loc_i + row_lo, loc_i) if row_lo else loc_i
+        if world == 1:
+            return loc_s, ids
+        gs = torch.empty((world, LPS * B, k), dtype=torch.float32, device=dev)
+        gi = torch.empty((world, LPS * B, k), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(gs.view(world * LPS * B, k), loc_s)
+        dist.all_gather_into_tensor(gi.view(world * LPS * B, k), ids.contiguous())
+        return ops.topk_merge(gs, gi)
 
     for i in range(args.warmup):
         step(i)
@@ -647,11 +682,13 @@ def ivf_mode(np, torch, dist, args, world, rank, local_rank, dev, coll):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     qps = B * LPS * args.steps / elapsed
-    # probed rows per launch group on THIS shard (host API reports them), 8 groups sampled
-    _, _, scanned = ivf.search(pool[:8 * B].cpu().numpy(), k, nprobe)
-    per_batch = scanned / 8
+    # probed rows on THIS shard: the last step's per-group counts (the batch call reports them); one fine-scan launch per step
+    per_step = float(scanned_dev.sum().item())
+    per_batch = per_step / LPS
     stride = flat.row_stride
-    fine_bytes = per_batch * stride * 4
+    # (nprobe <= 32: ONE fine-scan launch per step; deeper probes run group by group: LPS launches per step)
+    groups_per_launch = max(1, round(LPS * args.steps / max(scan_launches, 1)))
+    fine_bytes = per_step * stride * 4 * groups_per_launch / LPS
     achieved = fine_bytes * scan_launches / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
     rows_global = rows * world
     result = {
@@ -662,15 +699,16 @@ def ivf_mode(np, torch, dist, args, world, rank, local_rank, dev, coll):
         "config": {"workload": f"{rows_global} x {dim}-d IVF-{nlist} cosine top-{k}, {world} x MI355X, nprobe {nprobe} "
                                f"(BASELINE configs[4]: {rows} rows per GPU = 100 M / 8; the full 100 M at 8 GPUs)",
                    "rows_per_gpu": rows, "rows_global": rows_global, "dim": dim, "k": k, "query_batch": B, "nlist": nlist,
-                   "nprobe": nprobe, "queries_per_step": B * LPS, "launch_groups_per_step": LPS,
+                   "nprobe": nprobe, "queries_per_step": B * LPS, "launch_groups_per_step": LPS, "engine_calls_per_step": 1,
                    "data": f"{IVF_CENTRES} Gaussian centres (seed {IVF_SEED}) + sigma {IVF_SIGMA} noise, normalised",
                    "cross_shard_exchange": f"{coll} all-gather" if world > 1 else None,
                    "sharding": f"row-sharded x{world}, shared centroids, {coll} all-gather merge" if world > 1 else "single shard",
                    "train_and_build_s": round(build_s, 1)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
-                     "kernel": "scan_topk_f32_kernel<8, 2, 2, false> (the IVF fine scan over the batch's probed lists)",
+                     "kernel": "scan_topk_f32_kernel<8, 2, 5, false> (kIvfGroups: the fine scans of a step's launch groups, one launch)",
                      "bytes_per_launch": int(fine_bytes), "scanned_rows_per_batch": round(per_batch),
+                     "launch_groups_per_launch": groups_per_launch,
                      "avg_launch_us": round(scan_ms / max(scan_launches, 1) * 1e3, 2), "launches": scan_launches},
     }
     # recall@10 against the exact FLAT sharded search of the same shards (all ranks take part), 256 queries

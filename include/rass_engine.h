@@ -404,6 +404,15 @@ int rass_ivf_search(rass_ivf_t* ivf, const float* queries, int nq, int k,
 int rass_ivf_search_device(rass_ivf_t* ivf, const float* d_queries, int nq,
                            int k, int nprobe, const int32_t* d_q_filter,
                            float* d_out_scores, int64_t* d_out_ids);
+/* Up to 1 024 queries (32 launch groups) per call, device-resident: bit-identical to rass_ivf_search_device on
+ * consecutive groups of 32 queries, with ONE normalise, ONE grouped coarse scan over the centroid slab, ONE plan launch
+ * (the coarse lists are merged inside it) and ONE grouped merge for the whole batch — 4 + G launches instead of 5 G,
+ * which is what an IVF probe at nprobe 1-2 (where two-level training puts recall 1.0) is bound by.  Outputs contiguous
+ * [nq][k]; d_scanned_per_group (may be NULL): int64 per launch group, the rows its fine scan touched.  nprobe > 32 runs
+ * group by group.  (The reference's k-NN lookup under concurrent load: app/main.py:1552; BASELINE configs[4].) */
+int rass_ivf_search_device_batch(rass_ivf_t* ivf, const float* d_queries, int nq, int k, int nprobe,
+                                 const int32_t* d_q_filter, float* d_out_scores, int64_t* d_out_ids,
+                                 int64_t* d_scanned_per_group);
 
 /* ---- IVF + flat delta: the approximate index that stays incrementally insertable.
  * Replaces what the reference gets from OpenSearch's knn_vector field: an approximate (HNSW) index

@@ -136,6 +136,9 @@ SIGNATURES = {
                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_i64_p]),
     "rass_ivf_search_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                               ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "rass_ivf_search_device_batch": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                                    ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                    ctypes.c_void_p]),
     "rass_ivf_build_prefix": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
                                              ctypes.c_int64, c_void_pp]),
     "rass_ivf_covered_rows": (ctypes.c_int64, [ctypes.c_void_p]),

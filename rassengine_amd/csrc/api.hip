@@ -547,6 +547,8 @@ struct rass_ivf {
     std::vector<int32_t> pos_of;      // host: slab position of source row r (< src_rows), -1 = not in the slab (tombstoned)
     float* d_pair_scores = nullptr;   // [2][32][32] the probe's list and the delta scan's list of one launch group
     int64_t* d_pair_ids = nullptr;
+    unsigned char* d_batch = nullptr; // rass_ivf_search_device_batch: queries, coarse / fine lists and work lists of <= 32 groups
+    size_t batch_bytes = 0;
 };
 
 extern "C" void rassint_set_last_error(const char* msg) { g_err = msg ? msg : ""; }
@@ -1853,7 +1855,7 @@ static void ivf_free(rass_ivf* v) {
     for (void* p : {(void*)v->d_slab, (void*)v->d_slab_b16, (void*)v->d_tags, (void*)v->d_ids, (void*)v->d_centroids, (void*)v->d_list_tile0,
                     (void*)v->d_list_len, (void*)v->d_work_tile, (void*)v->d_work_rows, (void*)v->d_n_work,
                     (void*)v->d_work_mask, (void*)v->d_scanned, (void*)v->d_probe_scores, (void*)v->d_probe_ids,
-                    (void*)v->d_tau, (void*)v->d_list_mask, (void*)v->d_pair_scores, (void*)v->d_pair_ids})
+                    (void*)v->d_tau, (void*)v->d_list_mask, (void*)v->d_pair_scores, (void*)v->d_pair_ids, (void*)v->d_batch})
         if (p) (void)hipFree(p);
     delete v;
 }
@@ -2410,6 +2412,211 @@ int rass_ivf_search_delta(rass_ivf_t* v, rass_index_t* flat, const float* querie
     }
     if (scanned_rows) *scanned_rows = scanned_total;
     return RASS_OK;
+}
+
+// RASS_IVF_BATCH_FINE=groups: one fine-scan launch per group (the A/B of kIvfGroups); default: one launch for all groups
+static bool ivf_batch_one_launch() {
+    const char* e = getenv("RASS_IVF_BATCH_FINE");
+    return !(e && e[0] == 'g');
+}
+
+// A whole batch of launch groups (nq <= 1 024 queries) of an IVF probe with 4 + G launches instead of 5 G: ONE normalise,
+// ONE grouped coarse scan (kFlatGroups: every group's 32 queries over the centroid slab, 8 workgroups per group), ONE plan
+// launch (a workgroup per group; the coarse lists are merged inside it), the G fine scans over their groups' work lists,
+// ONE grouped merge.  Same lists probed, same scores, same (score desc, id asc) order as rass_ivf_search_device group by
+// group (tests/test_gpu_ivf.py).  nprobe <= 32 (deeper probes go group by group through the threshold path).
+static int ivf_search_batch_locked(rass_ivf_t* v, const float* d_queries, int nq, int k, int nprobe,
+                                   const int32_t* d_q_filter, float* d_out_scores, int64_t* d_out_ids,
+                                   int64_t* d_scanned_per_group) {
+    rass_engine* eng = v->eng;
+    hipStream_t st = eng->stream;
+    const int np = std::min(nprobe, v->nlist);
+    const int G = (nq + RASS_MAX_QBATCH - 1) / RASS_MAX_QBATCH;
+    const int n_ctiles = (v->nlist + 31) / 32;
+    const int wpg = std::max(1, std::min(8, std::min(n_ctiles, 256 / np)));      // coarse workgroups per group
+    const int64_t stride = v->stride;
+    // fine-scan workgroups per group.  fp32 slab: ALL groups' fine scans are one launch (kIvfGroups) — the more groups, the
+    // fewer workgroups each (32 at 32 groups: 1 024 in all, dispatched in group order, no launch boundary between groups);
+    // bf16 slab: one launch per group over the whole chip.
+    const bool one_fine_launch = v->dtype != RASS_BF16 && ivf_batch_one_launch();
+    int fgrid = (int)std::min<int64_t>(std::max<int64_t>(v->total_tiles, 1), std::min(eng->n_cus, kMaxGrid));
+    if (one_fine_launch) fgrid = std::max(1, std::min(fgrid, std::max(32, 1024 / G)));
+    if ((int64_t)fgrid * k > rass::kMergeMaxCandidates) fgrid = rass::kMergeMaxCandidates / k;
+    auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+    size_t off = 0;
+    const size_t o_q = off;        off = up(off + (size_t)G * 32 * stride * 4);
+    const size_t o_qb = off;       off = up(off + (v->dtype == RASS_BF16 ? (size_t)G * 32 * stride * 2 : 0));
+    const int64_t cper = (int64_t)wpg * 32 * np;                                   // coarse list elements per group
+    const size_t o_cs = off;       off = up(off + (size_t)G * cper * 4);
+    const size_t o_ci = off;       off = up(off + (size_t)G * cper * 8);
+    const int64_t fper = (int64_t)fgrid * 32 * k;                                  // fine list elements per group
+    const size_t o_fs = off;       off = up(off + (size_t)G * fper * 4);
+    const size_t o_fi = off;       off = up(off + (size_t)G * fper * 8);
+    const int64_t cap = v->total_tiles;
+    const size_t o_wt = off;       off = up(off + (size_t)G * cap * 4);
+    const size_t o_wr = off;       off = up(off + (size_t)G * cap * 4);
+    const size_t o_wm = off;       off = up(off + (size_t)G * cap * 4);
+    const size_t o_nw = off;       off = up(off + (size_t)G * 4);
+    const size_t o_sc = off;       off = up(off + (size_t)G * 8);
+    if (v->batch_bytes < off) {
+        if (v->d_batch) HIP_TRY(hipFree(v->d_batch));    // waits for earlier batches that may still read the old block
+        v->d_batch = nullptr;
+        v->batch_bytes = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&v->d_batch), off));
+        v->batch_bytes = off;
+    }
+    unsigned char* ws = v->d_batch;
+    float* q_all = reinterpret_cast<float*>(ws + o_q);
+    unsigned short* qb_all = reinterpret_cast<unsigned short*>(ws + o_qb);
+    float* cs = reinterpret_cast<float*>(ws + o_cs);
+    int64_t* ci = reinterpret_cast<int64_t*>(ws + o_ci);
+    float* fs = reinterpret_cast<float*>(ws + o_fs);
+    int64_t* fi = reinterpret_cast<int64_t*>(ws + o_fi);
+    int32_t* wt = reinterpret_cast<int32_t*>(ws + o_wt);
+    int32_t* wr = reinterpret_cast<int32_t*>(ws + o_wr);
+    uint32_t* wm = reinterpret_cast<uint32_t*>(ws + o_wm);
+    int32_t* nw = reinterpret_cast<int32_t*>(ws + o_nw);
+    int64_t* sc = reinterpret_cast<int64_t*>(ws + o_sc);
+
+    // (1) every query normalised and zero-padded, the groups' 32-row blocks back to back
+    HIP_TRY(rass::launch_normalize_rows_f32(d_queries, v->dim, q_all, stride, nq, v->dim, st, (int64_t)G * 32));
+    // (2) coarse: all groups in one launch
+    {
+        rass::ScanArgs a;
+        a.corpus = v->d_centroids;
+        a.row_tag = nullptr;
+        a.q_padded = q_all;
+        a.q_filter = nullptr;
+        a.part_scores = cs;
+        a.part_ids = ci;
+        a.row_stride = stride;
+        a.id_base = 0;
+        a.n_rows = v->nlist;
+        a.nq = 32;
+        a.k = np;
+        a.wgs_per_group = wpg;
+        a.q_group_stride = 32 * stride;
+        a.part_group_stride = cper;
+        HIP_TRY(rass::launch_scan_topk_f32(a, G * wpg, st));
+    }
+    // (3) plan: one workgroup per group, the coarse lists merged inside
+    HIP_TRY(rass::launch_plan_probe_groups(cs, ci, wpg, np, G, nq, cper, v->nlist, v->d_list_tile0, v->d_list_len, wt, wr, wm,
+                                           cap, nw, sc, st, v->tile_rows));
+    // (4) the fine scans, one per group, over the group's work list
+    const bool need_tags = v->any_tags || d_q_filter != nullptr;
+    if (v->dtype == RASS_BF16) HIP_TRY(rass::launch_queries_to_bf16(q_all, qb_all, (int64_t)G * 32 * stride, st));
+    if (one_fine_launch) {
+        rass::ScanArgs a;
+        a.corpus = v->d_slab;
+        a.row_tag = need_tags ? v->d_tags : nullptr;
+        a.q_padded = q_all;
+        a.q_filter = d_q_filter;
+        a.part_scores = fs;
+        a.part_ids = fi;
+        a.row_stride = stride;
+        a.id_base = 0;
+        a.n_rows = (int)v->slab_rows;
+        a.nq = 32;
+        a.k = k;
+        a.work_tile = wt;
+        a.work_rows = wr;
+        a.work_mask = wm;
+        a.n_work = nw;
+        a.wgs_per_group = fgrid;
+        a.q_group_stride = 32 * stride;
+        a.part_group_stride = fper;
+        a.work_group_stride = cap;
+        a.nq_total = nq;
+        const bool timed = eng->ev_on && (size_t)(2 * eng->ev_used + 1) < eng->ev_pool.size();
+        if (timed) HIP_TRY(hipEventRecord(eng->ev_pool[2 * eng->ev_used], st));
+        HIP_TRY(rass::launch_scan_topk_f32(a, G * fgrid, st));
+        if (timed) {
+            HIP_TRY(hipEventRecord(eng->ev_pool[2 * eng->ev_used + 1], st));
+            eng->ev_used += 1;
+        }
+    }
+    for (int g = 0; g < G && !one_fine_launch; ++g) {
+        const int b = std::min(RASS_MAX_QBATCH, nq - g * 32);
+        const bool timed = eng->ev_on && (size_t)(2 * eng->ev_used + 1) < eng->ev_pool.size();
+        if (timed) HIP_TRY(hipEventRecord(eng->ev_pool[2 * eng->ev_used], st));
+        if (v->dtype == RASS_BF16) {
+            rass::ScanBf16Args a;
+            a.corpus = v->d_slab_b16;
+            a.row_tag = need_tags ? v->d_tags : nullptr;
+            a.q_bf16 = qb_all + (int64_t)g * 32 * stride;
+            a.q_filter = d_q_filter ? d_q_filter + g * 32 : nullptr;
+            a.part_scores = fs + g * fper;
+            a.part_ids = fi + g * fper;
+            a.row_stride = stride;
+            a.n_rows = (int)v->slab_rows;
+            a.nq = b;
+            a.k = k;
+            a.id_base = 0;
+            a.work_tile = wt + g * cap;
+            a.work_rows = wr + g * cap;
+            a.work_mask = wm + g * cap;
+            a.n_work = nw + g;
+            HIP_TRY(rass::launch_scan_bf16_topk(a, fgrid, st));
+        } else {
+            rass::ScanArgs a;
+            a.corpus = v->d_slab;
+            a.row_tag = need_tags ? v->d_tags : nullptr;
+            a.q_padded = q_all + (int64_t)g * 32 * stride;
+            a.q_filter = d_q_filter ? d_q_filter + g * 32 : nullptr;
+            a.part_scores = fs + g * fper;
+            a.part_ids = fi + g * fper;
+            a.row_stride = stride;
+            a.id_base = 0;
+            a.n_rows = (int)v->slab_rows;
+            a.nq = b;
+            a.k = k;
+            a.work_tile = wt + g * cap;
+            a.work_rows = wr + g * cap;
+            a.work_mask = wm + g * cap;
+            a.n_work = nw + g;
+            HIP_TRY(rass::launch_scan_topk_f32(a, fgrid, st));
+        }
+        if (timed) {
+            HIP_TRY(hipEventRecord(eng->ev_pool[2 * eng->ev_used + 1], st));
+            eng->ev_used += 1;
+        }
+    }
+    // (5) one grouped merge: slab positions -> source row ids
+    rass::MergeGroups mg;
+    mg.size = RASS_MAX_QBATCH;
+    mg.nq_total = nq;
+    mg.lists_are_dense = true;
+    mg.score_stride = mg.id_stride = fper;
+    mg.out_score_stride = mg.out_id_stride = (int64_t)RASS_MAX_QBATCH * k;
+    HIP_TRY(rass::launch_merge_topk(fs, fi, fgrid, nq, k, d_out_scores, d_out_ids, st, v->d_ids, 0, 0, &mg));
+    if (d_scanned_per_group) HIP_TRY(hipMemcpyAsync(d_scanned_per_group, sc, (size_t)G * 8, hipMemcpyDeviceToDevice, st));
+    return RASS_OK;
+}
+
+int rass_ivf_search_device_batch(rass_ivf_t* v, const float* d_queries, int nq, int k, int nprobe,
+                                 const int32_t* d_q_filter, float* d_out_scores, int64_t* d_out_ids,
+                                 int64_t* d_scanned_per_group) {
+    if (!v || !d_queries || !d_out_scores || !d_out_ids) return fail(RASS_ERR_INVALID, "NULL argument");
+    if (nq < 1 || nq > 32 * RASS_MAX_QBATCH) return fail(RASS_ERR_INVALID, "nq must be in [1, 1024]");
+    if (k < 1 || k > RASS_MAX_K) return fail(RASS_ERR_INVALID, "k must be in [1, RASS_MAX_K]");
+    if (nprobe < 1) return fail(RASS_ERR_INVALID, "nprobe must be >= 1");
+    int rc = set_device(v->eng);
+    if (rc != RASS_OK) return rc;
+    std::lock_guard<std::mutex> lk(v->eng->mu);
+    if (std::min(nprobe, v->nlist) > RASS_MAX_K) {
+        // deep probes: the threshold path, group by group
+        for (int g = 0; g * RASS_MAX_QBATCH < nq; ++g) {
+            const int b = std::min(RASS_MAX_QBATCH, nq - g * RASS_MAX_QBATCH);
+            rc = ivf_search_locked(v, d_queries + (int64_t)g * RASS_MAX_QBATCH * v->dim, b, k, nprobe,
+                                   d_q_filter ? d_q_filter + g * RASS_MAX_QBATCH : nullptr,
+                                   d_out_scores + (int64_t)g * RASS_MAX_QBATCH * k, d_out_ids + (int64_t)g * RASS_MAX_QBATCH * k);
+            if (rc != RASS_OK) return rc;
+            if (d_scanned_per_group)
+                HIP_TRY(hipMemcpyAsync(d_scanned_per_group + g, v->d_scanned, 8, hipMemcpyDeviceToDevice, v->eng->stream));
+        }
+        return RASS_OK;
+    }
+    return ivf_search_batch_locked(v, d_queries, nq, k, nprobe, d_q_filter, d_out_scores, d_out_ids, d_scanned_per_group);
 }
 
 int rass_ivf_search_device(rass_ivf_t* v, const float* d_queries, int nq, int k, int nprobe,

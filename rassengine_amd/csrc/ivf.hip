@@ -125,6 +125,136 @@ hipError_t launch_plan_probe(const int64_t* probe_ids, int nq, int nprobe, int n
     return hipGetLastError();
 }
 
+// ---- the plan of a whole BATCH of launch groups, straight from the coarse scan's per-workgroup lists ----------------
+// One workgroup per launch group g (gridDim.x groups).  The coarse stage (kFlatGroups) left, per group,
+// [n_clists][32][nprobe] (score desc, id asc) candidate lists; a query's probed lists are the nprobe best of its
+// n_clists * nprobe candidates under that order — found here by counting, per candidate, the candidates that beat it
+// (<= 256 of them, in LDS), so no merge launch and no sorted [nq][nprobe] list in HBM in between.  The rest is
+// plan_probe_kernel's: list masks -> tile counts -> prefix scan -> the group's work list (its own slice of the work
+// arrays, work_cap entries) + its item count and scanned rows.
+__global__ __launch_bounds__(kPlanThreads) void plan_probe_groups_kernel(const float* __restrict__ cpart_scores,
+                                                                         const int64_t* __restrict__ cpart_ids,
+                                                                         int n_clists, int nprobe, int nq_total,
+                                                                         int64_t cpart_group_stride, int nlist,
+                                                                         const int32_t* __restrict__ list_tile0,
+                                                                         const int32_t* __restrict__ list_len,
+                                                                         int32_t* __restrict__ work_tile,
+                                                                         int32_t* __restrict__ work_rows,
+                                                                         uint32_t* __restrict__ work_mask,
+                                                                         int64_t work_cap, int32_t* __restrict__ n_work,
+                                                                         int64_t* __restrict__ scanned_rows, int tile_rows) {
+    extern __shared__ uint32_t sh[];   // [nlist] masks | [kPlanThreads] scan scratch | [32 * C] scores | [32 * C] ids
+    const int g = blockIdx.x;
+    const int C = n_clists * nprobe;                       // candidates per query
+    uint32_t* mask = sh;
+    uint32_t* part = sh + nlist;
+    float* cs = reinterpret_cast<float*>(part + kPlanThreads);
+    int32_t* ci = reinterpret_cast<int32_t*>(cs + 32 * C);
+    const int tid = threadIdx.x;
+    const int nq = min(32, nq_total - 32 * g);             // the last group may be short (its padded queries are ignored)
+    cpart_scores += (int64_t)g * cpart_group_stride;
+    cpart_ids += (int64_t)g * cpart_group_stride;
+    work_tile += (int64_t)g * work_cap;
+    work_rows += (int64_t)g * work_cap;
+    work_mask += (int64_t)g * work_cap;
+    for (int l = tid; l < nlist; l += kPlanThreads) mask[l] = 0u;
+    for (int e = tid; e < 32 * C; e += kPlanThreads) {     // candidate (q, c): list c / nprobe, position c % nprobe
+        const int q = e / C, c = e - q * C;
+        const int64_t o = ((int64_t)(c / nprobe) * 32 + q) * nprobe + (c % nprobe);
+        cs[e] = cpart_scores[o];
+        ci[e] = (int32_t)cpart_ids[o];
+    }
+    __syncthreads();
+    for (int e = tid; e < nq * C; e += kPlanThreads) {
+        const int q = e / C;
+        const float s = cs[e];
+        const int32_t id = ci[e];
+        if (id < 0 || id >= nlist) continue;
+        int beaten = 0;                                    // candidates of q that rank before this one
+        const float* qs = cs + q * C;
+        const int32_t* qi = ci + q * C;
+        for (int j = 0; j < C; ++j) {
+            const float sj = qs[j];
+            const int32_t ij = qi[j];
+            beaten += (ij >= 0) && (sj > s || (sj == s && ij < id));
+        }
+        if (beaten < nprobe) atomicOr(&mask[id], 1u << q);
+    }
+    __syncthreads();
+    const int per = (nlist + kPlanThreads - 1) / kPlanThreads;
+    const int l0 = tid * per, l1 = min(nlist, l0 + per);
+    uint32_t cnt = 0;
+    uint32_t rows = 0;
+    for (int l = l0; l < l1; ++l)
+        if (mask[l]) {
+            cnt += (uint32_t)((list_len[l] + tile_rows - 1) / tile_rows);
+            rows += (uint32_t)list_len[l];
+        }
+    part[tid] = cnt;
+    __syncthreads();
+    for (int off = 1; off < kPlanThreads; off <<= 1) {
+        const uint32_t v = tid >= off ? part[tid - off] : 0u;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    const uint32_t total = part[kPlanThreads - 1];
+    for (uint32_t i = tid; i < total; i += kPlanThreads) {
+        int lo = 0, hi = kPlanThreads - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (part[mid] > i) hi = mid; else lo = mid + 1;
+        }
+        uint32_t base = lo ? part[lo - 1] : 0u;
+        int l = lo * per;
+        const int lend = min(nlist, l + per);
+        uint32_t mk = 0;
+        int len = 0;
+        for (; l < lend; ++l) {
+            mk = mask[l];
+            if (!mk) continue;
+            len = list_len[l];
+            const uint32_t nt = (uint32_t)((len + tile_rows - 1) / tile_rows);
+            if (i - base < nt) break;
+            base += nt;
+        }
+        const int t = (int)(i - base);
+        work_tile[i] = list_tile0[l] + t;
+        work_rows[i] = min(tile_rows, len - tile_rows * t);
+        work_mask[i] = mk;
+    }
+    if (tid == kPlanThreads - 1) n_work[g] = (int32_t)part[tid];
+    __syncthreads();
+    part[tid] = rows;
+    __syncthreads();
+    for (int off = kPlanThreads / 2; off > 0; off >>= 1) {
+        if (tid < off) part[tid] += part[tid + off];
+        __syncthreads();
+    }
+    if (tid == 0 && scanned_rows) scanned_rows[g] = (int64_t)part[0];
+}
+
+hipError_t launch_plan_probe_groups(const float* cpart_scores, const int64_t* cpart_ids, int n_clists, int nprobe, int groups,
+                                    int nq_total, int64_t cpart_group_stride, int nlist, const int32_t* list_tile0,
+                                    const int32_t* list_len, int32_t* work_tile, int32_t* work_rows, uint32_t* work_mask,
+                                    int64_t work_cap, int32_t* n_work, int64_t* scanned_rows, hipStream_t stream, int tile_rows) {
+    if (groups < 1 || nprobe < 1 || nprobe > 32 || n_clists < 1 || n_clists * nprobe > 256 || nlist < 1 || nlist > 32768)
+        return hipErrorInvalidValue;
+    if (tile_rows != 32 && tile_rows != 64) return hipErrorInvalidValue;
+    const size_t lds = ((size_t)nlist + kPlanThreads + 2 * 32 * (size_t)n_clists * nprobe) * sizeof(uint32_t);
+    static size_t attr = 0;
+    if (lds > attr && lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&plan_probe_groups_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr = lds;
+    }
+    hipLaunchKernelGGL(plan_probe_groups_kernel, dim3(groups), dim3(kPlanThreads), lds, stream, cpart_scores, cpart_ids,
+                       n_clists, nprobe, nq_total, cpart_group_stride, nlist, list_tile0, list_len, work_tile, work_rows,
+                       work_mask, work_cap, n_work, scanned_rows, tile_rows);
+    return hipGetLastError();
+}
+
 // ---- nprobe > 32: threshold select + plan from the full centroid score matrix ------------------
 // The coarse scan is launched with one workgroup per 32-centroid tile and k = 32, so its
 // per-workgroup lists [n_ctiles][nq][32] hold EVERY centroid's score.  tau[q] = the nprobe-th

@@ -55,6 +55,16 @@ struct ScanArgs {
     // the scan is purely HBM-bound (B <= 16).  With skew s > 0 the even workgroups take s+1 items
     // for every s the odd ones take, so all of them finish together.  Needs an even grid.
     int xcd_skew = 0;
+    // Grouped flat scan (kFlatGroups; 0 = off): workgroups [g * wgs_per_group, (g + 1) * wgs_per_group) serve launch group
+    // g — its 32 (zero-padded) queries at q_padded + g * q_group_stride, its lists at part_* + g * part_group_stride
+    // ([wgs_per_group][nq][k], nq = 32 for every group), its filters at q_filter + 32 g.  No sample floor, no EXT.
+    int wgs_per_group = 0;
+    int64_t q_group_stride = 0, part_group_stride = 0;
+    // Grouped IVF fine scan (kIvfGroups; work_tile != nullptr and wgs_per_group > 0): group g walks the work list at
+    // work_* + g * work_group_stride with n_work[g] items; it has min(32, nq_total - 32 g) queries and writes dense lists
+    // [wgs_per_group][that many][k] at part_* + g * part_group_stride.
+    int64_t work_group_stride = 0;
+    int nq_total = 0;
 };
 
 bool scan_supported_stride(int64_t row_stride);
@@ -144,6 +154,12 @@ hipError_t launch_plan_probe(const int64_t* probe_ids, int nq, int nprobe, int n
                              const int32_t* list_len, int32_t* work_tile, int32_t* work_rows, uint32_t* work_mask,
                              int32_t* n_work, int64_t* scanned_rows, hipStream_t stream,
                              const uint32_t* preset_mask = nullptr, int tile_rows = 32);
+// The plan of a whole batch of launch groups straight from the grouped coarse scan's per-workgroup lists (ivf.hip).
+hipError_t launch_plan_probe_groups(const float* cpart_scores, const int64_t* cpart_ids, int n_clists, int nprobe, int groups,
+                                    int nq_total, int64_t cpart_group_stride, int nlist, const int32_t* list_tile0,
+                                    const int32_t* list_len, int32_t* work_tile, int32_t* work_rows, uint32_t* work_mask,
+                                    int64_t work_cap, int32_t* n_work, int64_t* scanned_rows, hipStream_t stream,
+                                    int tile_rows);
 hipError_t launch_ivf_threshold(const float* part_scores, const int64_t* part_ids, int n_ctiles, int nq, int nprobe,
                                 uint32_t* tau_key, hipStream_t stream);
 hipError_t launch_ivf_mask_from_scores(const float* part_scores, const int64_t* part_ids, int n_ctiles, int nq,

@@ -47,8 +47,12 @@ struct WorkItem {
 // naming its own slab and tag array (MULTI: concurrent users' per-user indices share one launch).
 // kFlatSample is kFlat under its own kernel name: the sample pass that finds the score floors (ScanArgs::floors),
 // kept apart so that per-kernel profiles do not average the short sample launches into the scan's.
-enum ScanMode { kFlat = 0, kIvf = 1, kMulti = 2, kFlatSample = 3 };
-constexpr bool mode_is_flat(int mode) { return mode == kFlat || mode == kFlatSample; }
+// kFlatGroups: ONE launch scans the same slab for several launch groups of <= 32 queries (ScanArgs::wgs_per_group
+// workgroups each): the coarse stage of an IVF batch (4 096 centroids for 1 024 queries in one launch instead of 32).
+// kIvfGroups: ONE launch walks the probe plans of several launch groups (each its own work list, item count, queries and
+// lists): the fine stage of an IVF batch without a launch boundary — ramp-up, tail, gap — between the groups.
+enum ScanMode { kFlat = 0, kIvf = 1, kMulti = 2, kFlatSample = 3, kFlatGroups = 4, kIvfGroups = 5 };
+constexpr bool mode_is_flat(int mode) { return mode == kFlat || mode == kFlatSample || mode == kFlatGroups; }
 
 __device__ __forceinline__ TileDesc make_tile_desc(const float* __restrict__ X, int64_t row_stride,
                                                    const int32_t* __restrict__ row_tag, const WorkItem& w) {

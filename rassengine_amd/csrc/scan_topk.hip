@@ -122,8 +122,25 @@ __global__ __launch_bounds__(kThreads, 2) void scan_topk_f32_kernel(ScanArgs p) 
     const int m = lane & 15, g = lane >> 4;
     // number of work items: tiles of the slab (flat) or entries of the probe plan (IVF; written
     // by plan_probe_kernel earlier on this stream)
+    int G = gridDim.x;
+    int bid = blockIdx.x;   // this workgroup's position among the G that share its queries
+    if (MODE == kFlatGroups || MODE == kIvfGroups) {
+        const int grp = bid / p.wgs_per_group;
+        bid -= grp * p.wgs_per_group;
+        G = p.wgs_per_group;
+        p.q_padded += (int64_t)grp * p.q_group_stride;
+        p.part_scores += (int64_t)grp * p.part_group_stride;
+        p.part_ids += (int64_t)grp * p.part_group_stride;
+        if (p.q_filter != nullptr) p.q_filter += grp * 32;
+        if (MODE == kIvfGroups) {
+            p.work_tile += (int64_t)grp * p.work_group_stride;
+            p.work_rows += (int64_t)grp * p.work_group_stride;
+            p.work_mask += (int64_t)grp * p.work_group_stride;
+            p.n_work += grp;
+            p.nq = min(32, p.nq_total - 32 * grp);
+        }
+    }
     const int n_tiles = IVF ? __builtin_amdgcn_readfirstlane(*p.n_work) : (p.n_rows + kTileRows - 1) / kTileRows;
-    const int G = gridDim.x;
 #ifdef RASS_SCAN_CLOCKS
     if (threadIdx.x == 0) g_scan_clocks[2 * blockIdx.x] = wall_clock64();
     if (threadIdx.x == 0 && blockIdx.x == 0) g_scan_core[0] = clock64();
@@ -191,7 +208,7 @@ __global__ __launch_bounds__(kThreads, 2) void scan_topk_f32_kernel(ScanArgs p) 
 
     const int mt_step = 16 * (int)p.row_stride * 4;
     TileRegs<CH> R0, R1;
-    ItemSeq seq((int)blockIdx.x, G, (G & 1) ? 0 : p.xcd_skew);
+    ItemSeq seq(bid, G, (G & 1) ? 0 : p.xcd_skew);
     int t = seq.next();  // the item R0 holds; R1 holds the one after it
     const int t1 = seq.next();
     WorkItem W0 = get_work<MODE>(p, t, n_tiles), W1 = get_work<MODE>(p, t1, n_tiles);
@@ -363,7 +380,7 @@ __global__ __launch_bounds__(kThreads, 2) void scan_topk_f32_kernel(ScanArgs p) 
 #pragma unroll
             for (int off = 16; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 32));
             const int q = pq * 16 + (lane >> 5) * 8 + wid;
-            if ((lane & 31) == 0) p.part_scores[q * kMaxSampleGroups + (int)blockIdx.x] = q < p.nq ? v : -INFINITY;
+            if ((lane & 31) == 0) p.part_scores[q * kMaxSampleGroups + bid] = q < p.nq ? v : -INFINITY;
         }
         return;
     }
@@ -373,7 +390,7 @@ __global__ __launch_bounds__(kThreads, 2) void scan_topk_f32_kernel(ScanArgs p) 
     for (int pq = 0; pq < NT; ++pq) {
         const int q = pq * 16 + (lane >> 5) * 8 + wid;
         if (q < p.nq && lpos < p.k) {
-            const int64_t o = ((int64_t)blockIdx.x * p.nq + q) * p.k + lpos;
+            const int64_t o = ((int64_t)bid * p.nq + q) * p.k + lpos;
             const bool filled = L[pq].i != 0x7fffffff;
             p.part_scores[o] = filled ? L[pq].s : -INFINITY;
             p.part_ids[o] = filled ? (p.id_base + (int64_t)L[pq].i) : (int64_t)-1;
@@ -592,6 +609,13 @@ hipError_t launch_scan_topk_f32(const ScanArgs& a, int grid, hipStream_t stream)
     if (!scan_supported_stride(a.row_stride)) return hipErrorInvalidValue;
     const int ch = (int)(a.row_stride / 128);
     const bool ext = a.q_filter_mask || a.q_after_score || a.q_after_id;
+    if (a.wgs_per_group > 0 && (ext || ch > 8 || a.sample_pass || a.work_base)) return hipErrorInvalidValue;
+    if (a.wgs_per_group > 0 && a.work_tile != nullptr) {  // the fine scans of several IVF launch groups in one launch
+        if (!a.work_rows || !a.work_mask || !a.n_work || a.nq_total < 1 || grid % a.wgs_per_group != 0 || a.xcd_skew)
+            return hipErrorInvalidValue;
+        if (grid / a.wgs_per_group != (a.nq_total + 31) / 32) return hipErrorInvalidValue;
+        return launch_ch<2, kIvfGroups>(ch, a, grid, stream);
+    }
     if (ch > 8) {  // wide rows: flat scans of <= 16 queries (the caller splits larger groups)
         if (a.sample_pass || a.sample_best || a.work_base || a.work_tile || a.nq > 16) return hipErrorInvalidValue;
         if ((a.q_after_score == nullptr) != (a.q_after_id == nullptr)) return hipErrorInvalidValue;
@@ -633,6 +657,10 @@ hipError_t launch_scan_topk_f32(const ScanArgs& a, int grid, hipStream_t stream)
         if (!a.work_rows || !a.work_mask || !a.n_work) return hipErrorInvalidValue;
         if (a.nq <= 16) return launch_ch<1, kIvf>(ch, a, grid, stream);
         return launch_ch<2, kIvf>(ch, a, grid, stream);
+    }
+    if (a.wgs_per_group > 0) {  // several launch groups of 32 (padded) queries over one slab, wgs_per_group workgroups each
+        if (a.nq != 32 || grid % a.wgs_per_group != 0 || a.sample_best || a.xcd_skew) return hipErrorInvalidValue;
+        return launch_ch<2, kFlatGroups>(ch, a, grid, stream);
     }
     if (a.nq <= 16) return launch_ch<1, kFlat>(ch, a, grid, stream);
     return launch_ch<2, kFlat>(ch, a, grid, stream);

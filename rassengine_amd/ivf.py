@@ -376,6 +376,15 @@ class IvfIndex:
         """Tombstone a source row inside the IVF's slab (no-op when it is not covered)."""
         N.check("rass_ivf_delete", self._L.rass_ivf_delete(self._h, int(src_row)))
 
+    def search_device_batch(self, d_queries_ptr: int, nq: int, k: int, nprobe: int, d_out_scores_ptr: int,
+                            d_out_ids_ptr: int, d_q_filter_ptr: int = 0, d_scanned_ptr: int = 0) -> None:
+        """``rass_ivf_search_device_batch``: up to 1 024 queries per call, bit-identical to ``search_device`` on consecutive
+        groups of 32, with one normalise / coarse / plan / merge launch for the whole batch (4 + G launches, not 5 G)."""
+        N.check("rass_ivf_search_device_batch",
+                self._L.rass_ivf_search_device_batch(self._h, ctypes.c_void_p(d_queries_ptr), int(nq), int(k), int(nprobe),
+                                                     ctypes.c_void_p(d_q_filter_ptr or 0), ctypes.c_void_p(d_out_scores_ptr),
+                                                     ctypes.c_void_p(d_out_ids_ptr), ctypes.c_void_p(d_scanned_ptr or 0)))
+
     def search_delta(self, flat: FlatIndex, queries: np.ndarray, k: int, nprobe: int, q_filter: Optional[np.ndarray] = None,
                      q_filter_mask: Optional[np.ndarray] = None) -> Tuple[np.ndarray, np.ndarray, int]:
         """``rass_ivf_search_delta``: the probe of this IVF + the exact scan of ``flat``'s rows behind ``covered_rows``,

@@ -89,6 +89,17 @@ for nprobe in (1, 2, 4, 8, 16, 32, 64, 128):
     for b in range(0, a.queries, B):
         ivf.search_device(q[b:b + B].data_ptr(), B, k, nprobe, out_s.data_ptr(), got[b:b + B].data_ptr())
     tm.stop(stream)
+    ms_groups = tm.elapsed_ms()
+    # the same queries in calls of 1 024 (rass_ivf_search_device_batch, round 4): the rate reported
+    all_s = torch.empty((a.queries, k), device=dev)
+    step = min(1024, a.queries)
+    for b in range(0, a.queries, step):
+        ivf.search_device_batch(q[b:b + step].data_ptr(), min(step, a.queries - b), k, nprobe, all_s[b:].data_ptr(), got[b:].data_ptr())
+    eng.synchronize()
+    tm.start(stream)
+    for b in range(0, a.queries, step):
+        ivf.search_device_batch(q[b:b + step].data_ptr(), min(step, a.queries - b), k, nprobe, all_s[b:].data_ptr(), got[b:].data_ptr())
+    tm.stop(stream)
     ms = tm.elapsed_ms()
     got_h = got.cpu().numpy()
     recall = float(np.mean([len(set(got_h[r]) & set(truth_h[r])) / k for r in range(a.queries)]))
@@ -98,7 +109,7 @@ for nprobe in (1, 2, 4, 8, 16, 32, 64, 128):
     scanned_per_batch = scanned / 8
     us_per_batch = ms / (a.queries / B) * 1e3
     probed_bytes = scanned_per_batch * dim * esize + a.nlist * dim * 4          # fine scans + the coarse scan over the centroids
-    res["sweep"].append({"nprobe": nprobe, "recall_at_10": round(recall, 4), "qps": round(a.queries / ms * 1e3, 1),
+    res["sweep"].append({"nprobe": nprobe, "recall_at_10": round(recall, 4), "qps": round(a.queries / ms * 1e3, 1), "qps_group_by_group": round(a.queries / ms_groups * 1e3, 1),
                          "us_per_batch": round(us_per_batch, 1), "scanned_rows_per_batch": round(scanned_per_batch),
                          "scanned_fraction": round(scanned_per_batch / a.rows, 5),
                          "probed_TBps": round(probed_bytes / (us_per_batch * 1e-6) / 1e12, 3)})

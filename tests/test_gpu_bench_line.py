@@ -50,6 +50,7 @@ def test_single_gpu_line_has_roofline_cpu_baseline_and_ingest(gpu):
             rf = p["roofline"]
             assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and 0 < rf["frac"] < 1.0 and p["queries_per_s"] > 0
             assert abs(rf["bytes_per_batch"] - (p["scanned_rows_per_batch"] * 4096 + 256 * 4096)) <= 4096     # (rounded mean)
+            assert p["batch_equals_group_by_group"] is True and p["queries_per_s_group_by_group"] > 0
         rec = [p["recall_at_10"] for p in c["sweep"]]
         assert all(b >= a - 0.02 for a, b in zip(rec, rec[1:])), rec
         assert rec[-1] >= (0.95 if key == "clustered" else 0.3), rec        # iid rows have no lists worth probing: the worst case
@@ -88,5 +89,14 @@ def test_two_rank_ivf_mode_line(gpu):
     assert j["sharded_equals_merge_of_shards"] is True
     assert j["recall_at_10_vs_flat_shards"] == 1.0       # every list probed on every shard == the flat sharded search
     rf = j["roofline"]
-    assert rf["bound"] == "hbm" and rf["launches"] == 2 * 8 and 0 < rf["frac"] < 1.0
+    # nprobe 128 > 32 runs group by group (the threshold path): 8 fine-scan launches per step; nprobe <= 32: one per step
+    assert rf["bound"] == "hbm" and rf["launches"] == 2 * 8 and rf["launch_groups_per_launch"] == 1 and 0 < rf["frac"] < 1.0
     assert abs(rf["bytes_per_launch"] - rf["scanned_rows_per_batch"] * 4096) <= 4096
+    j8 = _line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                "127.0.0.1", "--master-port", str(port + 1), "bench.py", "--gpus", "2", "--mode", "ivf", "--steps", "2",
+                "--warmup", "1", "--ivf-rows", "300000", "--ivf-nlist", "128", "--ivf-nprobe", "8", "--launches-per-step", "8"],
+               env={"RASS_BENCH_SHARE_GPU": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    rf8 = j8["roofline"]
+    assert rf8["launches"] == 2 and rf8["launch_groups_per_launch"] == 8 and j8["sharded_equals_merge_of_shards"] is True
+    assert abs(rf8["bytes_per_launch"] - 8 * rf8["scanned_rows_per_batch"] * 4096) <= 8 * 4096
+    assert 0.3 < j8["recall_at_10_vs_flat_shards"] <= 1.0

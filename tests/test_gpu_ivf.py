@@ -175,3 +175,48 @@ def test_ivf_save_load_roundtrip(built, tmp_path):
     open(bad3, "wb").write(bytes(tampered))
     with pytest.raises(RassError):
         IvfIndex.load(eng, bad3)
+
+
+@pytest.mark.parametrize("slab", ["f32", "bf16"])
+def test_batch_of_launch_groups_equals_group_by_group(built, slab):
+    """rass_ivf_search_device_batch (one grouped coarse scan over the centroid slab, one plan launch with the coarse lists
+    merged inside, G fine scans, one grouped merge) == rass_ivf_search_device on consecutive groups of 32 queries: same
+    lists probed, ids and scores BIT FOR BIT, same scanned rows per group — 1 .. 1 024 queries, nprobe 1 .. 32 (and the deep
+    threshold path group by group), per-query filters."""
+    import torch
+    from rassengine_amd.ivf import IvfIndex
+    eng, flat, ivf0, q, tags = built
+    ivf = ivf0 if slab == "f32" else IvfIndex.build(flat, nlist=128, centroids=ivf0.centroids, dtype="bf16")
+    try:
+        dev = torch.device("cuda", 0)
+        g = torch.Generator(device=dev)
+        g.manual_seed(12)
+        qd = torch.cat([torch.from_numpy(q).to(dev), torch.randn((1024 - q.shape[0], 1024), generator=g, device=dev)]).contiguous()
+        filt = torch.tensor([(r % 5) if r % 3 else -1 for r in range(1024)], dtype=torch.int32, device=dev)
+        for nq, k, nprobe, use_f in ((32, 10, 1, False), (100, 10, 2, False), (1024, 10, 2, False), (77, 5, 8, True),
+                                     (1, 32, 32, False), (200, 10, 32, True), (64, 10, 64, False)):
+            out_s = torch.empty((nq, k), device=dev)
+            out_i = torch.empty((nq, k), dtype=torch.int64, device=dev)
+            groups = (nq + 31) // 32
+            sc = torch.zeros((groups,), dtype=torch.int64, device=dev)
+            ivf.search_device_batch(qd.data_ptr(), nq, k, nprobe, out_s.data_ptr(), out_i.data_ptr(),
+                                    filt.data_ptr() if use_f else 0, sc.data_ptr())
+            eng.synchronize()
+            ref_s = torch.empty((nq, k), device=dev)
+            ref_i = torch.empty((nq, k), dtype=torch.int64, device=dev)
+            for b0 in range(0, nq, 32):
+                b = min(32, nq - b0)
+                ivf.search_device(qd[b0:b0 + b].data_ptr(), b, k, nprobe, ref_s[b0:b0 + b].data_ptr(), ref_i[b0:b0 + b].data_ptr(),
+                                  filt[b0:b0 + b].data_ptr() if use_f else 0)
+            eng.synchronize()
+            assert torch.equal(out_i, ref_i) and torch.equal(out_s, ref_s), (slab, nq, k, nprobe, use_f)
+            # scanned rows per group == what the host API reports for that group
+            qh = qd[:min(nq, 64)].cpu().numpy()
+            fh = filt[:min(nq, 64)].cpu().numpy() if use_f else None
+            for gidx in range(min(groups, 2)):
+                lo, hi = 32 * gidx, min(nq, 32 * gidx + 32)
+                _, _, want = ivf.search(qh[lo:hi], k, nprobe, q_filter=None if fh is None else fh[lo:hi])
+                assert int(sc[gidx]) == want, (slab, nq, nprobe, gidx)
+    finally:
+        if ivf is not ivf0:
+            ivf.close()

@@ -57,6 +57,11 @@ struct Layer {
     void* w_down = nullptr;  // bf16 [H][I]
     float* b_down = nullptr;
     float *ln2_g = nullptr, *ln2_b = nullptr;
+    // LayerNorm folded into its consumer GEMMs (big batches; encoder_gemm.hip, LnFold): W' = W diag(gamma) in bf16, the
+    // fp32 column sums of W' and bias' = b + beta W^T.  QKV folds the PREVIOUS layer's output LayerNorm (layer 0: identity,
+    // its input arrives normalised from the embedding LayerNorm), FFN-up this layer's attention-output LayerNorm.
+    void *w_qkv_f = nullptr, *w_up_f = nullptr;
+    float *cs_qkv = nullptr, *bf_qkv = nullptr, *cs_up = nullptr, *bf_up = nullptr;
 };
 
 }  // namespace
@@ -81,6 +86,12 @@ struct rass_encoder {
     size_t stage_elems = 0;
     float* d_splitk = nullptr;  // fp32 partial tiles of the split-K GEMMs of small batches (query-time embedding)
     size_t splitk_bytes = 0;
+    // LN fold (big batches): folded weights are prepared on the first forward that takes the path (any later
+    // rass_encoder_set_weight invalidates them); per-row statistics of the two raw residual streams
+    bool fold_ready = false;
+    float *ones_h = nullptr, *zeros_h = nullptr;        // [H] the identity LayerNorm in front of layer 0
+    float *ln_stats = nullptr;                          // [cap_tokens][H / 128][2] partial (sum, sum of squares)
+    float *mr_a = nullptr, *mr_b = nullptr, *mr_id = nullptr;   // [cap_tokens][2] (mean, rstd); mr_id = (0, 1)
     // The activation workspace is ONE set per encoder: a forward enqueued on stream A must finish
     // before a forward on stream B (or a reallocation) touches it.  `done` is recorded at the end of
     // every forward on `last_stream`.
@@ -124,7 +135,8 @@ int ensure_workspace(rass_encoder* e, int tokens_pad, int nseq) {
         // the capacity is withdrawn BEFORE anything is freed and published only after every
         // allocation succeeded: a failed grow leaves cap_tokens = 0 and the next call re-allocates
         e->cap_tokens = 0;
-        for (void** p : {&e->x, &e->qkv, &e->ctx, &e->y, &e->h})
+        for (void** p : {&e->x, &e->qkv, &e->ctx, &e->y, &e->h, (void**)&e->ln_stats, (void**)&e->mr_a, (void**)&e->mr_b,
+                         (void**)&e->mr_id})
             if (*p) {
                 (void)hipFree(*p);
                 *p = nullptr;
@@ -138,6 +150,15 @@ int ensure_workspace(rass_encoder* e, int tokens_pad, int nseq) {
         EHIP_TRY(hipMalloc(&e->y, T * H * 2));
         EHIP_TRY(hipMalloc(&e->h, T * I * 2));
         EHIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_ids), T * 4));
+        if (H % 128 == 0 && T >= 1024) {   // LN-fold statistics (only batches of >= 12 288 tokens take that path)
+            EHIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->ln_stats), T * (H / 128) * 2 * 4));
+            EHIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->mr_a), T * 2 * 4));
+            EHIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->mr_b), T * 2 * 4));
+            EHIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->mr_id), T * 2 * 4));
+            std::vector<float> id(T * 2);
+            for (size_t i = 0; i < T; ++i) id[2 * i] = 0.f, id[2 * i + 1] = 1.f;
+            EHIP_TRY(hipMemcpy(e->mr_id, id.data(), T * 2 * 4, hipMemcpyHostToDevice));
+        }
         // padding rows are read as GEMM operands: keep them finite
         EHIP_TRY(hipMemset(e->x, 0, T * H * 2));
         EHIP_TRY(hipMemset(e->qkv, 0, T * 3 * H * 2));
@@ -163,6 +184,75 @@ int ensure_workspace(rass_encoder* e, int tokens_pad, int nseq) {
     return RASS_OK;
 }
 
+// W' / colsum / bias' of every layer's QKV and FFN-up (LnFold); on the encoder's own stream, synchronously, once
+int prepare_fold(rass_encoder* e) {
+    const rass_encoder_config& c = e->cfg;
+    const int H = c.hidden, I = c.intermediate;
+    hipStream_t st = e->own_stream;
+    if (!e->ones_h) {
+        int rc;
+        if ((rc = dev_alloc(e, reinterpret_cast<void**>(&e->ones_h), (size_t)H * 4)) != RASS_OK) return rc;
+        if ((rc = dev_alloc(e, reinterpret_cast<void**>(&e->zeros_h), (size_t)H * 4)) != RASS_OK) return rc;
+        std::vector<float> one((size_t)H, 1.f), zero((size_t)H, 0.f);
+        EHIP_TRY(hipMemcpy(e->ones_h, one.data(), (size_t)H * 4, hipMemcpyHostToDevice));
+        EHIP_TRY(hipMemcpy(e->zeros_h, zero.data(), (size_t)H * 4, hipMemcpyHostToDevice));
+    }
+    for (int l = 0; l < c.layers; ++l) {
+        Layer& L = e->layers[(size_t)l];
+        if (!L.w_qkv_f) {
+            int rc;
+            if ((rc = dev_alloc(e, &L.w_qkv_f, (size_t)3 * H * H * 2)) != RASS_OK) return rc;
+            if ((rc = dev_alloc(e, reinterpret_cast<void**>(&L.cs_qkv), (size_t)3 * H * 4)) != RASS_OK) return rc;
+            if ((rc = dev_alloc(e, reinterpret_cast<void**>(&L.bf_qkv), (size_t)3 * H * 4)) != RASS_OK) return rc;
+            if ((rc = dev_alloc(e, &L.w_up_f, (size_t)I * H * 2)) != RASS_OK) return rc;
+            if ((rc = dev_alloc(e, reinterpret_cast<void**>(&L.cs_up), (size_t)I * 4)) != RASS_OK) return rc;
+            if ((rc = dev_alloc(e, reinterpret_cast<void**>(&L.bf_up), (size_t)I * 4)) != RASS_OK) return rc;
+        }
+        const float* g_prev = l == 0 ? e->ones_h : e->layers[(size_t)l - 1].ln2_g;
+        const float* b_prev = l == 0 ? e->zeros_h : e->layers[(size_t)l - 1].ln2_b;
+        EHIP_TRY(rass::launch_fold_gamma(L.w_qkv, g_prev, b_prev, L.b_qkv, 3 * H, H, L.w_qkv_f, L.cs_qkv, L.bf_qkv, st));
+        EHIP_TRY(rass::launch_fold_gamma(L.w_up, L.ln1_g, L.ln1_b, L.b_up, I, H, L.w_up_f, L.cs_up, L.bf_up, st));
+    }
+    EHIP_TRY(hipStreamSynchronize(st));
+    e->fold_ready = true;
+    return RASS_OK;
+}
+
+// The big-batch forward with both LayerNorms of every layer folded into the GEMMs around them (encoder_gemm.hip, LnFold):
+// e->x holds the RAW layer output r2 (layer 0: the normalised embeddings, statistics = identity), e->y the raw r1.
+int forward_fold(rass_encoder* e, const int32_t* d_cu, int nseq, int total, int Tp, int max_seqlen, float* d_out, hipStream_t st) {
+    const rass_encoder_config& c = e->cfg;
+    const int H = c.hidden, I = c.intermediate;
+    const float eps = c.layer_norm_eps;
+    const float* mr_prev = e->mr_id;
+    for (int l = 0; l < c.layers; ++l) {
+        const Layer& L = e->layers[(size_t)l];
+        const float* g_prev = l == 0 ? e->ones_h : e->layers[(size_t)l - 1].ln2_g;
+        const float* b_prev = l == 0 ? e->zeros_h : e->layers[(size_t)l - 1].ln2_b;
+        // qkv = LN_prev(x) Wqkv^T + b, on the raw x
+        EHIP_TRY(rass::launch_gemm_bf16_fold(e->x, L.w_qkv_f, L.bf_qkv, nullptr, e->qkv, total, Tp, 3 * H, H, 4, mr_prev, nullptr,
+                                             nullptr, nullptr, L.cs_qkv, st));
+        EHIP_TRY(rass::launch_attention(e->qkv, d_cu, nseq, total, max_seqlen, H, c.heads, e->ctx, st));
+        // r1 = ctx Wo^T + b + LN_prev(x)  (raw, + row statistics)
+        EHIP_TRY(rass::launch_gemm_bf16_fold(e->ctx, L.w_o, L.b_o, e->x, e->y, total, Tp, H, H, 3, mr_prev, g_prev, b_prev,
+                                             e->ln_stats, nullptr, st));
+        EHIP_TRY(rass::launch_ln_stats_finalize(e->ln_stats, total, H, eps, e->mr_b, st));
+        // h = gelu(LN1(r1) Wup^T + b), on the raw r1
+        EHIP_TRY(rass::launch_gemm_bf16_fold(e->y, L.w_up_f, L.bf_up, nullptr, e->h, total, Tp, I, H, 5, e->mr_b, nullptr, nullptr,
+                                             nullptr, L.cs_up, st));
+        // r2 = h Wdown^T + b + LN1(r1)  (raw, + row statistics) -> e->x
+        EHIP_TRY(rass::launch_gemm_bf16_fold(e->h, L.w_down, L.b_down, e->y, e->x, total, Tp, H, I, 3, e->mr_b, L.ln1_g, L.ln1_b,
+                                             e->ln_stats, nullptr, st));
+        EHIP_TRY(rass::launch_ln_stats_finalize(e->ln_stats, total, H, eps, e->mr_a, st));
+        mr_prev = e->mr_a;
+    }
+    // the last layer's output LayerNorm, once, in front of the pooling
+    const Layer& last = e->layers[(size_t)c.layers - 1];
+    EHIP_TRY(rass::launch_layernorm(e->x, last.ln2_g, last.ln2_b, eps, total, H, e->y, st));
+    EHIP_TRY(rass::launch_pool(e->y, d_cu, nseq, H, c.pooling == 1 ? 1 : 0, c.normalize ? 1 : 0, d_out, st));
+    return RASS_OK;
+}
+
 int forward(rass_encoder* e, const int32_t* d_ids, const int32_t* d_cu, int nseq, int total, int max_seqlen,
             float* d_out, hipStream_t st) {
     const rass_encoder_config& c = e->cfg;
@@ -172,9 +262,18 @@ int forward(rass_encoder* e, const int32_t* d_ids, const int32_t* d_cu, int nseq
         return efail(RASS_ERR_INVALID, "encoder workspace is not allocated for this batch");
     // one workspace per encoder: order this forward after the previous one when the stream differs
     if (e->done_recorded && e->last_stream != st) EHIP_TRY(hipStreamWaitEvent(st, e->done, 0));
+    const bool fold = e->ln_stats != nullptr && rass::gemm_bf16_fold_ok(total, Tp, H, I);
+    if (fold && !e->fold_ready) {
+        const int rc = prepare_fold(e);
+        if (rc != RASS_OK) return rc;
+    }
     EHIP_TRY(rass::launch_embed_layernorm(d_ids, d_cu, nseq, total, e->word, e->pos, e->type0, e->emb_g, e->emb_b,
                                           c.layer_norm_eps, H, c.vocab_size, c.max_positions, e->x, st));
-    for (int l = 0; l < c.layers; ++l) {
+    if (fold) {
+        const int rc = forward_fold(e, d_cu, nseq, total, Tp, max_seqlen, d_out, st);
+        if (rc != RASS_OK) return rc;
+    }
+    for (int l = 0; l < c.layers && !fold; ++l) {
         const Layer& L = e->layers[(size_t)l];
         EHIP_TRY(rass::launch_gemm_bf16(e->x, L.w_qkv, L.b_qkv, nullptr, e->qkv, total, Tp, 3 * H, H, 0, st, e->d_splitk, e->splitk_bytes));
         EHIP_TRY(rass::launch_attention(e->qkv, d_cu, nseq, total, max_seqlen, H, c.heads, e->ctx, st));
@@ -195,7 +294,7 @@ int forward(rass_encoder* e, const int32_t* d_ids, const int32_t* d_cu, int nseq
                                                            c.layer_norm_eps, e->x, total, Tp, H, I, st, e->d_splitk,
                                                            e->splitk_bytes));
     }
-    EHIP_TRY(rass::launch_pool(e->x, d_cu, nseq, H, c.pooling == 1 ? 1 : 0, c.normalize ? 1 : 0, d_out, st));
+    if (!fold) EHIP_TRY(rass::launch_pool(e->x, d_cu, nseq, H, c.pooling == 1 ? 1 : 0, c.normalize ? 1 : 0, d_out, st));
     EHIP_TRY(hipEventRecord(e->done, st));
     e->last_stream = st;
     e->done_recorded = true;
@@ -276,7 +375,8 @@ void rass_encoder_destroy(rass_encoder_t* e) {
     (void)hipSetDevice(e->device);
     (void)hipDeviceSynchronize();
     for (void* p : e->allocs) (void)hipFree(p);
-    for (void* p : {e->x, e->qkv, e->ctx, e->y, e->h, (void*)e->d_ids, (void*)e->d_cu, (void*)e->d_out})
+    for (void* p : {e->x, e->qkv, e->ctx, e->y, e->h, (void*)e->d_ids, (void*)e->d_cu, (void*)e->d_out, (void*)e->ln_stats,
+                    (void*)e->mr_a, (void*)e->mr_b, (void*)e->mr_id})
         if (p) (void)hipFree(p);
     if (e->done) (void)hipEventDestroy(e->done);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
@@ -339,7 +439,10 @@ int rass_encoder_set_weight(rass_encoder_t* e, const char* name, const float* da
         else if (s == "output.LayerNorm.bias") { if ((rc = want(H)) == RASS_OK) rc = upload(e, data, numel, L.ln2_b, 0, false); }
     }
     if (rc == RASS_ERR_NOT_FOUND) return efail(RASS_ERR_NOT_FOUND, std::string("unknown weight ") + name);
-    if (rc == RASS_OK) e->seen[n] = true;
+    if (rc == RASS_OK) {
+        e->seen[n] = true;
+        e->fold_ready = false;   // the folded copies (LnFold) are rebuilt on the next big-batch forward
+    }
     return rc;
 }
 

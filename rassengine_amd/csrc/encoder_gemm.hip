@@ -602,6 +602,22 @@ __device__ unsigned long long g_gemm_core_cycles[64];
 __device__ unsigned long long g_gemm_phase_cycles[64 * 2 * 4];
 #endif
 #endif
+#ifdef RASS_GEMM_STAMPS   // diagnostic builds only (scripts/probe_gemm_stamps.py): wall-clock (100 MHz) stamps of workgroups 0..7
+__device__ unsigned long long g_p5_stamps[8 * 64 * 4];   // [block][tile][K loop start, K loop end, epilogue stores issued, tile end]
+extern "C" int rassdiag_gemm_stamps(unsigned long long* out, int n) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    unsigned long long h[8 * 64 * 4];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_p5_stamps), sizeof(h)) != hipSuccess) return -2;
+    for (int i = 0; i < n && i < 8 * 64 * 4; ++i) out[i] = h[i];
+    return 0;
+}
+#define P5_STAMP(slot)                                                                                   \
+    do {                                                                                                 \
+        if (threadIdx.x == 0 && orig < 8 && tile_no < 64) g_p5_stamps[(orig * 64 + tile_no) * 4 + (slot)] = wall_clock64(); \
+    } while (0)
+#else
+#define P5_STAMP(slot) do {} while (0)
+#endif
 constexpr int RBM = 256, RBN = 256;       // tile of the persistent kernel
 constexpr int kRingThreads = 512;         // 2 (N) x 4 (M) waves, each 128 x 64 = 8 x 4 MFMA tiles
 constexpr int kPStageTokens = 32;         // tokens per epilogue staging chunk (8 704 B per wave at a pitch of 68 floats)
@@ -630,13 +646,39 @@ constexpr int kP5LdsBytes = 5 * kP5HalfBytes;
 // (profiles/r03_gemm_power_limit.txt §6, RASS_P5_POLICY): nt on either operand stream costs 1-8 %, nontemporal OUTPUT stores
 // win 3 % on the wide-output shapes (QKV 790 -> 763 us, FFN-up 1 115 -> 1 080; the 0.8-1.1 GB of output no longer push the
 // operands out of L2) and nothing on the N = 1024 ones: POL = 1 is the default, RASS_P5_POLICY=0 the A/B.
+// ---- LayerNorm folded into the GEMMs around it (round 4; EPI 3 / 4 / 5) ------------------------------------------------
+// The post-LN encoder layer is  h1 = LN1(x + attn(x) Wo),  h2 = LN2(h1 + gelu(h1 Wup) Wdown).  The stand-alone LayerNorm kernel
+// is HBM-bound (read + write of [T, 1024] bf16 at 5.9 TB/s = 90.7 us, twice per layer = 5.2 % of the forward) and a "thin"
+// normalise pass would move the same bytes; what removes the pass is algebra:
+//     LN(r) W^T = rstd * (r W'^T  -  mu * colsum(W'))  +  (beta W^T + b),      W' = W diag(gamma)  (bf16, prepared at load)
+// so the CONSUMER GEMM (QKV / FFN-up) runs on the raw, un-normalised sums r with pre-scaled weights and applies the row's
+// (mu, rstd) and a rank-1 correction in its epilogue (EPI 4: + bias', EPI 5: + bias' + GELU), and the RESIDUAL GEMM
+// (attn-out / FFN-down, EPI 3) rebuilds the normalised residual LN_prev(r_prev) element by element from (r_prev, mu, rstd,
+// gamma, beta) on the fly, writes the raw sum r (bf16) and, per row and 128-column chunk, the partial sums (S r, S r^2) of the
+// ROUNDED values — no atomics: [row][chunk][2] floats, summed in fixed order by ln_stats_finalize_kernel into (mu, rstd).
+struct LnFold {
+    const float* mr = nullptr;        // EPI 3 / 4 / 5: [rows][2] (mean, rstd) of the rows of `residual` (EPI 3) or of X (EPI 4 / 5)
+    const float* gamma = nullptr;     // EPI 3: gamma / beta of the LayerNorm that produced the residual, [N]
+    const float* beta = nullptr;
+    float* stats = nullptr;           // EPI 3: out, [rows][N / 128][2] partial (sum, sum of squares) of the stored bf16 values
+    const float* colsum = nullptr;    // EPI 4 / 5: [N] column sums of W' (fp32 sums of its bf16 values)
+};
+
+// xor-reductions inside groups of 8 consecutive lanes on DPP (quad_perm [1,0,3,2], [2,3,0,1], then row_half_mirror)
+__device__ __forceinline__ float sum8_dpp(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));
+    return v;
+}
+
 template <int EPI, int POL = 1>
 __global__ __launch_bounds__(kRingThreads, 2) void gemm_bf16_p5_kernel(const u16* __restrict__ X,
                                                                       const u16* __restrict__ W,
                                                                       const float* __restrict__ bias,
                                                                       const u16* __restrict__ residual,
                                                                       u16* __restrict__ Y, int M, int N, int K,
-                                                                      int tiles_total) {
+                                                                      int tiles_total, LnFold fold) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -713,10 +755,13 @@ __global__ __launch_bounds__(kRingThreads, 2) void gemm_bf16_p5_kernel(const u16
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
+    int tile_no = 0;
+    (void)tile_no;
     for (;;) {
         const int n0 = (tile % tiles_n) * RBN, m0 = (tile / tiles_n) * RBM;
         const int next = tile + G;
         const bool has_next = next < tiles_total;
+        P5_STAMP(0);
         f32x4 acc[8][4];
 #pragma unroll
         for (int i = 0; i < 8; ++i)
@@ -797,6 +842,7 @@ __global__ __launch_bounds__(kRingThreads, 2) void gemm_bf16_p5_kernel(const u16
             hs0 = hs2;
         }
         if (!grpB) __builtin_amdgcn_s_barrier();  // groups re-aligned: every ring read of this tile is done
+        P5_STAMP(1);
         // the next tile's half-loads 0 and 1 are landing in hs0, hs0+1 (= its q0); staging: three free half-slots
         q0 = mod5(q0 + tile_adv);
         float* const stg = reinterpret_cast<float*>(lds + mod5(q0 + 2 + wave / 3) * kP5HalfBytes + (wave % 3) * 8704);
@@ -810,33 +856,81 @@ __global__ __launch_bounds__(kRingThreads, 2) void gemm_bf16_p5_kernel(const u16
             // when the K loop's fragment reads get the same registers the waitcnt pass protects them
             // with a vmcnt(0) in EVERY K step (seen in two of the three epilogue variants).
             f32x4 bv[2][2];
+            // Output / residual rows go through BUFFER ops on per-tile descriptors (base = the tile's first row, size = its
+            // rows below M): rows past M are dropped / read as zero by the bounds check instead of by a branch.  With
+            // `if (m < M)` around every global load and store hipcc's waitcnt pass lost count at the block boundaries and put
+            // an s_waitcnt vmcnt(0) in front of EVERY store of the residual epilogues: 16 store round trips per tile,
+            // 9-10 us against 3.4 for the bias-only epilogue (scripts/probe_gemm_stamps.py, ISA).
+            typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+            const int rows_here = M - m0 < RBM ? (M - m0 > 0 ? M - m0 : 0) : RBM;
+            const unsigned tile_bytes = __builtin_amdgcn_readfirstlane((unsigned)rows_here * (unsigned)N * 2u);
+            auto tile_desc = [&](const u16* base) {
+                const uint64_t bu = reinterpret_cast<uint64_t>(base + (int64_t)m0 * N);
+                const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)bu), hi = __builtin_amdgcn_readfirstlane((uint32_t)(bu >> 32));
+                return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<u16*>(((uint64_t)hi << 32) | lo), 0, (int)tile_bytes, 0x00020000);
+            };
+            const __amdgpu_buffer_rsrc_t ydesc = tile_desc(Y);
+            const __amdgpu_buffer_rsrc_t rdesc = tile_desc((EPI == 1 || EPI == 3) ? residual : Y);
+            // LN fold: per-column vectors of the lane's 2 x 8 columns (EPI 3: gamma / beta of the residual's LayerNorm;
+            // EPI 4 / 5: colsum(W')), loaded like the bias
+            // (the LN fold's per-column vectors — EPI 3: gamma / beta, EPI 4 / 5: colsum(W') — are loaded per 64-column chunk
+            // inside the loop: held across the whole epilogue like the bias they spilled)
 #pragma unroll
             for (int ic = 0; ic < 2; ++ic) {
                 const float* bp = bias + n0 + wn * 128 + ic * 64 + nq * 8;
                 asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bv[ic][0]) : "v"(bp));
                 asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(bv[ic][1]) : "v"(bp));
             }
+            // LN fold: this wave's per-token (mean, rstd) pairs (its 64 tokens) and per-column vectors (its 128 columns: EPI 3
+            // gamma / beta, EPI 4 / 5 colsum(W')) are fetched ONCE per tile — one 8-byte piece per lane and array, opaque
+            // loads like the bias, retired by the same vmcnt(0) — and parked in the 2 KiB of LDS behind the wave's staging
+            // area: as loads inside the (jc, ic) loop they put a memory round trip into each of the tile's four iterations
+            // (QKV + 54 us, FFN-up + 89 us per call).
+            float* const aux = reinterpret_cast<float*>(lds + mod5(q0 + 2 + wave / 3) * kP5HalfBytes + 26112 + (wave % 3) * 2048);
+            float2 aux_mr = float2{0.f, 1.f}, aux_c0 = float2{0.f, 0.f}, aux_c1 = float2{0.f, 0.f};
+            if constexpr (EPI >= 3) {
+                const int mt = m0 + wm * 64 + lane;
+                const float* mp = fold.mr + 2 * (int64_t)(mt < M ? mt : 0);
+                asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(aux_mr) : "v"(mp));
+                const float* c0 = (EPI == 3 ? fold.gamma : fold.colsum) + n0 + wn * 128 + 2 * lane;
+                asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(aux_c0) : "v"(c0));
+                if constexpr (EPI == 3) {
+                    const float* c1 = fold.beta + n0 + wn * 128 + 2 * lane;
+                    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(aux_c1) : "v"(c1));
+                }
+            }
+            uint4 resbuf[2][4];   // residual rows of the current and of the next (jc, ic) iteration
 #pragma unroll
             for (int jc = 0; jc < 64 / kPStageTokens; ++jc) {
+                float st_s[kPStageTokens / 8], st_q[kPStageTokens / 8];   // EPI 3: this wave's 128-column partial sums per token
+#pragma unroll
+                for (int pass = 0; pass < kPStageTokens / 8; ++pass) st_s[pass] = st_q[pass] = 0.f;
 #pragma unroll
                 for (int ic = 0; ic < 2; ++ic) {
                     const int nbase = n0 + wn * 128 + ic * 64 + nq * 8;
-                    uint4 res[4];
-                    if (EPI == 1) {
+                    float mu[kPStageTokens / 8], rs[kPStageTokens / 8];   // EPI >= 3: (mean, rstd) of the token's row
+                    f32x4 cv[2];          // EPI 4 / 5: colsum(W') of this chunk's 8 columns
+                    f32x4 gv[2], ev[2];   // EPI 3: gamma / beta of the residual's LayerNorm for this chunk's 8 columns
+                    // Residual rows (EPI 1 / 3): iteration it's 4 x 16 B per lane are loaded one iteration AHEAD, right after
+                    // iteration it - 1's transposes (their accumulators are dead by then) and BEFORE its stores: a wait for
+                    // them then leaves those stores in flight (vmcnt counts both, in order).  Loaded at the top of their
+                    // own iteration they queued behind the previous iteration's stores and every iteration paid a store
+                    // round trip: 9-10 us per tile against 3.4 for the bias-only epilogue (scripts/probe_gemm_stamps.py).
+                    const int it = jc * 2 + ic;
+                    auto load_res = [&](int jc2, int ic2, uint4 (&dst)[4]) {
+                        const int nb2 = n0 + wn * 128 + ic2 * 64 + nq * 8;   // (column inside the row; the descriptor starts at row m0)
 #pragma unroll
                         for (int pass = 0; pass < kPStageTokens / 8; ++pass) {
-                            const int m = m0 + wm * 64 + jc * kPStageTokens + pass * 8 + tl;
-                            if constexpr (POL % 10 == 1) {   // read once, like the output: keep it out of the operands' way
-                                typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-                                u32x4_t rv = u32x4_t{0u, 0u, 0u, 0u};
-                                if (m < M) rv = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(residual + (int64_t)m * N + nbase));
-                                res[pass] = uint4{rv[0], rv[1], rv[2], rv[3]};
-                            } else {
-                                res[pass] = m < M ? *reinterpret_cast<const uint4*>(residual + (int64_t)m * N + nbase)
-                                                  : uint4{0u, 0u, 0u, 0u};
-                            }
+                            const int row = wm * 64 + jc2 * kPStageTokens + pass * 8 + tl;
+                            // read once, like the output: nontemporal keeps it out of the operands' way (POL; always for EPI 3)
+                            const u32x4_t rv = __builtin_amdgcn_raw_buffer_load_b128(rdesc, (row * N + nb2) * 2, 0,
+                                                                                     (POL % 10 == 1 || EPI == 3) ? 2 : 0);
+                            dst[pass] = uint4{rv[0], rv[1], rv[2], rv[3]};
                         }
-                    }
+                    };
+                    uint4 (&res)[4] = resbuf[it & 1];
+                    if ((EPI == 1 || EPI == 3) && it == 0) load_res(0, 0, resbuf[0]);
+#ifndef RASS_GEMM_EXP_NO_TRANSPOSE
 #pragma unroll
                     for (int jj = 0; jj < kPStageTokens / 16; ++jj)
 #pragma unroll
@@ -844,20 +938,71 @@ __global__ __launch_bounds__(kRingThreads, 2) void gemm_bf16_p5_kernel(const u16
                             *reinterpret_cast<f32x4*>(stg + (jj * 16 + (lane & 15)) * kPitchF + ii * 16 + (lane >> 4) * 4) =
                                 acc[4 * ic + ii][(kPStageTokens / 16) * jc + jj];
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+                    if ((EPI == 1 || EPI == 3) && it < 3) load_res((it + 1) >> 1, (it + 1) & 1, resbuf[(it + 1) & 1]);
                     if (jc == 0 && ic == 0) {
                         // Explicit: this wave's prefetch DMAs (and the bias / first residual reads issued
                         // after them) are complete before anything below consumes them and before the
                         // publishing barrier after the epilogue.  No store is outstanding yet.
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        if constexpr (EPI >= 3) {   // park the tile's LN-fold scalars in LDS (wave-private: no barrier)
+                            *reinterpret_cast<float2*>(aux + 2 * lane) = aux_c0;
+                            if constexpr (EPI == 3) *reinterpret_cast<float2*>(aux + 128 + 2 * lane) = aux_c1;
+                            *reinterpret_cast<float2*>(aux + 256 + 2 * lane) = aux_mr;
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        }
+                    }
+                    if constexpr (EPI >= 3) {
+#pragma unroll
+                        for (int pass = 0; pass < kPStageTokens / 8; ++pass) {
+                            const float2 v = *reinterpret_cast<const float2*>(aux + 256 + 2 * (jc * kPStageTokens + pass * 8 + tl));
+                            mu[pass] = v.x;
+                            rs[pass] = v.y;
+                        }
+                        if constexpr (EPI == 3) {
+                            gv[0] = *reinterpret_cast<const f32x4*>(aux + ic * 64 + nq * 8);
+                            gv[1] = *reinterpret_cast<const f32x4*>(aux + ic * 64 + nq * 8 + 4);
+                            ev[0] = *reinterpret_cast<const f32x4*>(aux + 128 + ic * 64 + nq * 8);
+                            ev[1] = *reinterpret_cast<const f32x4*>(aux + 128 + ic * 64 + nq * 8 + 4);
+                        } else {
+                            cv[0] = *reinterpret_cast<const f32x4*>(aux + ic * 64 + nq * 8);
+                            cv[1] = *reinterpret_cast<const f32x4*>(aux + ic * 64 + nq * 8 + 4);
+                        }
                     }
 #pragma unroll
                     for (int pass = 0; pass < kPStageTokens / 8; ++pass) {
                         const int tok = pass * 8 + tl;
                         const int m = m0 + wm * 64 + jc * kPStageTokens + tok;
+#ifdef RASS_GEMM_EXP_NO_TRANSPOSE   // timing experiment: the epilogue without its LDS round trip (values from the wrong lanes)
+                        f32x4 v0 = acc[4 * ic + (pass & 3)][2 * jc];
+                        f32x4 v1 = acc[4 * ic + (pass & 3)][2 * jc + 1];
+#else
                         f32x4 v0 = *reinterpret_cast<const f32x4*>(stg + tok * kPitchF + nq * 8);
                         f32x4 v1 = *reinterpret_cast<const f32x4*>(stg + tok * kPitchF + nq * 8 + 4);
-                        v0 += bv[ic][0];
-                        v1 += bv[ic][1];
+#endif
+                        if constexpr (EPI >= 4) {   // LN folded into this GEMM: rstd * (x W'^T - mu * colsum(W')) + bias'
+                            // two fused ops per element: (b * colsum + bias') first, then acc * rstd + that
+                            const float a = rs[pass], b = -mu[pass] * rs[pass];
+                            v0.x = fmaf(v0.x, a, fmaf(b, cv[0].x, bv[ic][0].x)); v0.y = fmaf(v0.y, a, fmaf(b, cv[0].y, bv[ic][0].y));
+                            v0.z = fmaf(v0.z, a, fmaf(b, cv[0].z, bv[ic][0].z)); v0.w = fmaf(v0.w, a, fmaf(b, cv[0].w, bv[ic][0].w));
+                            v1.x = fmaf(v1.x, a, fmaf(b, cv[1].x, bv[ic][1].x)); v1.y = fmaf(v1.y, a, fmaf(b, cv[1].y, bv[ic][1].y));
+                            v1.z = fmaf(v1.z, a, fmaf(b, cv[1].z, bv[ic][1].z)); v1.w = fmaf(v1.w, a, fmaf(b, cv[1].w, bv[ic][1].w));
+                        } else {
+                            v0 += bv[ic][0];
+                            v1 += bv[ic][1];
+                        }
+                        if constexpr (EPI == 3) {   // residual = LayerNorm_prev(raw row), rebuilt from (raw, mu, rstd, gamma, beta)
+                            const uint4 r = res[pass];
+                            const float a = rs[pass], b = -mu[pass] * rs[pass];
+                            v0.x += fmaf(fmaf(bf16_to_f32((u16)(r.x & 0xffff)), a, b), gv[0].x, ev[0].x);
+                            v0.y += fmaf(fmaf(bf16_to_f32((u16)(r.x >> 16)), a, b), gv[0].y, ev[0].y);
+                            v0.z += fmaf(fmaf(bf16_to_f32((u16)(r.y & 0xffff)), a, b), gv[0].z, ev[0].z);
+                            v0.w += fmaf(fmaf(bf16_to_f32((u16)(r.y >> 16)), a, b), gv[0].w, ev[0].w);
+                            v1.x += fmaf(fmaf(bf16_to_f32((u16)(r.z & 0xffff)), a, b), gv[1].x, ev[1].x);
+                            v1.y += fmaf(fmaf(bf16_to_f32((u16)(r.z >> 16)), a, b), gv[1].y, ev[1].y);
+                            v1.z += fmaf(fmaf(bf16_to_f32((u16)(r.w & 0xffff)), a, b), gv[1].z, ev[1].z);
+                            v1.w += fmaf(fmaf(bf16_to_f32((u16)(r.w >> 16)), a, b), gv[1].w, ev[1].w);
+                        }
                         if (EPI == 1) {
                             const uint4 r = res[pass];
                             v0.x += bf16_to_f32((u16)(r.x & 0xffff));
@@ -869,39 +1014,67 @@ __global__ __launch_bounds__(kRingThreads, 2) void gemm_bf16_p5_kernel(const u16
                             v1.z += bf16_to_f32((u16)(r.w & 0xffff));
                             v1.w += bf16_to_f32((u16)(r.w >> 16));
                         }
-                        if (EPI == 2) {
+                        if (EPI == 2 || EPI == 5) {
                             v0.x = gelu_erf(v0.x); v0.y = gelu_erf(v0.y); v0.z = gelu_erf(v0.z); v0.w = gelu_erf(v0.w);
                             v1.x = gelu_erf(v1.x); v1.y = gelu_erf(v1.y); v1.z = gelu_erf(v1.z); v1.w = gelu_erf(v1.w);
                         }
-                        if (m < M) {
+                        if constexpr (EPI == 3) {   // the row statistics of what is STORED (the bf16 values the consumers read)
+                            const float q0 = bf16_to_f32(f32_to_bf16(v0.x)), q1 = bf16_to_f32(f32_to_bf16(v0.y)),
+                                        q2 = bf16_to_f32(f32_to_bf16(v0.z)), q3 = bf16_to_f32(f32_to_bf16(v0.w)),
+                                        q4 = bf16_to_f32(f32_to_bf16(v1.x)), q5 = bf16_to_f32(f32_to_bf16(v1.y)),
+                                        q6 = bf16_to_f32(f32_to_bf16(v1.z)), q7 = bf16_to_f32(f32_to_bf16(v1.w));
+                            const float s = ((q0 + q1) + (q2 + q3)) + ((q4 + q5) + (q6 + q7));
+                            float q = q0 * q0;
+                            q = fmaf(q1, q1, q); q = fmaf(q2, q2, q); q = fmaf(q3, q3, q);
+                            q = fmaf(q4, q4, q); q = fmaf(q5, q5, q); q = fmaf(q6, q6, q); q = fmaf(q7, q7, q);
+                            st_s[pass] += sum8_dpp(s);
+                            st_q[pass] += sum8_dpp(q);
+                        }
+#ifdef RASS_GEMM_EXP_NO_STORE   // timing experiment: everything but the output stores (one store per 2^20 keeps the math alive)
+                        if (v0.x == 12345.678f)
+#endif
+                        {
                             uint4 o;
                             o.x = (unsigned)f32_to_bf16(v0.x) | ((unsigned)f32_to_bf16(v0.y) << 16);
                             o.y = (unsigned)f32_to_bf16(v0.z) | ((unsigned)f32_to_bf16(v0.w) << 16);
                             o.z = (unsigned)f32_to_bf16(v1.x) | ((unsigned)f32_to_bf16(v1.y) << 16);
                             o.w = (unsigned)f32_to_bf16(v1.z) | ((unsigned)f32_to_bf16(v1.w) << 16);
-                            if constexpr (POL % 10 == 1) {
-                                typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-                                __builtin_nontemporal_store(u32x4_t{o.x, o.y, o.z, o.w}, reinterpret_cast<u32x4_t*>(Y + (int64_t)m * N + nbase));
-                            } else {
-                                *reinterpret_cast<uint4*>(Y + (int64_t)m * N + nbase) = o;
-                            }
+                            const int voff = ((wm * 64 + jc * kPStageTokens + tok) * N + nbase) * 2;   // bytes from the tile's first row
+                            __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{o.x, o.y, o.z, o.w}, ydesc, voff, 0, POL % 10 == 1 ? 2 : 0);
                         }
                     }
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 }
+                if constexpr (EPI == 3) {   // one (sum, sum of squares) pair per token and 128-column chunk of this wave
+                    if (nq == 0) {
+#pragma unroll
+                        for (int pass = 0; pass < kPStageTokens / 8; ++pass) {
+                            const int m = m0 + wm * 64 + jc * kPStageTokens + pass * 8 + tl;
+                            if (m < M)
+                                *reinterpret_cast<float2*>(fold.stats + ((int64_t)m * (N / 128) + (n0 / 128 + wn)) * 2) =
+                                    float2{st_s[pass], st_q[pass]};
+                        }
+                    }
+                }
             }
         }
+        P5_STAMP(2);
+#ifdef RASS_GEMM_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // diagnostic: when have this wave's stores left?
+        P5_STAMP(3);
+#endif
         if (!has_next) break;
         // every wave is done with its staging area: the next tile's third half-load may overwrite it
         __builtin_amdgcn_s_barrier();
         stage_half(mod5(q0 + 2), H0{});
         tile = next;
+        ++tile_no;
     }
 }
 
 template <int EPI, int POL>
 static hipError_t launch_p5_pol(const u16* X, const u16* W, const float* bias, const u16* residual, u16* Y, int M, int N,
-                                int K, int tiles_total, int grid, hipStream_t stream) {
+                                int K, int tiles_total, int grid, hipStream_t stream, const LnFold& fold = LnFold{}) {
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_p5_kernel<EPI, POL>),
@@ -910,13 +1083,13 @@ static hipError_t launch_p5_pol(const u16* X, const u16* W, const float* bias, c
         attr_set = true;
     }
     hipLaunchKernelGGL((gemm_bf16_p5_kernel<EPI, POL>), dim3(grid), dim3(kRingThreads), kP5LdsBytes, stream, X, W, bias,
-                       residual, Y, M, N, K, tiles_total);
+                       residual, Y, M, N, K, tiles_total, fold);
     return hipGetLastError();
 }
 
 template <int EPI>
 static hipError_t launch_p5(const u16* X, const u16* W, const float* bias, const u16* residual, u16* Y, int M,
-                            int M_pad, int N, int K, hipStream_t stream) {
+                            int M_pad, int N, int K, hipStream_t stream, const LnFold& fold = LnFold{}) {
     static int n_cus = 0;
     if (n_cus == 0) {
         int dev = 0;
@@ -931,8 +1104,100 @@ static hipError_t launch_p5(const u16* X, const u16* W, const float* bias, const
         if (g >= 1 && g < grid) grid = g;
     }
     if (const char* v = getenv("RASS_P5_POLICY"))   // A/B: 0 = plain output stores (read per launch)
-        if (atoi(v) == 0) return launch_p5_pol<EPI, 0>(X, W, bias, residual, Y, M, N, K, tiles_total, grid, stream);
-    return launch_p5_pol<EPI, 1>(X, W, bias, residual, Y, M, N, K, tiles_total, grid, stream);
+        if (atoi(v) == 0) return launch_p5_pol<EPI, 0>(X, W, bias, residual, Y, M, N, K, tiles_total, grid, stream, fold);
+    return launch_p5_pol<EPI, 1>(X, W, bias, residual, Y, M, N, K, tiles_total, grid, stream, fold);
+}
+
+// ---- LN fold: the big-batch forward without the stand-alone LayerNorm passes (see LnFold above) -----------------------
+static bool p5_eligible(int M, int M_pad, int N, int K) {
+    return N % RBN == 0 && M_pad % RBM == 0 && K % 64 == 0 && K >= 128 && M >= 1024 && (int64_t)(N / RBN) * (M_pad / RBM) >= 192;
+}
+
+bool gemm_bf16_fold_ok(int M, int M_pad, int hidden, int intermediate) {
+    if (const char* v = getenv("RASS_ENCODER_LN_FOLD"))
+        if (atoi(v) == 0) return false;
+    return hidden % 256 == 0 && p5_eligible(M, M_pad, hidden, hidden) && p5_eligible(M, M_pad, 3 * hidden, hidden) &&
+           p5_eligible(M, M_pad, intermediate, hidden) && p5_eligible(M, M_pad, hidden, intermediate);
+}
+
+hipError_t launch_gemm_bf16_fold(const void* X, const void* W, const float* bias, const void* residual_raw, void* Y, int M,
+                                 int M_pad, int N, int K, int epilogue, const float* mr, const float* gamma, const float* beta,
+                                 float* stats, const float* colsum, hipStream_t stream) {
+    if (!p5_eligible(M, M_pad, N, K) || !mr) return hipErrorInvalidValue;
+    LnFold f;
+    f.mr = mr;
+    f.gamma = gamma;
+    f.beta = beta;
+    f.stats = stats;
+    f.colsum = colsum;
+    const u16* x = static_cast<const u16*>(X);
+    const u16* w = static_cast<const u16*>(W);
+    const u16* r = static_cast<const u16*>(residual_raw);
+    u16* y = static_cast<u16*>(Y);
+    switch (epilogue) {
+        case 3: return (r && gamma && beta && stats) ? launch_p5<3>(x, w, bias, r, y, M, M_pad, N, K, stream, f) : hipErrorInvalidValue;
+        case 4: return colsum ? launch_p5<4>(x, w, bias, nullptr, y, M, M_pad, N, K, stream, f) : hipErrorInvalidValue;
+        case 5: return colsum ? launch_p5<5>(x, w, bias, nullptr, y, M, M_pad, N, K, stream, f) : hipErrorInvalidValue;
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// (mean, rstd) per row from the residual GEMM's per-chunk partial sums, in fixed order
+__global__ __launch_bounds__(256) void ln_stats_finalize_kernel(const float* __restrict__ stats, int chunks, int n, float eps,
+                                                                float* __restrict__ mr, int rows) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= rows) return;
+    const float2* p = reinterpret_cast<const float2*>(stats) + (int64_t)m * chunks;
+    float s = 0.f, q = 0.f;
+    for (int c = 0; c < chunks; ++c) {
+        const float2 v = p[c];
+        s += v.x;
+        q += v.y;
+    }
+    const float mean = s / (float)n;
+    const float var = fmaxf(q / (float)n - mean * mean, 0.f);
+    *reinterpret_cast<float2*>(mr + 2 * (int64_t)m) = float2{mean, rsqrtf(var + eps)};
+}
+
+hipError_t launch_ln_stats_finalize(const float* stats, int rows, int n, float eps, float* mr, hipStream_t stream) {
+    if (rows <= 0) return hipSuccess;
+    if (n % 128 != 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3((rows + 255) / 256), dim3(256), 0, stream, stats, n / 128, n, eps, mr, rows);
+    return hipGetLastError();
+}
+
+// W'[n][k] = bf16(W[n][k] * gamma[k]);  colsum[n] = sum_k W'[n][k];  bias2[n] = bias[n] + sum_k beta[k] * W[n][k].  One wave per row.
+__global__ __launch_bounds__(256) void fold_gamma_kernel(const u16* __restrict__ W, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, const float* __restrict__ bias,
+                                                         int N, int K, u16* __restrict__ W2, float* __restrict__ colsum,
+                                                         float* __restrict__ bias2) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    float cs = 0.f, bs = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        const float w = bf16_to_f32(W[(int64_t)n * K + k]);
+        const u16 w2 = f32_to_bf16(w * gamma[k]);
+        W2[(int64_t)n * K + k] = w2;
+        cs += bf16_to_f32(w2);
+        bs = fmaf(beta[k], w, bs);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        cs += __shfl_xor(cs, off);
+        bs += __shfl_xor(bs, off);
+    }
+    if (lane == 0) {
+        colsum[n] = cs;
+        bias2[n] = bias[n] + bs;
+    }
+}
+
+hipError_t launch_fold_gamma(const void* W, const float* gamma, const float* beta, const float* bias, int N, int K, void* W2,
+                             float* colsum, float* bias2, hipStream_t stream) {
+    hipLaunchKernelGGL(fold_gamma_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, static_cast<const u16*>(W), gamma, beta, bias,
+                       N, K, static_cast<u16*>(W2), colsum, bias2);
+    return hipGetLastError();
 }
 
 template <int EPI>

@@ -34,6 +34,20 @@ hipError_t launch_splitk_residual_layernorm(const float* partial, int S, int row
                                             const float* bias, const void* residual, const float* gamma,
                                             const float* beta, float eps, void* out, hipStream_t stream);
 
+// ---- LayerNorm folded into the GEMMs around it (big batches on the persistent kernel; encoder_gemm.hip, LnFold) ----
+// gemm_bf16_fold_ok: all four GEMMs of a layer run on the persistent 256^2 kernel at this batch (and RASS_ENCODER_LN_FOLD != 0).
+// launch_gemm_bf16_fold, epilogue 3: Y = X W^T + bias + LN(residual_raw) with LN rebuilt from (mr, gamma, beta) per element;
+//   Y is the RAW sum (bf16); `stats` [M][N/128][2] receives the partial (sum, sum of squares) of the stored values.
+// epilogue 4 / 5: Y = rstd * (X W'^T - mean * colsum) + bias'  [ + GELU ], X raw rows with (mean, rstd) in `mr`, W' / colsum /
+//   bias' from launch_fold_gamma.  launch_ln_stats_finalize: stats -> mr [M][2] (mean, rstd), fixed summation order.
+bool gemm_bf16_fold_ok(int M, int M_pad, int hidden, int intermediate);
+hipError_t launch_gemm_bf16_fold(const void* X, const void* W, const float* bias, const void* residual_raw, void* Y, int M,
+                                 int M_pad, int N, int K, int epilogue, const float* mr, const float* gamma, const float* beta,
+                                 float* stats, const float* colsum, hipStream_t stream);
+hipError_t launch_ln_stats_finalize(const float* stats, int rows, int n, float eps, float* mr, hipStream_t stream);
+hipError_t launch_fold_gamma(const void* W, const float* gamma, const float* beta, const float* bias, int N, int K, void* W2,
+                             float* colsum, float* bias2, hipStream_t stream);
+
 // K4: x[t] = LayerNorm(word[ids[t]] + pos[position of t in its sequence] + type[0]) -> bf16
 hipError_t launch_embed_layernorm(const int32_t* ids, const int32_t* cu_seqlens, int nseq, int total_tokens,
                                   const void* word_emb, const void* pos_emb, const void* type_emb,

@@ -150,8 +150,8 @@ def _ingest_batch_checks(large, torch, seqs, sample):
     """One ingest batch at cfg 3's shape through BOTH paths: rass_encode -> rass_index_add (host) and rass_encode_device ->
     rass_index_add_device (K8, no host round trip).  Every stored row finite and unit-norm, the two paths' rows and
     embeddings bit-equal, `sample` sequences >= 0.999 cosine to the fp32 CPU oracle, and the same `sample` sequences
-    embedded as a batch of their own within the kernels' tolerance (cosine >= 0.9999: other GEMM / attention kernels run
-    for 4 sequences than for 256)."""
+    embedded as a batch of their own within the kernels' tolerance (cosine >= 0.9998: other GEMM / attention kernels run
+    for 4 sequences than for 256 — and the LayerNorm-folded GEMM epilogues from 12 288 tokens on)."""
     from oracle import bert_ref
     from rassengine_amd.engine import Engine
     d, enc = large
@@ -186,7 +186,11 @@ def _ingest_batch_checks(large, torch, seqs, sample):
     print(f"cfg-3 batch of {n} sequences / {sum(len(s) for s in seqs)} tokens: cosine vs fp32 oracle >= {c_ref.min():.6f}, "
           f"vs the same sequences in a batch of {len(sub)} >= {c_alone.min():.7f}")
     assert np.all(c_ref >= 0.999), c_ref
-    assert np.all(c_alone >= 0.9999), c_alone
+    # 0.9998: since round 4 a batch of >= 12 288 tokens runs with both LayerNorms of every layer folded into the GEMMs around
+    # them (weights pre-scaled by gamma and re-rounded to bf16, csrc/encoder_gemm.hip LnFold), a batch of 4 sequences the
+    # unfused kernels: two bf16 evaluations of the same fp32 function, each 0.99987 from the fp32 oracle over 24 layers and
+    # 0.99989 from each other (0.99994 between the big and the small unfused paths); tests/test_gpu_ln_fold.py pins the pair
+    assert np.all(c_alone >= 0.9998), c_alone
 
 
 def test_cfg3_full_batch_256x512(large):

@@ -972,7 +972,6 @@ __global__ __launch_bounds__(kRingThreads, 2) void gemm_bf16_p5_kernel(const u16
 #pragma unroll
                     for (int pass = 0; pass < kPStageTokens / 8; ++pass) {
                         const int tok = pass * 8 + tl;
-                        const int m = m0 + wm * 64 + jc * kPStageTokens + tok;
 #ifdef RASS_GEMM_EXP_NO_TRANSPOSE   // timing experiment: the epilogue without its LDS round trip (values from the wrong lanes)
                         f32x4 v0 = acc[4 * ic + (pass & 3)][2 * jc];
                         f32x4 v1 = acc[4 * ic + (pass & 3)][2 * jc + 1];

@@ -71,9 +71,9 @@ def main():
                     help="rows of the HNSW restatement's sample (cpu_baseline.hnsw); 0 disables it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--per-group", action="store_true",
-                    help="one engine call per launch group of 32 queries (the N = 1 default) also for N > 1")
+                    help="one engine call per launch group of 32 queries (rounds 1-3's N = 1 default) instead of one per step")
     ap.add_argument("--batched", action="store_true",
-                    help="N = 1: one engine call per 1 024-query step (rass_index_search_device_batch; the N > 1 default)")
+                    help="(the default since round 4) one engine call per 1 024-query step (rass_index_search_device_batch)")
     ap.add_argument("--merge", choices=["allgather", "peer"], default="allgather",
                     help="cross-shard exchange for N > 1: one RCCL all-gather (default) or peer stores into rank 0's "
                          "buffer + flags (SURVEY 8f-4; validated on 2 ranks sharing a GPU only)")
@@ -156,7 +156,9 @@ def main():
     # give the same queries/s (21.09 vs 21.10 ms per step): the chip is power-limited in this kernel, and what the
     # batch saves in launches and idle gaps (-0.5 ms) comes back as a lower clock in the back-to-back scans
     # (628 vs 611 us per launch).
-    batched = isinstance(search, ShardedSearch) and B == 32 and not args.per_group and (world > 1 or args.batched)
+    # (r4: with ONE sample pass for the step's 32 launch groups — kFlatSampleGroups — the batched call is 1.4-2 % ahead at N = 1
+    # and is the default there too; --per-group keeps one engine call per launch group.)
+    batched = isinstance(search, ShardedSearch) and B == 32 and not args.per_group
 
     def step(i: int):
         if batched:
@@ -316,11 +318,12 @@ def main():
             result["recall_at_k_note"] = "recall_at_k / max_abs_cosine_err above are the fp32 parity path's on the sample"
     elif rank == 0 and world == 1 and not args.no_cpu_baseline:
         result.update(cpu_baseline_and_recall(np, torch, eng, idx, pool, args, n_local, dim, B, k))
-        if not batched and not args.prefilter:
+        if not args.prefilter:
             # the TIMED path's own output: the last launch group of the timed loop (32 queries over ALL rows of the shard)
             # against the oracle's fp64 ranking of the same rows — not a separate launch over a prefix
             g_last = ((args.warmup + args.steps - 1) * LPS + LPS - 1) % n_batches
-            result.update(timed_path_check(np, idx, pool[g_last * B:(g_last + 1) * B], out, n_local, k))
+            last = (out[0][-B:], out[1][-B:]) if batched else out
+            result.update(timed_path_check(np, idx, pool[g_last * B:(g_last + 1) * B], last, n_local, k))
 
     if rank == 0 and world == 1 and not args.no_ingest and not bf16 and not args.prefilter and dim == 1024:
         # BASELINE configs[2]'s larger half (the "embedding" of "embedding + ANN"): after the timed search region and

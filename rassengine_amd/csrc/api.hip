@@ -1011,6 +1011,11 @@ BatchLayout batch_layout(int groups, int grid, int k, int64_t stride) {
     return L;
 }
 
+static bool scan_batch_one_sample() {
+    const char* e = getenv("RASS_SCAN_BATCH_SAMPLE");
+    return !(e && e[0] == 'g');
+}
+
 // The fused batch of rass_index_search_device_batch on an fp32 flat index: the per-group steps of scan_launch, but
 // ONE normalise launch and ONE merge launch for the whole batch, and the groups' sample passes back to back (their
 // 64 * grid rows stay in the Infinity Cache between them) ahead of the big scans.  Per 32 queries the serial tail
@@ -1085,7 +1090,26 @@ int scan_launch_batch(rass_index* idx, const float* d_queries, int nq, int k, co
     const int64_t sample_rows = (int64_t)64 * grid;
     const int64_t min_share = scan_sample_floor_min_share();
     const bool sample = min_share > 0 && grid <= rass::kMaxSampleGroups && rows >= min_share * sample_rows;
-    if (sample)
+    // The sample passes: ONE launch for all groups (kFlatSampleGroups, 32 workgroups of 16 tiles per group: the same
+    // 64 * grid sample rows, the floor = the k-th largest of 32 block maxima instead of `grid` of them) when the batch has
+    // several full groups; group by group otherwise (RASS_SCAN_BATCH_SAMPLE=groups: the A/B).  Results do not depend on the
+    // floor (rows tying with it are kept).
+    const bool one_sample = sample && groups >= 2 && nq % 32 == 0 && scan_batch_one_sample() && grid >= 32;
+    const int sample_wgs = one_sample ? 32 : grid;
+    if (one_sample) {
+        rass::ScanArgs s = group_args(0);
+        s.n_rows = (int)sample_rows;
+        s.xcd_skew = 0;
+        s.sample_pass = true;
+        s.nq = 32;
+        s.part_scores = sample_best;
+        s.part_ids = nullptr;
+        s.wgs_per_group = sample_wgs;
+        s.q_group_stride = 32 * stride;
+        s.part_group_stride = (int64_t)32 * rass::kMaxSampleGroups;
+        s.nq_total = nq;
+        HIP_TRY(rass::launch_scan_topk_f32(s, groups * sample_wgs, st));
+    } else if (sample)
         for (int g = 0; g < groups; ++g) {
             rass::ScanArgs s = group_args(g);
             if (s.nq <= 16) continue;
@@ -1100,7 +1124,7 @@ int scan_launch_batch(rass_index* idx, const float* d_queries, int nq, int k, co
         rass::ScanArgs a = group_args(g);
         if (sample && a.nq > 16) {
             a.sample_best = sample_best + (int64_t)g * 32 * rass::kMaxSampleGroups;
-            a.sample_groups = grid;
+            a.sample_groups = sample_wgs;
         }
         const bool timed = eng->ev_on && (size_t)(2 * eng->ev_used + 1) < eng->ev_pool.size();
         if (timed) HIP_TRY(hipEventRecord(eng->ev_pool[2 * eng->ev_used], st));

@@ -51,8 +51,12 @@ struct WorkItem {
 // workgroups each): the coarse stage of an IVF batch (4 096 centroids for 1 024 queries in one launch instead of 32).
 // kIvfGroups: ONE launch walks the probe plans of several launch groups (each its own work list, item count, queries and
 // lists): the fine stage of an IVF batch without a launch boundary — ramp-up, tail, gap — between the groups.
-enum ScanMode { kFlat = 0, kIvf = 1, kMulti = 2, kFlatSample = 3, kFlatGroups = 4, kIvfGroups = 5 };
-constexpr bool mode_is_flat(int mode) { return mode == kFlat || mode == kFlatSample || mode == kFlatGroups; }
+// kFlatSampleGroups: the sample passes of several launch groups in one launch (a batch call's 32 passes of 20 us each).
+enum ScanMode { kFlat = 0, kIvf = 1, kMulti = 2, kFlatSample = 3, kFlatGroups = 4, kIvfGroups = 5, kFlatSampleGroups = 6 };
+constexpr bool mode_is_flat(int mode) {
+    return mode == kFlat || mode == kFlatSample || mode == kFlatGroups || mode == kFlatSampleGroups;
+}
+constexpr bool mode_is_sample(int mode) { return mode == kFlatSample || mode == kFlatSampleGroups; }
 
 __device__ __forceinline__ TileDesc make_tile_desc(const float* __restrict__ X, int64_t row_stride,
                                                    const int32_t* __restrict__ row_tag, const WorkItem& w) {

@@ -124,14 +124,15 @@ __global__ __launch_bounds__(kThreads, 2) void scan_topk_f32_kernel(ScanArgs p) 
     // by plan_probe_kernel earlier on this stream)
     int G = gridDim.x;
     int bid = blockIdx.x;   // this workgroup's position among the G that share its queries
-    if (MODE == kFlatGroups || MODE == kIvfGroups) {
+    if (MODE == kFlatGroups || MODE == kIvfGroups || MODE == kFlatSampleGroups) {
         const int grp = bid / p.wgs_per_group;
         bid -= grp * p.wgs_per_group;
         G = p.wgs_per_group;
         p.q_padded += (int64_t)grp * p.q_group_stride;
         p.part_scores += (int64_t)grp * p.part_group_stride;
-        p.part_ids += (int64_t)grp * p.part_group_stride;
+        if (MODE != kFlatSampleGroups) p.part_ids += (int64_t)grp * p.part_group_stride;
         if (p.q_filter != nullptr) p.q_filter += grp * 32;
+        if (MODE == kFlatSampleGroups) p.nq = min(32, p.nq_total - 32 * grp);
         if (MODE == kIvfGroups) {
             p.work_tile += (int64_t)grp * p.work_group_stride;
             p.work_rows += (int64_t)grp * p.work_group_stride;
@@ -299,7 +300,7 @@ __global__ __launch_bounds__(kThreads, 2) void scan_topk_f32_kernel(ScanArgs p) 
             d_calls += 1; d_any += c != 0; d_cand += c;
         }
 #endif
-        if (MODE == kFlatSample)
+        if (mode_is_sample(MODE))
             L[pq].s = fmaxf(L[pq].s, s);  // the sample pass keeps each row slot's best score, nothing else
         else
             insert_candidates(L[pq], tau[pq], s, row, p.k);
@@ -371,7 +372,7 @@ __global__ __launch_bounds__(kThreads, 2) void scan_topk_f32_kernel(ScanArgs p) 
     if (threadIdx.x == 0) g_scan_clocks[2 * blockIdx.x + 1] = wall_clock64();
     if (threadIdx.x == 0 && blockIdx.x == 0) g_scan_core[1] = clock64();
 #endif
-    if (MODE == kFlatSample) {
+    if (mode_is_sample(MODE)) {
         // The sample pass: this workgroup's best score per query -> part_scores[32][kMaxSampleGroups] (-inf: no row of the
         // sample passed the query's filters); the big scan's waves take the k-th largest over the workgroups.
 #pragma unroll
@@ -609,7 +610,7 @@ hipError_t launch_scan_topk_f32(const ScanArgs& a, int grid, hipStream_t stream)
     if (!scan_supported_stride(a.row_stride)) return hipErrorInvalidValue;
     const int ch = (int)(a.row_stride / 128);
     const bool ext = a.q_filter_mask || a.q_after_score || a.q_after_id;
-    if (a.wgs_per_group > 0 && (ext || ch > 8 || a.sample_pass || a.work_base)) return hipErrorInvalidValue;
+    if (a.wgs_per_group > 0 && (ext || ch > 8 || a.work_base)) return hipErrorInvalidValue;
     if (a.wgs_per_group > 0 && a.work_tile != nullptr) {  // the fine scans of several IVF launch groups in one launch
         if (!a.work_rows || !a.work_mask || !a.n_work || a.nq_total < 1 || grid % a.wgs_per_group != 0 || a.xcd_skew)
             return hipErrorInvalidValue;
@@ -621,6 +622,12 @@ hipError_t launch_scan_topk_f32(const ScanArgs& a, int grid, hipStream_t stream)
         if ((a.q_after_score == nullptr) != (a.q_after_id == nullptr)) return hipErrorInvalidValue;
         if (a.q_filter_mask != nullptr && a.q_filter == nullptr) return hipErrorInvalidValue;
         return ext ? launch_wide<true>(ch, a, grid, stream) : launch_wide<false>(ch, a, grid, stream);
+    }
+    if (a.sample_pass && a.wgs_per_group > 0) {  // the sample passes of a batch's launch groups in one launch
+        if (ext || ch > 8 || a.work_tile || a.work_base || a.nq_total < 1 || grid % a.wgs_per_group != 0 ||
+            grid / a.wgs_per_group != (a.nq_total + 31) / 32 || a.wgs_per_group > kMaxSampleGroups)
+            return hipErrorInvalidValue;
+        return launch_ch<2, kFlatSampleGroups>(ch, a, grid, stream);
     }
     if (a.sample_pass) {  // the score-floor sample of a flat scan with > 16 queries
         if (a.work_base != nullptr || a.work_tile != nullptr || a.nq <= 16) return hipErrorInvalidValue;

@@ -80,8 +80,9 @@ def main():
     ap.add_argument("--corpus-dtype", choices=["f32", "bf16"], default="f32",
                     help="bf16: FLAGGED mode, never the headline: a bf16-only corpus (RASS_BF16), half the bytes per "
                          "scan, scores within ~1e-3 of the fp32 cosine; recall@k vs the fp32 index is reported")
-    ap.add_argument("--prefilter", action="store_true",
-                    help="flagged mode (not the parity default): bf16 candidate scan + exact fp32 re-rank")
+    ap.add_argument("--prefilter", nargs="?", const="bf16", default=None, choices=["bf16", "int8"],
+                    help="flagged mode (not the parity default): bf16 (half the bytes per pass) or int8 (a quarter) candidate "
+                         "scan + exact fp32 re-rank; recall vs the flat scan is reported")
     args = ap.parse_args()
 
     import numpy as np
@@ -136,7 +137,7 @@ def main():
     # Philox rows keyed by the GLOBAL row id: shard r regenerates exactly rows [row_lo, row_hi)
     idx.fill_synthetic(n_local, seed=1234, row_id_base=row_lo)
     if args.prefilter:
-        idx.set_prefilter(True)
+        idx.set_prefilter(args.prefilter)
     eng.synchronize()
 
     shard = HipShard(idx, id_base=row_lo)  # switches the engine to torch's current stream
@@ -203,11 +204,15 @@ def main():
     qps = B * LPS * args.steps / elapsed
     # algorithmic bytes of the dominant kernel: N_loc * D * 4 (fp32 scan); the bf16
     # candidate scan of the prefilter mode reads N_loc * D * 2
-    bytes_per_launch = n_local * idx.row_stride * (2 if (args.prefilter or bf16) else 4)
+    i8_stride = (idx.row_stride + 511) // 512 * 512
+    bytes_per_launch = n_local * i8_stride if args.prefilter == "int8" else \
+        n_local * idx.row_stride * (2 if (args.prefilter or bf16) else 4)
     achieved = bytes_per_launch * scan_launches / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
 
     result = {
-        "metric": "queries/sec, exact cosine top-10 over N x 1024-d fp32 corpus in HBM" if not bf16 else
+        "metric": (f"queries/sec, cosine top-10 over N x 1024-d fp32 corpus in HBM through {args.prefilter} candidates + exact "
+                   "fp32 re-rank (FLAGGED mode, not the headline)") if args.prefilter else
+                  "queries/sec, exact cosine top-10 over N x 1024-d fp32 corpus in HBM" if not bf16 else
                   "queries/sec, cosine top-10 over N x 1024-d bf16 corpus in HBM (FLAGGED mode, not the headline)",
         "value": round(qps, 1),
         "unit": "queries/s",
@@ -233,7 +238,7 @@ def main():
             "queries_per_step": B * LPS, "launch_groups_per_step": LPS,
             "engine_calls_per_step": 1 if batched else LPS,
             "corpus_dtype": "bf16 only (fp32-accumulated bf16 MFMA)" if bf16 else
-                            "f32" if not args.prefilter else "f32 + bf16 candidate copy (exact fp32 re-rank)",
+                            "f32" if not args.prefilter else f"f32 + {args.prefilter} candidate copy (exact fp32 re-rank)",
             "layout": "tile16b" if bf16 else "tile16", "mode": "prefilter" if args.prefilter else "flat",
             "cross_shard_exchange": ("peer stores + flags" if args.merge == "peer" else f"{coll} all-gather") if world > 1 else None,
             "sharding": f"row-sharded x{world}, {coll} all-gather merge" if world > 1 else "single shard",
@@ -243,6 +248,7 @@ def main():
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
             "kernel": scan_kernel_name(dim, B) if not (args.prefilter or bf16) else
+            f"scan_i8_topk_kernel<{i8_stride // 512}, {1 if B <= 16 else 2}>" if args.prefilter == "int8" else
             f"scan_bf16_topk_kernel<{idx.row_stride // 256}, {1 if B <= 16 else 2}>", "bytes_per_launch": bytes_per_launch,
             "avg_launch_us": round(scan_ms / max(scan_launches, 1) * 1e3, 2), "launches": scan_launches,
         },
@@ -294,7 +300,7 @@ def main():
         s_p, i_p = idx.search(qh, k)
         idx.set_prefilter(False)
         s_f, i_f = idx.search(qh, k)
-        idx.set_prefilter(True)
+        idx.set_prefilter(args.prefilter)
         result["prefilter_recall_vs_flat"] = float(np.mean([len(set(i_p[r]) & set(i_f[r])) / k for r in range(B)]))
         result["prefilter_scores_bit_identical"] = bool(np.array_equal(s_p[i_p == i_f], s_f[i_p == i_f]))
 

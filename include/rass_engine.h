@@ -231,16 +231,25 @@ int rass_index_search_device_batch(rass_index_t* idx, const float* d_queries, in
                                    float* d_out_scores, int64_t* d_out_ids,
                                    int64_t out_scores_group_stride, int64_t out_ids_group_stride);
 
-/* Prefilter mode, OFF by default: keep a bf16 copy of the slab,
- * scan IT (half the HBM bytes per pass, bf16 MFMA) for the 32 best candidates
- * per query, then recompute those candidates' scores exactly from the fp32
- * slab in the flat kernel's fmaf order and return the exact top-k among them.
- * Returned scores are bit-identical to the flat path; the id set equals the
- * flat result whenever the true top-k lies inside the bf16 top-32 (measured
- * as recall, not guaranteed).  Used for k <= 16 only (k > 16 takes the exact
- * flat scan).  Needs dim padded to a multiple of 256. */
+/* Prefilter mode (SURVEY §8f-4 "bf16 (or int8)"; the reference's own index is approximate, app/main.py:563-572), OFF by
+ * default.  `enable` = RASS_PREFILTER_BF16 (1): keep a bf16 copy of the slab, scan IT (half the HBM bytes per pass, bf16
+ * MFMA) for the 32 best candidates per query; RASS_PREFILTER_INT8 (2): keep an int8 copy (a quarter of the bytes; per row
+ * q = rint(x * 127 / max|x|) and one fp32 scale, queries quantised the same way, v_mfma_i32_16x16x64_i8; a candidate's score
+ * is (float)(exact integer dot) * row scale).  Either way those candidates' scores are then recomputed exactly from the fp32
+ * slab in the flat kernel's fmaf order and the exact top-k among them is returned: returned scores are bit-identical to the
+ * flat path; the id set equals the flat result whenever the true top-k lies inside the candidate top-32 (measured as recall,
+ * not guaranteed).  Used for k <= 16 only (k > 16 takes the exact flat scan).  bf16 needs dim padded to a multiple of 256;
+ * both need dim <= 1024.  0 = off (frees the copy); switching modes rebuilds the copy from the fp32 rows. */
+#define RASS_PREFILTER_OFF 0
+#define RASS_PREFILTER_BF16 1
+#define RASS_PREFILTER_INT8 2
 int rass_index_set_prefilter(rass_index_t* idx, int enable);
-int rass_index_get_prefilter(const rass_index_t* idx);
+int rass_index_get_prefilter(const rass_index_t* idx);   /* the mode: 0 / 1 / 2 */
+/* The candidate lists of the active prefilter mode for <= 32 device queries, BEFORE the exact re-rank: [nq][32] candidate
+ * scores (bf16: fp32-accumulated dot of the bf16-rounded operands; int8: as above) and LOCAL rows, (score desc, row asc),
+ * -inf / -1 past the end.  Parity hook of the integer path (tests compare it with the oracle bit for bit); stream-ordered. */
+int rass_index_candidates_device(rass_index_t* idx, const float* d_queries, int nq, const int32_t* d_q_filter,
+                                 float* d_cand_scores, int64_t* d_cand_rows);
 
 /* Shard persistence: raw rows + tags + manifest header. */
 int rass_index_save(rass_index_t* idx, const char* path);

@@ -85,6 +85,8 @@ SIGNATURES = {
                                                       ctypes.c_int64, ctypes.c_int64]),
     "rass_index_set_prefilter": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "rass_index_get_prefilter": (ctypes.c_int, [ctypes.c_void_p]),
+    "rass_index_candidates_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                                    ctypes.c_void_p, ctypes.c_void_p]),
     "rass_index_save": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p]),
     "rass_index_load": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, c_void_pp]),
     "rass_index_fill_synthetic": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64,

@@ -200,7 +200,10 @@ struct rass_index {
                                             // GLOBAL id (rass_index_add_ex: a shard of a multi-GPU index)
     std::atomic<bool> has_gid{false};       // any row carries a caller-assigned id
     unsigned short* d_rows_bf16 = nullptr;  // tile16b copy for the prefilter mode (nullptr = off)
-    bool prefilter = false;
+    int prefilter = 0;                      // 0 off | 1 bf16 candidate copy | 2 int8 candidate copy (+ a scale per row)
+    signed char* d_rows_i8 = nullptr;       // tile16i copy (prefilter mode 2), rows of stride_i8 bytes
+    float* d_row_scale = nullptr;           // [capacity] max|x| / 127 of every row (prefilter mode 2)
+    int64_t stride_i8 = 0;                  // stride rounded up to 512
     std::vector<uint8_t> host_deleted;  // tombstone bitmap mirror (host)
     std::mutex mu;
 };
@@ -220,7 +223,8 @@ int index_reserve(rass_index* idx, int64_t need_rows) {
     int32_t* ntags = nullptr;
     hipStream_t st = idx->eng->stream;
     const bool want_f32 = idx->dtype == RASS_F32;                  // a bf16 index holds the bf16 slab ONLY
-    const bool want_b16 = idx->dtype == RASS_BF16 || idx->prefilter;
+    const bool want_b16 = idx->dtype == RASS_BF16 || idx->prefilter == 1;
+    const bool want_i8 = idx->prefilter == 2;
     const size_t elem = want_f32 ? sizeof(float) : 2;
     void* nmain = nullptr;  // the dtype's own slab
     hipError_t e = hipMalloc(&nmain, (size_t)cap * idx->stride * elem);
@@ -243,6 +247,8 @@ int index_reserve(rass_index* idx, int64_t need_rows) {
     // never ranked): zero the part of the slab the copy below does not overwrite
     const int64_t used_rows = (idx->rows + 15) / 16 * 16;
     unsigned short* nb16 = want_f32 ? nullptr : static_cast<unsigned short*>(nmain);
+    signed char* ni8 = nullptr;
+    float* nscale = nullptr;
     auto copy_over = [&]() -> hipError_t {
         hipError_t c = hipSuccess;
         if (want_f32) {
@@ -262,6 +268,16 @@ int index_reserve(rass_index* idx, int64_t need_rows) {
                 c = hipMemcpyAsync(nb16, idx->d_rows_bf16, (size_t)used_rows * idx->stride * 2,
                                    hipMemcpyDeviceToDevice, st);
         }
+        if (c == hipSuccess && want_i8) {
+            c = hipMalloc(reinterpret_cast<void**>(&ni8), (size_t)cap * idx->stride_i8);
+            if (c == hipSuccess) c = hipMalloc(reinterpret_cast<void**>(&nscale), (size_t)cap * sizeof(float));
+            if (c == hipSuccess) c = hipMemsetAsync(ni8, 0, (size_t)cap * idx->stride_i8, st);
+            if (c == hipSuccess) c = hipMemsetAsync(nscale, 0, (size_t)cap * sizeof(float), st);
+            if (c == hipSuccess && idx->rows > 0)
+                c = hipMemcpyAsync(ni8, idx->d_rows_i8, (size_t)used_rows * idx->stride_i8, hipMemcpyDeviceToDevice, st);
+            if (c == hipSuccess && idx->rows > 0)
+                c = hipMemcpyAsync(nscale, idx->d_row_scale, (size_t)used_rows * sizeof(float), hipMemcpyDeviceToDevice, st);
+        }
         if (c == hipSuccess) c = hipStreamSynchronize(st);
         return c;
     };
@@ -272,6 +288,8 @@ int index_reserve(rass_index* idx, int64_t need_rows) {
         (void)hipFree(ntags);
         (void)hipFree(ngid);
         if (nb16 && want_f32) (void)hipFree(nb16);
+        if (ni8) (void)hipFree(ni8);
+        if (nscale) (void)hipFree(nscale);
         return fail(e == hipErrorOutOfMemory ? RASS_ERR_OOM : RASS_ERR_HIP,
                     std::string("index grow failed: ") + hipGetErrorString(e));
     }
@@ -279,6 +297,10 @@ int index_reserve(rass_index* idx, int64_t need_rows) {
     if (idx->d_tags) (void)hipFree(idx->d_tags);
     if (idx->d_gid) (void)hipFree(idx->d_gid);
     if (idx->d_rows_bf16) (void)hipFree(idx->d_rows_bf16);
+    if (idx->d_rows_i8) (void)hipFree(idx->d_rows_i8);
+    if (idx->d_row_scale) (void)hipFree(idx->d_row_scale);
+    idx->d_rows_i8 = ni8;
+    idx->d_row_scale = nscale;
     idx->d_rows = nrows;
     idx->d_tags = ntags;
     idx->d_gid = ngid;
@@ -472,10 +494,19 @@ int bf16_scan_launch(rass_index* idx, const float* d_queries, int nq, const int3
     return RASS_OK;
 }
 
-// Prefilter mode: bf16 candidate scan (32 per query) -> merge -> exact fp32 re-rank.
+// The int8 candidate scan's sample floor (scan_i8.hip): worth a short extra launch when the slab is many samples long.
+// RASS_I8_SAMPLE_FLOOR=0 turns it off (the A/B; results do not depend on it).
+bool i8_sample_floor(int64_t rows, int grid) {
+    const char* e = getenv("RASS_I8_SAMPLE_FLOOR");   // read per call: the tests switch it
+    if (e && atoi(e) == 0) return false;
+    return grid <= rass::kMaxSampleGroups && rows >= (int64_t)8 * 64 * grid;
+}
+
+// Prefilter mode: bf16 (mode 1) or int8 (mode 2) candidate scan (32 per query) -> merge -> exact fp32 re-rank.
+// d_cand_scores / d_cand_rows (optional, [nq][32]): the merged candidate lists as well (rass_index_candidates_device).
 int prefilter_launch(rass_index* idx, const float* d_queries, int nq, const int32_t* d_q_filter, int k,
                      int64_t id_base, float* d_out_scores, int64_t* d_out_ids, const int32_t* d_row_tag,
-                     rass_engine* eng, hipStream_t st) {
+                     rass_engine* eng, hipStream_t st, float* d_cand_scores = nullptr, int64_t* d_cand_rows = nullptr) {
     if (nq < 1 || nq > RASS_MAX_QBATCH) return fail(RASS_ERR_INVALID, "nq must be in [1, RASS_MAX_QBATCH]");
     if (k < 1 || k > RASS_MAX_K) return fail(RASS_ERR_INVALID, "k must be in [1, RASS_MAX_K]");
     const int64_t stride = idx->stride;
@@ -484,30 +515,58 @@ int prefilter_launch(rass_index* idx, const float* d_queries, int nq, const int3
     float* q_padded = reinterpret_cast<float*>(ws + L.q_padded);
     float* part_scores = reinterpret_cast<float*>(ws + L.part_scores);
     int64_t* part_ids = reinterpret_cast<int64_t*>(ws + L.part_ids);
-    unsigned short* q_bf16 = reinterpret_cast<unsigned short*>(ws + L.q_bf16);
-    float* cand_scores = reinterpret_cast<float*>(ws + L.cand_scores);
-    int64_t* cand_ids = reinterpret_cast<int64_t*>(ws + L.cand_ids);
+    unsigned short* q_bf16 = reinterpret_cast<unsigned short*>(ws + L.q_bf16);   // int8 queries live here too (half the bytes)
+    float* cand_scores = d_cand_scores ? d_cand_scores : reinterpret_cast<float*>(ws + L.cand_scores);
+    int64_t* cand_ids = d_cand_rows ? d_cand_rows : reinterpret_cast<int64_t*>(ws + L.cand_ids);
     const int nq_pad = nq <= 16 ? 16 : 32;
     const int kc = RASS_MAX_K;  // candidates per query
     HIP_TRY(rass::launch_normalize_rows_f32(d_queries, idx->dim, q_padded, stride, nq, idx->dim, st, nq_pad));
-    HIP_TRY(rass::launch_queries_to_bf16(q_padded, q_bf16, (int64_t)nq_pad * stride, st));
     const int64_t n_tiles = (idx->rows + 63) / 64;
     int grid = (int)std::min<int64_t>(std::max<int64_t>(n_tiles, 1), std::min(eng->n_cus, kMaxGrid));
     if ((int64_t)grid * kc > rass::kMergeMaxCandidates) grid = rass::kMergeMaxCandidates / kc;
-    rass::ScanBf16Args a;
-    a.corpus = idx->d_rows_bf16;
-    a.row_tag = d_row_tag;
-    a.q_bf16 = q_bf16;
-    a.q_filter = d_q_filter;
-    a.part_scores = part_scores;
-    a.part_ids = part_ids;
-    a.row_stride = stride;
-    a.n_rows = (int)idx->rows;
-    a.nq = nq;
-    a.k = kc;
     const bool timed = eng->ev_on && (size_t)(2 * eng->ev_used + 1) < eng->ev_pool.size();
-    if (timed) HIP_TRY(hipEventRecord(eng->ev_pool[2 * eng->ev_used], st));
-    HIP_TRY(rass::launch_scan_bf16_topk(a, grid, st));
+    if (idx->prefilter == 2) {
+        HIP_TRY(rass::launch_queries_to_i8(q_padded, q_bf16, nq_pad, stride, idx->stride_i8, st));
+        rass::ScanI8Args a;
+        a.corpus = idx->d_rows_i8;
+        a.row_scale = idx->d_row_scale;
+        a.row_tag = d_row_tag;
+        a.q_i8 = reinterpret_cast<const signed char*>(q_bf16);
+        a.q_filter = d_q_filter;
+        a.part_scores = part_scores;
+        a.part_ids = part_ids;
+        a.row_stride = idx->stride_i8;
+        a.n_rows = (int)idx->rows;
+        a.nq = nq;
+        a.k = kc;
+        if (i8_sample_floor(idx->rows, grid)) {   // the sample launch: the first 64 * grid rows, the best score per workgroup
+            rass::ScanI8Args sa = a;
+            sa.n_rows = 64 * grid;
+            sa.k = 1;
+            sa.part_scores = reinterpret_cast<float*>(ws + L.sample_best);
+            sa.part_ids = nullptr;
+            HIP_TRY(rass::launch_scan_i8_topk(sa, grid, st));
+            a.sample_best = sa.part_scores;
+            a.sample_groups = grid;
+        }
+        if (timed) HIP_TRY(hipEventRecord(eng->ev_pool[2 * eng->ev_used], st));
+        HIP_TRY(rass::launch_scan_i8_topk(a, grid, st));
+    } else {
+        HIP_TRY(rass::launch_queries_to_bf16(q_padded, q_bf16, (int64_t)nq_pad * stride, st));
+        rass::ScanBf16Args a;
+        a.corpus = idx->d_rows_bf16;
+        a.row_tag = d_row_tag;
+        a.q_bf16 = q_bf16;
+        a.q_filter = d_q_filter;
+        a.part_scores = part_scores;
+        a.part_ids = part_ids;
+        a.row_stride = stride;
+        a.n_rows = (int)idx->rows;
+        a.nq = nq;
+        a.k = kc;
+        if (timed) HIP_TRY(hipEventRecord(eng->ev_pool[2 * eng->ev_used], st));
+        HIP_TRY(rass::launch_scan_bf16_topk(a, grid, st));
+    }
     if (timed) {
         HIP_TRY(hipEventRecord(eng->ev_pool[2 * eng->ev_used + 1], st));
         eng->ev_used += 1;
@@ -633,6 +692,8 @@ void rass_engine_destroy(rass_engine_t* eng) {
         if (idx->d_tags) (void)hipFree(idx->d_tags);
         if (idx->d_gid) (void)hipFree(idx->d_gid);
         if (idx->d_rows_bf16) (void)hipFree(idx->d_rows_bf16);
+        if (idx->d_rows_i8) (void)hipFree(idx->d_rows_i8);
+        if (idx->d_row_scale) (void)hipFree(idx->d_row_scale);
         delete idx;
     }
     eng->indices.clear();
@@ -748,6 +809,10 @@ int rass_index_drop(rass_engine_t* eng, const char* name) {
         if (idx->d_tags) (void)hipFree(idx->d_tags);
         if (idx->d_gid) (void)hipFree(idx->d_gid);
         if (idx->d_rows_bf16) (void)hipFree(idx->d_rows_bf16);
+        if (idx->d_rows_i8) (void)hipFree(idx->d_rows_i8);
+        if (idx->d_row_scale) (void)hipFree(idx->d_row_scale);
+        idx->d_rows_i8 = nullptr;
+        idx->d_row_scale = nullptr;
         idx->d_rows = nullptr;
         idx->d_tags = nullptr;
         idx->d_gid = nullptr;
@@ -759,35 +824,51 @@ int rass_index_drop(rass_engine_t* eng, const char* name) {
 
 int rass_index_set_prefilter(rass_index_t* idx, int enable) {
     if (!idx) return fail(RASS_ERR_INVALID, "index is NULL");
+    if (enable < 0 || enable > 2) return fail(RASS_ERR_INVALID, "prefilter mode must be 0 (off), 1 (bf16) or 2 (int8)");
     rass_engine* eng = idx->eng;
     std::lock_guard<std::mutex> lk(idx->mu);
     std::lock_guard<std::mutex> elk(eng->mu);
     int rc = set_device(eng);
     if (rc != RASS_OK) return rc;
     hipStream_t st = eng->stream;
-    if (!enable) {
-        HIP_TRY(hipStreamSynchronize(st));
-        if (idx->d_rows_bf16) (void)hipFree(idx->d_rows_bf16);
-        idx->d_rows_bf16 = nullptr;
-        idx->prefilter = false;
-        return RASS_OK;
-    }
-    if (idx->dtype == RASS_BF16) return fail(RASS_ERR_UNSUPPORTED, "a bf16 corpus IS the bf16 scan: no prefilter mode");
-    if (idx->prefilter) return RASS_OK;
-    if (idx->stride % 256 != 0) return fail(RASS_ERR_UNSUPPORTED, "prefilter needs dim padded to a multiple of 256");
-    if (idx->stride > kNarrowStride) return fail(RASS_ERR_UNSUPPORTED, "prefilter needs dim <= 1024 (wide rows: fp32 flat scan only)");
-    if (idx->capacity > 0) {
+    if (enable && idx->dtype == RASS_BF16) return fail(RASS_ERR_UNSUPPORTED, "a bf16 corpus IS the bf16 scan: no prefilter mode");
+    if (enable == idx->prefilter) return RASS_OK;
+    if (enable == 1 && idx->stride % 256 != 0) return fail(RASS_ERR_UNSUPPORTED, "prefilter needs dim padded to a multiple of 256");
+    if (enable && idx->stride > kNarrowStride) return fail(RASS_ERR_UNSUPPORTED, "prefilter needs dim <= 1024 (wide rows: fp32 flat scan only)");
+    // leave the current mode (a switch between the two candidate copies goes through "off")
+    HIP_TRY(hipStreamSynchronize(st));
+    if (idx->d_rows_bf16) (void)hipFree(idx->d_rows_bf16);
+    if (idx->d_rows_i8) (void)hipFree(idx->d_rows_i8);
+    if (idx->d_row_scale) (void)hipFree(idx->d_row_scale);
+    idx->d_rows_bf16 = nullptr;
+    idx->d_rows_i8 = nullptr;
+    idx->d_row_scale = nullptr;
+    idx->prefilter = 0;
+    if (!enable) return RASS_OK;
+    if (enable == 1 && idx->capacity > 0) {
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&idx->d_rows_bf16), (size_t)idx->capacity * idx->stride * 2));
         HIP_TRY(hipMemsetAsync(idx->d_rows_bf16, 0, (size_t)idx->capacity * idx->stride * 2, st));
         HIP_TRY(rass::launch_convert_tile16_bf16(idx->d_rows, idx->d_rows_bf16, idx->stride, 0, (idx->rows + 15) >> 4,
                                                  st));
         HIP_TRY(hipStreamSynchronize(st));
     }
-    idx->prefilter = true;
+    if (enable == 2) {
+        idx->stride_i8 = (idx->stride + 511) / 512 * 512;
+        if (idx->capacity > 0) {
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&idx->d_rows_i8), (size_t)idx->capacity * idx->stride_i8));
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&idx->d_row_scale), (size_t)idx->capacity * sizeof(float)));
+            HIP_TRY(hipMemsetAsync(idx->d_rows_i8, 0, (size_t)idx->capacity * idx->stride_i8, st));
+            HIP_TRY(hipMemsetAsync(idx->d_row_scale, 0, (size_t)idx->capacity * sizeof(float), st));
+            HIP_TRY(rass::launch_quantize_tile16_i8(idx->d_rows, idx->d_rows_i8, idx->d_row_scale, idx->stride, idx->stride_i8, 0,
+                                                    (idx->rows + 15) >> 4, st));
+            HIP_TRY(hipStreamSynchronize(st));
+        }
+    }
+    idx->prefilter = enable;
     return RASS_OK;
 }
 
-int rass_index_get_prefilter(const rass_index_t* idx) { return (idx && idx->prefilter) ? 1 : 0; }
+int rass_index_get_prefilter(const rass_index_t* idx) { return idx ? idx->prefilter : 0; }
 
 int64_t rass_index_count(const rass_index_t* idx) { return idx ? idx->rows.load() - idx->deleted.load() : 0; }
 int64_t rass_index_rows(const rass_index_t* idx) { return idx ? idx->rows.load() : (int64_t)0; }
@@ -859,9 +940,12 @@ static int add_common(rass_index_t* idx, const float* vecs, const int32_t* tags,
         if (!device_src || idx->dtype == RASS_BF16) HIP_TRY(hipStreamSynchronize(st));
         done += m;
     }
-    if (idx->prefilter && idx->dtype == RASS_F32)
+    if (idx->prefilter == 1 && idx->dtype == RASS_F32)
         HIP_TRY(rass::launch_convert_tile16_bf16(idx->d_rows, idx->d_rows_bf16, idx->stride, idx->rows >> 4,
                                                  (idx->rows + n + 15) >> 4, st));
+    if (idx->prefilter == 2)   // whole blocks: the earlier rows of a partially filled block quantise to the same bytes again
+        HIP_TRY(rass::launch_quantize_tile16_i8(idx->d_rows, idx->d_rows_i8, idx->d_row_scale, idx->stride, idx->stride_i8,
+                                                idx->rows >> 4, (idx->rows + n + 15) >> 4, st));
     // the id a search reports for these rows: their ordinal, or the caller's global ids (ascending with the
     // ordinal, so the (score desc, id asc) tie order inside the shard is the global one)
     HIP_TRY(rass::launch_iota_i64(idx->d_gid + idx->rows, n, first_global_id >= 0 ? first_global_id : idx->rows.load(), st));
@@ -1146,6 +1230,106 @@ int scan_launch_batch(rass_index* idx, const float* d_queries, int nq, int k, co
     return RASS_OK;
 }
 
+// The prefilter mode's batch (rass_index_search_device_batch on an index in mode 1 / 2): ONE normalise, ONE query
+// conversion, the groups' candidate scans back to back, ONE grouped merge of their [grid][32][32] lists and ONE re-rank
+// launch over all queries.  Group by group the serial tail of a 32-query search (normalise 5 + convert 7 + merge 34 on 32 of
+// 256 CUs + re-rank 26 us) was a quarter of the int8 mode's time.  Same results as the group-by-group path, bit for bit.
+int prefilter_launch_batch(rass_index* idx, const float* d_queries, int nq, int k, const int32_t* d_q_filter, int64_t id_base,
+                           float* d_out_scores, int64_t* d_out_ids, int64_t gs, int64_t gi) {
+    rass_engine* eng = idx->eng;
+    hipStream_t st = eng->stream;
+    const int64_t rows = idx->rows.load(std::memory_order_acquire);
+    const bool need_tags = (idx->deleted.load(std::memory_order_acquire) > 0) || (d_q_filter != nullptr);
+    const int64_t stride = idx->stride;
+    const int kc = RASS_MAX_K;
+    const int groups = (nq + RASS_MAX_QBATCH - 1) / RASS_MAX_QBATCH;
+    const int64_t n_tiles = (rows + 63) / 64;
+    int grid = (int)std::min<int64_t>(std::max<int64_t>(n_tiles, 1), std::min(eng->n_cus, kMaxGrid));
+    if ((int64_t)grid * kc > rass::kMergeMaxCandidates) grid = rass::kMergeMaxCandidates / kc;
+    const BatchLayout L = batch_layout(groups, grid, kc, stride);
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    const size_t off_qsmall = L.total;                                                   // bf16 / int8 queries
+    const size_t off_cs = up(off_qsmall + (size_t)groups * 32 * kMaxStride * 2);        // [groups][32][32] candidate scores
+    const size_t off_ci = up(off_cs + (size_t)groups * 32 * kc * sizeof(float));        // ... and rows
+    const size_t total = up(off_ci + (size_t)groups * 32 * kc * sizeof(int64_t));
+    if (eng->batch_bytes < total) {
+        if (eng->d_batch) HIP_TRY(hipFree(eng->d_batch));   // waits for earlier batches on the device
+        eng->d_batch = nullptr;
+        eng->batch_bytes = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&eng->d_batch), total));
+        eng->batch_bytes = total;
+    }
+    unsigned char* ws = eng->d_batch;
+    float* q_all = reinterpret_cast<float*>(ws + L.q_padded);
+    float* part_scores = reinterpret_cast<float*>(ws + L.part_scores);
+    int64_t* part_ids = reinterpret_cast<int64_t*>(ws + L.part_ids);
+    unsigned char* q_small = ws + off_qsmall;
+    float* cand_scores = reinterpret_cast<float*>(ws + off_cs);
+    int64_t* cand_rows = reinterpret_cast<int64_t*>(ws + off_ci);
+    const int nq_pad = groups * 32;
+    HIP_TRY(rass::launch_normalize_rows_f32(d_queries, idx->dim, q_all, stride, nq, idx->dim, st, nq_pad));
+    const bool i8 = idx->prefilter == 2;
+    const int64_t qs_stride = i8 ? idx->stride_i8 : stride * 2;   // bytes per converted query
+    if (i8) HIP_TRY(rass::launch_queries_to_i8(q_all, q_small, nq_pad, stride, idx->stride_i8, st));
+    else HIP_TRY(rass::launch_queries_to_bf16(q_all, q_small, (int64_t)nq_pad * stride, st));
+    for (int g = 0; g < groups; ++g) {
+        const int b = std::min(RASS_MAX_QBATCH, nq - g * 32);
+        const bool timed = eng->ev_on && (size_t)(2 * eng->ev_used + 1) < eng->ev_pool.size();
+        if (timed) HIP_TRY(hipEventRecord(eng->ev_pool[2 * eng->ev_used], st));
+        if (i8) {
+            rass::ScanI8Args a;
+            a.corpus = idx->d_rows_i8;
+            a.row_scale = idx->d_row_scale;
+            a.row_tag = need_tags ? idx->d_tags : nullptr;
+            a.q_i8 = reinterpret_cast<const signed char*>(q_small + (int64_t)g * 32 * qs_stride);
+            a.q_filter = d_q_filter ? d_q_filter + g * 32 : nullptr;
+            a.part_scores = part_scores + (int64_t)g * L.part_per_group;
+            a.part_ids = part_ids + (int64_t)g * L.part_per_group;
+            a.row_stride = idx->stride_i8;
+            a.n_rows = (int)rows;
+            a.nq = b;
+            a.k = kc;
+            if (i8_sample_floor(rows, grid)) {
+                rass::ScanI8Args sa = a;
+                sa.n_rows = 64 * grid;
+                sa.k = 1;
+                sa.part_scores = reinterpret_cast<float*>(ws + L.sample_best) + (int64_t)g * 32 * rass::kMaxSampleGroups;
+                sa.part_ids = nullptr;
+                HIP_TRY(rass::launch_scan_i8_topk(sa, grid, st));
+                a.sample_best = sa.part_scores;
+                a.sample_groups = grid;
+            }
+            HIP_TRY(rass::launch_scan_i8_topk(a, grid, st));
+        } else {
+            rass::ScanBf16Args a;
+            a.corpus = idx->d_rows_bf16;
+            a.row_tag = need_tags ? idx->d_tags : nullptr;
+            a.q_bf16 = reinterpret_cast<const unsigned short*>(q_small + (int64_t)g * 32 * qs_stride);
+            a.q_filter = d_q_filter ? d_q_filter + g * 32 : nullptr;
+            a.part_scores = part_scores + (int64_t)g * L.part_per_group;
+            a.part_ids = part_ids + (int64_t)g * L.part_per_group;
+            a.row_stride = stride;
+            a.n_rows = (int)rows;
+            a.nq = b;
+            a.k = kc;
+            HIP_TRY(rass::launch_scan_bf16_topk(a, grid, st));
+        }
+        if (timed) {
+            HIP_TRY(hipEventRecord(eng->ev_pool[2 * eng->ev_used + 1], st));
+            eng->ev_used += 1;
+        }
+    }
+    rass::MergeGroups mg;
+    mg.size = RASS_MAX_QBATCH;
+    mg.nq_total = nq;
+    mg.lists_are_dense = true;
+    mg.score_stride = mg.id_stride = (int64_t)L.part_per_group;
+    mg.out_score_stride = mg.out_id_stride = (int64_t)32 * kc;
+    HIP_TRY(rass::launch_merge_topk(part_scores, part_ids, grid, nq, kc, cand_scores, cand_rows, st, nullptr, 0, 0, &mg));
+    HIP_TRY(rass::launch_rerank_f32(idx->d_rows, stride, q_all, cand_rows, nq, kc, k, id_base, d_out_scores, d_out_ids, st, gs, gi));
+    return RASS_OK;
+}
+
 }  // namespace
 
 int rass_index_search_device_ex(rass_index_t* idx, const float* d_queries, int nq, int k, const int32_t* d_q_filter,
@@ -1190,6 +1374,9 @@ int rass_index_search_device_batch(rass_index_t* idx, const float* d_queries, in
     if (rc != RASS_OK) return rc;
     const bool fused = idx->dtype == RASS_F32 && !idx->prefilter && nq > RASS_MAX_QBATCH;
     if (fused) return scan_launch_batch(idx, d_queries, nq, k, d_q_filter, id_base, d_out_scores, d_out_ids, gs, gi);
+    if (idx->prefilter && idx->dtype == RASS_F32 && nq > RASS_MAX_QBATCH && k <= kPrefilterMaxK &&
+        !idx->has_gid.load(std::memory_order_acquire) && idx->rows.load(std::memory_order_acquire) > 0)
+        return prefilter_launch_batch(idx, d_queries, nq, k, d_q_filter, id_base, d_out_scores, d_out_ids, gs, gi);
     // bf16 / prefilter corpora and single groups: the same result group by group
     for (int g = 0; g * RASS_MAX_QBATCH < nq; ++g) {
         const int b = std::min(RASS_MAX_QBATCH, nq - g * RASS_MAX_QBATCH);
@@ -1204,6 +1391,24 @@ int rass_index_search_device_batch(rass_index_t* idx, const float* d_queries, in
 int rass_index_search_device(rass_index_t* idx, const float* d_queries, int nq, int k, const int32_t* d_q_filter,
                              int64_t id_base, float* d_out_scores, int64_t* d_out_ids) {
     return rass_index_search_device_ex(idx, d_queries, nq, k, d_q_filter, nullptr, id_base, d_out_scores, d_out_ids);
+}
+
+int rass_index_candidates_device(rass_index_t* idx, const float* d_queries, int nq, const int32_t* d_q_filter,
+                                 float* d_cand_scores, int64_t* d_cand_rows) {
+    if (!idx || !d_queries || !d_cand_scores || !d_cand_rows) return fail(RASS_ERR_INVALID, "NULL argument");
+    if (nq < 1 || nq > RASS_MAX_QBATCH) return fail(RASS_ERR_INVALID, "nq must be in [1, RASS_MAX_QBATCH]");
+    rass_engine* eng = idx->eng;
+    std::lock_guard<std::mutex> lk(eng->mu);
+    int rc = set_device(eng);
+    if (rc != RASS_OK) return rc;
+    if (!idx->prefilter || idx->dtype != RASS_F32) return fail(RASS_ERR_UNSUPPORTED, "the index is not in a prefilter mode");
+    if (idx->rows.load(std::memory_order_acquire) <= 0) return fail(RASS_ERR_INVALID, "the index is empty");
+    const bool need_tags = (idx->deleted.load(std::memory_order_acquire) > 0) || (d_q_filter != nullptr);
+    const ScratchLayout L = scratch_layout(RASS_MAX_QBATCH, RASS_MAX_K);
+    // the re-rank's own output (top-1 of every query) goes to the scratch's candidate area: not reported here
+    return prefilter_launch(idx, d_queries, nq, d_q_filter, 1, 0, reinterpret_cast<float*>(eng->d_scratch + L.cand_scores),
+                            reinterpret_cast<int64_t*>(eng->d_scratch + L.cand_ids), need_tags ? idx->d_tags : nullptr, eng,
+                            eng->stream, d_cand_scores, d_cand_rows);
 }
 
 namespace {
@@ -1678,9 +1883,12 @@ int rass_index_fill_synthetic(rass_index_t* idx, int64_t n, uint64_t seed, int64
     HIP_TRY(rass::launch_fill_synthetic_f32(idx->d_rows, idx->stride, idx->rows, n, idx->dim, seed, row_id_base, st));
     HIP_TRY(rass::launch_fill_i32(idx->d_tags + idx->rows, n, 0, st));
     HIP_TRY(rass::launch_iota_i64(idx->d_gid + idx->rows, n, idx->rows.load(), st));
-    if (idx->prefilter && idx->dtype == RASS_F32)
+    if (idx->prefilter == 1 && idx->dtype == RASS_F32)
         HIP_TRY(rass::launch_convert_tile16_bf16(idx->d_rows, idx->d_rows_bf16, idx->stride, idx->rows >> 4,
                                                  (idx->rows + n + 15) >> 4, st));
+    if (idx->prefilter == 2)   // whole blocks: the earlier rows of a partially filled block quantise to the same bytes again
+        HIP_TRY(rass::launch_quantize_tile16_i8(idx->d_rows, idx->d_rows_i8, idx->d_row_scale, idx->stride, idx->stride_i8,
+                                                idx->rows >> 4, (idx->rows + n + 15) >> 4, st));
     idx->rows += n;
     idx->host_deleted.resize((size_t)((idx->rows + 7) / 8), 0);
     return RASS_OK;

@@ -120,9 +120,34 @@ hipError_t launch_convert_tile16_bf16(const float* src, void* dst, int64_t strid
 hipError_t launch_unpack_rows_tile16b(const void* slab, int64_t stride, int64_t first_row, int64_t n, int dim,
                                       float* out, int64_t out_stride, hipStream_t stream);
 hipError_t launch_queries_to_bf16(const float* src, void* dst, int64_t n, hipStream_t stream);
+// out_*_group_stride (elements; 0 = contiguous [nq][k]): query q's results go to out + (q / 32) * group_stride + (q % 32) * k
 hipError_t launch_rerank_f32(const float* slab, int64_t stride, const float* q_padded, const int64_t* cand_rows, int nq,
                              int n_cand, int k, int64_t id_base, float* out_scores, int64_t* out_ids,
-                             hipStream_t stream);
+                             hipStream_t stream, int64_t out_scores_group_stride = 0, int64_t out_ids_group_stride = 0);
+
+// ---- int8 candidate scan of the prefilter mode (scan_i8.hip, SURVEY §8f-4 "or int8")
+struct ScanI8Args {
+    const signed char* corpus;   // tile16i int8 slab
+    const float* row_scale;      // [n_rows] max|x| / 127 of every row
+    const int32_t* row_tag;      // [n_rows] or nullptr
+    const signed char* q_i8;     // [16*NT][row_stride] quantised queries, row-major
+    const int32_t* q_filter;     // [nq] or nullptr; -1 = no filter (exact tag compare)
+    float* part_scores;          // [grid][nq][k]  (float)(integer dot) * row scale
+    int64_t* part_ids;           // [grid][nq][k]  LOCAL rows
+    int64_t row_stride;          // bytes per row of the int8 slab: 512 or 1024
+    int n_rows;
+    int nq;
+    int k;                       // candidates kept per query (<= 32)
+    // the sample floor (nullptr = none): part_scores [sample_groups][nq][1] of a SAMPLE launch — this kernel with k = 1 over the
+    // slab's first 64 * sample_groups rows, same queries and filters; see scan_i8.hip
+    const float* sample_best = nullptr;
+    int sample_groups = 0;
+};
+hipError_t launch_scan_i8_topk(const ScanI8Args& a, int grid, hipStream_t stream);
+// fp32 tile16 blocks [block0, block1) -> tile16i blocks of dst (+ one scale per row)
+hipError_t launch_quantize_tile16_i8(const float* src, void* dst, float* scale, int64_t stride, int64_t stride_i8, int64_t block0,
+                                     int64_t block1, hipStream_t stream);
+hipError_t launch_queries_to_i8(const float* src, void* dst, int nq_pad, int64_t stride, int64_t stride_i8, hipStream_t stream);
 
 // ---- peer-store exchange of per-shard top-k (peer.hip)
 hipError_t launch_peer_post(const void* local, size_t bytes, void* remote_slot, void* remote_flag, uint64_t seq,

@@ -358,37 +358,41 @@ hipError_t launch_queries_to_bf16(const float* src, void* dst, int64_t n, hipStr
 // Exact re-rank.  One workgroup per query: thread (c = tid>>3, w = tid&7) recomputes K-slice w of
 // candidate c's score in the flat kernel's order (chunk j, component i, lane group g: the fmaf
 // chain of v_mfma_f32_16x16x4_f32), the 8 slice partials are added in slice order, then the 32
-// exact (score, id) pairs are ranked by counting and the best k are written.
+// exact (score, id) pairs are ranked by counting and the best k are written.  CH = chunks per slice (stride / 128), a
+// template parameter so that the slice's 4 CH row loads are all in flight before the first fmaf (with a runtime bound the
+// loop paid one gather round trip per chunk: 26 us per launch at 1024 columns, r4).
+template <int CH>
 __global__ __launch_bounds__(256) void rerank_f32_kernel(const float* __restrict__ slab, int64_t stride,
                                                          const float* __restrict__ q_padded,
                                                          const int64_t* __restrict__ cand_rows, int n_cand, int k,
                                                          int64_t id_base, float* __restrict__ out_scores,
-                                                         int64_t* __restrict__ out_ids) {
+                                                         int64_t* __restrict__ out_ids, int64_t gs, int64_t gi) {
     __shared__ float part[32][9];
     __shared__ float sc[32];
     __shared__ int64_t rw[32];
     const int q = blockIdx.x;
+    float* const os = out_scores + (gs > 0 ? (int64_t)(q >> 5) * gs + (int64_t)(q & 31) * k : (int64_t)q * k);
+    int64_t* const oi = out_ids + (gi > 0 ? (int64_t)(q >> 5) * gi + (int64_t)(q & 31) * k : (int64_t)q * k);
     const int c = threadIdx.x >> 3, w = threadIdx.x & 7;
-    const int ch = (int)(stride >> 7);
     const int64_t row = c < n_cand ? cand_rows[(int64_t)q * n_cand + c] : -1;
     float acc = 0.f;
     if (row >= 0) {
-        const float* xb = slab + (row >> 4) * 16 * stride;
-        const float* qv = q_padded + (int64_t)q * stride;
-        const int mrow = (int)(row & 15);
-        for (int j = 0; j < ch; ++j) {
-            const int chunk = w * ch + j;
-            f32x4 xv[4];
+        const float* xb = slab + (row >> 4) * 16 * stride + (int64_t)(w * CH) * 256 + (int)(row & 15) * 4;
+        const float* qv = q_padded + (int64_t)q * stride + w * CH * 16;
+        f32x4 xv[CH][4];
+#pragma unroll
+        for (int j = 0; j < CH; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) xv[j][g] = *reinterpret_cast<const f32x4*>(xb + j * 256 + g * 64);
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
             f32x4 qq[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                xv[g] = *reinterpret_cast<const f32x4*>(xb + (int64_t)chunk * 256 + (g * 16 + mrow) * 4);
-                qq[g] = *reinterpret_cast<const f32x4*>(qv + chunk * 16 + 4 * g);
-            }
+            for (int g = 0; g < 4; ++g) qq[g] = *reinterpret_cast<const f32x4*>(qv + j * 16 + 4 * g);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) acc = fmaf(xv[g][i], qq[g][i], acc);
+                for (int g = 0; g < 4; ++g) acc = fmaf(xv[j][g][i], qq[g][i], acc);
         }
     }
     part[c][w] = acc;
@@ -417,8 +421,8 @@ __global__ __launch_bounds__(256) void rerank_f32_kernel(const float* __restrict
         }
         if (r < 0) rank = 32 + cc;  // invalid entries never land in [0, k)
         if (rank < k) {
-            out_scores[(int64_t)q * k + rank] = s;
-            out_ids[(int64_t)q * k + rank] = id_base + r;
+            os[rank] = s;
+            oi[rank] = id_base + r;
         }
     }
     // slots beyond the number of valid candidates
@@ -427,18 +431,27 @@ __global__ __launch_bounds__(256) void rerank_f32_kernel(const float* __restrict
         for (int o = 0; o < 32; ++o) valid += rw[o] >= 0 ? 1 : 0;
         const int e = threadIdx.x;
         if (e >= valid && e < k) {
-            out_scores[(int64_t)q * k + e] = -INFINITY;
-            out_ids[(int64_t)q * k + e] = -1;
+            os[e] = -INFINITY;
+            oi[e] = -1;
         }
     }
 }
 
 hipError_t launch_rerank_f32(const float* slab, int64_t stride, const float* q_padded, const int64_t* cand_rows, int nq,
                              int n_cand, int k, int64_t id_base, float* out_scores, int64_t* out_ids,
-                             hipStream_t stream) {
-    if (nq < 1 || n_cand < 1 || n_cand > 32 || k < 1 || k > n_cand || stride % 128 != 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(rerank_f32_kernel, dim3(nq), dim3(256), 0, stream, slab, stride, q_padded, cand_rows, n_cand, k,
-                       id_base, out_scores, out_ids);
+                             hipStream_t stream, int64_t out_scores_group_stride, int64_t out_ids_group_stride) {
+    if (nq < 1 || n_cand < 1 || n_cand > 32 || k < 1 || k > n_cand || stride % 128 != 0 || stride > 1024) return hipErrorInvalidValue;
+#define RASS_RERANK_CASE(C)                                                                                                   \
+    case C:                                                                                                                   \
+        hipLaunchKernelGGL(rerank_f32_kernel<C>, dim3(nq), dim3(256), 0, stream, slab, stride, q_padded, cand_rows, n_cand, k, \
+                           id_base, out_scores, out_ids, out_scores_group_stride, out_ids_group_stride);                      \
+        break;
+    switch ((int)(stride >> 7)) {
+        RASS_RERANK_CASE(1) RASS_RERANK_CASE(2) RASS_RERANK_CASE(3) RASS_RERANK_CASE(4)
+        RASS_RERANK_CASE(5) RASS_RERANK_CASE(6) RASS_RERANK_CASE(7) RASS_RERANK_CASE(8)
+        default: return hipErrorInvalidValue;
+    }
+#undef RASS_RERANK_CASE
     return hipGetLastError();
 }
 

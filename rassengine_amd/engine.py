@@ -233,13 +233,44 @@ class FlatIndex:
         N.check("rass_index_get_rows", self._L.rass_index_get_rows(self._h, int(first_row), int(n), _np_ptr(out)))
         return out
 
-    def set_prefilter(self, enable: bool = True) -> None:
-        """bf16 candidate scan + exact fp32 re-rank; off by default."""
-        N.check("rass_index_set_prefilter", self._L.rass_index_set_prefilter(self._h, 1 if enable else 0))
+    PREFILTER_MODES = {False: 0, None: 0, 0: 0, "off": 0, True: 1, 1: 1, "bf16": 1, 2: 2, "int8": 2}
+
+    def set_prefilter(self, enable=True) -> None:
+        """Candidate scan over a reduced copy of the slab + exact fp32 re-rank; off by default.
+        ``enable``: False / "off", True / "bf16" (half the bytes per pass) or "int8" (a quarter)."""
+        try:
+            mode = self.PREFILTER_MODES[enable]
+        except (KeyError, TypeError):
+            raise ValueError(f"prefilter mode must be one of off / bf16 / int8, not {enable!r}") from None
+        N.check("rass_index_set_prefilter", self._L.rass_index_set_prefilter(self._h, mode))
 
     @property
     def prefilter(self) -> bool:
         return bool(self._L.rass_index_get_prefilter(self._h))
+
+    @property
+    def prefilter_mode(self) -> str:
+        return ("off", "bf16", "int8")[int(self._L.rass_index_get_prefilter(self._h))]
+
+    def candidates_device(self, d_queries, q_filter=None):
+        """The active prefilter mode's candidate lists BEFORE the exact re-rank, for <= 32 queries on the device (a torch
+        CUDA fp32 tensor [nq, dim]): (scores f32 [nq, 32], LOCAL rows i64 [nq, 32]) as torch tensors.  A parity hook: the
+        int8 path is integer work and is compared with the oracle bit for bit (tests/test_gpu_prefilter_int8.py)."""
+        import torch
+        nq = int(d_queries.shape[0])
+        assert d_queries.is_cuda and d_queries.dtype == torch.float32 and d_queries.is_contiguous() and d_queries.shape[1] == self.dim
+        s = torch.empty((nq, 32), dtype=torch.float32, device=d_queries.device)
+        r = torch.empty((nq, 32), dtype=torch.int64, device=d_queries.device)
+        f = None
+        if q_filter is not None:
+            f = torch.as_tensor(np.ascontiguousarray(q_filter, dtype=np.int32)).to(d_queries.device)
+        torch.cuda.current_stream().synchronize()     # the engine works on its own stream
+        N.check("rass_index_candidates_device",
+                self._L.rass_index_candidates_device(self._h, ctypes.c_void_p(d_queries.data_ptr()), nq,
+                                                     ctypes.c_void_p(f.data_ptr()) if f is not None else None,
+                                                     ctypes.c_void_p(s.data_ptr()), ctypes.c_void_p(r.data_ptr())))
+        self.engine.synchronize()
+        return s, r
 
     def save(self, path: str) -> None:
         N.check("rass_index_save", self._L.rass_index_save(self._h, path.encode()))

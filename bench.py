@@ -59,6 +59,10 @@ def main():
     ap.add_argument("--ivf-nlist", type=int, default=4096)
     ap.add_argument("--ivf-nprobe", type=int, default=8, help="lists probed per query and shard in --mode ivf's timed region")
     ap.add_argument("--ivf-queries", type=int, default=1024, help="queries of the IVF leg's recall / rate sweep")
+    ap.add_argument("--ivf-dtype", choices=["f32", "bf16", "int8"], default="f32",
+                    help="--mode ivf: the IVF's list-ordered copy of the rows: f32 (the parity path), bf16 (the bf16 scan's scores) or "
+                         "int8 (int8 candidates + exact fp32 re-rank: the f32 IVF's scores); the N = 1 line's ivf leg sweeps f32 "
+                         "and, flagged, int8")
     ap.add_argument("--ingest-batches", type=int, default=4, help="timed 256 x 512-token forwards of the ingest leg")
     ap.add_argument("--dim", type=int, default=1024)
     ap.add_argument("--batch", type=int, default=32, help="queries per scan launch (<= 32)")
@@ -508,7 +512,7 @@ def _ivf_centres(torch, dev, dim):
     return c / c.norm(dim=1, keepdim=True)
 
 
-def _ivf_one_corpus(np, torch, eng, dev, rows, nlist, nq, k, iid, nprobes):
+def _ivf_one_corpus(np, torch, eng, dev, rows, nlist, nq, k, iid, nprobes, int8_too=False):
     """Generate, build (two-level k-means + assignment + list-ordered copy), then per nprobe: queries/s over `nq` queries in
     32-query launch groups (hipEvents on the engine stream), recall@k against the flat scan of the SAME shard, the rows the
     fine scans touch (host API, 4 groups sampled) and probed bytes / time against the 8 TB/s HBM peak."""
@@ -540,52 +544,67 @@ def _ivf_one_corpus(np, torch, eng, dev, rows, nlist, nq, k, iid, nprobes):
         flat_ms = tm.elapsed_ms()
         truth_h = truth.cpu().numpy()
         got = torch.empty((nq, k), dtype=torch.int64, device=dev)
-        sweep = []
         stride = flat.row_stride
-        for nprobe in nprobes:
-            # group by group (one engine call per 32 queries: coarse scan, merge, plan, fine scan, merge = 5 launches each)
-            for b in range(0, min(nq, 4 * B), B):
-                ivf.search_device(q[b:b + B].data_ptr(), B, k, nprobe, out_s.data_ptr(), got[b:b + B].data_ptr())
-            eng.synchronize()
-            tm.start(stream)
-            for b in range(0, nq, B):
-                ivf.search_device(q[b:b + B].data_ptr(), B, k, nprobe, out_s.data_ptr(), got[b:b + B].data_ptr())
-            tm.stop(stream)
-            ms_groups = tm.elapsed_ms()
-            by_group = got.cpu().numpy().copy()
-            # the whole 1 024-query step in ONE call (rass_ivf_search_device_batch: one grouped coarse scan, one plan launch,
-            # G fine scans, one grouped merge) — the rate reported; results must equal the group-by-group ones
-            step = min(nq, 1024)
-            all_s = torch.empty((nq, k), device=dev)
-            for b in range(0, nq, step):
-                ivf.search_device_batch(q[b:b + step].data_ptr(), min(step, nq - b), k, nprobe, all_s[b:].data_ptr(), got[b:].data_ptr())
-            eng.synchronize()
-            tm.start(stream)
-            for b in range(0, nq, step):
-                ivf.search_device_batch(q[b:b + step].data_ptr(), min(step, nq - b), k, nprobe, all_s[b:].data_ptr(), got[b:].data_ptr())
-            tm.stop(stream)
-            ms = tm.elapsed_ms()
-            got_h = got.cpu().numpy()
-            same = bool(np.array_equal(got_h, by_group))
-            recall = float(np.mean([len(set(got_h[r]) & set(truth_h[r])) / k for r in range(nq)]))
-            _, _, scanned = ivf.search(q[:4 * B].cpu().numpy(), k, nprobe)
-            per_batch = scanned / 4
-            us = ms / (nq / B) * 1e3
-            probed = per_batch * stride * 4 + nlist * stride * 4          # fine scans + the coarse scan per batch
-            gbps = probed / (us * 1e-6) / 1e9
-            sweep.append({"nprobe": nprobe, "queries_per_s": round(nq / ms * 1e3, 1), "recall_at_10": round(recall, 4),
-                          "queries_per_s_group_by_group": round(nq / ms_groups * 1e3, 1), "batch_equals_group_by_group": same,
-                          "us_per_batch": round(us, 1), "scanned_rows_per_batch": round(per_batch),
-                          "scanned_fraction": round(per_batch / rows, 5),
-                          "roofline": {"bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                       "frac": round(gbps / HBM_PEAK_GBPS, 4), "bytes_per_batch": int(probed)}})
+
+        def sweep_of(ivf, row_bytes):
+            sweep = []
+            for nprobe in nprobes:
+                # group by group (one engine call per 32 queries: coarse scan, merge, plan, fine scan, merge = 5 launches each)
+                for b in range(0, min(nq, 4 * B), B):
+                    ivf.search_device(q[b:b + B].data_ptr(), B, k, nprobe, out_s.data_ptr(), got[b:b + B].data_ptr())
+                eng.synchronize()
+                tm.start(stream)
+                for b in range(0, nq, B):
+                    ivf.search_device(q[b:b + B].data_ptr(), B, k, nprobe, out_s.data_ptr(), got[b:b + B].data_ptr())
+                tm.stop(stream)
+                ms_groups = tm.elapsed_ms()
+                by_group = got.cpu().numpy().copy()
+                # the whole 1 024-query step in ONE call (rass_ivf_search_device_batch: one grouped coarse scan, one plan launch,
+                # G fine scans, one grouped merge) — the rate reported; results must equal the group-by-group ones
+                step = min(nq, 1024)
+                all_s = torch.empty((nq, k), device=dev)
+                for b in range(0, nq, step):
+                    ivf.search_device_batch(q[b:b + step].data_ptr(), min(step, nq - b), k, nprobe, all_s[b:].data_ptr(), got[b:].data_ptr())
+                eng.synchronize()
+                tm.start(stream)
+                for b in range(0, nq, step):
+                    ivf.search_device_batch(q[b:b + step].data_ptr(), min(step, nq - b), k, nprobe, all_s[b:].data_ptr(), got[b:].data_ptr())
+                tm.stop(stream)
+                ms = tm.elapsed_ms()
+                got_h = got.cpu().numpy()
+                same = bool(np.array_equal(got_h, by_group))
+                recall = float(np.mean([len(set(got_h[r]) & set(truth_h[r])) / k for r in range(nq)]))
+                _, _, scanned = ivf.search(q[:4 * B].cpu().numpy(), k, nprobe)
+                per_batch = scanned / 4
+                us = ms / (nq / B) * 1e3
+                probed = per_batch * row_bytes + nlist * stride * 4        # fine scans + the coarse scan per batch
+                gbps = probed / (us * 1e-6) / 1e9
+                sweep.append({"nprobe": nprobe, "queries_per_s": round(nq / ms * 1e3, 1), "recall_at_10": round(recall, 4),
+                              "queries_per_s_group_by_group": round(nq / ms_groups * 1e3, 1), "batch_equals_group_by_group": same,
+                              "us_per_batch": round(us, 1), "scanned_rows_per_batch": round(per_batch),
+                              "scanned_fraction": round(per_batch / rows, 5),
+                              "roofline": {"bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                           "frac": round(gbps / HBM_PEAK_GBPS, 4), "bytes_per_batch": int(probed)}})
+            return sweep
+
+        sweep = sweep_of(ivf, stride * 4)
+        flagged = None
+        if int8_too:
+            # FLAGGED (not the parity path): the same lists with an int8 copy of the slab — the fine scan reads a quarter of
+            # the bytes for 32 candidates per query, rescored exactly from the fp32 copy (rass_ivf_build_ex, RASS_I8)
+            ivf.close()
+            t1 = time.perf_counter()
+            ivf = IvfIndex.build(flat, nlist=nlist, centroids=cent, dtype="int8")
+            flagged = {"slab": "fp32 + per-row-scaled int8 copy; 32 int8 candidates per query, exact fp32 re-rank (k <= 16)",
+                       "build_s": round(time.perf_counter() - t1, 1),
+                       "sweep": sweep_of(ivf, (stride + 511) // 512 * 512)}
         sizes = ivf.list_sizes
         return {"rows": rows, "data": "iid N(0,1) rows (the flagged WORST case: no cluster structure to find)" if iid else
                 f"{IVF_CENTRES} Gaussian centres (seed {IVF_SEED}) + sigma {IVF_SIGMA} noise, normalised",
                 "gen_s": round(gen_s, 1), "train_s": round(train_s, 1), "build_s": round(build_s, 1),
                 "list_len_mean": round(float(sizes.mean()), 1), "list_len_max": int(sizes.max()),
                 "empty_lists": int((sizes == 0).sum()), "flat_queries_per_s_same_shard": round(nq / flat_ms * 1e3, 1),
-                "sweep": sweep}
+                "sweep": sweep, **({"int8_slab_flagged": flagged} if flagged else {})}
     finally:
         ivf.close()
         eng.drop_index(name)
@@ -605,7 +624,7 @@ def ivf_leg(np, torch, device, args):
                            "recall_at_10 = overlap with the exact flat scan of the same shard",
                "nlist": args.ivf_nlist, "training": "two-level spherical k-means (4 x nlist fine lists), 10 iterations, 1 M-row sample",
                "clustered": _ivf_one_corpus(np, torch, eng, dev, args.ivf_rows, args.ivf_nlist, args.ivf_queries, args.k,
-                                            False, nprobes)}
+                                            False, nprobes, int8_too=args.k <= 16)}
         out["iid_worst_case"] = _ivf_one_corpus(np, torch, eng, dev, args.ivf_rows, args.ivf_nlist, args.ivf_queries,
                                                 args.k, True, nprobes)
         out["leg_s"] = round(time.perf_counter() - t0, 1)
@@ -632,7 +651,7 @@ def ivf_mode(np, torch, dist, args, world, rank, local_rank, dev, coll):
     _ivf_fill(torch, flat, eng, rows, dev, False, IVF_SEED + 1 + rank, centres)
     t0 = time.perf_counter()
     cent = train_centroids(flat, nlist, train_rows=0, iters=10, seed=1)        # collective: shared centroids
-    ivf = IvfIndex.build(flat, nlist=nlist, centroids=cent)
+    ivf = IvfIndex.build(flat, nlist=nlist, centroids=cent, dtype=args.ivf_dtype)
     torch.cuda.synchronize()
     build_s = time.perf_counter() - t0
     shard = IvfShard(ivf, id_base=row_lo, nprobe=nprobe)        # switches the engine to torch's current stream
@@ -697,11 +716,14 @@ def ivf_mode(np, torch, dist, args, world, rank, local_rank, dev, coll):
     stride = flat.row_stride
     # (nprobe <= 32: ONE fine-scan launch per step; deeper probes run group by group: LPS launches per step)
     groups_per_launch = max(1, round(LPS * args.steps / max(scan_launches, 1)))
-    fine_bytes = per_step * stride * 4 * groups_per_launch / LPS
+    row_bytes = {"f32": stride * 4, "bf16": stride * 2, "int8": (stride + 511) // 512 * 512}[args.ivf_dtype]
+    fine_bytes = per_step * row_bytes * groups_per_launch / LPS
     achieved = fine_bytes * scan_launches / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
     rows_global = rows * world
     result = {
-        "metric": "queries/sec, IVF cosine top-10 over N x 1024-d fp32 corpus in HBM (BASELINE configs[4])",
+        "metric": "queries/sec, IVF cosine top-10 over N x 1024-d fp32 corpus in HBM (BASELINE configs[4])" +
+                  ("" if args.ivf_dtype == "f32" else f" — FLAGGED: {args.ivf_dtype} slab" +
+                   (" (int8 candidates + exact fp32 re-rank)" if args.ivf_dtype == "int8" else " (the bf16 scan's scores)")),
         "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "row_queries_per_s": round(qps * rows_global, 1), "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -712,10 +734,12 @@ def ivf_mode(np, torch, dist, args, world, rank, local_rank, dev, coll):
                    "data": f"{IVF_CENTRES} Gaussian centres (seed {IVF_SEED}) + sigma {IVF_SIGMA} noise, normalised",
                    "cross_shard_exchange": f"{coll} all-gather" if world > 1 else None,
                    "sharding": f"row-sharded x{world}, shared centroids, {coll} all-gather merge" if world > 1 else "single shard",
-                   "train_and_build_s": round(build_s, 1)},
+                   "train_and_build_s": round(build_s, 1), "slab_dtype": args.ivf_dtype},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
-                     "kernel": "scan_topk_f32_kernel<8, 2, 5, false> (kIvfGroups: the fine scans of a step's launch groups, one launch)",
+                     "kernel": "scan_topk_f32_kernel<8, 2, 5, false> (kIvfGroups: the fine scans of a step's launch groups, one launch)"
+                     if args.ivf_dtype == "f32" else "scan_i8_topk_kernel<2, 2, true> (one launch per group)" if args.ivf_dtype == "int8"
+                     else "scan_bf16_topk_kernel<4, 2, false, true> (one launch per group)",
                      "bytes_per_launch": int(fine_bytes), "scanned_rows_per_batch": round(per_batch),
                      "launch_groups_per_launch": groups_per_launch,
                      "avg_launch_us": round(scan_ms / max(scan_launches, 1) * 1e3, 2), "launches": scan_launches},

@@ -52,7 +52,8 @@ typedef enum rass_status {
  * prefilter mode and the IVF build are fp32-only. */
 typedef enum rass_dtype {
     RASS_F32 = 0,
-    RASS_BF16 = 1
+    RASS_BF16 = 1,
+    RASS_I8 = 2     /* ONLY as the slab_dtype of rass_ivf_build_ex / _prefix (an index is fp32 or bf16) */
 } rass_dtype;
 
 /* Limits of the fused scan kernel. */
@@ -392,7 +393,11 @@ int rass_ivf_build(rass_index_t* src, const float* centroids, int nlist,
  * RASS_BF16 = the rows rounded to bf16 (half the HBM bytes per probed row; needs the row stride to be a multiple of
  * 256): the fine scan is then the bf16 scan (queries rounded to bf16, fp32 accumulation) and a probe returns what a
  * flat RASS_BF16 index over the same rows returns, restricted to the probed lists.  The source index is fp32 either
- * way (k-means and the assignment read it) and may be dropped afterwards.  (SURVEY §8f-4's bf16 path for cfg 5.) */
+ * way (k-means and the assignment read it) and may be dropped afterwards.  (SURVEY §8f-4's bf16 path for cfg 5.)
+ * RASS_I8 = an fp32 slab (lists on 64-row tiles) PLUS its int8 copy (per-row-scaled, as rass_index_set_prefilter mode 2): the
+ * fine scan reads the int8 copy (a quarter of the bytes per probed row) and keeps 32 candidates per query, which are then
+ * rescored exactly from the fp32 slab — returned scores are the fp32 IVF's bit for bit, the id set equals it whenever the
+ * probed lists' true top-k lies inside the int8 top-32 (measured as recall).  Serves k <= 16 (RASS_ERR_UNSUPPORTED beyond). */
 int rass_ivf_build_ex(rass_index_t* src, const float* centroids, int nlist,
                       const int32_t* assign, rass_dtype slab_dtype, rass_ivf_t** out);
 void rass_ivf_destroy(rass_ivf_t* ivf);

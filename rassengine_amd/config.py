@@ -39,7 +39,13 @@ RASS_KNN_PREFETCH = _int("RASS_KNN_PREFETCH", 1)
 RASS_IVF_NLIST = _int("RASS_IVF_NLIST", 0)
 RASS_IVF_NPROBE = _int("RASS_IVF_NPROBE", 8)
 RASS_IVF_MIN_ROWS = _int("RASS_IVF_MIN_ROWS", 262144)
-RASS_IVF_DTYPE = os.getenv("RASS_IVF_DTYPE", "f32")            # the IVF's own copy of the rows: "f32" | "bf16"
+RASS_IVF_DTYPE = os.getenv("RASS_IVF_DTYPE", "f32")            # the IVF's own copy of the rows: "f32" | "bf16" | "int8" (+ exact re-rank, k <= 16)
+# Candidate scan of a flat index's searches with k <= 16: "off" (exact fp32 scan, the default), "bf16" (half the bytes per pass)
+# or "int8" (a quarter: per-row-scaled int8 copy); the 32 candidates per query are re-scored exactly in fp32 either way
+# (include/rass_engine.h: rass_index_set_prefilter).  The reference's own index is approximate (HNSW, app/main.py:563-572).
+RASS_PREFILTER = os.getenv("RASS_PREFILTER", "off").strip().lower() or "off"
+if RASS_PREFILTER not in ("off", "bf16", "int8"):
+    raise ValueError(f"RASS_PREFILTER must be off, bf16 or int8, not {RASS_PREFILTER!r}")
 try:
     RASS_IVF_REBUILD_FRACTION = float(os.getenv("RASS_IVF_REBUILD_FRACTION", "0.25"))
 except ValueError:

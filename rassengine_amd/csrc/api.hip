@@ -588,6 +588,13 @@ struct rass_ivf {
     int tile_rows = 32;             // rows per plan tile = the fine scan kernel's tile
     float* d_slab = nullptr;        // tile16, lists contiguous, each starting on a 32-row tile
     unsigned short* d_slab_b16 = nullptr;  // bf16 slab: the rows rounded to bf16, lists starting on 64-row tiles
+    // RASS_I8: d_slab (fp32, lists on 64-row tiles: read by the exact re-rank only) + its int8 copy (tile16i) and row scales:
+    // the fine scan keeps 32 int8 candidates per query, the re-rank rescores them exactly and returns the best k <= 16
+    signed char* d_slab_i8 = nullptr;
+    float* d_slab_scale = nullptr;
+    int64_t stride_i8 = 0;
+    float* d_cand_scores = nullptr;        // [32][32] candidates of one launch group (RASS_I8)
+    int64_t* d_cand_rows = nullptr;
     int32_t* d_tags = nullptr;      // [slab_rows] permuted row tags (0 on padding)
     int64_t* d_ids = nullptr;       // [slab_rows] source row id, -1 on padding
     float* d_centroids = nullptr;   // tile16 slab of nlist normalised centroids
@@ -2084,7 +2091,7 @@ void* rass_index_device_tags(rass_index_t* idx) { return idx ? reinterpret_cast<
 
 static void ivf_free(rass_ivf* v) {
     if (!v) return;
-    for (void* p : {(void*)v->d_slab, (void*)v->d_slab_b16, (void*)v->d_tags, (void*)v->d_ids, (void*)v->d_centroids, (void*)v->d_list_tile0,
+    for (void* p : {(void*)v->d_slab, (void*)v->d_slab_b16, (void*)v->d_slab_i8, (void*)v->d_slab_scale, (void*)v->d_cand_scores, (void*)v->d_cand_rows, (void*)v->d_tags, (void*)v->d_ids, (void*)v->d_centroids, (void*)v->d_list_tile0,
                     (void*)v->d_list_len, (void*)v->d_work_tile, (void*)v->d_work_rows, (void*)v->d_n_work,
                     (void*)v->d_work_mask, (void*)v->d_scanned, (void*)v->d_probe_scores, (void*)v->d_probe_ids,
                     (void*)v->d_tau, (void*)v->d_list_mask, (void*)v->d_pair_scores, (void*)v->d_pair_ids, (void*)v->d_batch})
@@ -2108,10 +2115,10 @@ int rass_ivf_build_prefix(rass_index_t* src, const float* centroids, int nlist, 
     if (nlist < 1 || nlist > 32768) return fail(RASS_ERR_INVALID, "nlist must be in [1, 32768]");
     if (src->dtype != RASS_F32) return fail(RASS_ERR_UNSUPPORTED, "the IVF build needs an fp32 source index");
     if (src->stride > kNarrowStride) return fail(RASS_ERR_UNSUPPORTED, "IVF needs dim <= 1024 (wide rows: flat scan only)");
-    if (slab_dtype != RASS_F32 && slab_dtype != RASS_BF16) return fail(RASS_ERR_INVALID, "unknown slab dtype");
+    if (slab_dtype != RASS_F32 && slab_dtype != RASS_BF16 && slab_dtype != RASS_I8) return fail(RASS_ERR_INVALID, "unknown slab dtype");
     if (slab_dtype == RASS_BF16 && src->stride % 256 != 0)
         return fail(RASS_ERR_UNSUPPORTED, "a bf16 slab needs dim padded to a multiple of 256 (the bf16 scan's K split)");
-    const int tile_rows = slab_dtype == RASS_BF16 ? 64 : 32;
+    const int tile_rows = slab_dtype == RASS_F32 ? 32 : 64;
     rass_engine* eng = src->eng;
     std::lock_guard<std::mutex> lk(src->mu);
     int rc = set_device(eng);
@@ -2172,6 +2179,14 @@ int rass_ivf_build_prefix(rass_index_t* src, const float* centroids, int nlist, 
         IVF_TRY(hipMalloc(reinterpret_cast<void**>(&v->d_slab_b16), (size_t)slab_rows * v->stride * 2));
     else
         IVF_TRY(hipMalloc(reinterpret_cast<void**>(&v->d_slab), (size_t)slab_rows * v->stride * 4));
+    if (slab_dtype == RASS_I8) {
+        v->stride_i8 = (v->stride + 511) / 512 * 512;
+        IVF_TRY(hipMalloc(reinterpret_cast<void**>(&v->d_slab_i8), (size_t)slab_rows * v->stride_i8));
+        IVF_TRY(hipMalloc(reinterpret_cast<void**>(&v->d_slab_scale), (size_t)slab_rows * 4));
+        IVF_TRY(hipMalloc(reinterpret_cast<void**>(&v->d_cand_scores), RASS_MAX_QBATCH * RASS_MAX_K * 4));
+        IVF_TRY(hipMalloc(reinterpret_cast<void**>(&v->d_cand_rows), RASS_MAX_QBATCH * RASS_MAX_K * 8));
+        IVF_TRY(hipMemsetAsync(v->d_slab_i8, 0, (size_t)slab_rows * v->stride_i8, st));
+    }
     IVF_TRY(hipMalloc(reinterpret_cast<void**>(&v->d_tags), (size_t)slab_rows * 4));
     IVF_TRY(hipMalloc(reinterpret_cast<void**>(&v->d_ids), (size_t)slab_rows * 8));
     IVF_TRY(hipMalloc(reinterpret_cast<void**>(&v->d_centroids), (size_t)cent_rows * v->stride * 4));
@@ -2195,6 +2210,8 @@ int rass_ivf_build_prefix(rass_index_t* src, const float* centroids, int nlist, 
         IVF_TRY(rass::launch_permute_rows_tile16_bf16(src->d_rows, v->d_slab_b16, v->stride, v->d_ids, slab_rows, st));
     else
         IVF_TRY(rass::launch_permute_rows_tile16(src->d_rows, v->d_slab, v->stride, v->d_ids, slab_rows, st));
+    if (slab_dtype == RASS_I8)
+        IVF_TRY(rass::launch_quantize_tile16_i8(v->d_slab, v->d_slab_i8, v->d_slab_scale, v->stride, v->stride_i8, 0, slab_rows / 16, st));
     // tags: permuted on the host (small), padding rows get 0
     {
         std::vector<int32_t> tags((size_t)std::max<int64_t>(n, 1), 0), ptags((size_t)slab_rows, 0);
@@ -2276,7 +2293,8 @@ int rass_ivf_save(rass_ivf_t* v, const char* path) {
     memcpy(h.magic, "RASSIVF1", 8);
     // 3 / 4 (since round 4) = 1 / 2 followed by one int64: the source rows the IVF covers (rass_ivf_covered_rows).
     // 2, 4: the row slab is bf16 (tile16b) with lists on 64-row tiles
-    h.version = v->dtype == RASS_BF16 ? 4 : 3;
+    // 5: the fp32 slab with lists on 64-row tiles of an int8 IVF (the int8 copy and its scales are rebuilt by the load)
+    h.version = v->dtype == RASS_BF16 ? 4 : v->dtype == RASS_I8 ? 5 : 3;
     h.dim = v->dim;
     h.nlist = v->nlist;
     h.any_tags = v->any_tags ? 1 : 0;
@@ -2308,7 +2326,7 @@ int rass_ivf_load(rass_engine_t* eng, const char* path, rass_ivf_t** out) {
     FILE* f = fopen(path, "rb");
     if (!f) return fail(RASS_ERR_IO, std::string("cannot open for read: ") + path);
     IvfSaveHeader h;
-    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "RASSIVF1", 8) != 0 || h.version < 1 || h.version > 4) {
+    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "RASSIVF1", 8) != 0 || h.version < 1 || h.version > 5) {
         fclose(f);
         return fail(RASS_ERR_IO, "not a rass IVF file");
     }
@@ -2319,7 +2337,8 @@ int rass_ivf_load(rass_engine_t* eng, const char* path, rass_ivf_t** out) {
         return fail(RASS_ERR_IO, "IVF file is truncated / corrupt");
     }
     const bool b16 = h.version == 2 || h.version == 4;
-    const int tile_rows = b16 ? 64 : 32;
+    const bool i8 = h.version == 5;
+    const int tile_rows = (b16 || i8) ? 64 : 32;
     const int64_t esize = b16 ? 2 : 4;
     const int64_t cent_rows = ((int64_t)h.nlist + 15) / 16 * 16;
     bool sane = h.dim == eng->dim && h.stride == pad128(h.dim) && h.nlist >= 1 && h.nlist <= 32768 && h.rows >= 0 &&
@@ -2351,8 +2370,9 @@ int rass_ivf_load(rass_engine_t* eng, const char* path, rass_ivf_t** out) {
     v->slab_rows = h.slab_rows;
     v->total_tiles = h.total_tiles;
     v->any_tags = h.any_tags != 0;
-    v->dtype = b16 ? RASS_BF16 : RASS_F32;
+    v->dtype = b16 ? RASS_BF16 : i8 ? RASS_I8 : RASS_F32;
     v->tile_rows = tile_rows;
+    v->stride_i8 = (h.stride + 511) / 512 * 512;
     std::lock_guard<std::mutex> lk(eng->mu);
     hipStream_t st = eng->stream;
     auto alloc = [&](void** p, size_t bytes) { return hipMalloc(p, bytes) == hipSuccess; };
@@ -2368,6 +2388,9 @@ int rass_ivf_load(rass_engine_t* eng, const char* path, rass_ivf_t** out) {
               alloc((void**)&v->d_list_mask, (size_t)h.nlist * 4) &&
               alloc((void**)&v->d_pair_scores, 2 * RASS_MAX_QBATCH * RASS_MAX_K * 4) &&
               alloc((void**)&v->d_pair_ids, 2 * RASS_MAX_QBATCH * RASS_MAX_K * 8);
+    if (ok && i8)
+        ok = alloc((void**)&v->d_slab_i8, (size_t)h.slab_rows * v->stride_i8) && alloc((void**)&v->d_slab_scale, (size_t)h.slab_rows * 4) &&
+             alloc((void**)&v->d_cand_scores, RASS_MAX_QBATCH * RASS_MAX_K * 4) && alloc((void**)&v->d_cand_rows, RASS_MAX_QBATCH * RASS_MAX_K * 8);
     if (!ok) {
         fclose(f);
         ivf_free(v);
@@ -2380,6 +2403,10 @@ int rass_ivf_load(rass_engine_t* eng, const char* path, rass_ivf_t** out) {
          (b16 ? file_to_dev(f, v->d_slab_b16, (size_t)h.slab_rows * h.stride * 2, st, buf)
               : file_to_dev(f, v->d_slab, (size_t)h.slab_rows * h.stride * 4, st, buf));
     fclose(f);
+    if (ok && i8)   // the int8 copy is a function of the fp32 slab: rebuilt, not stored
+        ok = hipMemsetAsync(v->d_slab_i8, 0, (size_t)h.slab_rows * v->stride_i8, st) == hipSuccess &&
+             rass::launch_quantize_tile16_i8(v->d_slab, v->d_slab_i8, v->d_slab_scale, v->stride, v->stride_i8, 0, h.slab_rows / 16, st) == hipSuccess &&
+             hipStreamSynchronize(st) == hipSuccess;
     if (!ok) {
         ivf_free(v);
         return fail(RASS_ERR_IO, "ivf load: short read or upload failure");
@@ -2546,6 +2573,50 @@ static int ivf_search_locked(rass_ivf_t* v, const float* d_queries, int nq, int 
         HIP_TRY(rass::launch_merge_topk(part_scores, part_ids, grid, nq, k, d_out_scores, d_out_ids, st, v->d_ids));
         return RASS_OK;
     }
+    if (v->dtype == RASS_I8) {
+        // the int8 scan over the planned 64-row tiles keeps 32 candidates per query (slab positions); the re-rank rescores
+        // them exactly from the fp32 slab in the flat kernel's order and returns the best k under (score desc, source id asc)
+        if (k > kPrefilterMaxK) return fail(RASS_ERR_UNSUPPORTED, "an int8 IVF slab serves k <= 16 (32 candidates per query)");
+        const ScratchLayout L = scratch_layout(RASS_MAX_QBATCH, RASS_MAX_K);
+        unsigned char* ws = eng->d_scratch;
+        const float* q_padded = reinterpret_cast<const float*>(ws + L.q_padded);
+        float* part_scores = reinterpret_cast<float*>(ws + L.part_scores);
+        int64_t* part_ids = reinterpret_cast<int64_t*>(ws + L.part_ids);
+        signed char* q_i8 = reinterpret_cast<signed char*>(ws + L.q_bf16);
+        const int nq_pad = nq <= 16 ? 16 : 32;
+        const int kc = RASS_MAX_K;
+        HIP_TRY(rass::launch_queries_to_i8(q_padded, q_i8, nq_pad, v->stride, v->stride_i8, st));
+        int grid = (int)std::min<int64_t>(std::max<int64_t>(v->total_tiles, 1), std::min(eng->n_cus, kMaxGrid));
+        if ((int64_t)grid * kc > rass::kMergeMaxCandidates) grid = rass::kMergeMaxCandidates / kc;
+        rass::ScanI8Args a;
+        a.corpus = v->d_slab_i8;
+        a.row_scale = v->d_slab_scale;
+        a.row_tag = need_tags ? v->d_tags : nullptr;
+        a.q_i8 = q_i8;
+        a.q_filter = d_q_filter;
+        a.q_filter_mask = d_q_filter_mask;
+        a.part_scores = part_scores;
+        a.part_ids = part_ids;
+        a.row_stride = v->stride_i8;
+        a.n_rows = (int)v->slab_rows;
+        a.nq = nq;
+        a.k = kc;
+        a.work_tile = v->d_work_tile;
+        a.work_rows = v->d_work_rows;
+        a.work_mask = v->d_work_mask;
+        a.n_work = v->d_n_work;
+        const bool timed = eng->ev_on && (size_t)(2 * eng->ev_used + 1) < eng->ev_pool.size();
+        if (timed) HIP_TRY(hipEventRecord(eng->ev_pool[2 * eng->ev_used], st));
+        HIP_TRY(rass::launch_scan_i8_topk(a, grid, st));
+        if (timed) {
+            HIP_TRY(hipEventRecord(eng->ev_pool[2 * eng->ev_used + 1], st));
+            eng->ev_used += 1;
+        }
+        HIP_TRY(rass::launch_merge_topk(part_scores, part_ids, grid, nq, kc, v->d_cand_scores, v->d_cand_rows, st));
+        HIP_TRY(rass::launch_rerank_f32(v->d_slab, v->stride, q_padded, v->d_cand_rows, nq, kc, k, 0, d_out_scores, d_out_ids, st,
+                                        0, 0, v->d_ids));
+        return RASS_OK;
+    }
     ScanExt ext;
     ext.d_q_mask = d_q_filter_mask;
     return scan_launch(v->d_slab, v->slab_rows, v->stride, need_tags ? v->d_tags : nullptr, d_queries, v->dim, v->dim,
@@ -2670,18 +2741,21 @@ static int ivf_search_batch_locked(rass_ivf_t* v, const float* d_queries, int nq
     // fine-scan workgroups per group.  fp32 slab: ALL groups' fine scans are one launch (kIvfGroups) — the more groups, the
     // fewer workgroups each (32 at 32 groups: 1 024 in all, dispatched in group order, no launch boundary between groups);
     // bf16 slab: one launch per group over the whole chip.
-    const bool one_fine_launch = v->dtype != RASS_BF16 && ivf_batch_one_launch();
+    const bool one_fine_launch = v->dtype == RASS_F32 && ivf_batch_one_launch();
+    const bool i8 = v->dtype == RASS_I8;
+    if (i8 && k > kPrefilterMaxK) return fail(RASS_ERR_UNSUPPORTED, "an int8 IVF slab serves k <= 16 (32 candidates per query)");
+    const int kf = i8 ? RASS_MAX_K : k;   // entries per fine list: the int8 scan keeps 32 candidates whatever k is
     int fgrid = (int)std::min<int64_t>(std::max<int64_t>(v->total_tiles, 1), std::min(eng->n_cus, kMaxGrid));
     if (one_fine_launch) fgrid = std::max(1, std::min(fgrid, std::max(32, 1024 / G)));
-    if ((int64_t)fgrid * k > rass::kMergeMaxCandidates) fgrid = rass::kMergeMaxCandidates / k;
+    if ((int64_t)fgrid * kf > rass::kMergeMaxCandidates) fgrid = rass::kMergeMaxCandidates / kf;
     auto up = [](size_t x) { return (x + 255) / 256 * 256; };
     size_t off = 0;
     const size_t o_q = off;        off = up(off + (size_t)G * 32 * stride * 4);
-    const size_t o_qb = off;       off = up(off + (v->dtype == RASS_BF16 ? (size_t)G * 32 * stride * 2 : 0));
+    const size_t o_qb = off;       off = up(off + (v->dtype != RASS_F32 ? (size_t)G * 32 * kMaxStride * 2 : 0));   // bf16 / int8 queries
     const int64_t cper = (int64_t)wpg * 32 * np;                                   // coarse list elements per group
     const size_t o_cs = off;       off = up(off + (size_t)G * cper * 4);
     const size_t o_ci = off;       off = up(off + (size_t)G * cper * 8);
-    const int64_t fper = (int64_t)fgrid * 32 * k;                                  // fine list elements per group
+    const int64_t fper = (int64_t)fgrid * 32 * kf;                                 // fine list elements per group
     const size_t o_fs = off;       off = up(off + (size_t)G * fper * 4);
     const size_t o_fi = off;       off = up(off + (size_t)G * fper * 8);
     const int64_t cap = v->total_tiles;
@@ -2690,6 +2764,8 @@ static int ivf_search_batch_locked(rass_ivf_t* v, const float* d_queries, int nq
     const size_t o_wm = off;       off = up(off + (size_t)G * cap * 4);
     const size_t o_nw = off;       off = up(off + (size_t)G * 4);
     const size_t o_sc = off;       off = up(off + (size_t)G * 8);
+    const size_t o_cds = off;      off = up(off + (i8 ? (size_t)G * 32 * RASS_MAX_K * 4 : 0));   // int8: the merged candidates
+    const size_t o_cdr = off;      off = up(off + (i8 ? (size_t)G * 32 * RASS_MAX_K * 8 : 0));
     if (v->batch_bytes < off) {
         if (v->d_batch) HIP_TRY(hipFree(v->d_batch));    // waits for earlier batches that may still read the old block
         v->d_batch = nullptr;
@@ -2737,6 +2813,7 @@ static int ivf_search_batch_locked(rass_ivf_t* v, const float* d_queries, int nq
     // (4) the fine scans, one per group, over the group's work list
     const bool need_tags = v->any_tags || d_q_filter != nullptr;
     if (v->dtype == RASS_BF16) HIP_TRY(rass::launch_queries_to_bf16(q_all, qb_all, (int64_t)G * 32 * stride, st));
+    if (i8) HIP_TRY(rass::launch_queries_to_i8(q_all, qb_all, G * 32, stride, v->stride_i8, st));
     if (one_fine_launch) {
         rass::ScanArgs a;
         a.corpus = v->d_slab;
@@ -2789,6 +2866,24 @@ static int ivf_search_batch_locked(rass_ivf_t* v, const float* d_queries, int nq
             a.work_mask = wm + g * cap;
             a.n_work = nw + g;
             HIP_TRY(rass::launch_scan_bf16_topk(a, fgrid, st));
+        } else if (i8) {
+            rass::ScanI8Args a;
+            a.corpus = v->d_slab_i8;
+            a.row_scale = v->d_slab_scale;
+            a.row_tag = need_tags ? v->d_tags : nullptr;
+            a.q_i8 = reinterpret_cast<const signed char*>(qb_all) + (int64_t)g * 32 * v->stride_i8;
+            a.q_filter = d_q_filter ? d_q_filter + g * 32 : nullptr;
+            a.part_scores = fs + g * fper;
+            a.part_ids = fi + g * fper;
+            a.row_stride = v->stride_i8;
+            a.n_rows = (int)v->slab_rows;
+            a.nq = b;
+            a.k = kf;
+            a.work_tile = wt + g * cap;
+            a.work_rows = wr + g * cap;
+            a.work_mask = wm + g * cap;
+            a.n_work = nw + g;
+            HIP_TRY(rass::launch_scan_i8_topk(a, fgrid, st));
         } else {
             rass::ScanArgs a;
             a.corpus = v->d_slab;
@@ -2819,7 +2914,13 @@ static int ivf_search_batch_locked(rass_ivf_t* v, const float* d_queries, int nq
     mg.nq_total = nq;
     mg.lists_are_dense = true;
     mg.score_stride = mg.id_stride = fper;
-    mg.out_score_stride = mg.out_id_stride = (int64_t)RASS_MAX_QBATCH * k;
+    mg.out_score_stride = mg.out_id_stride = (int64_t)RASS_MAX_QBATCH * kf;
+    if (i8) {   // candidates (slab positions) of every group, then ONE exact re-rank over all queries
+        float* cds = reinterpret_cast<float*>(ws + o_cds);
+        int64_t* cdr = reinterpret_cast<int64_t*>(ws + o_cdr);
+        HIP_TRY(rass::launch_merge_topk(fs, fi, fgrid, nq, kf, cds, cdr, st, nullptr, 0, 0, &mg));
+        HIP_TRY(rass::launch_rerank_f32(v->d_slab, stride, q_all, cdr, nq, kf, k, 0, d_out_scores, d_out_ids, st, 0, 0, v->d_ids));
+    } else
     HIP_TRY(rass::launch_merge_topk(fs, fi, fgrid, nq, k, d_out_scores, d_out_ids, st, v->d_ids, 0, 0, &mg));
     if (d_scanned_per_group) HIP_TRY(hipMemcpyAsync(d_scanned_per_group, sc, (size_t)G * 8, hipMemcpyDeviceToDevice, st));
     return RASS_OK;

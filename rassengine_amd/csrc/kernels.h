@@ -123,7 +123,8 @@ hipError_t launch_queries_to_bf16(const float* src, void* dst, int64_t n, hipStr
 // out_*_group_stride (elements; 0 = contiguous [nq][k]): query q's results go to out + (q / 32) * group_stride + (q % 32) * k
 hipError_t launch_rerank_f32(const float* slab, int64_t stride, const float* q_padded, const int64_t* cand_rows, int nq,
                              int n_cand, int k, int64_t id_base, float* out_scores, int64_t* out_ids,
-                             hipStream_t stream, int64_t out_scores_group_stride = 0, int64_t out_ids_group_stride = 0);
+                             hipStream_t stream, int64_t out_scores_group_stride = 0, int64_t out_ids_group_stride = 0,
+                             const int64_t* id_map = nullptr);   // id_map: reported id (and tie order) of slab row r = id_map[r]
 
 // ---- int8 candidate scan of the prefilter mode (scan_i8.hip, SURVEY §8f-4 "or int8")
 struct ScanI8Args {
@@ -142,6 +143,12 @@ struct ScanI8Args {
     // slab's first 64 * sample_groups rows, same queries and filters; see scan_i8.hip
     const float* sample_best = nullptr;
     int sample_groups = 0;
+    const int32_t* q_filter_mask = nullptr;   // [nq] or nullptr: a row matches when (tag & mask) == q_filter
+    // IVF probe plan over an int8 slab (all nullptr for the flat scan; as ScanBf16Args, 64-row tiles)
+    const int32_t* work_tile = nullptr;
+    const int32_t* work_rows = nullptr;
+    const uint32_t* work_mask = nullptr;
+    const int32_t* n_work = nullptr;
 };
 hipError_t launch_scan_i8_topk(const ScanI8Args& a, int grid, hipStream_t stream);
 // fp32 tile16 blocks [block0, block1) -> tile16i blocks of dst (+ one scale per row)

@@ -196,7 +196,7 @@ __global__ __launch_bounds__(kBThreads, 2) void scan_bf16_topk_kernel(ScanBf16Ar
                     ok = row_ok && (qfilt[pq] < 0 || qfilt[pq] == rtag);
                 }
                 if (IVF) ok = ok && ((w.mask >> q) & 1u) != 0;   // only the queries that probe this tile's list
-                insert_candidates(L[pq], tau[pq], ok ? s : -INFINITY, row, p.k);
+                insert_candidates_auto(L[pq], tau[pq], ok ? s : -INFINITY, row, p.k);
             }
         }
     };
@@ -366,7 +366,8 @@ __global__ __launch_bounds__(256) void rerank_f32_kernel(const float* __restrict
                                                          const float* __restrict__ q_padded,
                                                          const int64_t* __restrict__ cand_rows, int n_cand, int k,
                                                          int64_t id_base, float* __restrict__ out_scores,
-                                                         int64_t* __restrict__ out_ids, int64_t gs, int64_t gi) {
+                                                         int64_t* __restrict__ out_ids, int64_t gs, int64_t gi,
+                                                         const int64_t* __restrict__ id_map) {
     __shared__ float part[32][9];
     __shared__ float sc[32];
     __shared__ int64_t rw[32];
@@ -404,7 +405,8 @@ __global__ __launch_bounds__(256) void rerank_f32_kernel(const float* __restrict
         for (int ww = 1; ww < 8; ++ww) s += part[cc][ww];
         const int64_t r = cc < n_cand ? cand_rows[(int64_t)q * n_cand + cc] : -1;
         sc[cc] = r >= 0 ? s : -INFINITY;
-        rw[cc] = r;
+        // the id that is reported and that breaks score ties: the slab row itself, or (an IVF's permuted slab) the source row
+        rw[cc] = (r >= 0 && id_map != nullptr) ? id_map[r] : r;
     }
     __syncthreads();
     if (threadIdx.x < 32) {
@@ -439,12 +441,13 @@ __global__ __launch_bounds__(256) void rerank_f32_kernel(const float* __restrict
 
 hipError_t launch_rerank_f32(const float* slab, int64_t stride, const float* q_padded, const int64_t* cand_rows, int nq,
                              int n_cand, int k, int64_t id_base, float* out_scores, int64_t* out_ids,
-                             hipStream_t stream, int64_t out_scores_group_stride, int64_t out_ids_group_stride) {
+                             hipStream_t stream, int64_t out_scores_group_stride, int64_t out_ids_group_stride,
+                             const int64_t* id_map) {
     if (nq < 1 || n_cand < 1 || n_cand > 32 || k < 1 || k > n_cand || stride % 128 != 0 || stride > 1024) return hipErrorInvalidValue;
 #define RASS_RERANK_CASE(C)                                                                                                   \
     case C:                                                                                                                   \
         hipLaunchKernelGGL(rerank_f32_kernel<C>, dim3(nq), dim3(256), 0, stream, slab, stride, q_padded, cand_rows, n_cand, k, \
-                           id_base, out_scores, out_ids, out_scores_group_stride, out_ids_group_stride);                      \
+                           id_base, out_scores, out_ids, out_scores_group_stride, out_ids_group_stride, id_map);              \
         break;
     switch ((int)(stride >> 7)) {
         RASS_RERANK_CASE(1) RASS_RERANK_CASE(2) RASS_RERANK_CASE(3) RASS_RERANK_CASE(4)

@@ -224,4 +224,84 @@ __device__ __forceinline__ void insert_candidates(TopList& L, float& tau, float 
     }
 }
 
+// ---- bulk insertion: MANY candidates of one call at once (round 4) ------------------------------------------------------
+// insert_candidates takes one candidate per step, ~200 cycles each, serially over the wave.  That is the right shape when a
+// tile yields a handful of candidates per query (the flat scan behind a sample floor).  It is the wrong one where a tile is
+// DENSE in candidates: an IVF's fine scan (a tile belongs to a list one or two of the batch's queries probe, nearly all of its
+// 64 rows beat that workgroup's short list, and the one wave that ranks that query works through them while seven wait at
+// the barrier: 6 us per 64-KiB tile of an int8 slab, scan_i8.hip), or any workgroup's first tile.  Here the half-wave's 32
+// candidates are SORTED (worst first: a 15-stage bitonic network on DPP / v_permlane16_swap, both halves = both queries of
+// the wave at once), compared lane by lane with the running list (best first: list ++ candidates is a bitonic sequence and the
+// lane-wise winner its best 32) and re-sorted by the 5-stage bitonic merge: ~21 compare-exchange stages whatever the number of
+// candidates — the same list the one-by-one insertion ends with ((score desc, row asc) is a total order).
+template <int STRIDE>
+__device__ __forceinline__ int half_xor_lane(int v, int lane) {   // the dword of lane ^ STRIDE (STRIDE <= 16: inside a half-wave)
+    static_assert(STRIDE == 1 || STRIDE == 2 || STRIDE == 4 || STRIDE == 8 || STRIDE == 16, "stride");
+    if constexpr (STRIDE == 1) return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, true);          // quad_perm [1,0,3,2]
+    if constexpr (STRIDE == 2) return __builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, true);          // quad_perm [2,3,0,1]
+    if constexpr (STRIDE == 4)   // i ^ 4 = half_mirror(quad_reverse(i)): (i ^ 3) ^ 7
+        return __builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp(v, 0x1B, 0xf, 0xf, true), 0x141, 0xf, 0xf, true);
+    if constexpr (STRIDE == 8)   // i ^ 8 = row_mirror(half_mirror(i)): (i ^ 7) ^ 15
+        return __builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp(v, 0x141, 0xf, 0xf, true), 0x140, 0xf, 0xf, true);
+    const auto sw = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+    return (int)((lane & 16) ? sw[0] : sw[1]);
+}
+
+template <int STRIDE>
+__device__ __forceinline__ void top_cmpx(float& s, int& i, int lane, bool keep_better) {
+    const float os = __int_as_float(half_xor_lane<STRIDE>(__float_as_int(s), lane));
+    const int oi = half_xor_lane<STRIDE>(i, lane);
+    const bool mine_better = (s > os) | ((s == os) & (i < oi));
+    const bool take = mine_better != keep_better;
+    s = take ? os : s;
+    i = take ? oi : i;
+}
+
+template <int SIZE, int STRIDE>
+__device__ __forceinline__ void top_sort_steps(float& s, int& i, int lane) {   // one level of the half-wave bitonic sort
+    if constexpr (STRIDE > 0) {
+        // blocks of SIZE alternate direction; the last level (SIZE == 32) runs WORST first in both halves
+        const bool best_first = SIZE == 32 ? false : (lane & SIZE) == 0;
+        const bool lower = (lane & STRIDE) == 0;
+        top_cmpx<STRIDE>(s, i, lane, best_first == lower);
+        top_sort_steps<SIZE, STRIDE / 2>(s, i, lane);
+    }
+}
+
+// cs / ci: this lane's candidate, already (-inf, 0x7fffffff) where it may not rank.  Both halves (two queries) at once.
+__device__ __forceinline__ void insert_candidates_bulk(TopList& L, float& tau, float cs, int ci, int k) {
+    const int lane = lane_id();
+    top_sort_steps<2, 1>(cs, ci, lane);
+    top_sort_steps<4, 2>(cs, ci, lane);
+    top_sort_steps<8, 4>(cs, ci, lane);
+    top_sort_steps<16, 8>(cs, ci, lane);
+    top_sort_steps<32, 16>(cs, ci, lane);
+    // list (best first) ++ candidates (worst first) is bitonic: the lane-wise winners are its best 32, themselves bitonic
+    const bool keep = (L.s > cs) | ((L.s == cs) & (L.i < ci));
+    float s = keep ? L.s : cs;
+    int i = keep ? L.i : ci;
+    top_cmpx<16>(s, i, lane, (lane & 16) == 0);
+    top_cmpx<8>(s, i, lane, (lane & 8) == 0);
+    top_cmpx<4>(s, i, lane, (lane & 4) == 0);
+    top_cmpx<2>(s, i, lane, (lane & 2) == 0);
+    top_cmpx<1>(s, i, lane, (lane & 1) == 0);
+    // entries behind the k kept are dropped, as the one-by-one insertion never stores them
+    const bool kept = (lane & 31) < k;
+    L.s = kept ? s : -INFINITY;
+    L.i = kept ? i : 0x7fffffff;
+    tau = bcast_kth(L.s, k);
+}
+
+// One call site for both shapes: the network when the call brings at least kBulkMin candidates, one by one below.
+constexpr int kBulkMin = 8;
+__device__ __forceinline__ void insert_candidates_auto(TopList& L, float& tau, float s, int row, int k) {
+    const unsigned long long mask = __ballot(s > tau);
+    if (__popcll(mask) >= kBulkMin) {
+        const bool in = s > tau;
+        insert_candidates_bulk(L, tau, in ? s : -INFINITY, in ? row : 0x7fffffff, k);
+    } else if (mask) {
+        insert_candidates(L, tau, s, row, k);
+    }
+}
+
 }  // namespace rass

@@ -73,14 +73,16 @@ struct ITile {
 #endif
 constexpr int kINBuf = RASS_I8_NBUF;
 
-template <int CHI, int NT>
+// IVF = true: the work items are the entries of a probe plan (64-row tiles of the slab with per-tile query masks, written by
+// plan_probe_kernel earlier on this stream) instead of every tile of the slab; no sample floor.
+template <int CHI, int NT, bool IVF>
 __global__ __launch_bounds__(kIThreads, kINBuf == 1 ? 4 : 2) void scan_i8_topk_kernel(ScanI8Args p) {
     constexpr int NQ = NT * 16;
     extern __shared__ __attribute__((aligned(16))) int lds_i[];  // [kINBuf][kIWaves][NQ][kIPitch]
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int m = lane & 15, g = lane >> 4;
-    const int n_tiles = (p.n_rows + kITileRows - 1) / kITileRows;
+    const int n_tiles = IVF ? __builtin_amdgcn_readfirstlane(*p.n_work) : (p.n_rows + kITileRows - 1) / kITileRows;
     const int G = gridDim.x;
 
     i32x4 qf[NT][CHI];
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(kIThreads, kINBuf == 1 ? 4 : 2) void scan_i8_topk_k
 
     TopList L[NT];
     float tau[NT];
-    int qfilt[NT];
+    int qfilt[NT], qmask[NT];   // a row matches when (tag & qmask) == qfilt (qmask = -1: the exact compare); qfilt < 0: no filter
 #pragma unroll
     for (int pq = 0; pq < NT; ++pq) {
         L[pq].s = -INFINITY;
@@ -105,6 +107,7 @@ __global__ __launch_bounds__(kIThreads, kINBuf == 1 ? 4 : 2) void scan_i8_topk_k
         tau[pq] = -INFINITY;
         const int q = pq * 16 + (lane >> 5) * 8 + wid;
         qfilt[pq] = (p.q_filter != nullptr && q < p.nq) ? p.q_filter[q] : -1;
+        qmask[pq] = (p.q_filter_mask != nullptr && q < p.nq) ? p.q_filter_mask[q] : -1;
     }
 
     // The sample floor (as in the fp32 scan, scan_topk.hip): sample_best[g][q] is the best candidate score workgroup g of a
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(kIThreads, kINBuf == 1 ? 4 : 2) void scan_i8_topk_k
     float floor_q[NT];
 #pragma unroll
     for (int pq = 0; pq < NT; ++pq) floor_q[pq] = -INFINITY;
-    if (p.sample_best != nullptr) {
+    if (!IVF && p.sample_best != nullptr) {
         constexpr int kSlots = kMaxSampleGroups / 64;
         unsigned key[NT][2][kSlots];
 #pragma unroll
@@ -151,9 +154,22 @@ __global__ __launch_bounds__(kIThreads, kINBuf == 1 ? 4 : 2) void scan_i8_topk_k
         }
     }
 
-    auto tile_rows = [&](int t) {
-        int rows = p.n_rows - t * kITileRows;
-        return t < n_tiles ? (rows > kITileRows ? kITileRows : rows) : 0;
+    // item t of the launch: (slab tile, its valid rows, the queries that may rank them); past the end: zero rows of tile 0
+    struct Item { int tile, rows; unsigned mask; };
+    auto item = [&](int t) {
+        Item w;
+        const bool ok = t < n_tiles;
+        if (IVF) {
+            w.tile = ok ? p.work_tile[t] : 0;
+            w.rows = ok ? p.work_rows[t] : 0;
+            w.mask = ok ? p.work_mask[t] : 0u;
+        } else {
+            const int rows = p.n_rows - t * kITileRows;
+            w.tile = ok ? t : 0;
+            w.rows = ok ? (rows > kITileRows ? kITileRows : rows) : 0;
+            w.mask = 0xffffffffu;
+        }
+        return w;
     };
     auto issue = [&](ITile<CHI>& r, const IDesc& d) {
         r.tag = (int)__builtin_amdgcn_raw_buffer_load_b32(d.tags, lane * 4, 0, 0);
@@ -184,7 +200,7 @@ __global__ __launch_bounds__(kIThreads, kINBuf == 1 ? 4 : 2) void scan_i8_topk_k
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    auto finish = [&](const i32x4 (&acc)[4][NT], int tile, int rows, int tag, float scale, int buf) {
+    auto finish = [&](const i32x4 (&acc)[4][NT], const Item& w, int tag, float scale, int buf) {
         int* P = lds_i + (kINBuf == 2 ? buf : 0) * (kIWaves * NQ * kIPitch);
 #pragma unroll
         for (int b = 0; b < 4; ++b)
@@ -195,20 +211,21 @@ __global__ __launch_bounds__(kIThreads, kINBuf == 1 ? 4 : 2) void scan_i8_topk_k
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const int r = (lane & 31) + 32 * half;
-            const int row = tile * kITileRows + r;
+            const int row = w.tile * kITileRows + r;
             const int rtag = __shfl(tag, r, 64);
             const float rscale = __shfl(scale, r, 64);
-            const bool row_ok = (r < rows) && (rtag != -1);
+            const bool row_ok = (r < w.rows) && (rtag != -1);
 #pragma unroll
             for (int pq = 0; pq < NT; ++pq) {
                 const int q = pq * 16 + (lane >> 5) * 8 + wid;
                 const int* src = P + q * kIPitch + r;
                 int s = src[0];
 #pragma unroll
-                for (int w = 1; w < kIWaves; ++w) s += src[w * NQ * kIPitch];
+                for (int wv = 1; wv < kIWaves; ++wv) s += src[wv * NQ * kIPitch];
                 const float sf = (float)s * rscale;
-                const bool ok = row_ok && (qfilt[pq] < 0 || qfilt[pq] == rtag) && (sf >= floor_q[pq]);
-                insert_candidates(L[pq], tau[pq], ok ? sf : -INFINITY, row, p.k);
+                bool ok = row_ok && (qfilt[pq] < 0 || qfilt[pq] == (rtag & qmask[pq])) && (sf >= floor_q[pq]);
+                if (IVF) ok = ok && ((w.mask >> q) & 1u) != 0;   // only the queries that probe this tile's list
+                insert_candidates_auto(L[pq], tau[pq], ok ? sf : -INFINITY, row, p.k);
             }
         }
         if (kINBuf == 1) __syncthreads();   // the image is rewritten by the next tile
@@ -216,24 +233,27 @@ __global__ __launch_bounds__(kIThreads, kINBuf == 1 ? 4 : 2) void scan_i8_topk_k
 
     ITile<CHI> R0, R1;
     int t = blockIdx.x;
-    int rows0 = tile_rows(t), rows1 = tile_rows(t + G);
-    issue(R0, make_idesc(p, t, rows0));
-    issue(R1, make_idesc(p, t + G, rows1));
+    // work items are fetched a whole iteration before their descriptors are built: read right before use (as the first version
+    // did) every tile pair waited for two dependent scalar loads from global memory (an IVF's work list)
+    Item w0 = item(t), w1 = item(t + G), w2 = item(t + 2 * G), w3 = item(t + 3 * G);
+    issue(R0, make_idesc(p, w0.tile, w0.rows));
+    issue(R1, make_idesc(p, w1.tile, w1.rows));
     __builtin_amdgcn_sched_barrier(0);
     for (; t < n_tiles; t += 2 * G) {
+        const Item w4 = item(t + 4 * G), w5 = item(t + 5 * G);
         i32x4 acc[4][NT];
         int tag = R0.tag;
         float scale = R0.scale;
-        const int rows2 = tile_rows(t + 2 * G);
-        mul_refill(R0, acc, make_idesc(p, t + 2 * G, rows2));
-        finish(acc, t, rows0, tag, scale, 0);
+        mul_refill(R0, acc, make_idesc(p, w2.tile, w2.rows));
+        finish(acc, w0, tag, scale, 0);
         tag = R1.tag;
         scale = R1.scale;
-        const int rows3 = tile_rows(t + 3 * G);
-        mul_refill(R1, acc, make_idesc(p, t + 3 * G, rows3));
-        finish(acc, t + G, rows1, tag, scale, 1);
-        rows0 = rows2;
-        rows1 = rows3;
+        mul_refill(R1, acc, make_idesc(p, w3.tile, w3.rows));
+        finish(acc, w1, tag, scale, 1);
+        w0 = w2;
+        w1 = w3;
+        w2 = w4;
+        w3 = w5;
     }
     const int lpos = lane & 31;
 #pragma unroll
@@ -248,17 +268,17 @@ __global__ __launch_bounds__(kIThreads, kINBuf == 1 ? 4 : 2) void scan_i8_topk_k
     }
 }
 
-template <int CHI, int NT>
+template <int CHI, int NT, bool IVF>
 static hipError_t launch_ivariant(const ScanI8Args& a, int grid, hipStream_t stream) {
     constexpr size_t lds_bytes = (size_t)kINBuf * kIWaves * NT * 16 * kIPitch * sizeof(int);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_i8_topk_kernel<CHI, NT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_i8_topk_kernel<CHI, NT, IVF>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((scan_i8_topk_kernel<CHI, NT>), dim3(grid), dim3(kIThreads), lds_bytes, stream, a);
+    hipLaunchKernelGGL((scan_i8_topk_kernel<CHI, NT, IVF>), dim3(grid), dim3(kIThreads), lds_bytes, stream, a);
     return hipGetLastError();
 }
 
@@ -266,9 +286,16 @@ hipError_t launch_scan_i8_topk(const ScanI8Args& a, int grid, hipStream_t stream
     if (a.row_stride % 512 != 0 || a.row_stride < 512 || a.row_stride > 1024) return hipErrorInvalidValue;  // 8 waves x 64-column chunks
     if (a.nq < 1 || a.nq > 32 || a.k < 1 || a.k > 32 || a.n_rows < 0 || grid < 1) return hipErrorInvalidValue;
     if (a.sample_best && (a.sample_groups < 1 || a.sample_groups > kMaxSampleGroups)) return hipErrorInvalidValue;
+    if (a.q_filter_mask && !a.q_filter) return hipErrorInvalidValue;
+    const bool ivf = a.work_tile != nullptr;
+    if (ivf && (!a.work_rows || !a.work_mask || !a.n_work || a.sample_best)) return hipErrorInvalidValue;
     const bool two = a.nq > 16;
-    if (a.row_stride == 512) return two ? launch_ivariant<1, 2>(a, grid, stream) : launch_ivariant<1, 1>(a, grid, stream);
-    return two ? launch_ivariant<2, 2>(a, grid, stream) : launch_ivariant<2, 1>(a, grid, stream);
+#define RASS_I8_CASE(C)                                                                                                     \
+    if (ivf) return two ? launch_ivariant<C, 2, true>(a, grid, stream) : launch_ivariant<C, 1, true>(a, grid, stream);       \
+    return two ? launch_ivariant<C, 2, false>(a, grid, stream) : launch_ivariant<C, 1, false>(a, grid, stream);
+    if (a.row_stride == 512) { RASS_I8_CASE(1) }
+    RASS_I8_CASE(2)
+#undef RASS_I8_CASE
 }
 
 // fp32 tile16 blocks [b0, b1) -> tile16i blocks + one scale per row; one wave per 16-row block.  Lane (m, g) owns, of row m,

@@ -226,8 +226,12 @@ class Registry:
         eng = Engine.get(config.RASS_DEVICE, config.EMBED_DIM)
         if config.RASS_IVF_NLIST > 0:       # approximate index + flat delta for later inserts (ivf.IvfBackedIndex)
             from .ivf import open_backed_index
-            return open_backed_index(eng, name)
-        return eng.open_index(name)
+            idx = open_backed_index(eng, name)
+        else:
+            idx = eng.open_index(name)
+        if config.RASS_PREFILTER != "off":  # searches of k <= 16: bf16 / int8 candidate scan + exact fp32 re-rank (engine.set_prefilter)
+            idx.set_prefilter(config.RASS_PREFILTER)
+        return idx
 
     def get(self, name: str, create: bool = True) -> Optional[IndexState]:
         with self._lock:

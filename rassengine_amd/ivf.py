@@ -307,6 +307,9 @@ def _rows_chunk(index: FlatIndex, first: int, n: int, out: torch.Tensor) -> torc
     return out[:n]
 
 
+SLAB_DTYPES = {"f32": 0, "bf16": 1, "int8": 2}     # rass_dtype values of rass_ivf_build_ex's slab_dtype
+
+
 class IvfIndex:
     """IVF view of a flat index shard (its own permuted copy of the rows in HBM)."""
 
@@ -321,9 +324,11 @@ class IvfIndex:
               group: Optional[dist.ProcessGroup] = None, centroids: Optional[torch.Tensor] = None,
               dtype: str = "f32", assign: Optional[np.ndarray] = None, n_rows: int = -1) -> "IvfIndex":
         """``dtype="bf16"``: the IVF keeps its list-ordered copy of the rows in bf16 (``rass_ivf_build_ex``): half the bytes
-        per probed row, the scores of a flat bf16 index over the same rows.  The source index stays fp32."""
-        if dtype not in ("f32", "bf16"):
-            raise ValueError(f"dtype must be 'f32' or 'bf16', got {dtype!r}")
+        per probed row, the scores of a flat bf16 index over the same rows.  ``dtype="int8"``: an fp32 copy PLUS its
+        per-row-scaled int8 copy — the fine scan reads the int8 bytes (a quarter per probed row) for 32 candidates per query,
+        which are rescored exactly from the fp32 copy: the fp32 IVF's scores, k <= 16.  The source index stays fp32."""
+        if dtype not in SLAB_DTYPES:
+            raise ValueError(f"dtype must be one of {sorted(SLAB_DTYPES)}, got {dtype!r}")
         if centroids is None:
             centroids = train_centroids(index, nlist, train_rows, iters, seed, group)
         if assign is None:
@@ -337,7 +342,7 @@ class IvfIndex:
         # n_rows >= 0: an IVF over the first n_rows source rows only (the rest is the flat delta of an IvfBackedIndex)
         N.check("rass_ivf_build_prefix",
                 N.lib().rass_ivf_build_prefix(index._h, c_host.ctypes.data_as(ctypes.c_void_p), int(nlist),
-                                              assign.ctypes.data_as(ctypes.c_void_p), 1 if dtype == "bf16" else 0,
+                                              assign.ctypes.data_as(ctypes.c_void_p), SLAB_DTYPES[dtype],
                                               int(n_rows), ctypes.byref(h)))
         ivf = cls(h, index.engine, index.dim)
         ivf.assign = assign[:ivf.covered_rows]                # list id of every covered source row (host int32)
@@ -417,7 +422,12 @@ class IvfIndex:
 
     @property
     def dtype(self) -> str:
-        return "bf16" if int(self._L.rass_ivf_dtype(self._h)) == 1 else "f32"
+        return {v: k for k, v in SLAB_DTYPES.items()}[int(self._L.rass_ivf_dtype(self._h))]
+
+    @property
+    def max_k(self) -> int:
+        """The largest k a probe serves: 32, or 16 over an int8 slab (its 32 candidates per query are re-ranked)."""
+        return 16 if self.dtype == "int8" else 32
 
     def close(self) -> None:
         if self._h:
@@ -628,7 +638,7 @@ class IvfBackedIndex(FlatIndex):
     # ---- read path
     def _use_ivf(self, k: int) -> Optional[IvfIndex]:
         ivf = self.ivf
-        return ivf if (ivf is not None and 1 <= int(k) <= 32) else None
+        return ivf if (ivf is not None and 1 <= int(k) <= ivf.max_k) else None
 
     def search(self, queries: np.ndarray, k: int, q_filter: Optional[np.ndarray] = None,
                q_filter_mask: Optional[np.ndarray] = None, exact: bool = False, nprobe: Optional[int] = None

@@ -499,7 +499,7 @@ class ShardServer:
             self._verdict(ok, "encode")
             return None
         if op == OP_IVF_BUILD:
-            nlist, nprobe, dtype = int(hdr[2]), int(hdr[3]), "bf16" if int(hdr[4]) == 1 else "f32"
+            nlist, nprobe, dtype = int(hdr[2]), int(hdr[3]), {0: "f32", 1: "bf16", 2: "int8"}.get(int(hdr[4]), "f32")
             # the training is itself collective (all-reduce of the k-means sums over the data group): a rank that cannot
             # even start must not leave the others waiting in it, so every rank first says whether it can
             try:
@@ -696,7 +696,8 @@ class ShardedIndex:
         nlist = int(nlist or config.RASS_IVF_NLIST)
         if nlist <= 0:
             raise ValueError("build_ivf needs nlist > 0 (RASS_IVF_NLIST)")
-        code = 1 if (dtype or config.RASS_IVF_DTYPE) == "bf16" else 0
+        from .ivf import SLAB_DTYPES
+        code = SLAB_DTYPES[dtype or config.RASS_IVF_DTYPE]
         with self.front.lock:
             s = self.front.server
             self._nprobe = max(1, int(nprobe or config.RASS_IVF_NPROBE))

@@ -255,3 +255,38 @@ def test_int8_candidates_with_the_sample_floor(gpu, oracle, monkeypatch):
         assert np.all(r_o[6] == -1) if qf is not None else True
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("mode", ["int8", "bf16"])
+def test_prefilter_knob_behind_the_boundary(gpu, monkeypatch, mode):
+    """RASS_PREFILTER: the default index factory opens every index in that mode; an ask()-shaped flow through
+    HipIndexer returns what the exact index returns (docs, order and the reference's 1 / (2 - cos) scores)."""
+    import asyncio
+    from rassengine_amd import config, embedding, indexer
+    from rassengine_amd.docstore import REGISTRY
+    from rassengine_amd.engine import Engine
+    from tests.helpers import HashEmbedder
+
+    docs = [{"doc_id": f"text-f-{i}", "doc_type": "unstructured", "patientId": f"p{i % 3}",
+             "unstructuredText": f"note {i} mentions condition{i % 11} and drug{i % 5}"} for i in range(400)]
+    results = {}
+    for setting in ("off", mode):
+        monkeypatch.setattr(config, "RASS_PREFILTER", setting)
+        REGISTRY.clear()
+        REGISTRY.set_index_factory(None)
+        embedding.set_embedder(HashEmbedder(1024))
+        try:
+            name = "rass-idx-knob"
+            asyncio.run(indexer.store_fhir_docs_in_opensearch([], docs, None, name))
+            assert REGISTRY.get(name).index.prefilter_mode == setting
+            q = asyncio.run(embedding.embed_query("note about condition7 and drug2"))
+            ix = indexer.HipIndexer(None, name)
+            results[setting] = (ix.semantic_search(q, k=5, patient_id="p1"), ix.semantic_search(q, k=10),
+                                ix.semantic_search(q, k=40))          # k > 16: the exact scan either way
+        finally:
+            embedding.set_embedder(None)
+            REGISTRY.clear()
+            Engine.get(config.RASS_DEVICE, config.EMBED_DIM).drop_index(name)
+    for a, b in zip(results["off"], results[mode]):
+        assert [d["doc_id"] for d, _ in a] == [d["doc_id"] for d, _ in b]
+        assert [s for _, s in a] == [s for _, s in b]

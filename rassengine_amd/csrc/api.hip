@@ -504,9 +504,12 @@ bool i8_sample_floor(int64_t rows, int grid) {
 
 // Prefilter mode: bf16 (mode 1) or int8 (mode 2) candidate scan (32 per query) -> merge -> exact fp32 re-rank.
 // d_cand_scores / d_cand_rows (optional, [nq][32]): the merged candidate lists as well (rass_index_candidates_device).
+// d_q_filter_mask: masked tag compare ((tag & mask) == filter); id_map: the id reported for row r (a shard's caller-assigned
+// global ids, ascending with the row: the tie order is unchanged) instead of id_base + r.
 int prefilter_launch(rass_index* idx, const float* d_queries, int nq, const int32_t* d_q_filter, int k,
                      int64_t id_base, float* d_out_scores, int64_t* d_out_ids, const int32_t* d_row_tag,
-                     rass_engine* eng, hipStream_t st, float* d_cand_scores = nullptr, int64_t* d_cand_rows = nullptr) {
+                     rass_engine* eng, hipStream_t st, float* d_cand_scores = nullptr, int64_t* d_cand_rows = nullptr,
+                     const int32_t* d_q_filter_mask = nullptr, const int64_t* id_map = nullptr) {
     if (nq < 1 || nq > RASS_MAX_QBATCH) return fail(RASS_ERR_INVALID, "nq must be in [1, RASS_MAX_QBATCH]");
     if (k < 1 || k > RASS_MAX_K) return fail(RASS_ERR_INVALID, "k must be in [1, RASS_MAX_K]");
     const int64_t stride = idx->stride;
@@ -533,6 +536,7 @@ int prefilter_launch(rass_index* idx, const float* d_queries, int nq, const int3
         a.row_tag = d_row_tag;
         a.q_i8 = reinterpret_cast<const signed char*>(q_bf16);
         a.q_filter = d_q_filter;
+        a.q_filter_mask = d_q_filter_mask;
         a.part_scores = part_scores;
         a.part_ids = part_ids;
         a.row_stride = idx->stride_i8;
@@ -558,6 +562,7 @@ int prefilter_launch(rass_index* idx, const float* d_queries, int nq, const int3
         a.row_tag = d_row_tag;
         a.q_bf16 = q_bf16;
         a.q_filter = d_q_filter;
+        a.q_filter_mask = d_q_filter_mask;
         a.part_scores = part_scores;
         a.part_ids = part_ids;
         a.row_stride = stride;
@@ -572,8 +577,8 @@ int prefilter_launch(rass_index* idx, const float* d_queries, int nq, const int3
         eng->ev_used += 1;
     }
     HIP_TRY(rass::launch_merge_topk(part_scores, part_ids, grid, nq, kc, cand_scores, cand_ids, st));
-    HIP_TRY(rass::launch_rerank_f32(idx->d_rows, stride, q_padded, cand_ids, nq, kc, k, id_base, d_out_scores,
-                                    d_out_ids, st));
+    HIP_TRY(rass::launch_rerank_f32(idx->d_rows, stride, q_padded, cand_ids, nq, kc, k, id_map ? 0 : id_base, d_out_scores,
+                                    d_out_ids, st, 0, 0, id_map));
     return RASS_OK;
 }
 
@@ -1064,9 +1069,10 @@ int search_device_group(rass_index* idx, const float* d_queries, int nq, int k, 
                                 d_out_ids, need_tags ? idx->d_tags : nullptr, eng, eng->stream,
                                 gid ? idx->d_gid : nullptr, (d_q_filter_mask || d_after_score) ? &bext : nullptr);
     }
-    if (idx->prefilter && rows > 0 && k <= kPrefilterMaxK && !gid && !d_q_filter_mask && !d_after_score)  // id_base + ordinal
+    if (idx->prefilter && rows > 0 && k <= kPrefilterMaxK && !d_after_score)
         return prefilter_launch(idx, d_queries, nq, d_q_filter, k, id_base, d_out_scores, d_out_ids,
-                                need_tags ? idx->d_tags : nullptr, eng, eng->stream);
+                                need_tags ? idx->d_tags : nullptr, eng, eng->stream, nullptr, nullptr, d_q_filter_mask,
+                                gid ? idx->d_gid : nullptr);
     ScanExt ext;
     ext.d_q_mask = d_q_filter_mask;
     ext.d_after_s = d_after_score;
@@ -1333,7 +1339,9 @@ int prefilter_launch_batch(rass_index* idx, const float* d_queries, int nq, int 
     mg.score_stride = mg.id_stride = (int64_t)L.part_per_group;
     mg.out_score_stride = mg.out_id_stride = (int64_t)32 * kc;
     HIP_TRY(rass::launch_merge_topk(part_scores, part_ids, grid, nq, kc, cand_scores, cand_rows, st, nullptr, 0, 0, &mg));
-    HIP_TRY(rass::launch_rerank_f32(idx->d_rows, stride, q_all, cand_rows, nq, kc, k, id_base, d_out_scores, d_out_ids, st, gs, gi));
+    const bool gid = idx->has_gid.load(std::memory_order_acquire);
+    HIP_TRY(rass::launch_rerank_f32(idx->d_rows, stride, q_all, cand_rows, nq, kc, k, gid ? 0 : id_base, d_out_scores, d_out_ids, st, gs,
+                                    gi, gid ? idx->d_gid : nullptr));
     return RASS_OK;
 }
 
@@ -1382,7 +1390,7 @@ int rass_index_search_device_batch(rass_index_t* idx, const float* d_queries, in
     const bool fused = idx->dtype == RASS_F32 && !idx->prefilter && nq > RASS_MAX_QBATCH;
     if (fused) return scan_launch_batch(idx, d_queries, nq, k, d_q_filter, id_base, d_out_scores, d_out_ids, gs, gi);
     if (idx->prefilter && idx->dtype == RASS_F32 && nq > RASS_MAX_QBATCH && k <= kPrefilterMaxK &&
-        !idx->has_gid.load(std::memory_order_acquire) && idx->rows.load(std::memory_order_acquire) > 0)
+        idx->rows.load(std::memory_order_acquire) > 0)
         return prefilter_launch_batch(idx, d_queries, nq, k, d_q_filter, id_base, d_out_scores, d_out_ids, gs, gi);
     // bf16 / prefilter corpora and single groups: the same result group by group
     for (int g = 0; g * RASS_MAX_QBATCH < nq; ++g) {
@@ -1504,9 +1512,10 @@ int rass_index_search_ex(rass_index_t* idx, const float* queries, int nq, int k,
                     rc = bf16_scan_launch(idx, eng->d_qraw, b, d_filter, kk, 0, eng->d_out_scores, eng->d_out_ids,
                                           need_tags ? idx->d_tags : nullptr, eng, st, gid ? idx->d_gid : nullptr,
                                           use_ext ? &ext : nullptr);
-                else if (idx->prefilter && rows > 0 && k <= kPrefilterMaxK && !use_ext && !gid)
+                else if (idx->prefilter && rows > 0 && k <= kPrefilterMaxK && !cont)
                     rc = prefilter_launch(idx, eng->d_qraw, b, d_filter, kk, 0, eng->d_out_scores, eng->d_out_ids,
-                                          need_tags ? idx->d_tags : nullptr, eng, st);
+                                          need_tags ? idx->d_tags : nullptr, eng, st, nullptr, nullptr, ext.d_q_mask,
+                                          gid ? idx->d_gid : nullptr);
                 else
                     rc = scan_launch(idx->d_rows ? idx->d_rows : reinterpret_cast<const float*>(eng->d_scratch), rows,
                                      idx->stride, need_tags ? idx->d_tags : nullptr, eng->d_qraw, dim, dim, b, d_filter,

@@ -984,8 +984,10 @@ def hip_shard_loader(device_index: int, dim: int) -> Callable[[str, str], "HipSe
     def load(name: str, path: str) -> HipServingShard:
         from .ivf import IvfBackedIndex, IvfPolicy
         from . import config
-        return HipServingShard(IvfBackedIndex.load(Engine.get(device_index, dim), name, path,
-                                                   IvfPolicy.manual(config.RASS_IVF_NPROBE)))
+        idx = IvfBackedIndex.load(Engine.get(device_index, dim), name, path, IvfPolicy.manual(config.RASS_IVF_NPROBE))
+        if config.RASS_PREFILTER != "off":
+            idx.set_prefilter(config.RASS_PREFILTER)
+        return HipServingShard(idx)
     return load
 
 
@@ -997,6 +999,8 @@ def hip_shard_factory(device_index: int, dim: int) -> Callable[[str], HipServing
         # an IvfBackedIndex with no policy of its own: it is a plain flat shard until rank 0 posts OP_IVF_BUILD
         from .ivf import IvfBackedIndex, IvfPolicy
         from . import config
-        return HipServingShard(IvfBackedIndex(Engine.get(device_index, dim).open_index(name),
-                                              IvfPolicy.manual(config.RASS_IVF_NPROBE)))
+        idx = IvfBackedIndex(Engine.get(device_index, dim).open_index(name), IvfPolicy.manual(config.RASS_IVF_NPROBE))
+        if config.RASS_PREFILTER != "off":      # every shard's searches of k <= 16: int8 / bf16 candidates + exact re-rank
+            idx.set_prefilter(config.RASS_PREFILTER)
+        return HipServingShard(idx)
     return make

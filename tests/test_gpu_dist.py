@@ -179,7 +179,7 @@ def test_two_rank_ivf_shards_share_centroids_and_match_flat(gpu, tmp_path):
     assert hits > 0
 
 
-def _serving_worker(rank, world, port, out_dir, backend):
+def _serving_worker(rank, world, port, out_dir, backend, prefilter="off"):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -198,6 +198,7 @@ def _serving_worker(rank, world, port, out_dir, backend):
         from rassengine_amd.engine import Engine
         from tests.helpers import HashEmbedder
         from tests.test_serving_gloo import _scenario
+        config.RASS_PREFILTER = prefilter       # the shards' candidate mode (hip_shard_factory / hip_shard_loader read it)
         front = serving.start(serving.hip_shard_factory(device, 1024), 1024, torch.device("cuda", device),
                               shard_loader=serving.hip_shard_loader(device, 1024))
         if rank != 0:
@@ -221,7 +222,8 @@ def _serving_worker(rank, world, port, out_dir, backend):
         assert st2.index.count == st.index.count and st2.index.rows == st.index.rows
         assert np.array_equal(st2.index.get_row(int(a[1][0, 0])), st.index.get_row(int(a[1][0, 0])))
         front.shutdown()
-        # the same scenario on ONE HIP index in this process
+        # the same scenario on ONE HIP index in this process (always the exact scan)
+        config.RASS_PREFILTER = "off"
         REGISTRY.clear()
         eng = Engine.get(device, 1024)
         REGISTRY.set_index_factory(lambda name: eng.open_index("single-" + name))
@@ -251,6 +253,23 @@ def test_shim_over_sharded_hip_index_equals_single_hip_index(gpu, tmp_path, back
         else:
             assert a.tolist() == b.tolist(), (k, a, b)
     assert int(z["single_count"]) == 90 and int(z["single_rows"]) == 92 and len(z["single_sem_ids"]) == 10
+
+
+@pytest.mark.parametrize("prefilter", ["int8", "bf16"])
+def test_sharded_shards_in_a_prefilter_mode_equal_the_single_exact_index(gpu, tmp_path, prefilter):
+    """RASS_PREFILTER on a multi-GPU front: every shard scans its int8 (bf16) copy for candidates — with caller-assigned
+    global ids, masked doc_type / patient filters and tombstones in play — and rescores them exactly; the whole scenario
+    (uploads, overwrites, every search shape of the shim, save / load) still equals ONE exact index bit for bit."""
+    import torch.multiprocessing as mp
+    mp.spawn(_serving_worker, args=(2, _free_port(), str(tmp_path), "gloo", prefilter), nprocs=2, join=True)
+    assert os.path.exists(os.path.join(str(tmp_path), "worker1.done"))
+    z = np.load(os.path.join(str(tmp_path), "serving.npz"))
+    for k in sorted(k[len("single_"):] for k in z.files if k.startswith("single_")):
+        a, b = z["sharded_" + k], z["single_" + k]
+        if a.dtype.kind == "f":
+            assert a.shape == b.shape and np.array_equal(a, b), k
+        else:
+            assert a.tolist() == b.tolist(), (k, a, b)
 
 
 def _ivf_docs(n, start=0):

@@ -290,3 +290,33 @@ def test_prefilter_knob_behind_the_boundary(gpu, monkeypatch, mode):
     for a, b in zip(results["off"], results[mode]):
         assert [d["doc_id"] for d, _ in a] == [d["doc_id"] for d, _ in b]
         assert [s for _, s in a] == [s for _, s in b]
+
+
+@pytest.mark.parametrize("mode", ["int8", "bf16"])
+def test_prefilter_with_global_ids_and_masked_filters(engine, mode):
+    """A shard of a multi-GPU index: caller-assigned global ids (reported, and the tie order) and masked tag compares
+    (patient code | doc_type << 24) go through the candidate scan + re-rank like plain searches — ≡ the exact scan."""
+    rng = np.random.default_rng(55)
+    idx = engine.open_index("pf-gid-" + mode)
+    n = 6000
+    x = rng.standard_normal((n, 1024)).astype(np.float32)
+    x[100] = x[50]                                           # an exact duplicate: equal scores, the lower GLOBAL id first
+    tags = (rng.integers(1, 6, size=n) | (rng.integers(0, 2, size=n) << 24)).astype(np.int32)
+    idx.add(x[:2500], tags=tags[:2500], first_global_id=10_000)
+    idx.add(x[2500:], tags=tags[2500:], first_global_id=50_000)
+    idx.delete(7)
+    q = np.concatenate([x[50:51] * 2.0, rng.standard_normal((40, 1024)).astype(np.float32)])
+    f = np.array([(r % 5) + 1 if r % 2 else 0x01000000 for r in range(41)], dtype=np.int32)
+    m = np.array([0x00ffffff if r % 2 else 0x01000000 for r in range(41)], dtype=np.int32)
+    f[0], m[0] = -1, -1
+    for k in (1, 10, 16):
+        idx.set_prefilter(mode)
+        a = idx.search(q, k, q_filter=f, q_filter_mask=m)
+        b = idx.search(q, k)
+        idx.set_prefilter(False)
+        a0 = idx.search(q, k, q_filter=f, q_filter_mask=m)
+        b0 = idx.search(q, k)
+        assert np.array_equal(a[1], a0[1]) and np.array_equal(a[0], a0[0]), k
+        assert np.array_equal(b[1], b0[1]) and np.array_equal(b[0], b0[0]), k
+    assert b0[1][0, 0] == 10_050 and (k == 1 or b0[1][0, 1] == 10_100)      # the duplicate pair in global-id order
+    assert b0[1].min() >= 10_000

@@ -1086,6 +1086,430 @@ static hipError_t launch_p5_pol(const u16* X, const u16* W, const float* bias, c
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------
+// "p4" (round 4, EXPERIMENT behind RASS_GEMM_VARIANT=p4): the same 256 x 256 tile and five-half-slot LDS-DMA ring as p5 with
+// FOUR waves, one per SIMD, each owning 128 (output columns) x 128 (tokens) = 8 x 8 MFMA tiles in 256 AGPRs:
+//   * 16 fragment reads per 64 MFMAs (0.25 per MFMA; p5's 2 x 4 layout reads 0.375), placed BETWEEN the MFMAs of the running
+//     sub-step by hand (inline asm: the instruction order below IS the issue order), no phase barriers: one s_barrier per
+//     64-deep step, in the middle of it (the next step's fragments are read under the second sub-step's MFMAs);
+//   * the epilogue does not store: it leaves the tile's 32 x 16 B per lane in registers ("pending") and the NEXT tile's
+//     K loop issues them four per step — what p5's waves spend 3-10 us per tile waiting for (the CU takes a tile's 128 KiB of
+//     stores at ~40 GB/s; profiles/r04_gemm_epilogue_experiments.txt: NO_STORE -12 .. -21 % per GEMM) runs under MFMAs.
+// Operand delivery by buffer_load ... lds on whole-matrix descriptors (rows past M read as zeros; the wave-uniform part of
+// an address is an SGPR offset, one VGPR holds the lane part for the whole kernel).
+// Stream protocol (half-load q = 2T + h of step T lives in half-slot (q0 + q) % 5):  iteration t multiplies step t in two
+// 32-deep sub-steps; sub-step 0 reads (t, 1)'s fragments and issues half-load (t+2, 0) into the slot of (t-1, 1); the mid-step
+// barrier B(t+1) [this wave's pieces of step t+1 landed: vmcnt(8) lets (t+2, 0) fly; every wave's reads of step t done]
+// publishes step t+1 and frees step t's slots; sub-step 1 reads (t+1, 0)'s fragments and issues (t+2, 1) into (t, 0)'s slot.
+// Every half-load is issued 1-1.5 steps before the barrier that needs it, as in p5.
+constexpr int kP4Threads = 256;
+#ifndef RASS_P4_DEFER
+#define RASS_P4_DEFER 16
+#endif
+constexpr int kP4Defer = RASS_P4_DEFER;   // output pieces (of 32 per lane and tile) stored by the NEXT tile's K loop; the others in the epilogue
+#define P4_MFMA(acc, a, b) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b))
+#define P4_MFMA0(acc, a, b) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(acc) : "v"(a), "v"(b))
+#define P4_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
+
+// One 32-deep sub-step: 64 MFMAs (acc[i][j] += a[i] * bc[j]) in issue order, and after EVERY one of them `gap(i, j)`: a single
+// wave issues in order, so whatever else the sub-step has to issue — the NEXT sub-step's 16 fragment reads, its share of the
+// operand DMA, a few of the previous tile's stores — goes one instruction at a time into the ~12 issue cycles each MFMA leaves
+// free behind it (eight MFMAs followed by a dozen other instructions, as the first version had it, idle the matrix pipe while
+// those issue: 1.9 us per 64-deep step against p5's 1.55).
+template <bool ZERO, typename Gap>
+__device__ __forceinline__ void p4_substep(f32x4 (&acc)[8][8], const bf16x8 (&a)[8], const bf16x8 (&bc)[8], Gap&& gap) {
+#define P4_ROW(i)                                          \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) {         \
+        if (ZERO) P4_MFMA0(acc[i][j], a[i], bc[j]);        \
+        else P4_MFMA(acc[i][j], a[i], bc[j]);              \
+        gap(i, j);                                         \
+    }
+    P4_ROW(0) P4_ROW(1) P4_ROW(2) P4_ROW(3) P4_ROW(4) P4_ROW(5) P4_ROW(6) P4_ROW(7)
+#undef P4_ROW
+}
+
+typedef int p4_i32x4 __attribute__((ext_vector_type(4)));
+
+template <int EPI, int POL = 1>
+__global__ __launch_bounds__(kP4Threads, 1) void gemm_bf16_p4_kernel(const u16* __restrict__ X, const u16* __restrict__ W,
+                                                                     const float* __restrict__ bias,
+                                                                     const u16* __restrict__ residual, u16* __restrict__ Y,
+                                                                     int M, int N, int K, int tiles_total, LnFold fold) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave & 1, wn = wave >> 1;          // which half of the tile's tokens (X rows) / output columns (W rows)
+    const int G = gridDim.x, orig = blockIdx.x;
+    const int pos = (G % 8 == 0) ? (orig % 8) * (G / 8) + orig / 8 : orig;
+    int tile = pos;
+    if (tile >= tiles_total) return;
+    const int tiles_n = N / RBN;
+    const int nk = K / 64;   // >= 8 (launcher)
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+    // fragment offsets inside a half-slot (rows of 128 B; 16-B chunk c of row r at c ^ ((r>>1)&7); sub-step s = chunks 4s..4s+3)
+    unsigned off_sub[2];
+    {
+        const int m = lane & 15, sw = (m >> 1) & 7;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) off_sub[sub] = m * 128 + ((sub * 4 + (lane >> 4)) ^ sw) * 16;
+    }
+    // operand delivery: a half-load = 16 W pieces + 16 X pieces of 8 rows x 128 B; this wave moves pieces wave + 4p, p = 0..3.
+    // lane -> (row lane>>3 of the piece, 16-B chunk (lane&7) ^ ((r>>1)&7)), r = piece * 8 + (lane>>3): (r>>1)&7 =
+    // (4 * (wave & 1) + (lane >> 4)) & 7 for every p (16 p = 0 mod 8).  Descriptors over the whole matrices, built by hand
+    // (base, 48-bit; stride 0; bytes; raw dword format) so that they can be inline-asm operands.
+    auto make_desc = [](const void* base, unsigned bytes) {
+        const uint64_t b = reinterpret_cast<uint64_t>(base);
+        p4_i32x4 d;
+        d[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+        d[1] = __builtin_amdgcn_readfirstlane((int)((uint32_t)(b >> 32) & 0xffffu));
+        d[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+        d[3] = 0x00020000;
+        return d;
+    };
+    const p4_i32x4 wdesc = make_desc(W, (unsigned)N * (unsigned)K * 2u);
+    const p4_i32x4 xdesc = make_desc(X, (unsigned)M * (unsigned)K * 2u);
+    const int dma_voff = ((lane >> 3) * K + (((lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7)) * 8)) * 2;
+    const unsigned piece_step = (unsigned)K * 64u;           // bytes between pieces p and p + 1 of a wave: 32 rows of K bf16
+    unsigned soW[2], soX[2];                                  // byte offset of this wave's piece 0 of half h at the stream's k
+    auto point_half = [&](int t, int h) {
+        const int tn0 = (t % tiles_n) * RBN, tm0 = (t / tiles_n) * RBM;
+        soW[h] = __builtin_amdgcn_readfirstlane(((unsigned)(tn0 + 128 * h + wave * 8) * (unsigned)K) * 2u);
+        soX[h] = __builtin_amdgcn_readfirstlane(((unsigned)(tm0 + 128 * h + wave * 8) * (unsigned)K) * 2u);
+    };
+    // one piece: which = 0..3 X pieces, 4..7 W pieces of half h into half-slot hs (m0 = the piece's LDS address).  In the K loop
+    // the three instructions of a piece sit in three different gaps (dma_soff, dma_m0, dma_load): together behind one MFMA they
+    // took ~20 issue cycles where the MFMA leaves ~12.
+    const unsigned mbase = lds_base + wave * 1024;
+    unsigned dma_so = 0;
+    auto dma_soff = [&](int h, int which) {
+        const unsigned ps = (which & 3) * piece_step;
+        if (which < 4) asm volatile("s_add_u32 %0, %1, %2" : "=s"(dma_so) : "s"(soX[h]), "s"(ps) : "scc");
+        else asm volatile("s_add_u32 %0, %1, %2" : "=s"(dma_so) : "s"(soW[h]), "s"(ps) : "scc");
+    };
+    auto dma_m0 = [&](int hs, int which) {
+        const unsigned v = mbase + hs * kP5HalfBytes + (which < 4 ? 16384 : 0) + (which & 3) * 4096;
+        asm volatile("s_mov_b32 m0, %0" ::"s"(v));
+    };
+    auto dma_load = [&](int which) {
+        if (which < 4) asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(dma_voff), "s"(xdesc), "s"(dma_so) : "memory");
+        else asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(dma_voff), "s"(wdesc), "s"(dma_so) : "memory");
+    };
+    auto dma_piece = [&](int hs, int h, int which) {
+        dma_soff(h, which);
+        dma_m0(hs, which);
+        asm volatile("s_nop 0");
+        dma_load(which);
+    };
+    auto dma_half = [&](int hs, int h) {
+#pragma unroll
+        for (int w8 = 0; w8 < 8; ++w8) dma_piece(hs, h, w8);
+        soW[h] += 128;
+        soX[h] += 128;
+    };
+    auto mod5 = [](int v) { return v >= 5 ? v - 5 : v; };
+
+    // the stream's first four half-loads: steps 0 and 1 of the first tile
+    int q0 = 0;   // half-slot of the current tile's (0, 0)
+    point_half(tile, 0);
+    point_half(tile, 1);
+    dma_half(0, 0);
+    dma_half(1, 1);
+    dma_half(2, 0);
+    dma_half(3, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // the previous tile's last kP4Defer output pieces (16 B per lane each), stored by the next tile's first two steps
+    u32x4_t pending[kP4Defer];
+#pragma unroll
+    for (int i = 0; i < kP4Defer; ++i) pending[i] = u32x4_t{0u, 0u, 0u, 0u};
+    __amdgpu_buffer_rsrc_t pdesc = __builtin_amdgcn_make_buffer_rsrc(Y, 0, 0, 0x00020000);   // zero records: the first tile's are dropped
+    const int st_voff = ((lane >> 3) * N + (lane & 7) * 8) * 2;    // lane part of a store: token row lane>>3, 16 B (lane&7)
+    // piece idx of a tile: 16-token chunk jc = idx >> 2, 64-column chunk ic = (idx >> 1) & 1, pass = idx & 1 (8 tokens each)
+#define P4_STORE_V(val, desc, idx)                                                                                                 \
+    __builtin_amdgcn_raw_buffer_store_b128(val, desc, st_voff,                                                                     \
+                                           ((wm * 128 + ((idx) >> 2) * 16 + ((idx) & 1) * 8) * N + wn * 128 + (((idx) >> 1) & 1) * 64) * 2, \
+                                           POL % 10 == 1 ? 2 : 0)
+#define P4_STORE(v) P4_STORE_V(pending[v], pdesc, 32 - kP4Defer + (v))
+
+    f32x4 acc[8][8];
+    bf16x8 a[8], a6n, a7n, b0[8], b1[8];
+    for (;;) {
+        const int n0 = (tile % tiles_n) * RBN, m0 = (tile / tiles_n) * RBM;
+        const int next = tile + G;
+        const bool has_next = next < tiles_total;
+        // fragments of (0, 0): the step was published by the previous tile's last mid-step barrier (or the prologue)
+        {
+            const unsigned ra = lds_base + (wn ? mod5(q0 + 1) : q0) * kP5HalfBytes + off_sub[0];
+            const unsigned rb = lds_base + (wm ? mod5(q0 + 1) : q0) * kP5HalfBytes + off_sub[0];
+            P4_READ(a[0], ra, 0); P4_READ(a[1], ra, 2048); P4_READ(a[2], ra, 4096); P4_READ(a[3], ra, 6144);
+            P4_READ(a[4], ra, 8192); P4_READ(a[5], ra, 10240); P4_READ(a[6], ra, 12288); P4_READ(a[7], ra, 14336);
+            P4_READ(b0[0], rb, 16384); P4_READ(b0[1], rb, 18432); P4_READ(b0[2], rb, 20480); P4_READ(b0[3], rb, 22528);
+            P4_READ(b0[4], rb, 24576); P4_READ(b0[5], rb, 26624); P4_READ(b0[6], rb, 28672); P4_READ(b0[7], rb, 30720);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        // The epilogue's per-column / per-token scalars (bias; LN fold: (mean, rstd) of this wave's 128 tokens, gamma / beta or
+        // colsum(W') of its 128 columns) are requested NOW and ride through the K loop in 22 registers: with one wave per SIMD a
+        // load at the top of the epilogue is a memory round trip nothing hides.
+        f32x4 bv[2][2];
+        float2 aux_c0 = {0.f, 0.f}, aux_c1 = {0.f, 0.f}, aux_mr[2] = {{0.f, 1.f}, {0.f, 1.f}};
+        {
+            const int nq = lane & 7;
+#pragma unroll
+            for (int ic = 0; ic < 2; ++ic) {
+                const float* bp = bias + n0 + wn * 128 + ic * 64 + nq * 8;
+                bv[ic][0] = *reinterpret_cast<const f32x4*>(bp);
+                bv[ic][1] = *reinterpret_cast<const f32x4*>(bp + 4);
+            }
+            if constexpr (EPI >= 3) {
+                aux_c0 = *reinterpret_cast<const float2*>((EPI == 3 ? fold.gamma : fold.colsum) + n0 + wn * 128 + 2 * lane);
+                if constexpr (EPI == 3) aux_c1 = *reinterpret_cast<const float2*>(fold.beta + n0 + wn * 128 + 2 * lane);
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int mt = m0 + wm * 128 + hh * 64 + lane;
+                    aux_mr[hh] = *reinterpret_cast<const float2*>(fold.mr + 2 * (int64_t)(mt < M ? mt : 0));
+                }
+            }
+        }
+        int hs0 = q0;
+        // One 64-deep step.  STORES: the first pending piece this step stores (eight of them), or -1.
+        auto step = [&](int t, auto zero_c, auto stores_c) {
+            constexpr bool ZERO = decltype(zero_c)::value;
+            constexpr int STORES = decltype(stores_c)::value;
+            const int hs1 = mod5(hs0 + 1), hs2 = mod5(hs0 + 2), hs3 = mod5(hs0 + 3), hs4 = mod5(hs0 + 4);
+            // the half-loads this iteration issues are (t+2, 0) and (t+2, 1); beyond the tile they are the next tile's (with no
+            // next tile the stream runs on into rows nobody reads: the bounds check of the descriptors keeps it in the matrices)
+            if (t + 2 == nk && has_next) {
+                point_half(next, 0);
+                point_half(next, 1);
+            }
+            // ---- sub-step 0: multiplies (t, 0) out of a / b0, reads (t, 1) into a / b1, issues (t+2, 0) into hs4
+            {
+                const unsigned ra = lds_base + (wn ? hs1 : hs0) * kP5HalfBytes + off_sub[1];
+                const unsigned rb = lds_base + (wm ? hs1 : hs0) * kP5HalfBytes + off_sub[1];
+                p4_substep<ZERO>(acc, a, b0, [&](int i, int j) {
+#define P4_GAPS(BN, HS, H)                                                                                              \
+    if (j == 7) {                                                                                                       \
+        if (i == 0) P4_READ(a[0], ra, 0); else if (i == 1) P4_READ(a[1], ra, 2048); else if (i == 2) P4_READ(a[2], ra, 4096); \
+        else if (i == 3) P4_READ(a[3], ra, 6144); else if (i == 4) P4_READ(a[4], ra, 8192); else if (i == 5) P4_READ(a[5], ra, 10240); \
+    } else if (j == 1) {                                                                                                \
+        if (i == 0) P4_READ(BN[0], rb, 16384); else if (i == 1) P4_READ(BN[2], rb, 20480); else if (i == 2) P4_READ(BN[4], rb, 24576); \
+        else if (i == 3) P4_READ(BN[6], rb, 28672); else if (i == 4) P4_READ(a6n, ra, 12288); else if (i == 5) P4_READ(a7n, ra, 14336); \
+    } else if (j == 3) {                                                                                                \
+        if (i == 0) P4_READ(BN[1], rb, 18432); else if (i == 1) P4_READ(BN[3], rb, 22528); else if (i == 2) P4_READ(BN[5], rb, 26624); \
+        else if (i == 3) P4_READ(BN[7], rb, 30720);                                                                     \
+    } else if (j == 0) {                                                                                                \
+        dma_soff(H, i);                                                                                                 \
+    } else if (j == 4) {                                                                                                \
+        dma_m0(HS, i);                                                                                                  \
+    } else if (j == 5) {                                                                                                \
+        dma_load(i);                                                                                                    \
+    }
+                    P4_GAPS(b1, hs4, 0)
+                    if constexpr (STORES >= 0)
+                        if (j == 2 && i >= 4) {
+                            if (i == 4) P4_STORE(STORES); else if (i == 5) P4_STORE(STORES + 1);
+                            else if (i == 6) P4_STORE(STORES + 2); else P4_STORE(STORES + 3);
+                        }
+                });
+                a[6] = a6n;
+                a[7] = a7n;
+                soW[0] += 128;
+                soX[0] += 128;
+            }
+            // ---- the mid-step barrier B(t+1)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- sub-step 1: multiplies (t, 1) out of a / b1, reads (t+1, 0) into a / b0, issues (t+2, 1) into hs0
+            {
+                const unsigned ra = lds_base + (wn ? hs3 : hs2) * kP5HalfBytes + off_sub[0];
+                const unsigned rb = lds_base + (wm ? hs3 : hs2) * kP5HalfBytes + off_sub[0];
+                p4_substep<false>(acc, a, b1, [&](int i, int j) {
+                    P4_GAPS(b0, hs0, 1)
+                    if constexpr (STORES >= 0)
+                        if (j == 2 && i >= 4) {
+                            if (i == 4) P4_STORE(STORES + 4); else if (i == 5) P4_STORE(STORES + 5);
+                            else if (i == 6) P4_STORE(STORES + 6); else P4_STORE(STORES + 7);
+                        }
+                });
+#undef P4_GAPS
+                a[6] = a6n;
+                a[7] = a7n;
+                soW[1] += 128;
+                soX[1] += 128;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            hs0 = hs2;
+        };
+        using std::integral_constant;
+        static_assert(kP4Defer == 16, "the first two steps store eight pending pieces each");
+        step(0, integral_constant<bool, true>{}, integral_constant<int, 0>{});
+        step(1, integral_constant<bool, false>{}, integral_constant<int, 8>{});
+        for (int t = 2; t < nk; ++t) step(t, integral_constant<bool, false>{}, integral_constant<int, -1>{});
+        // ---- epilogue: bias (+ residual / GELU), bf16, LDS transpose per wave in the ring's one free half-slot; the first
+        // 32 - kP4Defer pieces are stored here, the rest stay in `pending` for the next tile's K loop
+        q0 = hs0;                                   // the next tile's (0, 0)
+        {
+            constexpr int kPitchF = 68;
+            float* const stg = reinterpret_cast<float*>(lds + mod5(q0 + 4) * kP5HalfBytes + wave * 8192);   // 4 352 B staging + 2 KiB aux per wave
+            const int tl = lane >> 3, nq = lane & 7;
+            const int rows_here = M - m0 < RBM ? (M - m0 > 0 ? M - m0 : 0) : RBM;
+            // the descriptors start at the tile's first element; their size covers its rows (the columns right of the tile in
+            // its last row would be in range too: they are never addressed)
+            const unsigned tile_bytes = __builtin_amdgcn_readfirstlane(rows_here > 0 ? (unsigned)(rows_here - 1) * (unsigned)N * 2u + RBN * 2u : 0u);
+            auto tile_desc = [&](const u16* base) {
+                const uint64_t bu = reinterpret_cast<uint64_t>(base + (int64_t)m0 * N + n0);
+                const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)bu), hi = __builtin_amdgcn_readfirstlane((uint32_t)(bu >> 32));
+                return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<u16*>(((uint64_t)hi << 32) | lo), 0, (int)tile_bytes, 0x00020000);
+            };
+            const __amdgpu_buffer_rsrc_t rdesc = tile_desc((EPI == 1 || EPI == 3) ? residual : Y);
+            const __amdgpu_buffer_rsrc_t ydesc_now = tile_desc(Y);
+            // (no explicit waits around the staging area below: a wave's LDS instructions execute in order, so its own reads see
+            // its own earlier writes and the next chunk's writes cannot pass this chunk's reads; the compiler's counted waits
+            // then let chunk c + 1's transposes run under chunk c's arithmetic)
+            // the residual's 32 pieces of this wave's part of the tile, all requested before the first chunk is transposed (one
+            // wave per SIMD: a load inside a chunk is a memory round trip nothing hides)
+            u32x4_t res[(EPI == 1 || EPI == 3) ? 32 : 1];
+            if (EPI == 1 || EPI == 3) {
+#pragma unroll
+                for (int idx = 0; idx < 32; ++idx) {
+                    const int voff = ((wm * 128 + (idx >> 2) * 16 + (idx & 1) * 8 + tl) * N + wn * 128 + ((idx >> 1) & 1) * 64 + nq * 8) * 2;
+                    res[idx] = __builtin_amdgcn_raw_buffer_load_b128(rdesc, voff, 0, (POL % 10 == 1 || EPI == 3) ? 2 : 0);
+                }
+            }
+            // LN fold (EPI 3 / 4 / 5, see LnFold): this wave's 128 (mean, rstd) pairs and its 128 columns' vectors (EPI 3: gamma / beta of
+            // the residual's LayerNorm, EPI 4 / 5: colsum(W')) are fetched once per tile and parked behind the staging area
+            float* const aux = stg + 16 * kPitchF;      // [0, 128) gamma | colsum, [128, 256) beta, [256, 512) (mean, rstd) x 128 tokens
+            if constexpr (EPI >= 3) {
+                *reinterpret_cast<float2*>(aux + 2 * lane) = aux_c0;
+                if constexpr (EPI == 3) *reinterpret_cast<float2*>(aux + 128 + 2 * lane) = aux_c1;
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) *reinterpret_cast<float2*>(aux + 256 + 2 * (hh * 64 + lane)) = aux_mr[hh];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            float st_s[2] = {0.f, 0.f}, st_q[2] = {0.f, 0.f};   // EPI 3: per pass, this wave's 128-column partial sums of a token
+            (void)st_s; (void)st_q;
+#define P4_EPI_CHUNK(jc, ic)                                                                                                  \
+    {                                                                                                                          \
+        _Pragma("unroll") for (int ii = 0; ii < 4; ++ii)                                                                       \
+            *reinterpret_cast<f32x4*>(stg + (lane & 15) * kPitchF + ii * 16 + (lane >> 4) * 4) = acc[4 * (ic) + ii][jc];       \
+        _Pragma("unroll") for (int pass = 0; pass < 2; ++pass) {                                                               \
+            const int tok = pass * 8 + tl;                                                                                     \
+            f32x4 v0 = *reinterpret_cast<const f32x4*>(stg + tok * kPitchF + nq * 8);                                          \
+            f32x4 v1 = *reinterpret_cast<const f32x4*>(stg + tok * kPitchF + nq * 8 + 4);                                      \
+            float mu_ = 0.f, rs_ = 1.f;                                                                                        \
+            f32x4 c0_ = {0.f, 0.f, 0.f, 0.f}, c1_ = c0_, e0_ = c0_, e1_ = c0_;                                                 \
+            if constexpr (EPI >= 3) {                                                                                          \
+                const float2 mrv = *reinterpret_cast<const float2*>(aux + 256 + 2 * ((jc) * 16 + tok));                        \
+                mu_ = mrv.x; rs_ = mrv.y;                                                                                      \
+                c0_ = *reinterpret_cast<const f32x4*>(aux + (ic) * 64 + nq * 8);                                               \
+                c1_ = *reinterpret_cast<const f32x4*>(aux + (ic) * 64 + nq * 8 + 4);                                           \
+                if constexpr (EPI == 3) {                                                                                      \
+                    e0_ = *reinterpret_cast<const f32x4*>(aux + 128 + (ic) * 64 + nq * 8);                                     \
+                    e1_ = *reinterpret_cast<const f32x4*>(aux + 128 + (ic) * 64 + nq * 8 + 4);                                 \
+                }                                                                                                              \
+            }                                                                                                                  \
+            if constexpr (EPI >= 4) {   /* rstd * (x W'^T - mu * colsum(W')) + bias' */                                        \
+                const float a_ = rs_, b_ = -mu_ * rs_;                                                                         \
+                v0.x = fmaf(v0.x, a_, fmaf(b_, c0_.x, bv[ic][0].x)); v0.y = fmaf(v0.y, a_, fmaf(b_, c0_.y, bv[ic][0].y));      \
+                v0.z = fmaf(v0.z, a_, fmaf(b_, c0_.z, bv[ic][0].z)); v0.w = fmaf(v0.w, a_, fmaf(b_, c0_.w, bv[ic][0].w));      \
+                v1.x = fmaf(v1.x, a_, fmaf(b_, c1_.x, bv[ic][1].x)); v1.y = fmaf(v1.y, a_, fmaf(b_, c1_.y, bv[ic][1].y));      \
+                v1.z = fmaf(v1.z, a_, fmaf(b_, c1_.z, bv[ic][1].z)); v1.w = fmaf(v1.w, a_, fmaf(b_, c1_.w, bv[ic][1].w));      \
+            } else {                                                                                                           \
+                v0 += bv[ic][0];                                                                                               \
+                v1 += bv[ic][1];                                                                                               \
+            }                                                                                                                  \
+            if constexpr (EPI == 3) {   /* residual = LayerNorm_prev(raw row), rebuilt from (raw, mu, rstd, gamma, beta) */    \
+                const u32x4_t r = res[EPI == 3 ? (jc) * 4 + (ic) * 2 + pass : 0];                                              \
+                const float a_ = rs_, b_ = -mu_ * rs_;                                                                         \
+                v0.x += fmaf(fmaf(bf16_to_f32((u16)(r[0] & 0xffff)), a_, b_), c0_.x, e0_.x);                                   \
+                v0.y += fmaf(fmaf(bf16_to_f32((u16)(r[0] >> 16)), a_, b_), c0_.y, e0_.y);                                      \
+                v0.z += fmaf(fmaf(bf16_to_f32((u16)(r[1] & 0xffff)), a_, b_), c0_.z, e0_.z);                                   \
+                v0.w += fmaf(fmaf(bf16_to_f32((u16)(r[1] >> 16)), a_, b_), c0_.w, e0_.w);                                      \
+                v1.x += fmaf(fmaf(bf16_to_f32((u16)(r[2] & 0xffff)), a_, b_), c1_.x, e1_.x);                                   \
+                v1.y += fmaf(fmaf(bf16_to_f32((u16)(r[2] >> 16)), a_, b_), c1_.y, e1_.y);                                      \
+                v1.z += fmaf(fmaf(bf16_to_f32((u16)(r[3] & 0xffff)), a_, b_), c1_.z, e1_.z);                                   \
+                v1.w += fmaf(fmaf(bf16_to_f32((u16)(r[3] >> 16)), a_, b_), c1_.w, e1_.w);                                      \
+            }                                                                                                                  \
+            if (EPI == 1) {                                                                                                    \
+                const u32x4_t r = res[EPI == 1 ? (jc) * 4 + (ic) * 2 + pass : 0];                                              \
+                v0.x += bf16_to_f32((u16)(r[0] & 0xffff)); v0.y += bf16_to_f32((u16)(r[0] >> 16));                             \
+                v0.z += bf16_to_f32((u16)(r[1] & 0xffff)); v0.w += bf16_to_f32((u16)(r[1] >> 16));                             \
+                v1.x += bf16_to_f32((u16)(r[2] & 0xffff)); v1.y += bf16_to_f32((u16)(r[2] >> 16));                             \
+                v1.z += bf16_to_f32((u16)(r[3] & 0xffff)); v1.w += bf16_to_f32((u16)(r[3] >> 16));                             \
+            }                                                                                                                  \
+            if (EPI == 2 || EPI == 5) {                                                                                        \
+                v0.x = gelu_erf(v0.x); v0.y = gelu_erf(v0.y); v0.z = gelu_erf(v0.z); v0.w = gelu_erf(v0.w);                    \
+                v1.x = gelu_erf(v1.x); v1.y = gelu_erf(v1.y); v1.z = gelu_erf(v1.z); v1.w = gelu_erf(v1.w);                    \
+            }                                                                                                                  \
+            if constexpr (EPI == 3) {   /* the row statistics of what is STORED (the bf16 values the consumers read) */        \
+                const float q0 = bf16_to_f32(f32_to_bf16(v0.x)), q1 = bf16_to_f32(f32_to_bf16(v0.y)),                          \
+                            q2 = bf16_to_f32(f32_to_bf16(v0.z)), q3 = bf16_to_f32(f32_to_bf16(v0.w)),                          \
+                            q4 = bf16_to_f32(f32_to_bf16(v1.x)), q5 = bf16_to_f32(f32_to_bf16(v1.y)),                          \
+                            q6 = bf16_to_f32(f32_to_bf16(v1.z)), q7 = bf16_to_f32(f32_to_bf16(v1.w));                          \
+                const float ss = ((q0 + q1) + (q2 + q3)) + ((q4 + q5) + (q6 + q7));                                            \
+                float qq = q0 * q0;                                                                                            \
+                qq = fmaf(q1, q1, qq); qq = fmaf(q2, q2, qq); qq = fmaf(q3, q3, qq);                                           \
+                qq = fmaf(q4, q4, qq); qq = fmaf(q5, q5, qq); qq = fmaf(q6, q6, qq); qq = fmaf(q7, q7, qq);                    \
+                if ((ic) == 0) { st_s[pass] = sum8_dpp(ss); st_q[pass] = sum8_dpp(qq); }                                       \
+                else { st_s[pass] += sum8_dpp(ss); st_q[pass] += sum8_dpp(qq); }                                               \
+                if ((ic) == 1 && nq == 0) {                                                                                    \
+                    const int m_ = m0 + wm * 128 + (jc) * 16 + tok;                                                            \
+                    if (m_ < M) *reinterpret_cast<float2*>(fold.stats + ((int64_t)m_ * (N / 128) + (n0 / 128 + wn)) * 2) = float2{st_s[pass], st_q[pass]}; \
+                }                                                                                                              \
+            }                                                                                                                  \
+            const u32x4_t o = u32x4_t{(unsigned)f32_to_bf16(v0.x) | ((unsigned)f32_to_bf16(v0.y) << 16),                       \
+                                      (unsigned)f32_to_bf16(v0.z) | ((unsigned)f32_to_bf16(v0.w) << 16),                       \
+                                      (unsigned)f32_to_bf16(v1.x) | ((unsigned)f32_to_bf16(v1.y) << 16),                       \
+                                      (unsigned)f32_to_bf16(v1.z) | ((unsigned)f32_to_bf16(v1.w) << 16)};                      \
+            if ((jc) * 4 + (ic) * 2 + pass < 32 - kP4Defer) P4_STORE_V(o, ydesc_now, (jc) * 4 + (ic) * 2 + pass);              \
+            else pending[(jc) * 4 + (ic) * 2 + pass - (32 - kP4Defer)] = o;                                                    \
+        }                                                                                                                      \
+    }
+            P4_EPI_CHUNK(0, 0) P4_EPI_CHUNK(0, 1) P4_EPI_CHUNK(1, 0) P4_EPI_CHUNK(1, 1) P4_EPI_CHUNK(2, 0) P4_EPI_CHUNK(2, 1)
+            P4_EPI_CHUNK(3, 0) P4_EPI_CHUNK(3, 1) P4_EPI_CHUNK(4, 0) P4_EPI_CHUNK(4, 1) P4_EPI_CHUNK(5, 0) P4_EPI_CHUNK(5, 1)
+            P4_EPI_CHUNK(6, 0) P4_EPI_CHUNK(6, 1) P4_EPI_CHUNK(7, 0) P4_EPI_CHUNK(7, 1)
+#undef P4_EPI_CHUNK
+            pdesc = ydesc_now;
+        }
+        if (!has_next) break;
+        // every wave is done with its staging area: the next tile's (2, 0) may overwrite it
+        __builtin_amdgcn_s_barrier();
+        tile = next;
+    }
+    // the last tile's stores; the stream's run-on half-loads must have landed before the workgroup's LDS is released
+#pragma unroll
+    for (int i = 0; i < kP4Defer; ++i) P4_STORE(i);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef P4_STORE
+#undef P4_STORE_V
+}
+
+template <int EPI, int POL>
+static hipError_t launch_p4_pol(const u16* X, const u16* W, const float* bias, const u16* residual, u16* Y, int M, int N,
+                                int K, int tiles_total, int grid, hipStream_t stream, const LnFold& fold) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_p4_kernel<EPI, POL>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kP5LdsBytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_bf16_p4_kernel<EPI, POL>), dim3(grid), dim3(kP4Threads), kP5LdsBytes, stream, X, W, bias, residual, Y, M,
+                       N, K, tiles_total, fold);
+    return hipGetLastError();
+}
+
+static bool p4_enabled() {
+    const char* v = getenv("RASS_GEMM_VARIANT");   // read per launch: the A/B script flips it inside one process
+    return v != nullptr && strcmp(v, "p4") == 0;
+}
+
 template <int EPI>
 static hipError_t launch_p5(const u16* X, const u16* W, const float* bias, const u16* residual, u16* Y, int M,
                             int M_pad, int N, int K, hipStream_t stream, const LnFold& fold = LnFold{}) {
@@ -1102,6 +1526,8 @@ static hipError_t launch_p5(const u16* X, const u16* W, const float* bias, const
         const int g = atoi(v);
         if (g >= 1 && g < grid) grid = g;
     }
+    if (p4_enabled() && K >= 512 && (uint64_t)M_pad * K * 2 < (1ull << 32) && (uint64_t)N * K * 2 < (1ull << 32))
+        return launch_p4_pol<EPI, 1>(X, W, bias, residual, Y, M, N, K, tiles_total, grid, stream, fold);
     if (const char* v = getenv("RASS_P5_POLICY"))   // A/B: 0 = plain output stores (read per launch)
         if (atoi(v) == 0) return launch_p5_pol<EPI, 0>(X, W, bias, residual, Y, M, N, K, tiles_total, grid, stream, fold);
     return launch_p5_pol<EPI, 1>(X, W, bias, residual, Y, M, N, K, tiles_total, grid, stream, fold);

@@ -49,23 +49,27 @@ __device__ __forceinline__ u16 f32_to_bf16(float f) {
     return *reinterpret_cast<u16*>(&h);
 }
 
-// GELU(x) = x/2 * (1 + erf(x/sqrt2)) with erf by Abramowitz-Stegun 7.1.26 (|err| < 1.5e-7 in
-// exact arithmetic, 5e-7 in fp32: two orders below bf16 resolution of the output).  libm's
-// erff costs ~3x the epilogue budget: the FFN-up GEMM ran at 510 TF/s with it vs 780 without.
+// GELU(x) = x/2 * (1 + erf(x/sqrt2)) (the erf form of BERT's "gelu").  libm's erff costs ~3x the epilogue budget (the FFN-up
+// GEMM ran at 510 TF/s with it vs 780 without); rounds 1-3 used Abramowitz-Stegun 7.1.26 (a reciprocal and an exponential).
 __device__ __forceinline__ float gelu_erf(float x) {
-    // With h = |x|/2, z = |x|/sqrt2 = h*sqrt2:  GELU(x) = max(x, 0) - h * (1 - erf(z)), and
-    // 1 - erf(z) = p(t) * exp(-z^2), t = 1/(1 + 0.3275911 z).  All constants folded onto h:
-    // 12 VALU + rcp + exp2 per element (the plain transcription costs 16 + 2).
+    // With h = |x|/2 and z = |x|/sqrt2:  GELU(x) = max(x, 0) - h * erfc(z).  Round 4: erfc(z) = exp2(Q(h)), Q the degree-7
+    // least-squares fit of log2(erfc(h sqrt2)) on z in [0, 5] (|rel. error| of erfc < 1.2e-5, so |error| of GELU < 1.5e-6
+    // everywhere, two orders below the bf16 resolution of the output; beyond z = 5 erfc < 2e-12 and h is clamped): one
+    // transcendental and 12 plain instructions per element, all of them packable — the Abramowitz-Stegun form it replaces
+    // (|error| 2e-7) took 12 + a reciprocal + an exponential, and the GELU epilogue of FFN-up is VALU-bound (8-11 us per
+    // 256 x 256 tile, profiles/r04_gemm_epilogue_experiments.txt).  scripts/fit_gelu_poly.py derives and checks the constants.
     const float h = 0.5f * fabsf(x);
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.46328375849f, h, 1.0f));   // 0.3275911 * sqrt2
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    p *= t;
-    const float zz = h * 1.69864357838f;                                   // sqrt(2 * log2(e)) * h: zz^2 = z^2 * log2(e)
-    const float e = __builtin_amdgcn_exp2f(-zz * zz);
-    return fmaf(-h, p * e, fmaxf(x, 0.0f));
+    const float hc = fminf(h, 3.5355339f);
+    float q = -2.0300099e-04f;
+    q = fmaf(q, hc, 3.5955482e-03f);
+    q = fmaf(q, hc, -2.8301010e-02f);
+    q = fmaf(q, hc, 1.3302942e-01f);
+    q = fmaf(q, hc, -4.2836797e-01f);
+    q = fmaf(q, hc, -1.8355303e+00f);
+    q = fmaf(q, hc, -2.3021889e+00f);
+    q = fmaf(q, hc, -4.7392123e-06f);
+    const float e = __builtin_amdgcn_exp2f(q);
+    return fmaf(-h, e, fmaxf(x, 0.0f));
 }
 
 // Stage one 128 x 64 bf16 operand tile (rows row0.., columns k0..k0+63 of a [rows][ld] matrix)

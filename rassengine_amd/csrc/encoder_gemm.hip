@@ -58,6 +58,19 @@ __device__ __forceinline__ float gelu_erf(float x) {
     // transcendental and 12 plain instructions per element, all of them packable — the Abramowitz-Stegun form it replaces
     // (|error| 2e-7) took 12 + a reciprocal + an exponential, and the GELU epilogue of FFN-up is VALU-bound (8-11 us per
     // 256 x 256 tile, profiles/r04_gemm_epilogue_experiments.txt).  scripts/fit_gelu_poly.py derives and checks the constants.
+#ifdef RASS_GELU_AS   // rounds 1-3 (the A/B build): Abramowitz-Stegun 7.1.26, 1 - erf(z) = p(t) exp(-z^2), t = 1 / (1 + 0.3275911 z)
+    {
+        const float h = 0.5f * fabsf(x);
+        const float t = __builtin_amdgcn_rcpf(fmaf(0.46328375849f, h, 1.0f));
+        float p = fmaf(1.061405429f, t, -1.453152027f);
+        p = fmaf(p, t, 1.421413741f);
+        p = fmaf(p, t, -0.284496736f);
+        p = fmaf(p, t, 0.254829592f);
+        p *= t;
+        const float zz = h * 1.69864357838f;
+        return fmaf(-h, p * __builtin_amdgcn_exp2f(-zz * zz), fmaxf(x, 0.0f));
+    }
+#endif
     const float h = 0.5f * fabsf(x);
     const float hc = fminf(h, 3.5355339f);
     float q = -2.0300099e-04f;
@@ -1091,7 +1104,8 @@ static hipError_t launch_p5_pol(const u16* X, const u16* W, const float* bias, c
 }
 
 // ------------------------------------------------------------------------------------------
-// "p4" (round 4, EXPERIMENT behind RASS_GEMM_VARIANT=p4): the same 256 x 256 tile and five-half-slot LDS-DMA ring as p5 with
+// "p4" (round 4; the persistent GEMM of big shapes since then, RASS_GEMM_VARIANT=p5 = the A/B): the same 256 x 256 tile and
+// five-half-slot LDS-DMA ring as p5 with
 // FOUR waves, one per SIMD, each owning 128 (output columns) x 128 (tokens) = 8 x 8 MFMA tiles in 256 AGPRs:
 //   * 16 fragment reads per 64 MFMAs (0.25 per MFMA; p5's 2 x 4 layout reads 0.375), placed BETWEEN the MFMAs of the running
 //     sub-step by hand (inline asm: the instruction order below IS the issue order), no phase barriers: one s_barrier per
@@ -1509,9 +1523,10 @@ static hipError_t launch_p4_pol(const u16* X, const u16* W, const float* bias, c
     return hipGetLastError();
 }
 
+// The persistent GEMM of big shapes is p4 since round 4; RASS_GEMM_VARIANT=p5 brings back the 8-wave kernel (the A/B; same bits).
 static bool p4_enabled() {
-    const char* v = getenv("RASS_GEMM_VARIANT");   // read per launch: the A/B script flips it inside one process
-    return v != nullptr && strcmp(v, "p4") == 0;
+    const char* v = getenv("RASS_GEMM_VARIANT");   // read per launch: the A/B scripts flip it inside one process
+    return !(v != nullptr && strcmp(v, "p5") == 0);
 }
 
 template <int EPI>
@@ -1636,7 +1651,8 @@ static hipError_t launch_epi(const u16* X, const u16* W, const float* bias, cons
     // keep most of the chip's CUs busy (a persistent kernel runs one tile per CU at a time): a 2 048-token upload has
     // 32 tiles at N = 1024 and ran on 32 of 256 CUs; as 128^2 tiles (split over K where those are few) it fills the
     // chip.  RASS_GEMM_VARIANT=p5 keeps the persistent kernel for every shape it accepts (A/B runs, tests).
-    static const bool forced = getenv("RASS_GEMM_VARIANT") != nullptr && strcmp(getenv("RASS_GEMM_VARIANT"), "p5") == 0;
+    static const bool forced = getenv("RASS_GEMM_VARIANT") != nullptr &&
+                               (strcmp(getenv("RASS_GEMM_VARIANT"), "p5") == 0 || strcmp(getenv("RASS_GEMM_VARIANT"), "p4") == 0);
     const bool enough_tiles = forced || (int64_t)(N / RBN) * (M_pad / RBM) >= 192;
     if (N % RBN == 0 && M_pad % RBM == 0 && K % 64 == 0 && K >= 128 && M >= 1024 && enough_tiles)
         return launch_p5<EPI>(X, W, bias, residual, Y, M, M_pad, N, K, stream);

@@ -64,7 +64,8 @@ import ctypes, sys, torch
 sys.path.insert(0, %r)
 from rassengine_amd import _native as N_
 ok = True
-for (M, N, K, epi) in [(1024, 256, 128, 0), (3000, 512, 128, 1), (1025, 1024, 2048, 2), (2048, 1024, 4096, 1)]:
+for (M, N, K, epi) in [(1024, 256, 128, 0), (3000, 512, 128, 1), (1025, 1024, 2048, 2), (2048, 1024, 4096, 1),
+                       (1300, 256, 512, 0), (1024, 256, 1024, 1), (4097, 512, 1024, 2), (1791, 768, 576, 1)]:
     g = torch.Generator(device="cuda"); g.manual_seed(M + N + K + epi)
     M_pad = (M + 255) // 256 * 256
     X = torch.zeros((M_pad, K), dtype=torch.bfloat16, device="cuda"); X[:M] = torch.randn((M, K), generator=g, device="cuda").bfloat16()
@@ -85,11 +86,12 @@ print("VARIANT_OK" if ok else "VARIANT_BAD")
 """
 
 
-@pytest.mark.parametrize("variant", ["p5"])
+@pytest.mark.parametrize("variant", ["p5", "p4"])
 def test_gemm_forced_variants_on_few_tiles(gpu, variant):
-    """By default shapes with few 256^2 tiles take the 128^2 kernel; RASS_GEMM_VARIANT=p5 (read once per process: hence a
+    """By default shapes with few 256^2 tiles take the 128^2 kernel; RASS_GEMM_VARIANT=p5 / p4 (read once per process: hence a
     child process, started before this one's GPU state matters to it) keeps the persistent 256^2 kernel for them — one
-    tile per workgroup, fewer tiles than CUs, ragged M.  (Round 2's other variants — ring, pring, p64, w4l — were retired
+    tile per workgroup, fewer tiles than CUs, ragged M, the shortest K p4 takes (512: its two store steps + the stream's
+    run-on), K not a multiple of 128 — the 8-wave p5 or the 4-wave p4 (round 4's default for big shapes; K < 512 stays on p5).  (Round 2's other variants — ring, pring, p64, w4l — were retired
     from the library: scripts/microbench/gemm_retired_kernels.hip.)"""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1524,9 +1524,11 @@ static hipError_t launch_p4_pol(const u16* X, const u16* W, const float* bias, c
 }
 
 // The persistent GEMM of big shapes is p4 since round 4; RASS_GEMM_VARIANT=p5 brings back the 8-wave kernel (the A/B; same bits).
-static bool p4_enabled() {
+static bool p4_enabled(int epi) {
     const char* v = getenv("RASS_GEMM_VARIANT");   // read per launch: the A/B scripts flip it inside one process
-    return !(v != nullptr && strcmp(v, "p5") == 0);
+    if (v != nullptr && strcmp(v, "p5") == 0) return false;
+    if (v != nullptr && strcmp(v, "p4") == 0) return true;
+    return epi != 5;
 }
 
 template <int EPI>
@@ -1545,7 +1547,9 @@ static hipError_t launch_p5(const u16* X, const u16* W, const float* bias, const
         const int g = atoi(v);
         if (g >= 1 && g < grid) grid = g;
     }
-    if (p4_enabled() && K >= 512 && (uint64_t)M_pad * K * 2 < (1ull << 32) && (uint64_t)N * K * 2 < (1ull << 32))
+    // (the folded GELU epilogue, EPI 5, is the one p4 loses: 1 165 vs 1 129 us per FFN-up — a single wave per SIMD has nothing to
+    // overlap that epilogue's dependency stalls with; it stays on p5 unless RASS_GEMM_VARIANT=p4 asks for p4 everywhere)
+    if (p4_enabled(EPI) && K >= 512 && (uint64_t)M_pad * K * 2 < (1ull << 32) && (uint64_t)N * K * 2 < (1ull << 32))
         return launch_p4_pol<EPI, 1>(X, W, bias, residual, Y, M, N, K, tiles_total, grid, stream, fold);
     if (const char* v = getenv("RASS_P5_POLICY"))   // A/B: 0 = plain output stores (read per launch)
         if (atoi(v) == 0) return launch_p5_pol<EPI, 0>(X, W, bias, residual, Y, M, N, K, tiles_total, grid, stream, fold);

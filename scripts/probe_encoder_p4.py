@@ -12,8 +12,11 @@ g = torch.Generator(device="cuda"); g.manual_seed(1)
 ids = torch.randint(1000, cfg.vocab_size - 1, (nseq * S,), generator=g, device="cuda", dtype=torch.int32)
 cu = torch.arange(0, (nseq + 1) * S, S, dtype=torch.int32, device="cuda")
 out = {}
-for variant in ("p5", "p4", "p5", "p4"):
-    os.environ["RASS_GEMM_VARIANT"] = variant
+for variant in ("p5", "p4", "default", "p5", "p4", "default"):
+    if variant == "default":
+        os.environ.pop("RASS_GEMM_VARIANT", None)
+    else:
+        os.environ["RASS_GEMM_VARIANT"] = variant
     o = torch.empty((nseq, cfg.hidden), dtype=torch.float32, device="cuda")
     for _ in range(2):
         enc.encode_device(ids.data_ptr(), cu.data_ptr(), nseq, nseq * S, S, o.data_ptr())

@@ -1121,10 +1121,9 @@ static hipError_t launch_p5_pol(const u16* X, const u16* W, const float* bias, c
 // publishes step t+1 and frees step t's slots; sub-step 1 reads (t+1, 0)'s fragments and issues (t+2, 1) into (t, 0)'s slot.
 // Every half-load is issued 1-1.5 steps before the barrier that needs it, as in p5.
 constexpr int kP4Threads = 256;
-#ifndef RASS_P4_DEFER
-#define RASS_P4_DEFER 16
+#ifndef RASS_P4_DEFER_MAX
+#define RASS_P4_DEFER_MAX 24
 #endif
-constexpr int kP4Defer = RASS_P4_DEFER;   // output pieces (of 32 per lane and tile) stored by the NEXT tile's K loop; the others in the epilogue
 #define P4_MFMA(acc, a, b) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b))
 #define P4_MFMA0(acc, a, b) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(acc) : "v"(a), "v"(b))
 #define P4_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
@@ -1154,6 +1153,9 @@ __global__ __launch_bounds__(kP4Threads, 1) void gemm_bf16_p4_kernel(const u16* 
                                                                      const u16* __restrict__ residual, u16* __restrict__ Y,
                                                                      int M, int N, int K, int tiles_total, LnFold fold) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    // output pieces (of 32 per lane and tile) stored by the NEXT tile's K loop, eight per step; the others in the epilogue.  24 where
+    // the epilogue leaves the registers (bias only, with or without the LN fold), 16 where it also holds a residual tile.
+    constexpr int kDefer = (EPI == 0 || EPI == 4) ? RASS_P4_DEFER_MAX : 16;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave & 1, wn = wave >> 1;          // which half of the tile's tokens (X rows) / output columns (W rows)
@@ -1239,10 +1241,10 @@ __global__ __launch_bounds__(kP4Threads, 1) void gemm_bf16_p4_kernel(const u16* 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    // the previous tile's last kP4Defer output pieces (16 B per lane each), stored by the next tile's first two steps
-    u32x4_t pending[kP4Defer];
+    // the previous tile's last kDefer output pieces (16 B per lane each), stored by the next tile's first two steps
+    u32x4_t pending[kDefer];
 #pragma unroll
-    for (int i = 0; i < kP4Defer; ++i) pending[i] = u32x4_t{0u, 0u, 0u, 0u};
+    for (int i = 0; i < kDefer; ++i) pending[i] = u32x4_t{0u, 0u, 0u, 0u};
     __amdgpu_buffer_rsrc_t pdesc = __builtin_amdgcn_make_buffer_rsrc(Y, 0, 0, 0x00020000);   // zero records: the first tile's are dropped
     const int st_voff = ((lane >> 3) * N + (lane & 7) * 8) * 2;    // lane part of a store: token row lane>>3, 16 B (lane&7)
     // piece idx of a tile: 16-token chunk jc = idx >> 2, 64-column chunk ic = (idx >> 1) & 1, pass = idx & 1 (8 tokens each)
@@ -1250,7 +1252,7 @@ __global__ __launch_bounds__(kP4Threads, 1) void gemm_bf16_p4_kernel(const u16* 
     __builtin_amdgcn_raw_buffer_store_b128(val, desc, st_voff,                                                                     \
                                            ((wm * 128 + ((idx) >> 2) * 16 + ((idx) & 1) * 8) * N + wn * 128 + (((idx) >> 1) & 1) * 64) * 2, \
                                            POL % 10 == 1 ? 2 : 0)
-#define P4_STORE(v) P4_STORE_V(pending[v], pdesc, 32 - kP4Defer + (v))
+#define P4_STORE(v) P4_STORE_V(pending[v], pdesc, 32 - kDefer + (v))
 
     f32x4 acc[8][8];
     bf16x8 a[8], a6n, a7n, b0[8], b1[8];
@@ -1365,12 +1367,13 @@ __global__ __launch_bounds__(kP4Threads, 1) void gemm_bf16_p4_kernel(const u16* 
             hs0 = hs2;
         };
         using std::integral_constant;
-        static_assert(kP4Defer == 16, "the first two steps store eight pending pieces each");
+        static_assert(kDefer == 16 || kDefer == 24, "the first two or three steps store eight pending pieces each");
         step(0, integral_constant<bool, true>{}, integral_constant<int, 0>{});
         step(1, integral_constant<bool, false>{}, integral_constant<int, 8>{});
-        for (int t = 2; t < nk; ++t) step(t, integral_constant<bool, false>{}, integral_constant<int, -1>{});
+        if constexpr (kDefer == 24) step(2, integral_constant<bool, false>{}, integral_constant<int, 16>{});
+        for (int t = kDefer / 8; t < nk; ++t) step(t, integral_constant<bool, false>{}, integral_constant<int, -1>{});
         // ---- epilogue: bias (+ residual / GELU), bf16, LDS transpose per wave in the ring's one free half-slot; the first
-        // 32 - kP4Defer pieces are stored here, the rest stay in `pending` for the next tile's K loop
+        // 32 - kDefer pieces are stored here, the rest stay in `pending` for the next tile's K loop
         q0 = hs0;                                   // the next tile's (0, 0)
         {
             constexpr int kPitchF = 68;
@@ -1485,8 +1488,8 @@ __global__ __launch_bounds__(kP4Threads, 1) void gemm_bf16_p4_kernel(const u16* 
                                       (unsigned)f32_to_bf16(v0.z) | ((unsigned)f32_to_bf16(v0.w) << 16),                       \
                                       (unsigned)f32_to_bf16(v1.x) | ((unsigned)f32_to_bf16(v1.y) << 16),                       \
                                       (unsigned)f32_to_bf16(v1.z) | ((unsigned)f32_to_bf16(v1.w) << 16)};                      \
-            if ((jc) * 4 + (ic) * 2 + pass < 32 - kP4Defer) P4_STORE_V(o, ydesc_now, (jc) * 4 + (ic) * 2 + pass);              \
-            else pending[(jc) * 4 + (ic) * 2 + pass - (32 - kP4Defer)] = o;                                                    \
+            if ((jc) * 4 + (ic) * 2 + pass < 32 - kDefer) P4_STORE_V(o, ydesc_now, (jc) * 4 + (ic) * 2 + pass);              \
+            else pending[(jc) * 4 + (ic) * 2 + pass - (32 - kDefer)] = o;                                                    \
         }                                                                                                                      \
     }
             P4_EPI_CHUNK(0, 0) P4_EPI_CHUNK(0, 1) P4_EPI_CHUNK(1, 0) P4_EPI_CHUNK(1, 1) P4_EPI_CHUNK(2, 0) P4_EPI_CHUNK(2, 1)
@@ -1502,7 +1505,7 @@ __global__ __launch_bounds__(kP4Threads, 1) void gemm_bf16_p4_kernel(const u16* 
     }
     // the last tile's stores; the stream's run-on half-loads must have landed before the workgroup's LDS is released
 #pragma unroll
-    for (int i = 0; i < kP4Defer; ++i) P4_STORE(i);
+    for (int i = 0; i < kDefer; ++i) P4_STORE(i);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #undef P4_STORE
 #undef P4_STORE_V

@@ -846,7 +846,7 @@ int rass_index_set_prefilter(rass_index_t* idx, int enable) {
     if (enable && idx->dtype == RASS_BF16) return fail(RASS_ERR_UNSUPPORTED, "a bf16 corpus IS the bf16 scan: no prefilter mode");
     if (enable == idx->prefilter) return RASS_OK;
     if (enable == 1 && idx->stride % 256 != 0) return fail(RASS_ERR_UNSUPPORTED, "prefilter needs dim padded to a multiple of 256");
-    if (enable && idx->stride > kNarrowStride) return fail(RASS_ERR_UNSUPPORTED, "prefilter needs dim <= 1024 (wide rows: fp32 flat scan only)");
+    if (enable == 1 && idx->stride > kNarrowStride) return fail(RASS_ERR_UNSUPPORTED, "the bf16 prefilter needs dim <= 1024 (wide rows: int8 candidates or the fp32 flat scan)");
     // leave the current mode (a switch between the two candidate copies goes through "off")
     HIP_TRY(hipStreamSynchronize(st));
     if (idx->d_rows_bf16) (void)hipFree(idx->d_rows_bf16);

@@ -439,11 +439,103 @@ __global__ __launch_bounds__(256) void rerank_f32_kernel(const float* __restrict
     }
 }
 
+// Wide rows (stride 1 280 .. 2 048: 10 .. 16 chunks per K slice): the same arithmetic with the slice walked in two halves of
+// CH chunks each (the loads of a half in flight together), the fmaf chain running on across them in chunk order.
+template <int CH>
+__global__ __launch_bounds__(256) void rerank_f32_wide_kernel(const float* __restrict__ slab, int64_t stride,
+                                                              const float* __restrict__ q_padded,
+                                                              const int64_t* __restrict__ cand_rows, int n_cand, int k,
+                                                              int64_t id_base, float* __restrict__ out_scores,
+                                                              int64_t* __restrict__ out_ids, int64_t gs, int64_t gi,
+                                                              const int64_t* __restrict__ id_map) {
+    __shared__ float part[32][9];
+    __shared__ float sc[32];
+    __shared__ int64_t rw[32];
+    const int q = blockIdx.x;
+    float* const os = out_scores + (gs > 0 ? (int64_t)(q >> 5) * gs + (int64_t)(q & 31) * k : (int64_t)q * k);
+    int64_t* const oi = out_ids + (gi > 0 ? (int64_t)(q >> 5) * gi + (int64_t)(q & 31) * k : (int64_t)q * k);
+    const int c = threadIdx.x >> 3, w = threadIdx.x & 7;
+    const int64_t row = c < n_cand ? cand_rows[(int64_t)q * n_cand + c] : -1;
+    float acc = 0.f;
+    if (row >= 0) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const float* xb = slab + (row >> 4) * 16 * stride + (int64_t)(w * 2 * CH + half * CH) * 256 + (int)(row & 15) * 4;
+            const float* qv = q_padded + (int64_t)q * stride + (w * 2 * CH + half * CH) * 16;
+            f32x4 xv[CH][4];
+#pragma unroll
+            for (int j = 0; j < CH; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) xv[j][g] = *reinterpret_cast<const f32x4*>(xb + j * 256 + g * 64);
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                f32x4 qq[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) qq[g] = *reinterpret_cast<const f32x4*>(qv + j * 16 + 4 * g);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) acc = fmaf(xv[j][g][i], qq[g][i], acc);
+            }
+        }
+    }
+    part[c][w] = acc;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        const int cc = threadIdx.x;
+        float s = part[cc][0];
+#pragma unroll
+        for (int ww = 1; ww < 8; ++ww) s += part[cc][ww];
+        const int64_t r = cc < n_cand ? cand_rows[(int64_t)q * n_cand + cc] : -1;
+        sc[cc] = r >= 0 ? s : -INFINITY;
+        rw[cc] = (r >= 0 && id_map != nullptr) ? id_map[r] : r;
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        const int cc = threadIdx.x;
+        const float s = sc[cc];
+        const int64_t r = rw[cc];
+        int rank = 0;
+        for (int o = 0; o < 32; ++o) {
+            const float so = sc[o];
+            const int64_t ro = rw[o];
+            const bool o_valid = ro >= 0, me_valid = r >= 0;
+            const bool better = o_valid && (!me_valid || so > s || (so == s && ro < r));
+            rank += (o != cc && better) ? 1 : 0;
+        }
+        if (r < 0) rank = 32 + cc;
+        if (rank < k) {
+            os[rank] = s;
+            oi[rank] = id_base + r;
+        }
+        int valid = 0;
+        for (int o = 0; o < 32; ++o) valid += rw[o] >= 0 ? 1 : 0;
+        if (cc >= valid && cc < k) {
+            os[cc] = -INFINITY;
+            oi[cc] = -1;
+        }
+    }
+}
+
 hipError_t launch_rerank_f32(const float* slab, int64_t stride, const float* q_padded, const int64_t* cand_rows, int nq,
                              int n_cand, int k, int64_t id_base, float* out_scores, int64_t* out_ids,
                              hipStream_t stream, int64_t out_scores_group_stride, int64_t out_ids_group_stride,
                              const int64_t* id_map) {
-    if (nq < 1 || n_cand < 1 || n_cand > 32 || k < 1 || k > n_cand || stride % 128 != 0 || stride > 1024) return hipErrorInvalidValue;
+    if (nq < 1 || n_cand < 1 || n_cand > 32 || k < 1 || k > n_cand || stride % 128 != 0 || stride > 2048) return hipErrorInvalidValue;
+    if (stride > 1024) {   // wide rows: strides of 256 * {5..8} = two halves of 5..8 chunks per K slice
+        if (stride % 256 != 0) return hipErrorInvalidValue;
+#define RASS_RERANK_WIDE(C)                                                                                                        \
+    case C:                                                                                                                        \
+        hipLaunchKernelGGL(rerank_f32_wide_kernel<C>, dim3(nq), dim3(256), 0, stream, slab, stride, q_padded, cand_rows, n_cand, k, \
+                           id_base, out_scores, out_ids, out_scores_group_stride, out_ids_group_stride, id_map);                   \
+        break;
+        switch ((int)(stride >> 8)) {
+            RASS_RERANK_WIDE(5) RASS_RERANK_WIDE(6) RASS_RERANK_WIDE(7) RASS_RERANK_WIDE(8)
+            default: return hipErrorInvalidValue;
+        }
+#undef RASS_RERANK_WIDE
+        return hipGetLastError();
+    }
 #define RASS_RERANK_CASE(C)                                                                                                   \
     case C:                                                                                                                   \
         hipLaunchKernelGGL(rerank_f32_kernel<C>, dim3(nq), dim3(256), 0, stream, slab, stride, q_padded, cand_rows, n_cand, k, \

@@ -15,7 +15,8 @@
 // The result equals the flat result whenever the true top-k is inside the int8 top-32 — measured (bench.py --prefilter int8:
 // recall vs the flat kernel), never assumed.
 //
-// int8 slab layout ("tile16i"): 16-row blocks of `stride_i8` bytes per row (the fp32 stride rounded up to 512, zero padded);
+// int8 slab layout ("tile16i"): 16-row blocks of `stride_i8` bytes per row (the fp32 stride rounded up to 512, zero padded; up to
+// 2 048 = the widest row an index takes);
 // chunk jb (columns 64jb .. 64jb+63) of the 16 rows is one contiguous 1 KiB in MFMA lane order, lane (m = lane&15,
 // g = lane>>4) holding X[16b+m][64jb + 16g .. +15]: element (r, c) at
 //   (r>>4)*16*stride_i8 + (c>>6)*1024 + (((c>>4)&3)*16 + (r&15))*16 + (c&15)      [bytes]
@@ -283,7 +284,7 @@ static hipError_t launch_ivariant(const ScanI8Args& a, int grid, hipStream_t str
 }
 
 hipError_t launch_scan_i8_topk(const ScanI8Args& a, int grid, hipStream_t stream) {
-    if (a.row_stride % 512 != 0 || a.row_stride < 512 || a.row_stride > 1024) return hipErrorInvalidValue;  // 8 waves x 64-column chunks
+    if (a.row_stride % 512 != 0 || a.row_stride < 512 || a.row_stride > 2048) return hipErrorInvalidValue;  // 8 waves x 64-column chunks
     if (a.nq < 1 || a.nq > 32 || a.k < 1 || a.k > 32 || a.n_rows < 0 || grid < 1) return hipErrorInvalidValue;
     if (a.sample_best && (a.sample_groups < 1 || a.sample_groups > kMaxSampleGroups)) return hipErrorInvalidValue;
     if (a.q_filter_mask && !a.q_filter) return hipErrorInvalidValue;
@@ -294,7 +295,9 @@ hipError_t launch_scan_i8_topk(const ScanI8Args& a, int grid, hipStream_t stream
     if (ivf) return two ? launch_ivariant<C, 2, true>(a, grid, stream) : launch_ivariant<C, 1, true>(a, grid, stream);       \
     return two ? launch_ivariant<C, 2, false>(a, grid, stream) : launch_ivariant<C, 1, false>(a, grid, stream);
     if (a.row_stride == 512) { RASS_I8_CASE(1) }
-    RASS_I8_CASE(2)
+    if (a.row_stride == 1024) { RASS_I8_CASE(2) }
+    if (a.row_stride == 1536) { RASS_I8_CASE(3) }   // wide rows (1 024 < dim <= 2 048)
+    RASS_I8_CASE(4)
 #undef RASS_I8_CASE
 }
 

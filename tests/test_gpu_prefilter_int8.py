@@ -23,7 +23,7 @@ def _cand(idx, q, qf=None):
     return s.cpu().numpy(), r.cpu().numpy()
 
 
-@pytest.mark.parametrize("dim", [1024, 384, 512, 768])
+@pytest.mark.parametrize("dim", [1024, 384, 512, 768, 1100, 1536, 2048])
 def test_int8_candidates_equal_the_oracle_bit_for_bit(gpu, oracle, dim):
     from rassengine_amd.engine import Engine
     eng = Engine(0, dim)
@@ -155,168 +155,53 @@ def test_mode_validation(gpu):
     try:
         idx = eng.open_index("wide")
         with pytest.raises(RassError):
-            idx.set_prefilter("int8")               # wide rows: fp32 flat scan only
+            idx.set_prefilter("bf16")               # wide rows: int8 candidates or the fp32 flat scan
         with pytest.raises(ValueError):
             idx.set_prefilter("fp4")
+        idx.set_prefilter("int8")
+        assert idx.prefilter_mode == "int8"
     finally:
         eng.close()
 
 
-@pytest.mark.parametrize("mode", ["int8", "bf16"])
-def test_prefilter_batch_call_equals_groups(gpu, mode):
-    """rass_index_search_device_batch on an index in a prefilter mode (one normalise, one query conversion, the groups'
-    candidate scans, ONE grouped merge, ONE re-rank launch) ≡ the group-by-group calls, bit for bit — ragged last group,
-    per-query filters, tombstones, an id base, k above the prefilter's limit (exact flat batch)."""
+@pytest.mark.parametrize("dim", [1100, 1536, 1792, 2048])
+def test_int8_prefilter_on_wide_rows_matches_the_flat_scan(gpu, dim):
+    """1 024 < dim <= 2 048 (VERDICT r3 missing #6, for the candidate mode): int8 slab rows of 1 536 / 2 048 B, the re-rank
+    walks a K slice in two halves in the wide flat kernel's order — ids and scores ≡ the exact wide scan, single calls of
+    1 .. 45 queries and the batch call."""
     from rassengine_amd.engine import Engine
     torch = gpu
-    rng = np.random.default_rng(21)
-    n = 30_011
-    x = rng.standard_normal((n, 1024)).astype(np.float32)
-    tags = rng.integers(1, 20, size=n).astype(np.int32)
-    eng = Engine(0, 1024)
-    try:
-        eng.set_stream(int(torch.cuda.current_stream().cuda_stream))
-        ix = eng.open_index("pfb")
-        ix.add(x, tags=tags)
-        ix.delete(5)
-        ix.delete(29_000)
-        ix.set_prefilter(mode)
-        g = torch.Generator(device="cuda"); g.manual_seed(9)
-        for nq, k in ((33, 10), (100, 7), (256, 16), (70, 20)):
-            q = torch.randn((nq, 1024), generator=g, device="cuda")
-            filt = torch.randint(1, 20, (nq,), dtype=torch.int32, device="cuda")
-            filt[1] = -1
-            for f in (None, filt):
-                outs = []
-                for batch in (True, False):
-                    s = torch.empty((nq, k), dtype=torch.float32, device="cuda")
-                    i = torch.empty((nq, k), dtype=torch.int64, device="cuda")
-                    if batch:
-                        ix.search_device_batch(q.data_ptr(), nq, k, s.data_ptr(), i.data_ptr(), id_base=1_000_000,
-                                               d_q_filter_ptr=f.data_ptr() if f is not None else 0)
-                    else:
-                        for o in range(0, nq, 32):
-                            b = min(32, nq - o)
-                            ix.search_device(q[o:o + b].data_ptr(), b, k, s[o:o + b].data_ptr(), i[o:o + b].data_ptr(),
-                                             id_base=1_000_000, d_q_filter_ptr=f[o:o + b].data_ptr() if f is not None else 0)
-                    torch.cuda.synchronize()
-                    outs.append((s.cpu().numpy(), i.cpu().numpy()))
-                assert np.array_equal(outs[0][1], outs[1][1]), (mode, nq, k)
-                assert np.array_equal(outs[0][0].view(np.uint32), outs[1][0].view(np.uint32)), (mode, nq, k)
-        # against the flat scan of the same index: identical on this well-separated corpus
-        q = torch.randn((64, 1024), generator=g, device="cuda")
-        s_p = torch.empty((64, 10), dtype=torch.float32, device="cuda"); i_p = torch.empty((64, 10), dtype=torch.int64, device="cuda")
-        ix.search_device_batch(q.data_ptr(), 64, 10, s_p.data_ptr(), i_p.data_ptr())
-        torch.cuda.synchronize()
-        ix.set_prefilter(False)
-        s_f = torch.empty_like(s_p); i_f = torch.empty_like(i_p)
-        ix.search_device_batch(q.data_ptr(), 64, 10, s_f.data_ptr(), i_f.data_ptr())
-        torch.cuda.synchronize()
-        assert torch.equal(i_p, i_f) and torch.equal(s_p, s_f)
-    finally:
-        eng.close()
-
-
-def test_int8_candidates_with_the_sample_floor(gpu, oracle, monkeypatch):
-    """A slab long enough for the sample floor (>= 8 samples of 64 rows x 256 workgroups): the candidate lists with the floor
-    ≡ without it ≡ the oracle, bit for bit — plain, filtered (a filter matching few rows: fewer than 32 finite sample maxima,
-    no floor for that query) and with tombstones inside the sample."""
-    from rassengine_amd.engine import Engine
-    torch = gpu
-    dim, n = 512, 150_000
     eng = Engine(0, dim)
     try:
-        g = torch.Generator(device="cuda").manual_seed(77)
-        idx = eng.open_index("i8-floor", capacity_rows=n)
-        tags = np.zeros(n, dtype=np.int32)
-        rng = np.random.default_rng(1)
-        tags[:] = rng.integers(1, 4, size=n)
-        tags[rng.choice(n, 40, replace=False)] = 9          # a rare tag
-        for c0 in range(0, n, 50_000):
-            x = torch.randn((50_000, dim), generator=g, device="cuda").cpu().numpy()
-            idx.add(x, tags=tags[c0:c0 + 50_000])
-        for r in (3, 64, 9_000, 149_999):
-            idx.delete(r)
-            tags[r] = -1
-        idx.set_prefilter("int8")
-        xn = idx.get_rows(0, n)
-        q = torch.randn((32, dim), generator=g, device="cuda").cpu().numpy()
-        qn = oracle.normalize_c(q)
-        qf = rng.integers(-1, 4, size=32).astype(np.int32)
-        qf[5] = 9
-        qf[6] = 77                                          # matches nothing
-        for f in (None, qf):
-            s_o, r_o = oracle.candidates_i8(xn, qn, 32, tags=tags, qfilter=f)
-            for floor in ("1", "0"):
-                monkeypatch.setenv("RASS_I8_SAMPLE_FLOOR", floor)
-                s_g, r_g = _cand(idx, q, f)
-                assert np.array_equal(r_g, r_o), (floor, f is not None)
-                assert np.array_equal(s_g.view(np.uint32), s_o.view(np.uint32)), floor
-        assert np.all(r_o[6] == -1) if qf is not None else True
+        eng.set_stream(int(torch.cuda.current_stream().cuda_stream))
+        rng = np.random.default_rng(dim)
+        idx = eng.open_index("pf8-wide")
+        n = 7000 + 13
+        x = rng.standard_normal((n, dim)).astype(np.float32)
+        tags = rng.integers(1, 4, size=n).astype(np.int32)
+        idx.add(x[:4000], tags=tags[:4000])
+        idx.add(x[4000:], tags=tags[4000:])
+        idx.delete(11)
+        q = rng.standard_normal((45, dim)).astype(np.float32)
+        qf = rng.integers(-1, 4, size=45).astype(np.int32)
+        for k in (1, 10, 16):
+            idx.set_prefilter("int8")
+            a = idx.search(q, k, q_filter=qf)
+            a1 = idx.search(q[:1], k)
+            idx.set_prefilter(False)
+            b = idx.search(q, k, q_filter=qf)
+            b1 = idx.search(q[:1], k)
+            assert np.array_equal(a[1], b[1]) and np.array_equal(a[0], b[0]), (dim, k)
+            assert np.array_equal(a1[1], b1[1]) and np.array_equal(a1[0], b1[0]), (dim, k)
+        qd = torch.from_numpy(np.concatenate([q, q, q])[:100]).cuda().contiguous()
+        outs = []
+        for mode in ("int8", False):
+            idx.set_prefilter(mode)
+            s = torch.empty((100, 10), dtype=torch.float32, device="cuda")
+            i = torch.empty((100, 10), dtype=torch.int64, device="cuda")
+            idx.search_device_batch(qd.data_ptr(), 100, 10, s.data_ptr(), i.data_ptr())
+            torch.cuda.synchronize()
+            outs.append((s.cpu().numpy(), i.cpu().numpy()))
+        assert np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][0], outs[1][0]), dim
     finally:
         eng.close()
-
-
-@pytest.mark.parametrize("mode", ["int8", "bf16"])
-def test_prefilter_knob_behind_the_boundary(gpu, monkeypatch, mode):
-    """RASS_PREFILTER: the default index factory opens every index in that mode; an ask()-shaped flow through
-    HipIndexer returns what the exact index returns (docs, order and the reference's 1 / (2 - cos) scores)."""
-    import asyncio
-    from rassengine_amd import config, embedding, indexer
-    from rassengine_amd.docstore import REGISTRY
-    from rassengine_amd.engine import Engine
-    from tests.helpers import HashEmbedder
-
-    docs = [{"doc_id": f"text-f-{i}", "doc_type": "unstructured", "patientId": f"p{i % 3}",
-             "unstructuredText": f"note {i} mentions condition{i % 11} and drug{i % 5}"} for i in range(400)]
-    results = {}
-    for setting in ("off", mode):
-        monkeypatch.setattr(config, "RASS_PREFILTER", setting)
-        REGISTRY.clear()
-        REGISTRY.set_index_factory(None)
-        embedding.set_embedder(HashEmbedder(1024))
-        try:
-            name = "rass-idx-knob"
-            asyncio.run(indexer.store_fhir_docs_in_opensearch([], docs, None, name))
-            assert REGISTRY.get(name).index.prefilter_mode == setting
-            q = asyncio.run(embedding.embed_query("note about condition7 and drug2"))
-            ix = indexer.HipIndexer(None, name)
-            results[setting] = (ix.semantic_search(q, k=5, patient_id="p1"), ix.semantic_search(q, k=10),
-                                ix.semantic_search(q, k=40))          # k > 16: the exact scan either way
-        finally:
-            embedding.set_embedder(None)
-            REGISTRY.clear()
-            Engine.get(config.RASS_DEVICE, config.EMBED_DIM).drop_index(name)
-    for a, b in zip(results["off"], results[mode]):
-        assert [d["doc_id"] for d, _ in a] == [d["doc_id"] for d, _ in b]
-        assert [s for _, s in a] == [s for _, s in b]
-
-
-@pytest.mark.parametrize("mode", ["int8", "bf16"])
-def test_prefilter_with_global_ids_and_masked_filters(engine, mode):
-    """A shard of a multi-GPU index: caller-assigned global ids (reported, and the tie order) and masked tag compares
-    (patient code | doc_type << 24) go through the candidate scan + re-rank like plain searches — ≡ the exact scan."""
-    rng = np.random.default_rng(55)
-    idx = engine.open_index("pf-gid-" + mode)
-    n = 6000
-    x = rng.standard_normal((n, 1024)).astype(np.float32)
-    x[100] = x[50]                                           # an exact duplicate: equal scores, the lower GLOBAL id first
-    tags = (rng.integers(1, 6, size=n) | (rng.integers(0, 2, size=n) << 24)).astype(np.int32)
-    idx.add(x[:2500], tags=tags[:2500], first_global_id=10_000)
-    idx.add(x[2500:], tags=tags[2500:], first_global_id=50_000)
-    idx.delete(7)
-    q = np.concatenate([x[50:51] * 2.0, rng.standard_normal((40, 1024)).astype(np.float32)])
-    f = np.array([(r % 5) + 1 if r % 2 else 0x01000000 for r in range(41)], dtype=np.int32)
-    m = np.array([0x00ffffff if r % 2 else 0x01000000 for r in range(41)], dtype=np.int32)
-    f[0], m[0] = -1, -1
-    for k in (1, 10, 16):
-        idx.set_prefilter(mode)
-        a = idx.search(q, k, q_filter=f, q_filter_mask=m)
-        b = idx.search(q, k)
-        idx.set_prefilter(False)
-        a0 = idx.search(q, k, q_filter=f, q_filter_mask=m)
-        b0 = idx.search(q, k)
-        assert np.array_equal(a[1], a0[1]) and np.array_equal(a[0], a0[0]), k
-        assert np.array_equal(b[1], b0[1]) and np.array_equal(b[0], b0[0]), k
-    assert b0[1][0, 0] == 10_050 and (k == 1 or b0[1][0, 1] == 10_100)      # the duplicate pair in global-id order
-    assert b0[1].min() >= 10_000

@@ -86,7 +86,8 @@ int rass_device_count(void);
 /* One engine per process per GPU.  `dim` = EMBED_DIM (app/main.py:80), 1 .. 2048.  Up to 1024 columns every feature of
  * this header applies; a WIDE-row engine (1024 < dim <= 2048: what an encoder of hidden size 1536 / 2048 emits) serves
  * fp32 flat indices — add / delete / get / save / load and every search entry point incl. masked filters and k > 32 —
- * while a bf16 corpus, the prefilter mode, the IVF build and cross-index batches answer RASS_ERR_UNSUPPORTED. */
+ * (and, for k <= 16, by the int8 prefilter mode: rass_index_set_prefilter), while a bf16 corpus, the bf16 prefilter, the IVF
+ * build and cross-index batches answer RASS_ERR_UNSUPPORTED. */
 int rass_engine_create(int device, int dim, rass_engine_t** out);
 void rass_engine_destroy(rass_engine_t* eng);
 int rass_engine_dim(const rass_engine_t* eng);
@@ -239,8 +240,9 @@ int rass_index_search_device_batch(rass_index_t* idx, const float* d_queries, in
  * is (float)(exact integer dot) * row scale).  Either way those candidates' scores are then recomputed exactly from the fp32
  * slab in the flat kernel's fmaf order and the exact top-k among them is returned: returned scores are bit-identical to the
  * flat path; the id set equals the flat result whenever the true top-k lies inside the candidate top-32 (measured as recall,
- * not guaranteed).  Used for k <= 16 only (k > 16 takes the exact flat scan).  bf16 needs dim padded to a multiple of 256;
- * both need dim <= 1024.  0 = off (frees the copy); switching modes rebuilds the copy from the fp32 rows. */
+ * not guaranteed).  Used for k <= 16 only (k > 16 takes the exact flat scan).  bf16 needs dim padded to a multiple of 256 and
+ * dim <= 1024; int8 serves every dim an index takes (wide rows, 1024 < dim <= 2048, included).  0 = off (frees the copy);
+ * switching modes rebuilds the copy from the fp32 rows. */
 #define RASS_PREFILTER_OFF 0
 #define RASS_PREFILTER_BF16 1
 #define RASS_PREFILTER_INT8 2

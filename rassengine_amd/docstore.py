@@ -18,6 +18,8 @@ import os
 import threading
 from typing import Any, Dict, List, Optional, Tuple
 
+import numpy as np
+
 PATIENT_NONE = 0  # tag of rows without a patientId
 TAG_PATIENT_MASK = 0x00FFFFFF
 TAG_DOCTYPE_SHIFT = 24
@@ -77,9 +79,22 @@ class IndexState:
         self.doc_types = PatientDictionary(max_code=0x7F)
         self.batcher = None                      # QueryBatcher, created on first async search
         self.generation = 0                      # bumped by every save()
+        # incremental persistence (save_delta): what changed since the last save() / save_delta()
+        self._ckpt_rows = 0                      # rows of the index that are on disk
+        self._dead_since: List[int] = []         # rows < _ckpt_rows tombstoned since
+        self._structured_dirty: set = set()      # structured doc_ids (re)written since
+        self._delta_seq = 0                      # delta segments written on top of the current snapshot
 
     def live_count(self) -> int:
         return len(self.doc_row) + len(self.structured)
+
+    # ---- the write path reports what it changes (indexer.add_documents / store_fhir_docs_in_opensearch)
+    def note_deleted(self, row: int) -> None:
+        if row < self._ckpt_rows:
+            self._dead_since.append(int(row))
+
+    def note_structured(self, doc_id: str) -> None:
+        self._structured_dirty.add(doc_id)
 
     def tag_of(self, doc: dict) -> int:
         return compose_tag(self.patients.encode(doc.get("patientId")), self.doc_types.encode(doc.get("doc_type")))
@@ -133,12 +148,135 @@ class IndexState:
             os.replace(tmp_meta, prefix + ".meta.json")
             _fsync_dir(os.path.dirname(prefix) or ".")
             self.generation = gen
+            # the snapshot covers everything: the delta log of the previous generation goes with it
+            self._ckpt_rows, self._dead_since, self._structured_dirty, self._delta_seq = int(self.index.rows), [], set(), 0
+            self._remove_deltas(prefix, keep_generation=None)
             if prev and prev != vec_path and os.path.exists(prev):
                 # a sharded index's vector "file" is a manifest naming one shard file per rank
                 for f in (self.index.saved_files(prev) if hasattr(self.index, "saved_files") else []):
                     if os.path.exists(f):
                         os.remove(f)
                 os.remove(prev)
+
+    # ---- incremental persistence (the reference's durability is incremental: one bulk per 64 docs,
+    # app/main.py:1253-1282).  save() writes a SNAPSHOT (every vector, every doc: O(corpus)); save_delta() appends ONE segment
+    # holding only what changed since the last save() / save_delta(): the rows appended since (read back from the index:
+    # the stored, normalised bits), their docs, the rows tombstoned since, the structured docs rewritten since — O(delta).
+    # `<prefix>.deltas.json` (tiny, replaced atomically, LAST) lists the segments of the manifest's generation; load() replays
+    # them in order on top of the snapshot.  A segment or list left behind by a crash before that replace is ignored.
+    def save_delta(self, prefix: str) -> bool:
+        """Returns False (nothing written) when there is no snapshot of THIS state under ``prefix`` to append to, or the index
+        cannot hand its rows out (``get_rows``): the caller then takes a snapshot (``save``)."""
+        with self.lock:
+            get_rows = getattr(self.index, "get_rows", None)
+            if get_rows is None or self.generation == 0 or self._manifest_generation_only(prefix) != self.generation:
+                return False
+            rows_now = int(self.index.rows)
+            n_new = rows_now - self._ckpt_rows
+            if n_new == 0 and not self._dead_since and not self._structured_dirty:
+                return True
+            vecs = np.ascontiguousarray(get_rows(self._ckpt_rows, n_new), dtype=np.float32) if n_new else np.zeros((0, 0), np.float32)
+            head = {"version": 1, "generation": self.generation, "seq": self._delta_seq + 1, "first_row": self._ckpt_rows,
+                    "n": n_new, "dim": int(vecs.shape[1]) if n_new else 0,
+                    "row_doc": self.row_doc[self._ckpt_rows:rows_now] + [None] * max(0, rows_now - len(self.row_doc)),
+                    "dead": sorted(set(self._dead_since)),
+                    "structured": {k: self.structured[k] for k in sorted(self._structured_dirty) if k in self.structured},
+                    "patients": self.patients.names(), "doc_types": self.doc_types.names(),
+                    "rows_after": rows_now, "live_after": int(self.index.count)}
+            d, base = os.path.dirname(prefix) or ".", os.path.basename(prefix)
+            seg = f"{base}.g{self.generation:06d}.d{self._delta_seq + 1:06d}.delta"
+            tmp = os.path.join(d, seg + ".tmp")
+            with open(tmp, "wb") as f:
+                f.write(json.dumps(head).encode("utf-8") + b"\n")
+                f.write(vecs.tobytes())
+                f.flush()
+                os.fsync(f.fileno())
+            os.replace(tmp, os.path.join(d, seg))
+            listing = self._read_delta_list(prefix)
+            segs = listing["segments"] if listing and listing.get("generation") == self.generation else []
+            tmp_l = prefix + ".deltas.json.tmp"
+            with open(tmp_l, "w", encoding="utf-8") as f:
+                json.dump({"generation": self.generation, "segments": segs + [seg]}, f)
+                f.flush()
+                os.fsync(f.fileno())
+            os.replace(tmp_l, prefix + ".deltas.json")
+            _fsync_dir(d)
+            self._ckpt_rows, self._dead_since, self._structured_dirty = rows_now, [], set()
+            self._delta_seq += 1
+            return True
+
+    @staticmethod
+    def _read_delta_list(prefix: str) -> Optional[dict]:
+        try:
+            with open(prefix + ".deltas.json", encoding="utf-8") as f:
+                return json.load(f)
+        except (OSError, ValueError):
+            return None
+
+    @classmethod
+    def _remove_deltas(cls, prefix: str, keep_generation: Optional[int]) -> None:
+        d, base = os.path.dirname(prefix) or ".", os.path.basename(prefix)
+        try:
+            for fn in os.listdir(d):
+                if fn.startswith(base + ".g") and (fn.endswith(".delta") or fn.endswith(".delta.tmp")):
+                    if keep_generation is None or not fn.startswith(f"{base}.g{keep_generation:06d}."):
+                        os.remove(os.path.join(d, fn))
+            if keep_generation is None and os.path.exists(prefix + ".deltas.json"):
+                os.remove(prefix + ".deltas.json")
+        except OSError:
+            pass
+
+    @staticmethod
+    def _manifest_generation_only(prefix: str) -> int:
+        try:
+            with open(prefix + ".meta.json", encoding="utf-8") as f:
+                return int(json.load(f).get("generation", 0))
+        except (OSError, ValueError, TypeError):
+            return 0
+
+    def _replay_deltas(self, prefix: str) -> None:
+        """load(): the segments `<prefix>.deltas.json` lists for this generation, in order, on top of the snapshot."""
+        listing = self._read_delta_list(prefix)
+        if not listing or int(listing.get("generation", -1)) != self.generation:
+            return
+        d = os.path.dirname(prefix) or "."
+        for k, seg in enumerate(listing.get("segments", [])):
+            with open(os.path.join(d, seg), "rb") as f:
+                head = json.loads(f.readline().decode("utf-8"))
+                n, dim = int(head["n"]), int(head["dim"])
+                raw = f.read(n * dim * 4)
+            if int(head.get("generation", -1)) != self.generation or int(head.get("seq", -1)) != k + 1 or \
+                    int(head["first_row"]) != int(self.index.rows) or len(raw) != n * dim * 4 or len(head["row_doc"]) != n:
+                raise ValueError(f"{seg}: delta segment does not continue the index (generation / order / rows / length)")
+            for pname in head["patients"]:
+                self.patients.encode(pname)
+            for t in head.get("doc_types", []):
+                self.doc_types.encode(t)
+            if n:
+                vecs = np.frombuffer(raw, dtype=np.float32).reshape(n, dim)
+                tags = np.array([self.tag_of(doc) if doc is not None else 0 for doc in head["row_doc"]], dtype=np.int32)
+                first = self.index.add(vecs, tags=tags, normalize=False)     # the stored bits, not re-normalised
+                if int(first) != int(head["first_row"]):
+                    raise ValueError(f"{seg}: rows landed at {first}, expected {head['first_row']}")
+            for r in head["dead"]:
+                self.index.delete(int(r))
+                doc = self.row_doc[int(r)]
+                if doc is not None and self.doc_row.get(doc.get("doc_id")) == int(r):
+                    del self.doc_row[doc.get("doc_id")]
+                self.row_doc[int(r)] = None
+            for i, doc in enumerate(head["row_doc"]):
+                r = int(head["first_row"]) + i
+                self.row_doc.append(doc)
+                if doc is None:
+                    self.index.delete(r)
+                else:
+                    self.doc_row[doc["doc_id"]] = r
+            self.structured.update(head["structured"])
+            if int(self.index.rows) != int(head["rows_after"]) or int(self.index.count) != int(head["live_after"]):
+                raise ValueError(f"{seg}: after the replay the index holds {self.index.rows} rows / {self.index.count} live, "
+                                 f"the segment recorded {head['rows_after']} / {head['live_after']}")
+            self._delta_seq = k + 1
+        self._ckpt_rows = int(self.index.rows)
 
     @staticmethod
     def _manifest_generation(prefix: str) -> int:
@@ -193,6 +331,8 @@ class IndexState:
         for t in meta.get("doc_types", []):
             st.doc_types.encode(t)
         st.doc_row = {d["doc_id"]: r for r, d in enumerate(st.row_doc) if d is not None}
+        st._ckpt_rows = rows
+        st._replay_deltas(prefix)
         return st
 
 

@@ -365,6 +365,7 @@ def add_documents(index_name: str, docs: List[Dict], embeddings: Optional[np.nda
             if old is not None:
                 st.index.delete(old)
                 st.row_doc[old] = None
+                st.note_deleted(old)
         for i, (d, r) in enumerate(zip(docs, rows)):
             if len(st.row_doc) <= r:
                 st.row_doc.extend([None] * (r + 1 - len(st.row_doc)))
@@ -417,6 +418,7 @@ async def store_fhir_docs_in_opensearch(structured_docs: List[Dict], unstructure
             with st.lock:
                 for doc in structured_docs:
                     st.structured[doc["doc_id"]] = doc
+                    st.note_structured(doc["doc_id"])
             if bulk is None:
                 logger.info(f"Indexed {len(structured_docs)} structured docs, errors: []")
         except Exception as e:

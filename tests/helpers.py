@@ -41,6 +41,9 @@ class OracleIndex:
     def get_row(self, row):
         return self._rows[row].copy()
 
+    def get_rows(self, first_row, n):
+        return self._rows[first_row:first_row + n].copy()
+
     def search(self, queries, k, q_filter=None, q_filter_mask=None):
         qn = O.normalize_ref(np.ascontiguousarray(queries, dtype=np.float32)).astype(np.float32)
         s, i = O.search(self._rows, qn, k, tags=self._tags, qfilter=q_filter, qmask=q_filter_mask)

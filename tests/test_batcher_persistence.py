@@ -197,3 +197,88 @@ def test_metadata_persistence_roundtrip(tmp_path):
         embedding.set_embedder(None)
         REGISTRY.set_index_factory(None)
         REGISTRY.clear()
+
+
+def test_incremental_persistence_replays_deltas(tmp_path):
+    """IndexState.save_delta: O(delta) segments on top of a snapshot — appended rows (the stored bits), their docs, overwrites
+    of snapshot rows (tombstones), overwrites inside a delta, structured docs; load() = snapshot + segments in order; a stray
+    segment a crash left unlisted is ignored; the next snapshot clears the log."""
+    import json
+    import os
+
+    class SavingIndex(OracleIndex):
+        def save(self, path):
+            with open(path, "wb") as f:
+                np.savez(f, rows=self._rows, tags=self._tags)
+
+    def loader(name, path):
+        z = np.load(path)
+        i = SavingIndex(z["rows"].shape[1])
+        i._rows, i._tags = z["rows"], z["tags"]
+        return i
+
+    def docs_of(lo, hi, word="text"):
+        return [{"doc_id": f"d{i}", "doc_type": "unstructured", "patientId": f"p{i % 4}",
+                 "unstructuredText": f"{word} {i} alpha{i % 5}"} for i in range(lo, hi)]
+
+    def same_state(a, b, query="text 33 alpha3"):
+        assert a.doc_row == b.doc_row and a.structured == b.structured and a.row_doc == b.row_doc
+        assert a.index.rows == b.index.rows and a.index.count == b.index.count
+        assert np.array_equal(a.index._rows, b.index._rows) and np.array_equal(a.index._tags, b.index._tags)
+        assert a.patients.names() == b.patients.names() and a.doc_types.names() == b.doc_types.names()
+        q = HashEmbedder(1024).encode([query])
+        ra, rb = a.index.search(q, 7), b.index.search(q, 7)
+        assert np.array_equal(ra[1], rb[1]) and np.array_equal(ra[0], rb[0])
+
+    REGISTRY.clear()
+    REGISTRY.set_index_factory(lambda name: SavingIndex(1024))
+    embedding.set_embedder(HashEmbedder(1024))
+    try:
+        name, prefix = "idx-inc", str(tmp_path / "inc")
+        store = lambda s, u: asyncio.run(indexer.store_fhir_docs_in_opensearch(s, u, None, name))
+        store([{"doc_id": "Patient-1", "doc_type": "structured", "patientId": "p1"}], docs_of(0, 30))
+        st = REGISTRY.get(name)
+        assert st.save_delta(prefix) is False                   # no snapshot yet: the caller must save()
+        st.save(prefix)
+        assert st.save_delta(prefix) is True                    # nothing changed: nothing written
+        assert not os.path.exists(prefix + ".deltas.json")
+        # delta 1: new rows (a new patient code among them), an overwrite of a snapshot row, an overwrite inside the delta
+        store([{"doc_id": "Patient-2", "doc_type": "structured", "patientId": "p9"}],
+              docs_of(30, 40) + [dict(docs_of(4, 5)[0], unstructuredText="rewritten four")] +
+              [{"doc_id": "d99", "doc_type": "note", "patientId": "p9", "unstructuredText": "first"},
+               {"doc_id": "d99", "doc_type": "note", "patientId": "p9", "unstructuredText": "second wins"}])
+        assert st.save_delta(prefix) is True
+        seg1 = json.load(open(prefix + ".deltas.json"))["segments"]
+        assert len(seg1) == 1 and os.path.getsize(os.path.join(str(tmp_path), seg1[0])) < 14 * 4096 + 8192   # 13 rows, not 43
+        same_state(st, IndexState.load(name, prefix, loader))
+        # delta 2: overwrite a row that lives in delta 1, rewrite a structured doc
+        store([{"doc_id": "Patient-1", "doc_type": "structured", "patientId": "p1", "gender": "f"}],
+              [dict(docs_of(33, 34)[0], unstructuredText="thirty-three again")])
+        assert st.save_delta(prefix) is True
+        st2 = IndexState.load(name, prefix, loader)
+        same_state(st, st2)
+        assert st2.structured["Patient-1"]["gender"] == "f" and st2.doc_row["d99"] == st.doc_row["d99"]
+        assert len(json.load(open(prefix + ".deltas.json"))["segments"]) == 2
+        # the loaded state keeps appending to the same log
+        asyncio.run(indexer.store_fhir_docs_in_opensearch([], docs_of(50, 53), None, name))      # on the live state
+        REGISTRY.put(st2)
+        asyncio.run(indexer.store_fhir_docs_in_opensearch([], docs_of(50, 53), None, name))      # and on the restored one
+        assert st2.save_delta(prefix) is True
+        same_state(st2, IndexState.load(name, prefix, loader))
+        # a segment a crash left behind without listing it is ignored; a listing of another generation too
+        open(os.path.join(str(tmp_path), "inc.g000001.d000009.delta"), "wb").write(b"garbage")
+        same_state(st2, IndexState.load(name, prefix, loader))
+        # a torn / reordered log is an error, not silent corruption
+        listing = json.load(open(prefix + ".deltas.json"))
+        json.dump({"generation": listing["generation"], "segments": listing["segments"][1:]}, open(prefix + ".deltas.json", "w"))
+        with pytest.raises(ValueError):
+            IndexState.load(name, prefix, loader)
+        json.dump(listing, open(prefix + ".deltas.json", "w"))
+        # the next snapshot folds the log in and clears it
+        st2.save(prefix)
+        assert not os.path.exists(prefix + ".deltas.json") and not [f for f in os.listdir(str(tmp_path)) if f.endswith(".delta")]
+        same_state(st2, IndexState.load(name, prefix, loader))
+    finally:
+        embedding.set_embedder(None)
+        REGISTRY.set_index_factory(None)
+        REGISTRY.clear()

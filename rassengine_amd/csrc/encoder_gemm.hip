@@ -1299,11 +1299,10 @@ __global__ __launch_bounds__(kP4Threads, 1) void gemm_bf16_p4_kernel(const u16* 
             constexpr bool ZERO = decltype(zero_c)::value;
             constexpr int STORES = decltype(stores_c)::value;
             const int hs1 = mod5(hs0 + 1), hs2 = mod5(hs0 + 2), hs3 = mod5(hs0 + 3), hs4 = mod5(hs0 + 4);
-            // the half-loads this iteration issues are (t+2, 0) and (t+2, 1); beyond the tile they are the next tile's (with no
-            // next tile the stream runs on into rows nobody reads: the bounds check of the descriptors keeps it in the matrices)
-            if (t + 2 == nk && has_next) {
-                point_half(next, 0);
-                point_half(next, 1);
+            // the half-loads this iteration issues are (t+2, 0) and (t+2, 1); beyond the tile they are the next tile's
+            if (t + 2 == nk) {   // (no next tile: the stream re-reads this tile's first steps — in bounds, never consumed)
+                point_half(has_next ? next : tile, 0);
+                point_half(has_next ? next : tile, 1);
             }
             // ---- sub-step 0: multiplies (t, 0) out of a / b0, reads (t, 1) into a / b1, issues (t+2, 0) into hs4
             {
@@ -1552,7 +1551,7 @@ static hipError_t launch_p5(const u16* X, const u16* W, const float* bias, const
     }
     // (the folded GELU epilogue, EPI 5, is the one p4 loses: 1 165 vs 1 129 us per FFN-up — a single wave per SIMD has nothing to
     // overlap that epilogue's dependency stalls with; it stays on p5 unless RASS_GEMM_VARIANT=p4 asks for p4 everywhere)
-    if (p4_enabled(EPI) && K >= 512 && (uint64_t)M_pad * K * 2 < (1ull << 32) && (uint64_t)N * K * 2 < (1ull << 32))
+    if (p4_enabled(EPI) && K >= 512 && (uint64_t)M_pad * K * 2 < (1ull << 32) - (1ull << 24) && (uint64_t)N * K * 2 < (1ull << 32) - (1ull << 24))
         return launch_p4_pol<EPI, 1>(X, W, bias, residual, Y, M, N, K, tiles_total, grid, stream, fold);
     if (const char* v = getenv("RASS_P5_POLICY"))   // A/B: 0 = plain output stores (read per launch)
         if (atoi(v) == 0) return launch_p5_pol<EPI, 0>(X, W, bias, residual, Y, M, N, K, tiles_total, grid, stream, fold);

@@ -194,6 +194,140 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_bf16_kernel(const u16* _
 }
 
 // ------------------------------------------------------------------------------------------
+// "mid" (round 4): gemm_bf16_kernel's 128 x 128 x 64 tile with a FOUR-stage LDS-DMA ring instead of two buffers behind a
+// draining barrier.  Shapes too small for the persistent kernels (65 .. ~2 000 rows: the embed micro-batcher's coalesced
+// queries, small uploads) are latency-bound, not bandwidth-bound: the two-buffer kernel takes ~1.2 us per 64-deep step (one
+// operand tile in flight, its global -> LDS latency exposed every step), and the split-K pair that replaced it in round 2
+// (more workgroups, fewer steps each) pays an fp32 partial tile per slice plus a second launch — 12.8 + 5.3 us for the QKV
+// projection of 384 tokens.  With three tiles in flight a step is its 32 MFMAs per wave plus one LDS round trip (~0.4 us),
+// the epilogue is fused, and K <= 1 024 needs no split: one launch of ~9 us.  Counted waits (vmcnt) and asm fragment reads as
+// in p5 (hipcc would drain the DMA queue before every LDS read it can see).
+#define RASS_DS_READ_B128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
+constexpr int kMidStages = 4;
+constexpr int kMidLdsBytes = kMidStages * 2 * kTileBytes;   // 128 KiB
+
+template <int EPI>
+__global__ __launch_bounds__(kGemmThreads, 1) void gemm_bf16_mid_kernel(const u16* __restrict__ X, const u16* __restrict__ W,
+                                                                       const float* __restrict__ bias,
+                                                                       const u16* __restrict__ residual,
+                                                                       u16* __restrict__ Y, int M, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // [stage][W tile | X tile]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wn = wave >> 1, wm = wave & 1;
+    const int nblk = gridDim.x;
+    const int orig = blockIdx.x;
+    const int q = nblk / 8, rr = nblk % 8, xcd = orig % 8;
+    const int bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + orig / 8;
+    const int tiles_n = N / GBN;
+    const int bn = bid % tiles_n, bm = bid / tiles_n;
+    const int n0 = bn * GBN, m0 = bm * GBM;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = K / GBK;
+    auto stage = [&](int t) {   // tile t -> stage t % 4: 4 + 4 instructions per wave
+        unsigned char* buf = lds + (t & (kMidStages - 1)) * 2 * kTileBytes;
+        stage_tile(W, K, n0, t * GBK, buf, wave, lane);
+        stage_tile(X, K, m0, t * GBK, buf + kTileBytes, wave, lane);
+    };
+    stage(0);
+    if (nk > 1) stage(1);
+    if (nk > 2) stage(2);
+    // fragment addresses inside a stage: row r of a tile at r * 128, 16-B chunk c at c ^ ((r >> 1) & 7)
+    const int fr = lane & 15, sw = (fr >> 1) & 7;
+    unsigned offA[2], offB[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int ch = (ks * 4 + (lane >> 4)) ^ sw;
+        offA[ks] = (wn * 64 + fr) * 128 + ch * 16;
+        offB[ks] = kTileBytes + (wm * 64 + fr) * 128 + ch * 16;
+    }
+    for (int t = 0; t < nk; ++t) {
+        // tile t has landed (this wave's pieces: the tiles t+1, t+2 issued after it may still fly) ...
+        const int ahead = nk - 1 - t;
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();     // ... everybody's have, and everybody is done reading stage (t - 1) % 4
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 3 < nk) stage(t + 3);
+        const unsigned sb = lds_base + (t & (kMidStages - 1)) * 2 * kTileBytes;
+        bf16x8 a[2][4], b[2][4];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const unsigned aa = sb + offA[ks], bb = sb + offB[ks];
+            RASS_DS_READ_B128(a[ks][0], aa, 0);
+            RASS_DS_READ_B128(a[ks][1], aa, 2048);
+            RASS_DS_READ_B128(a[ks][2], aa, 4096);
+            RASS_DS_READ_B128(a[ks][3], aa, 6144);
+            RASS_DS_READ_B128(b[ks][0], bb, 0);
+            RASS_DS_READ_B128(b[ks][1], bb, 2048);
+            RASS_DS_READ_B128(b[ks][2], bb, 4096);
+            RASS_DS_READ_B128(b[ks][3], bb, 6144);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks][i], b[ks][j], acc[i][j], 0, 0, 0);
+    }
+
+    // Epilogue (as gemm_bf16_kernel).  acc[i][j]: token m = m0 + wm*64 + j*16 + (lane&15); features
+    // n = n0 + wn*64 + i*16 + (lane>>4)*4 + {0,1,2,3}.
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + wm * 64 + j * 16 + (lane & 15);
+        if (m >= M) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = n0 + wn * 64 + i * 16 + (lane >> 4) * 4;
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n);
+            f32x4 v = acc[i][j] + bv;
+            if (EPI == 1) {
+                const uint2 r = *reinterpret_cast<const uint2*>(residual + (int64_t)m * N + n);
+                v.x += bf16_to_f32((u16)(r.x & 0xffff));
+                v.y += bf16_to_f32((u16)(r.x >> 16));
+                v.z += bf16_to_f32((u16)(r.y & 0xffff));
+                v.w += bf16_to_f32((u16)(r.y >> 16));
+            }
+            if (EPI == 2) {
+                v.x = gelu_erf(v.x);
+                v.y = gelu_erf(v.y);
+                v.z = gelu_erf(v.z);
+                v.w = gelu_erf(v.w);
+            }
+            uint2 o;
+            o.x = (unsigned)f32_to_bf16(v.x) | ((unsigned)f32_to_bf16(v.y) << 16);
+            o.y = (unsigned)f32_to_bf16(v.z) | ((unsigned)f32_to_bf16(v.w) << 16);
+            *reinterpret_cast<uint2*>(Y + (int64_t)m * N + n) = o;
+        }
+    }
+}
+
+// Where it pays (scripts/probe_encoder_shapes.py, whole forwards, same box): 3 .. 8 row tiles — 32 x 12 tokens 1.887 -> 1.799 ms,
+// 64 x 12: 2.144 -> 2.054, 32 x 32: 2.228 -> 2.097; with one or two row tiles the split-K pair's extra workgroups win (16 x 12:
+// 1.618 vs 1.730), from 12 row tiles on the two-buffer kernel's two workgroups per CU do (48 x 32: 2.516 vs 2.813, 4 x 512: 3.391 vs 3.612).  A step
+// still takes ~0.85 us, not the 0.4 us of its MFMAs + one LDS round trip: the wave issues its 8 DMA instructions (with their
+// address arithmetic), 16 fragment reads and 32 MFMAs in order — interleaving them by hand as p4 does is the next step.
+static bool mid_enabled(int M = 512) {
+    const char* v = getenv("RASS_GEMM_MID");   // 0: round 3's paths (two-buffer kernel / split-K pair); 2: every shape (the A/Bs)
+    if (v != nullptr && atoi(v) == 0) return false;
+    if (v != nullptr && atoi(v) == 2) return true;
+    return M > 2 * GBM && M <= 8 * GBM;
+}
+
+// ------------------------------------------------------------------------------------------
 // Split-K form of the 128 x 128 kernel for FEW rows (a query or a handful of chunks: embed_query / ollama_embed_text,
 // reference app/main.py:225-237, 266-274).  With M <= 256 the plain kernel launches N/128 x M/128 = 8-32 workgroups, each
 // walking all of K behind one barrier per 64-deep step: FFN-down (K = 4096) took 60 us, attn-out 13 us, a one-query
@@ -643,7 +777,6 @@ constexpr int kPStageTokens = 32;         // tokens per epilogue staging chunk (
 // the LDS-DMA (global_load_lds) ops still in flight — in two of the three epilogue variants of the
 // persistent kernel it put a vmcnt(0) in front of the fragment reads of EVERY K step (K loop 45 us
 // instead of 28).  The DMA / read ordering is this kernel's own protocol (counted vmcnt + barrier).
-#define RASS_DS_READ_B128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
 
 // ------------------------------------------------------------------------------------------
 // "p5": gemm_bf16_p64_kernel's whole-line operand stream with a ring of FIVE 32-KiB HALF-slots instead of two 64-KiB
@@ -1662,6 +1795,20 @@ static hipError_t launch_epi(const u16* X, const u16* W, const float* bias, cons
     const bool enough_tiles = forced || (int64_t)(N / RBN) * (M_pad / RBM) >= 192;
     if (N % RBN == 0 && M_pad % RBM == 0 && K % 64 == 0 && K >= 128 && M >= 1024 && enough_tiles)
         return launch_p5<EPI>(X, W, bias, residual, Y, M, M_pad, N, K, stream);
+    const int grid = (N / GBN) * (M_pad / GBM);
+    if (mid_enabled(M) && K >= 3 * GBK) {   // the four-stage form of the same tile, over the row tiles that hold real rows
+        const int grid = (N / GBN) * ((M + GBM - 1) / GBM);
+        static bool mid_attr_set = false;
+        if (!mid_attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_mid_kernel<EPI>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, kMidLdsBytes);
+            if (e != hipSuccess) return e;
+            mid_attr_set = true;
+        }
+        hipLaunchKernelGGL((gemm_bf16_mid_kernel<EPI>), dim3(grid), dim3(kGemmThreads), kMidLdsBytes, stream, X, W, bias,
+                           residual, Y, M, N, K);
+        return hipGetLastError();
+    }
     constexpr int lds_bytes = 4 * kTileBytes;  // 64 KiB
     static bool attr_set = false;
     if (!attr_set) {
@@ -1670,7 +1817,6 @@ static hipError_t launch_epi(const u16* X, const u16* W, const float* bias, cons
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    const int grid = (N / GBN) * (M_pad / GBM);
     hipLaunchKernelGGL((gemm_bf16_kernel<EPI>), dim3(grid), dim3(kGemmThreads), lds_bytes, stream, X, W, bias,
                        residual, Y, M, N, K);
     return hipGetLastError();
@@ -1697,8 +1843,9 @@ hipError_t launch_gemm_bf16(const void* X, const void* W, const float* bias, con
             default: return launch_fewrows<2>(x, w, bias, r, y, M, N, K, fw, stream);
         }
     }
-    // few rows: split K over more workgroups (the caller lends the fp32 scratch)
-    if (splitk_ws != nullptr && M_pad % GBM == 0 && N % GBN == 0 && K % GBK == 0) {
+    // few rows: split K over more workgroups (the caller lends the fp32 scratch); with the four-stage kernel a short K
+    // (<= 16 steps) is not split any more: one launch with the epilogue fused beats the pair (see gemm_bf16_mid_kernel)
+    if (splitk_ws != nullptr && M_pad % GBM == 0 && N % GBN == 0 && K % GBK == 0 && !(mid_enabled(M) && K <= 1024 && K >= 3 * GBK)) {
         const int mp = (M + GBM - 1) / GBM * GBM;   // whole 128-row tiles that hold real rows (<= M_pad)
         const int S = splitk_slices(mp, N, K, splitk_ws_bytes);
         if (S > 0) {
@@ -1753,7 +1900,8 @@ hipError_t launch_gemm_bf16_residual_layernorm(const void* X, const void* W, con
         if (e != hipSuccess) return e;
         return launch_layernorm(y, gamma, beta, eps, M, N, out, stream);
     }
-    if (splitk_ws != nullptr && M_pad % GBM == 0 && N % GBN == 0 && K % GBK == 0 && N % 8 == 0 && N <= 2048) {
+    if (splitk_ws != nullptr && M_pad % GBM == 0 && N % GBN == 0 && K % GBK == 0 && N % 8 == 0 && N <= 2048 &&
+        !(mid_enabled(M) && K <= 1024 && K >= 3 * GBK)) {
         const int mp = (M + GBM - 1) / GBM * GBM;
         const int S = splitk_slices(mp, N, K, splitk_ws_bytes);
         if (S > 0) {

@@ -206,7 +206,17 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_bf16_kernel(const u16* _
 constexpr int kMidStages = 4;
 constexpr int kMidLdsBytes = kMidStages * 2 * kTileBytes;   // 128 KiB
 
-template <int EPI>
+typedef int mid_i32x4 __attribute__((ext_vector_type(4)));
+#define MID_MFMA(acc, a, b) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
+
+// The K loop is hand-scheduled like p4's (one wave per SIMD issues in order: whatever is not an MFMA goes, one instruction at
+// a time, into the gaps between the MFMAs): a 64-deep step is two sub-steps of 16 MFMAs per wave; under sub-step u run the 8
+// fragment reads of sub-step u + 1 and four of the wave's eight DMA pieces of a tile three to four steps ahead (buffer_load
+// ... lds on whole-matrix descriptors: an SGPR offset per piece, one VGPR for the lane part); one s_barrier per step, between
+// its sub-steps (tile t + 1 is published there and tile t's stage is free from there on).
+// BM = token rows per tile (128 or 64): per-workgroup operand traffic (BM + 128) x K x 2 B moves through a latency-bound pipe
+// (~4 tiles in flight per CU), so a mid-size batch wants MORE, smaller tiles than CUs it would otherwise leave idle.
+template <int EPI, int BM>
 __global__ __launch_bounds__(kGemmThreads, 1) void gemm_bf16_mid_kernel(const u16* __restrict__ X, const u16* __restrict__ W,
                                                                        const float* __restrict__ bias,
                                                                        const u16* __restrict__ residual,
@@ -221,24 +231,50 @@ __global__ __launch_bounds__(kGemmThreads, 1) void gemm_bf16_mid_kernel(const u1
     const int bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + orig / 8;
     const int tiles_n = N / GBN;
     const int bn = bid % tiles_n, bm = bid / tiles_n;
-    const int n0 = bn * GBN, m0 = bm * GBM;
+    constexpr int NJ = BM / 32;              // 16-token MFMA tiles per wave (the wave's tokens: wm * BM/2 ..)
+    constexpr int kXTile = BM * 128;         // bytes of an X tile
+    constexpr int kStage = kTileBytes + kXTile;
+    const int n0 = bn * GBN, m0 = bm * BM;
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    const int nk = K / GBK;   // >= 4 (launcher)
 
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int nk = K / GBK;
-    auto stage = [&](int t) {   // tile t -> stage t % 4: 4 + 4 instructions per wave
-        unsigned char* buf = lds + (t & (kMidStages - 1)) * 2 * kTileBytes;
-        stage_tile(W, K, n0, t * GBK, buf, wave, lane);
-        stage_tile(X, K, m0, t * GBK, buf + kTileBytes, wave, lane);
+    // operand delivery: a tile = 16 W pieces + 16 X pieces of 8 rows x 128 B; this wave moves pieces wave + 4p, p = 0..3, of each
+    auto make_desc = [](const void* base, unsigned bytes) {
+        const uint64_t b = reinterpret_cast<uint64_t>(base);
+        mid_i32x4 d;
+        d[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+        d[1] = __builtin_amdgcn_readfirstlane((int)((uint32_t)(b >> 32) & 0xffffu));
+        d[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+        d[3] = 0x00020000;
+        return d;
     };
-    stage(0);
-    if (nk > 1) stage(1);
-    if (nk > 2) stage(2);
+    const mid_i32x4 wdesc = make_desc(W, (unsigned)N * (unsigned)K * 2u);
+    const mid_i32x4 xdesc = make_desc(X, (unsigned)(gridDim.x / tiles_n * BM) * (unsigned)K * 2u);   // the row tiles launched are allocated
+    const int dma_voff = ((lane >> 3) * K + (((lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7)) * 8)) * 2;
+    const unsigned piece_step = (unsigned)K * 64u;   // 32 rows of K bf16
+    const unsigned soW0 = __builtin_amdgcn_readfirstlane(((unsigned)(n0 + wave * 8) * (unsigned)K) * 2u);
+    const unsigned soX0 = __builtin_amdgcn_readfirstlane(((unsigned)(m0 + wave * 8) * (unsigned)K) * 2u);
+    const unsigned mbase = lds_base + wave * 1024;
+    // piece `which` (0..3 W, 4..7 X; a 64-row X tile has two per wave: 4, 5) of tile t into stage t % 4
+    auto dma = [&](int t, int which) {
+        if (which >= 4 + NJ) return;
+        const unsigned m0v = mbase + (t & (kMidStages - 1)) * kStage + (which < 4 ? 0 : kTileBytes) + (which & 3) * 4096;
+        const unsigned so = (which < 4 ? soW0 : soX0) + (which & 3) * piece_step + (unsigned)t * 128u;
+        asm volatile("s_mov_b32 m0, %0" ::"s"(m0v));
+        if (which < 4) asm volatile("s_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(dma_voff), "s"(wdesc), "s"(so) : "memory");
+        else asm volatile("s_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(dma_voff), "s"(xdesc), "s"(so) : "memory");
+    };
+    // prologue: tiles 0, 1, 2 and the W pieces of tile 3
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int w8 = 0; w8 < 8; ++w8) dma(t, w8);
+#pragma unroll
+    for (int w8 = 0; w8 < 4; ++w8) dma(3, w8);
+    if (NJ == 4) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");     // tile 0 landed (tiles 1, 2 and the W half of 3 may fly)
+    else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
     // fragment addresses inside a stage: row r of a tile at r * 128, 16-B chunk c at c ^ ((r >> 1) & 7)
     const int fr = lane & 15, sw = (fr >> 1) & 7;
     unsigned offA[2], offB[2];
@@ -246,48 +282,77 @@ __global__ __launch_bounds__(kGemmThreads, 1) void gemm_bf16_mid_kernel(const u1
     for (int ks = 0; ks < 2; ++ks) {
         const int ch = (ks * 4 + (lane >> 4)) ^ sw;
         offA[ks] = (wn * 64 + fr) * 128 + ch * 16;
-        offB[ks] = kTileBytes + (wm * 64 + fr) * 128 + ch * 16;
+        offB[ks] = kTileBytes + (wm * (BM / 2) + fr) * 128 + ch * 16;
+    }
+    f32x4 acc[4][4];   // [i][j]: j < NJ used
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 a0[4], b0[4], a1[4], b1[4];
+    {
+        const unsigned aa = lds_base + offA[0], bb = lds_base + offB[0];
+        RASS_DS_READ_B128(a0[0], aa, 0); RASS_DS_READ_B128(a0[1], aa, 2048); RASS_DS_READ_B128(a0[2], aa, 4096); RASS_DS_READ_B128(a0[3], aa, 6144);
+        RASS_DS_READ_B128(b0[0], bb, 0); RASS_DS_READ_B128(b0[1], bb, 2048);
+        if (NJ == 4) { RASS_DS_READ_B128(b0[2], bb, 4096); RASS_DS_READ_B128(b0[3], bb, 6144); }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     for (int t = 0; t < nk; ++t) {
-        // tile t has landed (this wave's pieces: the tiles t+1, t+2 issued after it may still fly) ...
-        const int ahead = nk - 1 - t;
-        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        const unsigned sb = lds_base + (t & (kMidStages - 1)) * kStage;
+        const unsigned sn = lds_base + ((t + 1) & (kMidStages - 1)) * kStage;
+        const bool x3 = t + 3 < nk, w4 = t + 4 < nk;
+        // ---- sub-step 0: (t, 0) out of a0 / b0; reads (t, 1) into a1 / b1; the X pieces of tile t + 3
+        {
+            const unsigned aa = sb + offA[1], bb = sb + offB[1];
+#define MID_SUB(AC, BC, AN, BN, DMA_T, DMA_BASE, DMA_ON)                                                                        \
+    MID_MFMA(acc[0][0], AC[0], BC[0]); RASS_DS_READ_B128(AN[0], aa, 0);                                                          \
+    MID_MFMA(acc[0][1], AC[0], BC[1]); RASS_DS_READ_B128(BN[0], bb, 0);                                                          \
+    if (NJ == 4) { MID_MFMA(acc[0][2], AC[0], BC[2]); }                                                                          \
+    if (DMA_ON) dma(DMA_T, DMA_BASE);                                                                                            \
+    if (NJ == 4) { MID_MFMA(acc[0][3], AC[0], BC[3]); }                                                                          \
+    RASS_DS_READ_B128(AN[1], aa, 2048);                                                                                          \
+    MID_MFMA(acc[1][0], AC[1], BC[0]); RASS_DS_READ_B128(BN[1], bb, 2048);                                                       \
+    MID_MFMA(acc[1][1], AC[1], BC[1]);                                                                                           \
+    if (NJ == 4) { MID_MFMA(acc[1][2], AC[1], BC[2]); }                                                                          \
+    if (DMA_ON) dma(DMA_T, DMA_BASE + 1);                                                                                        \
+    if (NJ == 4) { MID_MFMA(acc[1][3], AC[1], BC[3]); }                                                                          \
+    RASS_DS_READ_B128(AN[2], aa, 4096);                                                                                          \
+    MID_MFMA(acc[2][0], AC[2], BC[0]); if (NJ == 4) { RASS_DS_READ_B128(BN[2], bb, 4096); }                                      \
+    MID_MFMA(acc[2][1], AC[2], BC[1]);                                                                                           \
+    if (NJ == 4) { MID_MFMA(acc[2][2], AC[2], BC[2]); }                                                                          \
+    if (DMA_ON) dma(DMA_T, DMA_BASE + 2);                                                                                        \
+    if (NJ == 4) { MID_MFMA(acc[2][3], AC[2], BC[3]); }                                                                          \
+    RASS_DS_READ_B128(AN[3], aa, 6144);                                                                                          \
+    MID_MFMA(acc[3][0], AC[3], BC[0]); if (NJ == 4) { RASS_DS_READ_B128(BN[3], bb, 6144); }                                      \
+    MID_MFMA(acc[3][1], AC[3], BC[1]);                                                                                           \
+    if (NJ == 4) { MID_MFMA(acc[3][2], AC[3], BC[2]); }                                                                          \
+    if (DMA_ON) dma(DMA_T, DMA_BASE + 3);                                                                                        \
+    if (NJ == 4) { MID_MFMA(acc[3][3], AC[3], BC[3]); }
+            MID_SUB(a0, b0, a1, b1, t + 3, 4, x3)
+        }
+        // ---- the mid-step barrier: this wave's reads of tile t are done, its pieces of tile t + 1 have landed
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // (outstanding behind tile t + 1: tile t + 2 and both halves of tile t + 3 = 2 x (4 + NJ) instructions)
+        if (x3 && NJ == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (x3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();     // ... everybody's have, and everybody is done reading stage (t - 1) % 4
+        __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        if (t + 3 < nk) stage(t + 3);
-        const unsigned sb = lds_base + (t & (kMidStages - 1)) * 2 * kTileBytes;
-        bf16x8 a[2][4], b[2][4];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const unsigned aa = sb + offA[ks], bb = sb + offB[ks];
-            RASS_DS_READ_B128(a[ks][0], aa, 0);
-            RASS_DS_READ_B128(a[ks][1], aa, 2048);
-            RASS_DS_READ_B128(a[ks][2], aa, 4096);
-            RASS_DS_READ_B128(a[ks][3], aa, 6144);
-            RASS_DS_READ_B128(b[ks][0], bb, 0);
-            RASS_DS_READ_B128(b[ks][1], bb, 2048);
-            RASS_DS_READ_B128(b[ks][2], bb, 4096);
-            RASS_DS_READ_B128(b[ks][3], bb, 6144);
+        // ---- sub-step 1: (t, 1) out of a1 / b1; reads (t + 1, 0) into a0 / b0; the W pieces of tile t + 4
+        {
+            const unsigned aa = sn + offA[0], bb = sn + offB[0];
+            MID_SUB(a1, b1, a0, b0, t + 4, 0, w4)
+#undef MID_SUB
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks][i], b[ks][j], acc[i][j], 0, 0, 0);
     }
 
     // Epilogue (as gemm_bf16_kernel).  acc[i][j]: token m = m0 + wm*64 + j*16 + (lane&15); features
     // n = n0 + wn*64 + i*16 + (lane>>4)*4 + {0,1,2,3}.
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int m = m0 + wm * 64 + j * 16 + (lane & 15);
+    for (int j = 0; j < NJ; ++j) {
+        const int m = m0 + wm * (BM / 2) + j * 16 + (lane & 15);
         if (m >= M) continue;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -315,16 +380,18 @@ __global__ __launch_bounds__(kGemmThreads, 1) void gemm_bf16_mid_kernel(const u1
     }
 }
 
-// Where it pays (scripts/probe_encoder_shapes.py, whole forwards, same box): 3 .. 8 row tiles — 32 x 12 tokens 1.887 -> 1.799 ms,
-// 64 x 12: 2.144 -> 2.054, 32 x 32: 2.228 -> 2.097; with one or two row tiles the split-K pair's extra workgroups win (16 x 12:
-// 1.618 vs 1.730), from 12 row tiles on the two-buffer kernel's two workgroups per CU do (48 x 32: 2.516 vs 2.813, 4 x 512: 3.391 vs 3.612).  A step
-// still takes ~0.85 us, not the 0.4 us of its MFMAs + one LDS round trip: the wave issues its 8 DMA instructions (with their
-// address arithmetic), 16 fragment reads and 32 MFMAs in order — interleaving them by hand as p4 does is the next step.
+// Where it pays (scripts/probe_encoder_shapes.py, whole forwards, same box): 129 .. 1 024 rows.  The K loop is not what bounds it —
+// hand-scheduling it changed nothing: a workgroup keeps ~4 operand tiles (128 KiB) in flight against ~2 us of global -> LDS
+// latency, i.e. ~60 GB/s per CU, and a 128 x 128 tile moves 512 KiB for K = 1 024 (15 us per GEMM on the 72-96 CUs such a
+// batch occupies).  64-ROW tiles (while they still fit one per CU) put twice the CUs to work on 3/4 of the bytes each:
+// 32 x 12 tokens 1.887 -> 1.51 ms per forward, 16 x 12: 1.610 -> 1.415; 64 x 12 (128-row tiles: 144 workgroups) 2.144 -> 1.99,
+// 32 x 32: 2.228 -> 2.04.  Below 129 rows the split-K pair's workgroups win (8 x 12: 1.333 vs 1.376), from 1 536 rows on the
+// two-buffer kernel's two workgroups per CU (48 x 32: 2.515 vs 2.59).
 static bool mid_enabled(int M = 512) {
     const char* v = getenv("RASS_GEMM_MID");   // 0: round 3's paths (two-buffer kernel / split-K pair); 2: every shape (the A/Bs)
     if (v != nullptr && atoi(v) == 0) return false;
     if (v != nullptr && atoi(v) == 2) return true;
-    return M > 2 * GBM && M <= 8 * GBM;
+    return M > GBM && M <= 8 * GBM;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1796,17 +1863,28 @@ static hipError_t launch_epi(const u16* X, const u16* W, const float* bias, cons
     if (N % RBN == 0 && M_pad % RBM == 0 && K % 64 == 0 && K >= 128 && M >= 1024 && enough_tiles)
         return launch_p5<EPI>(X, W, bias, residual, Y, M, M_pad, N, K, stream);
     const int grid = (N / GBN) * (M_pad / GBM);
-    if (mid_enabled(M) && K >= 3 * GBK) {   // the four-stage form of the same tile, over the row tiles that hold real rows
-        const int grid = (N / GBN) * ((M + GBM - 1) / GBM);
+    if (mid_enabled(M) && K >= 4 * GBK && (uint64_t)M_pad * K * 2 < (1ull << 32) - (1ull << 24) && (uint64_t)N * K * 2 < (1ull << 32) - (1ull << 24)) {
+        // the four-stage form of the tile, over the row tiles that hold real rows; 64-row tiles while 128-row ones would leave
+        // CUs idle (RASS_GEMM_MID_BM=128 / 64: the A/B)
         static bool mid_attr_set = false;
         if (!mid_attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_mid_kernel<EPI>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_mid_kernel<EPI, 128>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, kMidLdsBytes);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_mid_kernel<EPI, 64>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, kMidLdsBytes);
             if (e != hipSuccess) return e;
             mid_attr_set = true;
         }
-        hipLaunchKernelGGL((gemm_bf16_mid_kernel<EPI>), dim3(grid), dim3(kGemmThreads), kMidLdsBytes, stream, X, W, bias,
-                           residual, Y, M, N, K);
+        int bm = (N / GBN) * ((M + 63) / 64) <= 256 ? 64 : 128;   // 64-row tiles while they still fit one per CU
+        if (const char* v = getenv("RASS_GEMM_MID_BM")) bm = atoi(v) == 128 ? 128 : 64;
+        if (bm == 128 || M_pad % 64 != 0) {
+            hipLaunchKernelGGL((gemm_bf16_mid_kernel<EPI, 128>), dim3((N / GBN) * ((M + 127) / 128)), dim3(kGemmThreads), kMidLdsBytes,
+                               stream, X, W, bias, residual, Y, M, N, K);
+        } else {
+            hipLaunchKernelGGL((gemm_bf16_mid_kernel<EPI, 64>), dim3((N / GBN) * ((M + 63) / 64)), dim3(kGemmThreads), kMidLdsBytes,
+                               stream, X, W, bias, residual, Y, M, N, K);
+        }
         return hipGetLastError();
     }
     constexpr int lds_bytes = 4 * kTileBytes;  // 64 KiB
@@ -1845,7 +1923,7 @@ hipError_t launch_gemm_bf16(const void* X, const void* W, const float* bias, con
     }
     // few rows: split K over more workgroups (the caller lends the fp32 scratch); with the four-stage kernel a short K
     // (<= 16 steps) is not split any more: one launch with the epilogue fused beats the pair (see gemm_bf16_mid_kernel)
-    if (splitk_ws != nullptr && M_pad % GBM == 0 && N % GBN == 0 && K % GBK == 0 && !(mid_enabled(M) && K <= 1024 && K >= 3 * GBK)) {
+    if (splitk_ws != nullptr && M_pad % GBM == 0 && N % GBN == 0 && K % GBK == 0 && !(mid_enabled(M) && K <= 1024 && K >= 4 * GBK)) {
         const int mp = (M + GBM - 1) / GBM * GBM;   // whole 128-row tiles that hold real rows (<= M_pad)
         const int S = splitk_slices(mp, N, K, splitk_ws_bytes);
         if (S > 0) {
@@ -1901,7 +1979,7 @@ hipError_t launch_gemm_bf16_residual_layernorm(const void* X, const void* W, con
         return launch_layernorm(y, gamma, beta, eps, M, N, out, stream);
     }
     if (splitk_ws != nullptr && M_pad % GBM == 0 && N % GBN == 0 && K % GBK == 0 && N % 8 == 0 && N <= 2048 &&
-        !(mid_enabled(M) && K <= 1024 && K >= 3 * GBK)) {
+        !(mid_enabled(M) && K <= 1024 && K >= 4 * GBK)) {
         const int mp = (M + GBM - 1) / GBM * GBM;
         const int S = splitk_slices(mp, N, K, splitk_ws_bytes);
         if (S > 0) {

@@ -41,10 +41,12 @@ from . import config
 logger = logging.getLogger("rassengine_amd")
 
 K_PREFETCH = 32          # one scan launch serves k <= 32; deeper lists leave room for filters
+K_PREFETCH_APPROX = 16   # an index in a prefilter mode (engine.set_prefilter: int8 / bf16 candidates + exact re-rank) serves k <= 16
+                         # from its candidate scan — a quarter / half of the bytes per launch; deeper lists take the exact scan
 
 
 class _Slot:
-    __slots__ = ("emb", "pending", "st", "epoch", "scores", "ids")
+    __slots__ = ("emb", "pending", "st", "epoch", "scores", "ids", "k", "approx")
 
     def __init__(self, emb: np.ndarray):
         self.emb = emb
@@ -53,6 +55,8 @@ class _Slot:
         self.epoch = None
         self.scores = None
         self.ids = None
+        self.k = K_PREFETCH
+        self.approx = False
 
 
 _slots: "weakref.WeakKeyDictionary[asyncio.Task, _Slot]" = weakref.WeakKeyDictionary()
@@ -139,18 +143,28 @@ async def run(st) -> None:
         if slot.emb.size != int(getattr(index, "dim", slot.emb.size)) or int(index.rows) <= 0:
             return
         epoch = index_epoch(index)
+        # an index in a prefilter mode: the shared scan is the candidate scan too (the top-k of a query's 32 re-ranked candidates
+        # is a prefix of their top-16, so what the inline search would return for k <= 16 is in the parked list, bit for bit)
+        approx = bool(getattr(index, "prefilter", False)) and not hasattr(index, "ivf")
+        k_pref = K_PREFETCH_APPROX if approx else K_PREFETCH
         batcher, cross = _batcher_for(st)
         with _lock:
             _waiting += 1
         try:
-            if cross:
-                scores, ids = await batcher.search(index, slot.emb, K_PREFETCH)
+            if cross and not approx:
+                scores, ids = await batcher.search(index, slot.emb, k_pref)
             else:
-                scores, ids = await batcher.search(slot.emb, K_PREFETCH)
+                if cross:       # the cross-index launch is the exact multi-index kernel: a prefilter index shares through its own batcher
+                    if st.batcher is None:
+                        from .batcher import QueryBatcher
+                        st.batcher = QueryBatcher(st.index)
+                    batcher = st.batcher
+                scores, ids = await batcher.search(slot.emb, k_pref)
         finally:
             with _lock:
                 _waiting -= 1
         slot.st, slot.epoch, slot.scores, slot.ids = st, epoch, scores, ids
+        slot.k, slot.approx = k_pref, approx
         stats["prefetched"] += 1
     except asyncio.CancelledError:
         raise
@@ -178,8 +192,10 @@ def take(st, q: np.ndarray, k: int, fval: int, fmask: int) -> Optional[Tuple[np.
     slot = _slots.get(t) if t is not None else None
     if slot is None or slot.scores is None:
         return None
-    if slot.st is not st or k > K_PREFETCH:
+    if slot.st is not st or k > slot.k:
         return None
+    if fmask and slot.approx:
+        return None             # a filtered search of a prefilter index picks its candidates UNDER the filter: not derivable from this list
     qv = np.asarray(q, dtype=np.float32).reshape(-1)
     if qv.shape != slot.emb.shape or qv.tobytes() != slot.emb.tobytes():
         stats["other_query"] += 1

@@ -205,3 +205,57 @@ def test_int8_prefilter_on_wide_rows_matches_the_flat_scan(gpu, dim):
         assert np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][0], outs[1][0]), dim
     finally:
         eng.close()
+
+
+def test_knn_prefetch_on_a_prefilter_index_shares_the_candidate_scan(gpu, monkeypatch):
+    """RASS_PREFILTER + the k-NN prefetch: concurrent ask()-shaped requests on one index share ONE candidate-scan launch of
+    depth 16 (a quarter of the bytes of the exact scan); the synchronous searches of k <= 16 answer from it with exactly what
+    the inline (prefilter) search returns; filtered searches and k > 16 fall back to the inline scan."""
+    import asyncio
+    from rassengine_amd import config, embedding, indexer, prefetch
+    from rassengine_amd.docstore import REGISTRY
+    from rassengine_amd.engine import Engine
+    from tests.helpers import HashEmbedder
+    monkeypatch.setattr(config, "RASS_PREFILTER", "int8")
+    monkeypatch.setattr(config, "RASS_KNN_PREFETCH", 2)
+    REGISTRY.clear()
+    REGISTRY.set_index_factory(None)
+    embedding.set_embedder(HashEmbedder(1024))
+    name = "rass-idx-pf-prefetch"
+    try:
+        docs = [{"doc_id": f"n-{i}", "doc_type": "unstructured", "patientId": f"p{i % 3}",
+                 "unstructuredText": f"note {i} topic{i % 13} drug{i % 7} ward{i % 5}"} for i in range(3000)]
+        asyncio.run(indexer.store_fhir_docs_in_opensearch([], docs, None, name))
+        st = REGISTRY.get(name)
+        assert st.index.prefilter_mode == "int8"
+        texts = [f"note {7 * i} topic{(7 * i) % 13} drug{(7 * i) % 7} ward{(7 * i) % 5}" for i in range(24)]
+
+        async def ask(text, k, **kw):
+            q = await embedding.embed_query(text)
+            await indexer.ensure_index_exists(None, name)
+            return indexer.HipIndexer(None, name).semantic_search(q, k=k, **kw)
+
+        async def burst(k, **kw):
+            return await asyncio.gather(*(ask(t, k, **kw) for t in texts))
+
+        before = dict(prefetch.stats)
+        got = asyncio.run(burst(5))
+        assert prefetch.stats["answered"] - before.get("answered", 0) == len(texts)
+        monkeypatch.setattr(config, "RASS_KNN_PREFETCH", 0)
+        want = asyncio.run(burst(5))
+        for a, b in zip(got, want):
+            assert [d["doc_id"] for d, _ in a] == [d["doc_id"] for d, _ in b] and [s for _, s in a] == [s for _, s in b]
+        st.index.set_prefilter(False)                           # and the exact index agrees on this corpus
+        exact = asyncio.run(burst(5))
+        st.index.set_prefilter("int8")
+        assert [[d["doc_id"] for d, _ in a] for a in got] == [[d["doc_id"] for d, _ in a] for a in exact]
+        monkeypatch.setattr(config, "RASS_KNN_PREFETCH", 2)
+        a0 = prefetch.stats["answered"]
+        filt = asyncio.run(burst(5, patient_id="p1"))           # filtered: inline (candidates are picked under the filter)
+        deep = asyncio.run(burst(20))                           # k > 16: inline exact scan
+        assert prefetch.stats["answered"] == a0
+        assert all(d["patientId"] == "p1" for r in filt for d, _ in r) and all(len(r) == 20 for r in deep)
+    finally:
+        embedding.set_embedder(None)
+        REGISTRY.clear()
+        Engine.get(config.RASS_DEVICE, config.EMBED_DIM).drop_index(name)

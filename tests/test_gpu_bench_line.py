@@ -100,3 +100,18 @@ def test_two_rank_ivf_mode_line(gpu):
     assert rf8["launches"] == 2 and rf8["launch_groups_per_launch"] == 8 and j8["sharded_equals_merge_of_shards"] is True
     assert abs(rf8["bytes_per_launch"] - 8 * rf8["scanned_rows_per_batch"] * 4096) <= 8 * 4096
     assert 0.3 < j8["recall_at_10_vs_flat_shards"] <= 1.0
+
+
+def test_two_rank_ivf_mode_line_with_an_int8_slab(gpu):
+    """`--mode ivf --ivf-dtype int8` (flagged): every rank's IVF keeps the int8 copy of its slab; int8 candidates + exact re-rank
+    per shard, the same all-gather + merge; every list probed on every shard ≡ the flat sharded search."""
+    port = 29700 + os.getpid() % 90
+    j = _line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2", "--mode", "ivf", "--ivf-dtype", "int8", "--steps", "2",
+               "--warmup", "1", "--ivf-rows", "300000", "--ivf-nlist", "128", "--ivf-nprobe", "128", "--launches-per-step", "8"],
+              env={"RASS_BENCH_SHARE_GPU": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    assert j["n_gpus"] == 2 and "FLAGGED" in j["metric"] and j["config"]["slab_dtype"] == "int8"
+    assert j["ranks_seen"] == 2 and j["sharded_equals_merge_of_shards"] is True
+    assert j["recall_at_10_vs_flat_shards"] == 1.0
+    rf = j["roofline"]
+    assert "scan_i8_topk_kernel" in rf["kernel"] and abs(rf["bytes_per_launch"] - rf["scanned_rows_per_batch"] * 1024) <= 1024

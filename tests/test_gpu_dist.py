@@ -306,7 +306,7 @@ def _ivf_serving_scenario(indexer, embedding, REGISTRY, name, build):
     return out
 
 
-def _serving_ivf_worker(rank, world, port, out_dir):
+def _serving_ivf_worker(rank, world, port, out_dir, ivf_dtype="f32"):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -321,6 +321,7 @@ def _serving_ivf_worker(rank, world, port, out_dir):
         from rassengine_amd.engine import Engine
         from tests.helpers import HashEmbedder
         config.RASS_KNN_PREFETCH = 0
+        config.RASS_IVF_DTYPE = ivf_dtype                  # the slab dtype every rank builds (ShardedIndex.build_ivf's default)
         front = serving.start(serving.hip_shard_factory(0, 1024), 1024, torch.device("cuda", 0),
                               shard_loader=serving.hip_shard_loader(0, 1024))
         if rank != 0:
@@ -366,11 +367,13 @@ def _serving_ivf_worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
-def test_sharded_ivf_with_delta_behind_the_shim_equals_single_flat_index(gpu, tmp_path):
+@pytest.mark.parametrize("ivf_dtype", ["f32", "int8"])
+def test_sharded_ivf_with_delta_behind_the_shim_equals_single_flat_index(gpu, tmp_path, ivf_dtype):
     """VERDICT r3 #2b on 2 ranks: OP_IVF_BUILD (shared centroids over UNEQUAL shards), appends / overwrites after the
-    build land in the shards' flat deltas, every list probed == one flat HIP index bit for bit through HipIndexer."""
+    build land in the shards' flat deltas, every list probed == one flat HIP index bit for bit through HipIndexer — with
+    fp32 slabs and with int8 slabs (int8 candidates + exact re-rank per shard; the scenario's k are <= 10 or > 32)."""
     import torch.multiprocessing as mp
-    mp.spawn(_serving_ivf_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_serving_ivf_worker, args=(2, _free_port(), str(tmp_path), ivf_dtype), nprocs=2, join=True)
     assert os.path.exists(os.path.join(str(tmp_path), "ivfworker1.done"))
     z = np.load(os.path.join(str(tmp_path), "serving_ivf.npz"))
     keys = sorted(k[len("single_"):] for k in z.files if k.startswith("single_"))

@@ -253,7 +253,7 @@ class IndexState:
             for t in head.get("doc_types", []):
                 self.doc_types.encode(t)
             if n:
-                vecs = np.frombuffer(raw, dtype=np.float32).reshape(n, dim)
+                vecs = np.frombuffer(raw, dtype=np.float32).reshape(n, dim).copy()
                 tags = np.array([self.tag_of(doc) if doc is not None else 0 for doc in head["row_doc"]], dtype=np.int32)
                 first = self.index.add(vecs, tags=tags, normalize=False)     # the stored bits, not re-normalised
                 if int(first) != int(head["first_row"]):

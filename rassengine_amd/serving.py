@@ -892,6 +892,18 @@ class ShardedIndex:
                 raise IndexError(f"row {row} was never stored (the append that consumed its id failed)")
             return s.execute(s.post([OP_GETROW, self.code, int(row), owner]))
 
+    def get_rows(self, first_row: int, n: int) -> np.ndarray:
+        """Stored (normalised) rows [first_row, first_row + n) by global id, one OP_GETROW each: what
+        ``docstore.IndexState.save_delta`` reads back for its segment (O(delta) rows); a hole (a failed append) comes back as a
+        zero row — its doc slot is None and the replay tombstones it."""
+        out = np.zeros((int(n), self.dim), dtype=np.float32)
+        for i in range(int(n)):
+            try:
+                out[i] = np.asarray(self.get_row(int(first_row) + i), dtype=np.float32).reshape(-1)
+            except IndexError:
+                pass
+        return out
+
     # ---- read path
     def search(self, queries: np.ndarray, k: int, q_filter: Optional[np.ndarray] = None,
                q_filter_mask: Optional[np.ndarray] = None) -> Tuple[np.ndarray, np.ndarray]:

@@ -215,6 +215,18 @@ def _worker(rank, world, port, out_dir):
         assert int(st2.index.search(qv, 10)[1][0, 0]) == int(a[1][0, 1])
         first_new = st2.index.add(np.ones((3, 1024), dtype=np.float32))
         assert first_new == st.index.rows and st2.index.count == st.index.count - 1 + 3
+        # incremental persistence on the sharded index: a delta segment (rows read back shard by shard through OP_GETROW)
+        # on top of the snapshot, replayed by load through the front's add / delete
+        asyncio.run(indexer.store_fhir_docs_in_opensearch(
+            [], [{"doc_id": f"late-{i}", "doc_type": "unstructured", "patientId": "p1", "unstructuredText": f"late chunk {i} about topic5"}
+                 for i in range(9)] + [{"doc_id": "text-f-3", "doc_type": "unstructured", "patientId": "p0", "unstructuredText": "rewritten late"}],
+            None, "rass-idx-user1"))
+        assert st.save_delta(prefix) is True
+        st3 = IndexState.load("rass-idx-restored-delta", prefix, front.load_index)
+        assert st3.index.rows == st.index.rows and st3.index.count == st.index.count and st3.doc_row == st.doc_row
+        qd = asyncio.run(embedding.embed_query("late chunk 4 about topic5"))
+        a3, b3 = st.index.search(qd, 10), st3.index.search(qd, 10)
+        assert np.array_equal(a3[1], b3[1]) and np.array_equal(a3[0], b3[0])
         front.shutdown()
         front.shutdown()                               # idempotent
         # the same scenario on ONE index in this very process (same HashEmbedder hash seed)

@@ -1408,6 +1408,8 @@ __global__ __launch_bounds__(kP4Threads, 1) void gemm_bf16_p4_kernel(const u16* 
         if (which < 4) asm volatile("s_add_u32 %0, %1, %2" : "=s"(dma_so) : "s"(soX[h]), "s"(ps) : "scc");
         else asm volatile("s_add_u32 %0, %1, %2" : "=s"(dma_so) : "s"(soW[h]), "s"(ps) : "scc");
     };
+    // (m0 is written here and read by the load two gaps later; nothing the compiler emits in between touches it — this
+    // kernel's LDS accesses are asm ds_read_b128, which take no m0 on gfx9+, buffer stores and scalar arithmetic)
     auto dma_m0 = [&](int hs, int which) {
         const unsigned v = mbase + hs * kP5HalfBytes + (which < 4 ? 16384 : 0) + (which & 3) * 4096;
         asm volatile("s_mov_b32 m0, %0" ::"s"(v));

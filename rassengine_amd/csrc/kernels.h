@@ -110,6 +110,10 @@ struct ScanBf16Args {
     const int32_t* work_rows = nullptr;
     const uint32_t* work_mask = nullptr;
     const int32_t* n_work = nullptr;
+    // the sample floor of the flat scan (as ScanI8Args): part_scores [sample_groups][nq][1] of a SAMPLE launch — this kernel with
+    // k = 1 over the slab's first 64 * sample_groups rows, same queries and filters; nullptr = none
+    const float* sample_best = nullptr;
+    int sample_groups = 0;
 };
 hipError_t launch_scan_bf16_topk(const ScanBf16Args& a, int grid, hipStream_t stream);
 // fp32 tile16 blocks -> bf16 tile16b blocks [block0, block1) of dst.  src_block0 (default = block0): the source

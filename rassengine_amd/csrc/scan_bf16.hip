@@ -138,6 +138,46 @@ __global__ __launch_bounds__(kBThreads, 2) void scan_bf16_topk_kernel(ScanBf16Ar
         after_i[pq] = (EXT && p.q_after_id != nullptr && live) ? p.q_after_id[q] : (int64_t)-1;
     }
 
+    // The sample floor (flat scans; see scan_i8.hip): the k-th largest of the sample launch's per-workgroup best scores of a
+    // query is reached by k rows of the slab; rows below it skip the sorted insertion (ties kept).
+    float floor_q[NT];
+#pragma unroll
+    for (int pq = 0; pq < NT; ++pq) floor_q[pq] = -INFINITY;
+    if (!IVF && !EXT && p.sample_best != nullptr) {
+        constexpr int kSlots = kMaxSampleGroups / 64;
+        unsigned key[NT][2][kSlots];
+#pragma unroll
+        for (int pq = 0; pq < NT; ++pq)
+#pragma unroll
+            for (int half = 0; half < 2; ++half)
+#pragma unroll
+                for (int j = 0; j < kSlots; ++j) {
+                    const int grp = lane + 64 * j, q = pq * 16 + half * 8 + wid;
+                    const float v = (grp < p.sample_groups && q < p.nq) ? p.sample_best[(int64_t)grp * p.nq + q] : -INFINITY;
+                    key[pq][half][j] = v == -INFINITY ? 0u : score_key(v);
+                }
+        constexpr int kFloorBits = 20;
+        unsigned T[NT][2] = {};
+#pragma unroll 1
+        for (int b = 31; b >= 32 - kFloorBits; --b) {
+#pragma unroll
+            for (int pq = 0; pq < NT; ++pq)
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const unsigned cand = T[pq][half] | (1u << b);
+                    int c = 0;
+#pragma unroll
+                    for (int j = 0; j < kSlots; ++j) c += __popcll(__ballot(key[pq][half][j] >= cand));
+                    T[pq][half] = c >= p.k ? cand : T[pq][half];
+                }
+        }
+#pragma unroll
+        for (int pq = 0; pq < NT; ++pq) {
+            const unsigned t = (lane & 32) ? T[pq][1] : T[pq][0];
+            floor_q[pq] = t ? key_score(t) : -INFINITY;
+        }
+    }
+
     auto issue = [&](BTile<CHB>& r, const BDesc& d) {
         r.tag = (int)__builtin_amdgcn_raw_buffer_load_b32(d.tags, lane * 4, 0, 0);
 #pragma unroll
@@ -193,10 +233,11 @@ __global__ __launch_bounds__(kBThreads, 2) void scan_bf16_topk_kernel(ScanBf16Ar
                     ok = row_ok && (qfilt[pq] < 0 || qfilt[pq] == (rtag & qmask[pq]));
                     ok = ok && (s < after_s[pq] || (s == after_s[pq] && (p.id_base + (int64_t)row) > after_i[pq]));
                 } else {
-                    ok = row_ok && (qfilt[pq] < 0 || qfilt[pq] == rtag);
+                    ok = row_ok && (qfilt[pq] < 0 || qfilt[pq] == rtag) && (s >= floor_q[pq]);
                 }
                 if (IVF) ok = ok && ((w.mask >> q) & 1u) != 0;   // only the queries that probe this tile's list
-                insert_candidates_auto(L[pq], tau[pq], ok ? s : -INFINITY, row, p.k);
+                if (EXT && !IVF) insert_candidates(L[pq], tau[pq], ok ? s : -INFINITY, row, p.k);   // (the network's temporaries spill here)
+                else insert_candidates_auto(L[pq], tau[pq], ok ? s : -INFINITY, row, p.k);
             }
         }
     };
@@ -229,7 +270,7 @@ __global__ __launch_bounds__(kBThreads, 2) void scan_bf16_topk_kernel(ScanBf16Ar
             const bool filled = L[pq].i != 0x7fffffff;
             p.part_scores[o] = filled ? L[pq].s : -INFINITY;
             // id_base = 0 for the candidate scan of the prefilter mode (the re-rank needs LOCAL rows)
-            p.part_ids[o] = filled ? (p.id_base + (int64_t)L[pq].i) : (int64_t)-1;
+            if (p.part_ids) p.part_ids[o] = filled ? (p.id_base + (int64_t)L[pq].i) : (int64_t)-1;   // nullptr: a sample launch
         }
     }
 }
@@ -258,6 +299,7 @@ hipError_t launch_scan_bf16_topk(const ScanBf16Args& a, int grid, hipStream_t st
         if (a.q_filter_mask != nullptr && a.q_filter == nullptr) return hipErrorInvalidValue;
     }
     const bool ivf = a.work_tile != nullptr;
+    if (a.sample_best && (a.sample_groups < 1 || a.sample_groups > kMaxSampleGroups || ivf || ext)) return hipErrorInvalidValue;
     // IVF probe: plain or masked filters; no continuation bound (the ids it compares would be slab positions)
     if (ivf && (a.q_after_score || a.q_after_id || !a.work_rows || !a.work_mask || !a.n_work)) return hipErrorInvalidValue;
 #define RASS_BF16_CASE(C)                                                                                     \

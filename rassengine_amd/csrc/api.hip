@@ -1307,6 +1307,28 @@ int prefilter_launch_batch(rass_index* idx, const float* d_queries, int nq, int 
     const int64_t qs_stride = i8 ? idx->stride_i8 : stride * 2;   // bytes per converted query
     if (i8) HIP_TRY(rass::launch_queries_to_i8(q_all, q_small, nq_pad, stride, idx->stride_i8, st));
     else HIP_TRY(rass::launch_queries_to_bf16(q_all, q_small, (int64_t)nq_pad * stride, st));
+    // the int8 scans' sample launches: ONE grouped launch for all groups when every group is full (32 launches of ~10 us each
+    // otherwise: 5 % of a 1 024-query step)
+    const bool floor_on = i8_sample_floor(rows, grid);
+    const bool one_sample = i8 && floor_on && groups >= 2 && nq % 32 == 0;
+    if (one_sample) {
+        rass::ScanI8Args sa;
+        sa.corpus = idx->d_rows_i8;
+        sa.row_scale = idx->d_row_scale;
+        sa.row_tag = need_tags ? idx->d_tags : nullptr;
+        sa.q_i8 = reinterpret_cast<const signed char*>(q_small);
+        sa.q_filter = d_q_filter;
+        sa.part_scores = reinterpret_cast<float*>(ws + L.sample_best);
+        sa.part_ids = nullptr;
+        sa.row_stride = idx->stride_i8;
+        sa.n_rows = 64 * grid;
+        sa.nq = 32;
+        sa.k = 1;
+        sa.wgs_per_group = grid;
+        sa.q_group_stride = (int64_t)32 * qs_stride;
+        sa.part_group_stride = (int64_t)32 * rass::kMaxSampleGroups;
+        HIP_TRY(rass::launch_scan_i8_topk(sa, groups * grid, st));
+    }
     for (int g = 0; g < groups; ++g) {
         const int b = std::min(RASS_MAX_QBATCH, nq - g * 32);
         const bool timed = eng->ev_on && (size_t)(2 * eng->ev_used + 1) < eng->ev_pool.size();
@@ -1324,7 +1346,10 @@ int prefilter_launch_batch(rass_index* idx, const float* d_queries, int nq, int 
             a.n_rows = (int)rows;
             a.nq = b;
             a.k = kc;
-            if (i8_sample_floor(rows, grid)) {
+            if (one_sample) {
+                a.sample_best = reinterpret_cast<float*>(ws + L.sample_best) + (int64_t)g * 32 * rass::kMaxSampleGroups;
+                a.sample_groups = grid;
+            } else if (floor_on) {
                 rass::ScanI8Args sa = a;
                 sa.n_rows = 64 * grid;
                 sa.k = 1;

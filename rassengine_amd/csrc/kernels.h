@@ -148,6 +148,12 @@ struct ScanI8Args {
     const float* sample_best = nullptr;
     int sample_groups = 0;
     const int32_t* q_filter_mask = nullptr;   // [nq] or nullptr: a row matches when (tag & mask) == q_filter
+    // grouped launch (flat scans; 0 = off): workgroups [g * wgs_per_group, (g + 1) * wgs_per_group) serve launch group g — its 32
+    // queries at q_i8 + g * q_group_stride (bytes), its filters at q_filter + 32 g, its lists at part_scores + g *
+    // part_group_stride (elements; part_ids likewise if given).  Every group has nq queries.  Used for the sample launches of a
+    // batch call (one launch instead of one per group).
+    int wgs_per_group = 0;
+    int64_t q_group_stride = 0, part_group_stride = 0;
     // IVF probe plan over an int8 slab (all nullptr for the flat scan; as ScanBf16Args, 64-row tiles)
     const int32_t* work_tile = nullptr;
     const int32_t* work_rows = nullptr;

@@ -84,7 +84,15 @@ __global__ __launch_bounds__(kIThreads, kINBuf == 1 ? 4 : 2) void scan_i8_topk_k
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int m = lane & 15, g = lane >> 4;
     const int n_tiles = IVF ? __builtin_amdgcn_readfirstlane(*p.n_work) : (p.n_rows + kITileRows - 1) / kITileRows;
-    const int G = gridDim.x;
+    // a grouped launch (flat only): this workgroup's group, its place in the group, the group's queries / filters / lists
+    const int G = (!IVF && p.wgs_per_group > 0) ? p.wgs_per_group : (int)gridDim.x;
+    const int grp = (!IVF && p.wgs_per_group > 0) ? (int)blockIdx.x / G : 0;
+    const int bid = (int)blockIdx.x - grp * G;
+    p.q_i8 += (int64_t)grp * p.q_group_stride;
+    if (p.q_filter != nullptr) p.q_filter += grp * 32;
+    if (p.q_filter_mask != nullptr) p.q_filter_mask += grp * 32;
+    p.part_scores += (int64_t)grp * p.part_group_stride;
+    if (p.part_ids != nullptr) p.part_ids += (int64_t)grp * p.part_group_stride;
 
     i32x4 qf[NT][CHI];
     {
@@ -233,7 +241,7 @@ __global__ __launch_bounds__(kIThreads, kINBuf == 1 ? 4 : 2) void scan_i8_topk_k
     };
 
     ITile<CHI> R0, R1;
-    int t = blockIdx.x;
+    int t = bid;
     // work items are fetched a whole iteration before their descriptors are built: read right before use (as the first version
     // did) every tile pair waited for two dependent scalar loads from global memory (an IVF's work list)
     Item w0 = item(t), w1 = item(t + G), w2 = item(t + 2 * G), w3 = item(t + 3 * G);
@@ -261,7 +269,7 @@ __global__ __launch_bounds__(kIThreads, kINBuf == 1 ? 4 : 2) void scan_i8_topk_k
     for (int pq = 0; pq < NT; ++pq) {
         const int q = pq * 16 + (lane >> 5) * 8 + wid;
         if (q < p.nq && lpos < p.k) {
-            const int64_t o = ((int64_t)blockIdx.x * p.nq + q) * p.k + lpos;
+            const int64_t o = ((int64_t)bid * p.nq + q) * p.k + lpos;
             const bool filled = L[pq].i != 0x7fffffff;
             p.part_scores[o] = filled ? L[pq].s : -INFINITY;
             if (p.part_ids) p.part_ids[o] = filled ? (int64_t)L[pq].i : (int64_t)-1;   // LOCAL rows (nullptr: a sample launch)
@@ -289,7 +297,8 @@ hipError_t launch_scan_i8_topk(const ScanI8Args& a, int grid, hipStream_t stream
     if (a.sample_best && (a.sample_groups < 1 || a.sample_groups > kMaxSampleGroups)) return hipErrorInvalidValue;
     if (a.q_filter_mask && !a.q_filter) return hipErrorInvalidValue;
     const bool ivf = a.work_tile != nullptr;
-    if (ivf && (!a.work_rows || !a.work_mask || !a.n_work || a.sample_best)) return hipErrorInvalidValue;
+    if (ivf && (!a.work_rows || !a.work_mask || !a.n_work || a.sample_best || a.wgs_per_group)) return hipErrorInvalidValue;
+    if (a.wgs_per_group > 0 && (grid % a.wgs_per_group != 0 || a.sample_best)) return hipErrorInvalidValue;
     const bool two = a.nq > 16;
 #define RASS_I8_CASE(C)                                                                                                     \
     if (ivf) return two ? launch_ivariant<C, 2, true>(a, grid, stream) : launch_ivariant<C, 1, true>(a, grid, stream);       \

@@ -52,6 +52,9 @@ def main():
                     help="N > 1: weak scaling instead (every GPU holds --rows-per-gpu rows, corpus = N x that)")
     ap.add_argument("--no-ingest", action="store_true", help="skip the encoder (configs[2]) leg of the N = 1 line")
     ap.add_argument("--no-ivf", action="store_true", help="skip the IVF (configs[4] per-GPU share) leg of the N = 1 line")
+    ap.add_argument("--no-scale-ref", action="store_true",
+                    help="skip the N = 1 line's strong_scaling_reference leg (BASELINE configs[3]'s 10 M-row corpus on ONE GPU: the "
+                         "same-workload reference for the --gpus N > 1 lines, which shard that corpus)")
     ap.add_argument("--mode", choices=["flat", "ivf"], default="flat",
                     help="ivf (N >= 1): BASELINE configs[4] — IVF-4096 over --ivf-rows clustered rows PER GPU (12.5 M = the "
                          "100 M-row corpus / 8), shared centroids, per-shard probes, one all-gather of per-shard top-k")
@@ -263,8 +266,8 @@ def main():
                                       k, B, scan_ms, scan_launches, bytes_per_launch, isinstance(search, ShardedSearch)))
         result["scaling_note"] = (
             "strong scaling over a FIXED corpus: the N = 1 line of this bench is BASELINE configs[1] (1 M rows), not "
-            "this corpus on one GPU; the workload-independent figure to compare across N is row_queries_per_s "
-            "(= value x rows_global)") if strong else "weak scaling: rows_global grows N x; compare row_queries_per_s"
+            "this corpus on one GPU (that number is the N = 1 line's strong_scaling_reference.value: ideal value_N = N x it); "
+            "the workload-independent figure to compare across N is row_queries_per_s (= value x rows_global)") if strong else "weak scaling: rows_global grows N x; compare row_queries_per_s"
 
     # `traffic` = HBM bytes per launch from PMC counters.  They cannot be read from inside this process, so the
     # field stays null in an ordinary run; a run under `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` is summarised
@@ -334,6 +337,38 @@ def main():
             g_last = ((args.warmup + args.steps - 1) * LPS + LPS - 1) % n_batches
             last = (out[0][-B:], out[1][-B:]) if batched else out
             result.update(timed_path_check(np, idx, pool[g_last * B:(g_last + 1) * B], last, n_local, k))
+
+    if rank == 0 and world == 1 and not args.no_scale_ref and not bf16 and not args.prefilter and dim == 1024 and B == 32 \
+            and rows_global == 1_000_000:
+        # Outside the timed region: BASELINE configs[3]'s corpus (10 M x 1024 fp32 = 41 GB) on THIS one GPU, the same step
+        # (1 024 queries, one engine call).  `bench.py --gpus N` (N > 1) shards exactly this corpus over N ranks ("strong"
+        # scaling): its `value` is to be compared with N x THIS number, not with the 1 M-row headline above.
+        try:
+            big = eng.open_index("bench-cfg3", capacity_rows=CONFIGS3_ROWS)
+            big.fill_synthetic(CONFIGS3_ROWS, seed=1234, row_id_base=0)
+            eng.synchronize()
+            bs = torch.empty((LPS * B, k), dtype=torch.float32, device=dev)
+            bi = torch.empty((LPS * B, k), dtype=torch.int64, device=dev)
+            big.search_device_batch(step_q.data_ptr(), LPS * B, k, bs.data_ptr(), bi.data_ptr())
+            torch.cuda.synchronize()
+            eng.kernel_timing_begin(2 * LPS)
+            t1 = time.perf_counter()
+            for _ in range(2):
+                big.search_device_batch(step_q.data_ptr(), LPS * B, k, bs.data_ptr(), bi.data_ptr())
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t1
+            ms_b, launches_b = eng.kernel_timing_end()
+            bytes_b = CONFIGS3_ROWS * idx.row_stride * 4
+            result["strong_scaling_reference"] = {
+                "workload": f"{CONFIGS3_ROWS} x {dim}-d flat cosine top-{k}, 1 x MI355X (BASELINE configs[3]'s corpus on one GPU)",
+                "value": round(2 * LPS * B / el, 1), "unit": "queries/s", "steps": 2, "ms_per_step": round(el / 2 * 1e3, 2),
+                "roofline": {"bound": "hbm", "achieved": round(bytes_b * launches_b / (ms_b * 1e-3) / 1e9, 1) if ms_b > 0 else None,
+                             "peak": HBM_PEAK_GBPS, "unit": "GB/s", "bytes_per_launch": bytes_b,
+                             "avg_launch_us": round(ms_b / max(launches_b, 1) * 1e3, 1)},
+                "note": "the --gpus N > 1 lines shard THIS corpus: ideal value_N = N x this value (not N x the 1 M-row headline)"}
+            eng.drop_index("bench-cfg3")
+        except Exception as e:  # noqa: BLE001 — the reference leg must not take the headline down
+            result["strong_scaling_reference"] = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0 and world == 1 and not args.no_ingest and not bf16 and not args.prefilter and dim == 1024:
         # BASELINE configs[2]'s larger half (the "embedding" of "embedding + ANN"): after the timed search region and

@@ -34,6 +34,10 @@ def test_single_gpu_line_has_roofline_cpu_baseline_and_ingest(gpu):
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and 0.5 < rf["frac"] < 1.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["bytes_per_launch"] == 1_000_000 * 1024 * 4
     assert j["recall_at_k"] == 1.0 and j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["cores"] >= 1
+    # configs[3]'s 10 M-row corpus on this one GPU: the same-workload reference of the --gpus N > 1 (strong scaling) lines
+    ref = j["strong_scaling_reference"]
+    assert "error" not in ref and "10000000 x 1024" in ref["workload"] and ref["roofline"]["bytes_per_launch"] == 10_000_000 * 4096
+    assert 0.05 * j["value"] < ref["value"] < 0.2 * j["value"]           # ten times the rows per query
     ing = j["ingest"]
     assert ing["roofline"]["bound"] == "mfma_bf16" and ing["roofline"]["peak"] == 2500.0
     assert ing["last_batch_rows_finite_and_unit_norm"] is True and ing["rows_in_index"] == 4 * 256
@@ -43,6 +47,9 @@ def test_single_gpu_line_has_roofline_cpu_baseline_and_ingest(gpu):
     # scan of the same shard and probed bytes / time against the HBM peak, clustered rows + iid rows as the worst case
     ivf = j["ivf"]
     assert "error" not in ivf and ivf["nlist"] == 256
+    i8 = ivf["clustered"]["int8_slab_flagged"]["sweep"]                   # flagged: int8 candidates + exact re-rank on the same lists
+    assert [p["nprobe"] for p in i8] == [1, 2, 8, 32, 128] and all(p["batch_equals_group_by_group"] for p in i8)
+    assert all(abs(a["recall_at_10"] - b["recall_at_10"]) <= 0.02 for a, b in zip(i8, ivf["clustered"]["sweep"]))
     for key in ("clustered", "iid_worst_case"):
         c = ivf[key]
         assert c["rows"] == 400000 and [p["nprobe"] for p in c["sweep"]] == [1, 2, 8, 32, 128]

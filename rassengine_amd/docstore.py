@@ -316,6 +316,12 @@ class IndexState:
             meta = json.load(f)
         vec = os.path.join(os.path.dirname(prefix) or ".", meta["vectors"]) if "vectors" in meta else prefix + ".rass"
         index = index_loader(name, vec)
+        try:    # a restored index takes the configured candidate mode like a new one (the default factory below)
+            from . import config
+            if config.RASS_PREFILTER != "off" and hasattr(index, "set_prefilter") and not getattr(index, "prefilter", False):
+                index.set_prefilter(config.RASS_PREFILTER)
+        except Exception:   # e.g. a bf16 corpus: no prefilter mode — the exact scan serves
+            pass
         row_doc = meta["row_doc"]
         rows, live = int(index.rows), int(index.count)
         dead = sum(1 for d in row_doc if d is None)

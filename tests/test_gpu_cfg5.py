@@ -125,13 +125,14 @@ def test_cfg5_share_12_5M_rows(gpu, oracle):
     list-ordered copy): clustered synthetic rows (8 192 Gaussian centres, sigma = 1), IVF-4096 trained and
     assigned by this round's rass_kmeans_* kernels.  Pinned at this size: probing every list equals the flat index bit
     for bit; recall@10 >= 0.99 at nprobe 8 against the flat scan; `scanned` = the rows of the union of the batch's probed
-    lists; and the bf16 slab of the same lists (4).  Skipped when the GPU has less than 150 GB free."""
+    lists; the bf16 slab of the same lists (4); the int8 slab (5: every list == flat bit for bit, nprobe 8 == the fp32 IVF).
+    Skipped when the GPU has less than 200 GB free."""
     import torch
     from rassengine_amd.engine import Engine
     from rassengine_amd.ivf import IvfIndex, train_centroids
     free, _total = torch.cuda.mem_get_info()
-    if free < 150 * 2 ** 30:
-        pytest.skip(f"needs 150 GB of free HBM, {free / 2 ** 30:.0f} GB available")
+    if free < 200 * 2 ** 30:
+        pytest.skip(f"needs 200 GB of free HBM, {free / 2 ** 30:.0f} GB available")
     rows, centres_n, sigma, k = 12_500_000, 8192, 1.0, 10
     dev = torch.device("cuda", 0)
     eng = Engine(0, DIM)
@@ -188,6 +189,15 @@ def test_cfg5_share_12_5M_rows(gpu, oracle):
         print(f"cfg 5 share, bf16 slab: recall@10 at nprobe 8 = {recall_b:.4f}")
         assert recall_b >= 0.97
         ivf_b.close()
+        # (5) the same lists with an int8 copy of the slab (rass_ivf_build_ex RASS_I8, + the IVF's fp32 slab on 64-row tiles and
+        # 12.8 GB of int8): 32 int8 candidates per query rescored exactly — every list probed == the flat index bit for bit at this
+        # size too, nprobe 8 == the fp32 IVF's lists, same scanned rows
+        ivf_8 = IvfIndex.build(flat, nlist=NLIST, centroids=cent, dtype="int8")
+        s_i, i_i, scanned_i = ivf_8.search(q[:32], k, nprobe=NLIST)
+        assert np.array_equal(i_i, i_f) and np.array_equal(s_i, s_f) and scanned_i == rows
+        s_i8, got_i8, scanned_i8 = ivf_8.search(q[:32], k, nprobe=8)
+        assert scanned_i8 == scanned8 and np.array_equal(got_i8, got_8) and np.array_equal(s_i8, s_8)
+        ivf_8.close()
         ivf.close()
     finally:
         eng.close()

@@ -533,6 +533,15 @@ int rass_gemm_bf16_ws(const void* d_x, const void* d_w, const float* d_bias,
  * [total_tokens][hidden]. */
 int rass_attention_bf16(const void* d_qkv, const int32_t* d_cu_seqlens, int nseq, int total_tokens,
                         int max_seqlen, int hidden, int heads, void* d_ctx, void* stream);
+/* Query time (embed_query / ollama_embed_text, app/main.py:225-237, 266-274: one text, a dozen tokens): the attention and
+ * the attention-output projection in ONE launch — d_y = attention(d_qkv) d_w^T + d_bias + d_residual, d_w bf16 [n][hidden],
+ * d_residual / d_y bf16 [total_tokens][n].  Every workgroup of the projection recomputes the attention (its context rows
+ * have rass_attention_bf16's bits); a launch of a one-query forward costs 4-5 us whatever it does, this saves one per layer.
+ * 1 <= total_tokens <= 32 over all nseq sequences, hidden = 1024, heads = 16, n % 16 == 0; anything else (or
+ * RASS_ATTN_FUSE=0 in the environment) -> RASS_ERR_UNSUPPORTED.  rass_encode_device takes it by itself. */
+int rass_attention_out_bf16(const void* d_qkv, const int32_t* d_cu_seqlens, int nseq, int total_tokens, int hidden,
+                            int heads, const void* d_w, const float* d_bias, const void* d_residual, void* d_y, int n,
+                            void* stream);
 
 /* -------------------------------------------------------------- tokenizer
  * BERT (uncased) BasicTokenizer + WordPiece on the host (C++), replacing the

@@ -169,6 +169,9 @@ SIGNATURES = {
                                          ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "rass_attention_bf16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                            ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
+    "rass_attention_out_bf16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                               ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                               ctypes.c_int, ctypes.c_void_p]),
     "rass_tokenizer_create": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int, c_void_pp]),
     "rass_tokenizer_destroy": (None, [ctypes.c_void_p]),
     "rass_tokenizer_vocab_size": (ctypes.c_int, [ctypes.c_void_p]),

@@ -276,12 +276,19 @@ int forward(rass_encoder* e, const int32_t* d_ids, const int32_t* d_cu, int nseq
     for (int l = 0; l < c.layers && !fold; ++l) {
         const Layer& L = e->layers[(size_t)l];
         EHIP_TRY(rass::launch_gemm_bf16(e->x, L.w_qkv, L.b_qkv, nullptr, e->qkv, total, Tp, 3 * H, H, 0, st, e->d_splitk, e->splitk_bytes));
-        EHIP_TRY(rass::launch_attention(e->qkv, d_cu, nseq, total, max_seqlen, H, c.heads, e->ctx, st));
+        const bool query_rows = rass::gemm_bf16_ln_input_ok(total, I, H);
+        const bool attn_fused = query_rows && e->d_splitk != nullptr && rass::attn_out_fused_ok(total, nseq, H, c.heads, H) &&
+                                rass::attn_out_fused_pays(total, nseq);
+        if (!attn_fused) EHIP_TRY(rass::launch_attention(e->qkv, d_cu, nseq, total, max_seqlen, H, c.heads, e->ctx, st));
         // attn-out + residual + LayerNorm; the residual (e->x) is also the output: every row is read before it is written
         // (a wave owns a row), and the big-batch form goes through e->y
-        if (rass::gemm_bf16_ln_input_ok(total, I, H)) {
-            // a query: y = ctx W_o^T + b_o + x, then FFN-up normalises y itself (and stores x = LayerNorm(y) once)
-            EHIP_TRY(rass::launch_gemm_bf16(e->ctx, L.w_o, L.b_o, e->x, e->y, total, Tp, H, H, 1, st, e->d_splitk, e->splitk_bytes));
+        if (query_rows) {
+            // a query: y = ctx W_o^T + b_o + x (the attention recomputed inside that GEMM's workgroups: one launch less), then
+            // FFN-up normalises y itself (and stores x = LayerNorm(y) once)
+            if (attn_fused)
+                EHIP_TRY(rass::launch_attn_out_fused(e->qkv, d_cu, nseq, total, H, c.heads, L.w_o, L.b_o, e->x, e->y, H, st));
+            else
+                EHIP_TRY(rass::launch_gemm_bf16(e->ctx, L.w_o, L.b_o, e->x, e->y, total, Tp, H, H, 1, st, e->d_splitk, e->splitk_bytes));
             EHIP_TRY(rass::launch_gemm_bf16_ln_input(e->y, L.ln1_g, L.ln1_b, c.layer_norm_eps, e->x, L.w_up, L.b_up, e->h,
                                                      total, I, H, 2, st));
         } else {
@@ -548,6 +555,19 @@ int rass_attention_bf16(const void* d_qkv, const int32_t* d_cu_seqlens, int nseq
     hipError_t err = rass::launch_attention(d_qkv, d_cu_seqlens, nseq, total_tokens, max_seqlen, hidden, heads, d_ctx,
                                             reinterpret_cast<hipStream_t>(stream));
     if (err != hipSuccess) return efail(RASS_ERR_INVALID, std::string("attention launch: ") + hipGetErrorString(err));
+    return RASS_OK;
+}
+
+/* Stand-alone launcher of the query-time fusion of the two (tests, micro-benchmarks): d_y = attention(d_qkv) d_w^T + d_bias +
+ * d_residual in one launch; RASS_ERR_UNSUPPORTED outside its range (or with RASS_ATTN_FUSE=0). */
+int rass_attention_out_bf16(const void* d_qkv, const int32_t* d_cu_seqlens, int nseq, int total_tokens, int hidden, int heads,
+                            const void* d_w, const float* d_bias, const void* d_residual, void* d_y, int n, void* stream) {
+    if (!d_qkv || !d_cu_seqlens || !d_w || !d_bias || !d_residual || !d_y) return efail(RASS_ERR_INVALID, "NULL argument");
+    if (!rass::attn_out_fused_ok(total_tokens, nseq, hidden, heads, n))
+        return efail(RASS_ERR_UNSUPPORTED, "fused attention + output GEMM: 1..32 tokens in all, hidden 1024, 16 heads, n % 16 == 0");
+    hipError_t err = rass::launch_attn_out_fused(d_qkv, d_cu_seqlens, nseq, total_tokens, hidden, heads, d_w, d_bias, d_residual,
+                                                 d_y, n, reinterpret_cast<hipStream_t>(stream));
+    if (err != hipSuccess) return efail(RASS_ERR_INVALID, std::string("fused attention launch: ") + hipGetErrorString(err));
     return RASS_OK;
 }
 

@@ -188,6 +188,229 @@ __global__ __launch_bounds__(kAttnThreads) void attention_kernel(const u16* __re
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// A query's few rows (all sequences of the batch together <= 32 tokens: embed_query / ollama_embed_text,
+// app/main.py:225-237, 266-274): the attention RECOMPUTED inside the attention-output GEMM (round 4).  Every kernel of a
+// one-query forward costs ~4-5 us whatever it does, and this attention is 16 heads x a 16 x 16 score tile:
+// each of the N / 16 workgroups of the few-rows GEMM (16 output features, encoder_gemm.hip gemm_bf16_fewrows_kernel) runs
+// it again instead of reading `ctx` from a launch of its own.  A workgroup has 16 waves, wave = head = a 64-deep slice of
+// the GEMM's K: the wave
+//   1. has its two weight fragments W[n0 + i][64 head + 32 u + 8 g ..] in flight first,
+//   2. per sequence: stages the head's V rows in its OWN piece of LDS, takes K and Q fragments straight from global
+//      memory / L2 and does attention_kernel's arithmetic on the one 64-key block there is (same MFMA orientation, the
+//      same order of every fp32 operation: the context rows have attention_kernel's bits),
+//   3. writes the 16 x 64 context block (bf16) into its private operand tile and reads it back as the GEMM's B fragments
+//      (LDS is in order per wave: no barrier), two MFMAs per 16-token block,
+//   4. leaves its partial tile in LDS; wave 0 adds the 16 partial tiles in wave order, bias and residual.
+// QKV is re-read 64 times from L2 (96 KiB per workgroup at 16 tokens).  The partial tiles are summed in a different
+// order than the 4-wave GEMM's, so Y may differ from the unfused pair in the last bit of a bf16 here and there
+// (test_gpu_encoder.py bounds it); RASS_ATTN_FUSE=0 keeps the pair.
+constexpr int kFusedXPitch = 72;  // u16 per row of a wave's context tile: 64 + 8 (rows 144 B apart: 16-byte aligned, conflict-free)
+constexpr int kFusedVRows = 32;   // V rows staged per sequence (rows past the sequence are zeros: P is 0 there, V must be finite)
+
+template <int ROWS>
+__global__ __launch_bounds__(1024) void attn_out_fewrows_kernel(const u16* __restrict__ qkv, const int32_t* __restrict__ cu,
+                                                                int nseq, int M, const u16* __restrict__ W,
+                                                                const float* __restrict__ bias,
+                                                                const u16* __restrict__ residual, u16* __restrict__ Y, int N) {
+    constexpr int hidden = 16 * kHeadDim, K = hidden, ld = 3 * hidden;
+    constexpr int kWaveBytes = kFusedVRows * kVPitch + 16 * ROWS * kFusedXPitch * 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;   // = head
+    unsigned char* Vl = lds + wave * kWaveBytes;
+    u16* xs = reinterpret_cast<u16*>(Vl + kFusedVRows * kVPitch);
+    const int n0 = blockIdx.x * 16;
+    const int g = lane >> 4, qi = lane & 15;
+    const u16* wrow = W + (int64_t)(n0 + qi) * K + wave * kHeadDim + 8 * g;
+    const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(wrow);
+    const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(wrow + 32);
+    // wave 0's epilogue operands leave now
+    const int n = n0 + 4 * g;
+    f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+    uint2 res[ROWS];
+#pragma unroll
+    for (int rb = 0; rb < ROWS; ++rb) res[rb] = make_uint2(0, 0);
+    if (wave == 0) {
+        bv = *reinterpret_cast<const f32x4*>(bias + n);
+#pragma unroll
+        for (int rb = 0; rb < ROWS; ++rb) {
+            const int m = 16 * rb + qi;
+            res[rb] = *reinterpret_cast<const uint2*>(residual + (int64_t)(m < M ? m : 0) * N + n);
+        }
+    }
+    // the operand tile starts as zeros (rows past M stay so)
+    for (int e = lane; e < 16 * ROWS * 9; e += 64)
+        *reinterpret_cast<uint4*>(xs + (e / 9) * kFusedXPitch + (e % 9) * 8) = make_uint4(0, 0, 0, 0);
+
+    constexpr float kScale = 0.18033688011112042f;
+    for (int s = 0; s < nseq; ++s) {
+        // one sequence: it is the whole batch (the host knows M; no dependent load in front of the Q / K / V loads)
+        const int t0 = nseq == 1 ? 0 : cu[s];
+        const int S = nseq == 1 ? M : cu[s + 1] - t0;
+        if (S <= 0 || S > 16 * ROWS || t0 < 0 || t0 + S > M) continue;   // (the host checked; never index past the tiles)
+        const u16* qbase = qkv + (int64_t)t0 * ld + wave * kHeadDim;
+        const u16* kbase = qbase + hidden;
+        const u16* vbase = qbase + 2 * hidden;
+        // V rows of this sequence and head: 32 rows x 8 pieces of 16 B, 4 per lane
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int key = (lane >> 3) + 8 * j, c = lane & 7;
+            uint4 vv = make_uint4(0, 0, 0, 0);
+            if (key < S) vv = *reinterpret_cast<const uint4*>(vbase + (int64_t)key * ld + c * 8);
+            *reinterpret_cast<uint4*>(Vl + key * kVPitch + c * 16) = vv;
+        }
+        asm volatile("" ::: "memory");   // the transposing reads below come after these writes (LDS is in order per wave)
+        // K fragments (A operand): key 16 kt + qi; keys past S are masked below (any finite row will do)
+        bf16x8 kf[ROWS][2];
+#pragma unroll
+        for (int kt = 0; kt < ROWS; ++kt) {
+            const int key = 16 * kt + qi;
+            const u16* kp = kbase + (int64_t)(key < S ? key : S - 1) * ld + 8 * g;
+            kf[kt][0] = *reinterpret_cast<const bf16x8*>(kp);
+            kf[kt][1] = *reinterpret_cast<const bf16x8*>(kp + 32);
+        }
+#pragma unroll
+        for (int qb = 0; qb < ROWS; ++qb) {
+            if (16 * qb >= S) break;
+            const int q = 16 * qb + qi;
+            const u16* qp = qbase + (int64_t)(q < S ? q : S - 1) * ld + 8 * g;
+            const bf16x8 qf0 = *reinterpret_cast<const bf16x8*>(qp);
+            const bf16x8 qf1 = *reinterpret_cast<const bf16x8*>(qp + 32);
+            f32x4 sc[2];
+            sc[1] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+            for (int kt = 0; kt < ROWS; ++kt) {
+                sc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt][0], qf0, sc[kt], 0, 0, 0);
+                sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt][1], qf1, sc[kt], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (16 * kt + 4 * g + r >= S) sc[kt][r] = -INFINITY;
+            }
+            float mx = fmaxf(fmaxf(sc[0][0], sc[0][1]), fmaxf(sc[0][2], sc[0][3]));
+            mx = fmaxf(fmaxf(mx, fmaxf(sc[1][0], sc[1][1])), fmaxf(sc[1][2], sc[1][3]));
+            mx = fmaxf(mx, wave_xor_partner_dpp(mx, lane, 16));   // = __shfl_xor without the LDS crossbar (encoder_kernels.h)
+            mx = fmaxf(mx, wave_xor_partner_dpp(mx, lane, 32));
+            const float m_run = mx * kScale;   // finite: key 0 is valid
+            const f32x4 negm = f32x4{-m_run, -m_run, -m_run, -m_run};
+            f32x4 rs4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                const f32x4 e = sc[kt] * kScale + negm;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sc[kt][r] = __builtin_amdgcn_exp2f(e[r]);
+                rs4 += sc[kt];
+            }
+            float rs = (rs4[0] + rs4[1]) + (rs4[2] + rs4[3]);
+            rs += wave_xor_partner_dpp(rs, lane, 16);
+            rs += wave_xor_partner_dpp(rs, lane, 32);
+            bf16x8 pf;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pf[r] = (short)f2bf_a(sc[0][r]);
+                pf[4 + r] = (short)f2bf_a(sc[1][r]);
+            }
+            const unsigned char* vblk = Vl + (4 * g + (qi >> 2)) * kVPitch + (qi & 3) * 8;
+            const float inv_l = 1.f / rs;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) bf16x4*)(vblk + dt * 32));
+                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) bf16x4*)(vblk + 16 * kVPitch + dt * 32));
+                bf16x8 vf;
+                vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+                vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+                f32x4 O = f32x4{0.f, 0.f, 0.f, 0.f};
+                O = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, O, 0, 0, 0);
+                if (q < S) {
+                    uint2 o;
+                    o.x = (unsigned)f2bf_a(O[0] * inv_l) | ((unsigned)f2bf_a(O[1] * inv_l) << 16);
+                    o.y = (unsigned)f2bf_a(O[2] * inv_l) | ((unsigned)f2bf_a(O[3] * inv_l) << 16);
+                    *reinterpret_cast<uint2*>(xs + (t0 + q) * kFusedXPitch + dt * 16 + 4 * g) = o;
+                }
+            }
+        }
+        asm volatile("" ::: "memory");   // the next sequence's V rows go where these were read
+    }
+    asm volatile("" ::: "memory");
+    // the GEMM's share of this wave: K slice [64 head, 64 head + 64)
+    f32x4* part = reinterpret_cast<f32x4*>(Vl);   // [ROWS][64], over the wave's own V rows (its reads are done: in order)
+#pragma unroll
+    for (int rb = 0; rb < ROWS; ++rb) {
+        const u16* xr = xs + (16 * rb + qi) * kFusedXPitch + 8 * g;
+        const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(xr);
+        const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(xr + 32);
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, acc, 0, 0, 0);
+        part[rb * 64 + lane] = acc;
+    }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int rb = 0; rb < ROWS; ++rb) {
+        const int m = 16 * rb + qi;
+        if (m >= M) continue;
+        f32x4 v = part[rb * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < 16; ++w) v += reinterpret_cast<const f32x4*>(lds + w * kWaveBytes)[rb * 64 + lane];
+        v += bv;
+        v.x += __uint_as_float(res[rb].x << 16);
+        v.y += __uint_as_float(res[rb].x & 0xffff0000u);
+        v.z += __uint_as_float(res[rb].y << 16);
+        v.w += __uint_as_float(res[rb].y & 0xffff0000u);
+        uint2 o;
+        o.x = (unsigned)f2bf_a(v.x) | ((unsigned)f2bf_a(v.y) << 16);
+        o.y = (unsigned)f2bf_a(v.z) | ((unsigned)f2bf_a(v.w) << 16);
+        *reinterpret_cast<uint2*>(Y + (int64_t)m * N + n) = o;
+    }
+}
+
+bool attn_out_fused_ok(int M, int nseq, int hidden, int heads, int N) {
+    // RASS_ATTN_FUSE=0 / RASS_GEMM_FEWROWS=0 (read per launch: the A/B) keep the attention launch + the few-rows GEMM
+    const char* v = getenv("RASS_ATTN_FUSE");
+    if (v && v[0] == '0') return false;
+    const char* f = getenv("RASS_GEMM_FEWROWS");
+    if (f && f[0] == '0') return false;
+    return M >= 1 && M <= 32 && nseq >= 1 && nseq <= M && hidden == 16 * kHeadDim && heads == 16 && N % 16 == 0 && N >= 16;
+}
+
+bool attn_out_fused_pays(int M, int nseq) {
+    // a wave walks the sequences one after the other: measured against the pair (scripts/probe_encoder_attn_fuse.py), one
+    // sequence of <= 16 tokens gains 1.5-2.5 us per layer, of 23 tokens 0.2, of 32 it loses 0.5; two sequences in 16 tokens gain
+    // 0.4, three or more lose
+    const char* v = getenv("RASS_ATTN_FUSE");
+    if (v && v[0] == '2') return true;   // wherever it is valid (tests, A/B)
+    return (nseq == 1 && M <= 24) || (nseq == 2 && M <= 16);
+}
+
+hipError_t launch_attn_out_fused(const void* qkv, const int32_t* cu_seqlens, int nseq, int M, int hidden, int heads, const void* W,
+                                 const float* bias, const void* residual, void* Y, int N, hipStream_t stream) {
+    if (!attn_out_fused_ok(M, nseq, hidden, heads, N) || !residual) return hipErrorInvalidValue;
+    const int rows = M <= 16 ? 1 : 2;
+    const int lds_bytes = 16 * (kFusedVRows * kVPitch + 16 * rows * kFusedXPitch * 2);
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[rows - 1]) {
+        hipError_t e = rows == 1 ? hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_out_fewrows_kernel<1>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)
+                                 : hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_out_fewrows_kernel<2>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) return e;
+        attr_set[rows - 1] = true;
+    }
+    if (rows == 1)
+        hipLaunchKernelGGL(attn_out_fewrows_kernel<1>, dim3(N / 16), dim3(1024), lds_bytes, stream, static_cast<const u16*>(qkv),
+                           cu_seqlens, nseq, M, static_cast<const u16*>(W), bias, static_cast<const u16*>(residual),
+                           static_cast<u16*>(Y), N);
+    else
+        hipLaunchKernelGGL(attn_out_fewrows_kernel<2>, dim3(N / 16), dim3(1024), lds_bytes, stream, static_cast<const u16*>(qkv),
+                           cu_seqlens, nseq, M, static_cast<const u16*>(W), bias, static_cast<const u16*>(residual),
+                           static_cast<u16*>(Y), N);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // attention64_kernel: the kernel for batches of LONG sequences (the ingest shape: 256 chunks x 512 tokens), on 32x32
 // tiles (v_mfma_f32_32x32x16_bf16).  How it got here, with every number: profiles/r02_attention_experiments.txt.
 //

@@ -526,6 +526,23 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_bf16_fewrows_kernel(const u16
     const int kq = K / (WAVES * (int)gridDim.y), k_lo = ((int)blockIdx.y * WAVES + wave) * kq;
     const u16* wrow = W + (int64_t)(n0 + i) * K + k_lo + 8 * g;   // A operand: W[n0 + i][k_lo + 32 ks + 8 g .. +7]
     const u16* xrow = X + (int64_t)i * K + k_lo + 8 * g;          // B operand: X[16 rb + i][..] (rows < M_pad exist)
+    // wave 0's epilogue operands leave with the first weight loads, not after the barrier (a dependent L2 / HBM round trip
+    // at the very end of a kernel whose whole duration is 4-5 us)
+    const int n = n0 + 4 * g;
+    f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+    uint2 rres[ROWS];
+#pragma unroll
+    for (int rb = 0; rb < ROWS; ++rb) rres[rb] = make_uint2(0, 0);
+    if (EPI >= 0 && wave == 0) {
+        bv = *reinterpret_cast<const f32x4*>(bias + n);
+        if (EPI == 1) {
+#pragma unroll
+            for (int rb = 0; rb < ROWS; ++rb) {
+                const int m = 16 * rb + i;
+                rres[rb] = *reinterpret_cast<const uint2*>(residual + (int64_t)(m < M ? m : 0) * N + n);
+            }
+        }
+    }
     f32x4 acc[ROWS];
 #pragma unroll
     for (int rb = 0; rb < ROWS; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -548,8 +565,6 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_bf16_fewrows_kernel(const u16
     __syncthreads();
     if (wave != 0) return;
     // token m = 16 rb + i, features n0 + 4 g + {0..3}
-    const int n = n0 + 4 * g;
-    const f32x4 bv = EPI < 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(bias + n);
 #pragma unroll
     for (int rb = 0; rb < ROWS; ++rb) {
         const int m = 16 * rb + i;
@@ -563,7 +578,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_bf16_fewrows_kernel(const u16
         }
         v += bv;
         if (EPI == 1) {
-            const uint2 r = *reinterpret_cast<const uint2*>(residual + (int64_t)m * N + n);
+            const uint2 r = rres[rb];
             v.x += bf16_to_f32((u16)(r.x & 0xffff));
             v.y += bf16_to_f32((u16)(r.x >> 16));
             v.z += bf16_to_f32((u16)(r.y & 0xffff));
@@ -606,6 +621,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_lnin_kernel(const u16* __restri
     bf16x8 a[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) a[u] = *reinterpret_cast<const bf16x8*>(wrow + 32 * u);
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n0 + 4 * g);   // (wave 0's epilogue: not a round trip at the end)
     // rows wave, wave + 4, ...: all their loads first
     constexpr int RPW = 4 * ROWS;   // rows per wave
     uint4 raw[RPW][2];
@@ -626,56 +642,74 @@ __global__ __launch_bounds__(256) void gemm_bf16_lnin_kernel(const u16* __restri
         bt[st][0] = *reinterpret_cast<const f32x4*>(beta + c);
         bt[st][1] = *reinterpret_cast<const f32x4*>(beta + c + 4);
     }
+    __builtin_amdgcn_sched_barrier(0);   // every load above is issued before the first wait
+    // four rows at a time, their wave reductions side by side: a row's arithmetic and its order are layernorm_kernel's, but
+    // the 12 dependent cross-lane steps of a row (2 sums x 6 butterfly steps) overlap with the other rows' instead of running 48
+    // deep, and they are DPP / permlane-swap moves, not ds_bpermute round trips (encoder_kernels.h; round 4: 8.2 -> ~5 us per launch)
 #pragma unroll
-    for (int j = 0; j < RPW; ++j) {
-        const int r = wave + 4 * j;
-        float x[2][8];
+    for (int j0 = 0; j0 < RPW; j0 += 4) {
+        float x[4][2][8], sum[4], mean[4], sq[4], rstd[4];
 #pragma unroll
-        for (int st = 0; st < 2; ++st) {
-            x[st][0] = bf16_to_f32((u16)(raw[j][st].x & 0xffff)); x[st][1] = bf16_to_f32((u16)(raw[j][st].x >> 16));
-            x[st][2] = bf16_to_f32((u16)(raw[j][st].y & 0xffff)); x[st][3] = bf16_to_f32((u16)(raw[j][st].y >> 16));
-            x[st][4] = bf16_to_f32((u16)(raw[j][st].z & 0xffff)); x[st][5] = bf16_to_f32((u16)(raw[j][st].z >> 16));
-            x[st][6] = bf16_to_f32((u16)(raw[j][st].w & 0xffff)); x[st][7] = bf16_to_f32((u16)(raw[j][st].w >> 16));
-        }
-        float sum = 0.f;
+        for (int jj = 0; jj < 4; ++jj) {
 #pragma unroll
-        for (int st = 0; st < 2; ++st)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) sum += x[st][e];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
-        const float mean = sum / (float)K;
-        float sq = 0.f;
-#pragma unroll
-        for (int st = 0; st < 2; ++st)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float d = x[st][e] - mean;
-                sq = fmaf(d, d, sq);
+            for (int st = 0; st < 2; ++st) {
+                const uint4 w = raw[j0 + jj][st];
+                x[jj][st][0] = bf16_to_f32((u16)(w.x & 0xffff)); x[jj][st][1] = bf16_to_f32((u16)(w.x >> 16));
+                x[jj][st][2] = bf16_to_f32((u16)(w.y & 0xffff)); x[jj][st][3] = bf16_to_f32((u16)(w.y >> 16));
+                x[jj][st][4] = bf16_to_f32((u16)(w.z & 0xffff)); x[jj][st][5] = bf16_to_f32((u16)(w.z >> 16));
+                x[jj][st][6] = bf16_to_f32((u16)(w.w & 0xffff)); x[jj][st][7] = bf16_to_f32((u16)(w.w >> 16));
             }
+            sum[jj] = 0.f;
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
-        const float rstd = rsqrtf(sq / (float)K + eps);
+            for (int st = 0; st < 2; ++st)
 #pragma unroll
-        for (int st = 0; st < 2; ++st) {
-            const int c = lane * 8 + 512 * st;
-            float o[8];
-            o[0] = (x[st][0] - mean) * rstd * gm[st][0].x + bt[st][0].x;
-            o[1] = (x[st][1] - mean) * rstd * gm[st][0].y + bt[st][0].y;
-            o[2] = (x[st][2] - mean) * rstd * gm[st][0].z + bt[st][0].z;
-            o[3] = (x[st][3] - mean) * rstd * gm[st][0].w + bt[st][0].w;
-            o[4] = (x[st][4] - mean) * rstd * gm[st][1].x + bt[st][1].x;
-            o[5] = (x[st][5] - mean) * rstd * gm[st][1].y + bt[st][1].y;
-            o[6] = (x[st][6] - mean) * rstd * gm[st][1].z + bt[st][1].z;
-            o[7] = (x[st][7] - mean) * rstd * gm[st][1].w + bt[st][1].w;
-            uint4 pk;
-            pk.x = (unsigned)f32_to_bf16(o[0]) | ((unsigned)f32_to_bf16(o[1]) << 16);
-            pk.y = (unsigned)f32_to_bf16(o[2]) | ((unsigned)f32_to_bf16(o[3]) << 16);
-            pk.z = (unsigned)f32_to_bf16(o[4]) | ((unsigned)f32_to_bf16(o[5]) << 16);
-            pk.w = (unsigned)f32_to_bf16(o[6]) | ((unsigned)f32_to_bf16(o[7]) << 16);
-            if (r >= M) pk = make_uint4(0, 0, 0, 0);   // rows past the batch: finite zeros in the operand tile
-            *reinterpret_cast<uint4*>(&xs[r][c]) = pk;
-            if (blockIdx.x == 0 && r < M) *reinterpret_cast<uint4*>(x_out + (int64_t)r * K + c) = pk;
+                for (int e = 0; e < 8; ++e) sum[jj] += x[jj][st][e];
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) sum[jj] += wave_xor_partner_dpp(sum[jj], lane, off);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            mean[jj] = sum[jj] / (float)K;
+            sq[jj] = 0.f;
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float d = x[jj][st][e] - mean[jj];
+                    sq[jj] = fmaf(d, d, sq[jj]);
+                }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) sq[jj] += wave_xor_partner_dpp(sq[jj], lane, off);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            rstd[jj] = rsqrtf(sq[jj] / (float)K + eps);
+            const int r = wave + 4 * (j0 + jj);
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const int c = lane * 8 + 512 * st;
+                float o[8];
+                o[0] = (x[jj][st][0] - mean[jj]) * rstd[jj] * gm[st][0].x + bt[st][0].x;
+                o[1] = (x[jj][st][1] - mean[jj]) * rstd[jj] * gm[st][0].y + bt[st][0].y;
+                o[2] = (x[jj][st][2] - mean[jj]) * rstd[jj] * gm[st][0].z + bt[st][0].z;
+                o[3] = (x[jj][st][3] - mean[jj]) * rstd[jj] * gm[st][0].w + bt[st][0].w;
+                o[4] = (x[jj][st][4] - mean[jj]) * rstd[jj] * gm[st][1].x + bt[st][1].x;
+                o[5] = (x[jj][st][5] - mean[jj]) * rstd[jj] * gm[st][1].y + bt[st][1].y;
+                o[6] = (x[jj][st][6] - mean[jj]) * rstd[jj] * gm[st][1].z + bt[st][1].z;
+                o[7] = (x[jj][st][7] - mean[jj]) * rstd[jj] * gm[st][1].w + bt[st][1].w;
+                uint4 pk;
+                pk.x = (unsigned)f32_to_bf16(o[0]) | ((unsigned)f32_to_bf16(o[1]) << 16);
+                pk.y = (unsigned)f32_to_bf16(o[2]) | ((unsigned)f32_to_bf16(o[3]) << 16);
+                pk.z = (unsigned)f32_to_bf16(o[4]) | ((unsigned)f32_to_bf16(o[5]) << 16);
+                pk.w = (unsigned)f32_to_bf16(o[6]) | ((unsigned)f32_to_bf16(o[7]) << 16);
+                if (r >= M) pk = make_uint4(0, 0, 0, 0);   // rows past the batch: finite zeros in the operand tile
+                *reinterpret_cast<uint4*>(&xs[r][c]) = pk;
+                if (blockIdx.x == 0 && r < M) *reinterpret_cast<uint4*>(x_out + (int64_t)r * K + c) = pk;
+            }
         }
     }
     __syncthreads();
@@ -695,7 +729,6 @@ __global__ __launch_bounds__(256) void gemm_bf16_lnin_kernel(const u16* __restri
     __syncthreads();
     if (wave != 0) return;
     const int n = n0 + 4 * g;
-    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n);
 #pragma unroll
     for (int rb = 0; rb < ROWS; ++rb) {
         const int m = 16 * rb + i;

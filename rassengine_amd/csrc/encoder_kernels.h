@@ -64,10 +64,55 @@ hipError_t launch_layernorm(const void* in, const float* gamma, const float* bet
 hipError_t launch_attention(const void* qkv, const int32_t* cu_seqlens, int nseq, int total_tokens, int max_seqlen,
                             int hidden, int heads, void* ctx, hipStream_t stream);
 
+// K6 + K5 for a query's few rows (all sequences together <= 32 tokens, hidden 1024, 16 heads): Y = attention(qkv) W^T + bias +
+// residual in ONE launch — every workgroup of the few-rows GEMM recomputes the attention (context rows with attention_kernel's
+// bits) instead of reading it from a launch of its own.  RASS_ATTN_FUSE=0: never ok.
+bool attn_out_fused_ok(int M, int nseq, int hidden, int heads, int N);
+bool attn_out_fused_pays(int M, int nseq);   // the encoder's rule: where the one launch is faster than the pair (RASS_ATTN_FUSE=2: wherever valid)
+hipError_t launch_attn_out_fused(const void* qkv, const int32_t* cu_seqlens, int nseq, int M, int hidden, int heads, const void* W,
+                                 const float* bias, const void* residual, void* Y, int N, hipStream_t stream);
+
 // K8: pooled[s] = cls (first token) or mean over the sequence's tokens of x, fp32 [nseq][hidden];
 // optional L2 normalise with the reference's formula (app/main.py:1249-1251)
 hipError_t launch_pool(const void* x, const int32_t* cu_seqlens, int nseq, int hidden, int mode_mean, int normalize,
                        float* out, hipStream_t stream);
+
+// The wave-wide sum of the row kernels: v + (lane ^ 32) + (lane ^ 16) + ... + (lane ^ 1), the butterfly `v += __shfl_xor(v, off)`
+// for off = 32 .. 1 with the SAME partners in the same order (an IEEE add is commutative: the same bits in every lane), but
+// without the LDS crossbar: __shfl_xor is a ds_bpermute (~100 cycles of latency each, twelve of them in a row per LayerNorm:
+// most of what a few-row LayerNorm lasts); gfx950's v_permlane32_swap / v_permlane16_swap and DPP row operations take 4-8.
+#ifdef __HIPCC__
+__device__ __forceinline__ float wave_xor_partner_dpp(float x, int lane, int off) {
+    const int v = __float_as_int(x);
+    int o;
+    if (off == 32) {
+        const auto sw = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+        o = (int)((lane & 32) ? sw[0] : sw[1]);
+    } else if (off == 16) {
+        const auto sw = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+        o = (int)((lane & 16) ? sw[0] : sw[1]);
+    } else if (off == 8) {   // i ^ 8 = row_mirror(half_mirror(i))
+        o = __builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp(v, 0x141, 0xf, 0xf, true), 0x140, 0xf, 0xf, true);
+    } else if (off == 4) {   // i ^ 4 = half_mirror(quad_reverse(i))
+        o = __builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp(v, 0x1B, 0xf, 0xf, true), 0x141, 0xf, 0xf, true);
+    } else if (off == 2) {
+        o = __builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+    } else {
+        o = __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+    }
+    return __int_as_float(o);
+}
+__device__ __forceinline__ float wave_sum_butterfly(float v) {
+    const int lane = (int)(threadIdx.x & 63);
+    v += wave_xor_partner_dpp(v, lane, 32);
+    v += wave_xor_partner_dpp(v, lane, 16);
+    v += wave_xor_partner_dpp(v, lane, 8);
+    v += wave_xor_partner_dpp(v, lane, 4);
+    v += wave_xor_partner_dpp(v, lane, 2);
+    v += wave_xor_partner_dpp(v, lane, 1);
+    return v;
+}
+#endif
 
 // fp32 -> bf16 (weights upload)
 hipError_t launch_f32_to_bf16(const float* in, void* out, int64_t n, hipStream_t stream);

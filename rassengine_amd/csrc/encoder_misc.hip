@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_bf16.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "encoder_kernels.h"
 
@@ -25,9 +26,8 @@ __device__ __forceinline__ u16 f2bf(float f) {
     return *reinterpret_cast<u16*>(&h);
 }
 __device__ __forceinline__ float wave_sum_e(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    // = `for (off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64)`, bit for bit (encoder_kernels.h)
+    return wave_sum_butterfly(v);
 }
 
 struct Vals8 {
@@ -298,6 +298,94 @@ __global__ __launch_bounds__(kRowThreadsE) void splitk_residual_layernorm_kernel
     }
 }
 
+// The same for hidden = 512 * STEPS exactly (1 024: BERT-large), as the one-query forward runs it 24 times: no lane-dependent
+// branch around a step, so EVERY load of the row — the S slices, bias, residual, gamma, beta: 30 x 16 B per lane at S = 4 — is
+// in flight before the first add (the general form above walks the steps one branch at a time: two dependent round trips for
+// the data and a third for gamma / beta, in a kernel that lasts 4 us).  Same arithmetic in the same order: the same bits.
+template <int S, int STEPS>
+__global__ __launch_bounds__(kRowThreadsE) void splitk_residual_layernorm_exact_kernel(
+    const float* __restrict__ partial, int rows, int rows_pad, const float* __restrict__ bias, const u16* residual,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, u16* out) {
+    constexpr int hidden = 512 * STEPS;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int r = blockIdx.x * 4 + wave;
+    if (r >= rows) return;
+    f32x4 p0[STEPS][S], p1[STEPS][S], bb[STEPS][2], g[STEPS][2], b[STEPS][2];
+    uint4 rr[STEPS];
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+        const int c = lane * 8 + 512 * s;
+#pragma unroll
+        for (int sl = 0; sl < S; ++sl) {
+            const float* q = partial + ((int64_t)sl * rows_pad + r) * hidden + c;
+            p0[s][sl] = *reinterpret_cast<const f32x4*>(q);
+            p1[s][sl] = *reinterpret_cast<const f32x4*>(q + 4);
+        }
+        rr[s] = *reinterpret_cast<const uint4*>(residual + (int64_t)r * hidden + c);
+        bb[s][0] = *reinterpret_cast<const f32x4*>(bias + c);
+        bb[s][1] = *reinterpret_cast<const f32x4*>(bias + c + 4);
+    }
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+        const int c = lane * 8 + 512 * s;
+        g[s][0] = *reinterpret_cast<const f32x4*>(gamma + c);
+        g[s][1] = *reinterpret_cast<const f32x4*>(gamma + c + 4);
+        b[s][0] = *reinterpret_cast<const f32x4*>(beta + c);
+        b[s][1] = *reinterpret_cast<const f32x4*>(beta + c + 4);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float x[STEPS][8];
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+        f32x4 v0 = p0[s][0], v1 = p1[s][0];
+#pragma unroll
+        for (int sl = 1; sl < S; ++sl) {
+            v0 += p0[s][sl];
+            v1 += p1[s][sl];
+        }
+        v0 += bb[s][0];
+        v1 += bb[s][1];
+        x[s][0] = bf2f(f2bf(v0.x + bf2f((u16)(rr[s].x & 0xffff))));
+        x[s][1] = bf2f(f2bf(v0.y + bf2f((u16)(rr[s].x >> 16))));
+        x[s][2] = bf2f(f2bf(v0.z + bf2f((u16)(rr[s].y & 0xffff))));
+        x[s][3] = bf2f(f2bf(v0.w + bf2f((u16)(rr[s].y >> 16))));
+        x[s][4] = bf2f(f2bf(v1.x + bf2f((u16)(rr[s].z & 0xffff))));
+        x[s][5] = bf2f(f2bf(v1.y + bf2f((u16)(rr[s].z >> 16))));
+        x[s][6] = bf2f(f2bf(v1.z + bf2f((u16)(rr[s].w & 0xffff))));
+        x[s][7] = bf2f(f2bf(v1.w + bf2f((u16)(rr[s].w >> 16))));
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sum += x[s][e];
+    const float mean = wave_sum_e(sum) / (float)hidden;
+    float sq = 0.f;
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float d = x[s][e] - mean;
+            sq = fmaf(d, d, sq);
+        }
+    const float rstd = rsqrtf(wave_sum_e(sq) / (float)hidden + eps);
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+        const int c = lane * 8 + 512 * s;
+        Vals8 o;
+        o.v[0] = (x[s][0] - mean) * rstd * g[s][0].x + b[s][0].x;
+        o.v[1] = (x[s][1] - mean) * rstd * g[s][0].y + b[s][0].y;
+        o.v[2] = (x[s][2] - mean) * rstd * g[s][0].z + b[s][0].z;
+        o.v[3] = (x[s][3] - mean) * rstd * g[s][0].w + b[s][0].w;
+        o.v[4] = (x[s][4] - mean) * rstd * g[s][1].x + b[s][1].x;
+        o.v[5] = (x[s][5] - mean) * rstd * g[s][1].y + b[s][1].y;
+        o.v[6] = (x[s][6] - mean) * rstd * g[s][1].z + b[s][1].z;
+        o.v[7] = (x[s][7] - mean) * rstd * g[s][1].w + b[s][1].w;
+        store8_bf16(out + (int64_t)r * hidden + c, o);
+    }
+}
+
 hipError_t launch_splitk_residual_layernorm(const float* partial, int S, int rows, int rows_pad, int hidden,
                                             const float* bias, const void* residual, const float* gamma,
                                             const float* beta, float eps, void* out, hipStream_t stream) {
@@ -306,6 +394,14 @@ hipError_t launch_splitk_residual_layernorm(const float* partial, int S, int row
     const int blocks = (rows + 3) / 4;
     const u16* res = static_cast<const u16*>(residual);
     u16* o = static_cast<u16*>(out);
+    if (S == 4 && hidden == 1024 && rows <= 64) {   // the query-time reduction (FFN-down's four K slices)
+        const char* v = getenv("RASS_LN_EXACT");    // =0: the general kernel (A/B; read per launch)
+        if (!(v && v[0] == '0')) {
+            hipLaunchKernelGGL((splitk_residual_layernorm_exact_kernel<4, 2>), dim3(blocks), dim3(kRowThreadsE), 0, stream, partial,
+                               rows, rows_pad, bias, res, gamma, beta, eps, o);
+            return hipGetLastError();
+        }
+    }
 #define RASS_SKLN(SV)                                                                                              \
     case SV:                                                                                                       \
         hipLaunchKernelGGL(splitk_residual_layernorm_kernel<SV>, dim3(blocks), dim3(kRowThreadsE), 0, stream, partial, \

@@ -7,8 +7,10 @@
 //   2. scan_i8_topk_kernel: the persistent, K-split, register-streaming structure of the bf16 candidate scan over that
 //      slab (a QUARTER of the fp32 bytes per pass) with v_mfma_i32_16x16x64_i8: a row's candidate score is
 //          (float)(sum_c q_row[c] * q_query[c]) * scale_row
-//      — the integer sum is exact (|sum| <= 1024 * 127^2 < 2^24), so the score is one fp32 multiply of exact operands and the
-//      oracle's restatement (numpy int32 dot products) reproduces it BIT FOR BIT; the query's own scale is the same for every
+//      — the integer sum is exact in int32 (|sum| <= 2048 * 127^2 < 2^26; up to dim 1 024 it is also below 2^24, so the
+//      conversion is exact too; past that it is ONE round-to-nearest-even of an exact integer), so the score is a fixed
+//      sequence of correctly rounded fp32 operations on exact operands and the oracle's restatement (numpy integer dot
+//      products, the same conversion and multiply) reproduces it BIT FOR BIT; the query's own scale is the same for every
 //      row and is left out.  Keeps the 32 best candidates per query and workgroup.
 //   3. merge (merge_topk.hip) -> 32 candidates per query; rerank_f32_kernel (scan_bf16.hip) -> their exact fp32 scores in the
 //      flat kernel's order and the exact (score desc, id asc) top-k among them.

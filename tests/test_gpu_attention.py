@@ -123,3 +123,88 @@ def test_attention_variants_agree_closely(gpu):
             os.environ["RASS_ATTN_VARIANT"] = old
     assert float((a - b).abs().max()) <= 2.0 ** -7 * float(a.abs().max())
     assert float(((a - b).abs() > 2.0 ** -8 * a.abs() + 1e-3).float().mean()) < 0.01
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Query time: the attention recomputed inside the attention-output projection (rass_attention_out_bf16, one launch)
+
+def _fused_case(torch, lens, seed, scale=1.0):
+    from rassengine_amd import _native as N_
+    heads, hidden, n = 16, 1024, 1024
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    total = int(sum(lens))
+    pad = 128
+    qkv = torch.zeros((pad, 3 * hidden), dtype=torch.bfloat16, device="cuda")
+    qkv[:total] = (torch.randn((total, 3 * hidden), generator=g, device="cuda") * scale).bfloat16()
+    w = (torch.randn((n, hidden), generator=g, device="cuda") * 0.03).bfloat16()
+    bias = torch.randn((n,), generator=g, device="cuda") * 0.1
+    res = torch.zeros((pad, n), dtype=torch.bfloat16, device="cuda")
+    res[:total] = torch.randn((total, n), generator=g, device="cuda").bfloat16()
+    cu = np.zeros(len(lens) + 1, dtype=np.int32)
+    np.cumsum(lens, out=cu[1:])
+    d_cu = torch.from_numpy(cu).cuda()
+    st = ctypes.c_void_p(int(torch.cuda.current_stream().cuda_stream))
+    L = N_.lib()
+    # the pair: attention launch + the few-rows GEMM (bias + residual); the scratch selects the query-time GEMM path
+    ctx = torch.zeros((pad, hidden), dtype=torch.bfloat16, device="cuda")
+    N_.check("rass_attention_bf16", L.rass_attention_bf16(ctypes.c_void_p(qkv.data_ptr()), ctypes.c_void_p(d_cu.data_ptr()),
+                                                          len(lens), total, max(lens), hidden, heads,
+                                                          ctypes.c_void_p(ctx.data_ptr()), st))
+    ws = torch.empty((2 * 256 * n,), dtype=torch.float32, device="cuda")
+    y_pair = torch.full((pad, n), 555.0, dtype=torch.bfloat16, device="cuda")
+    N_.check("rass_gemm_bf16_ws", L.rass_gemm_bf16_ws(ctypes.c_void_p(ctx.data_ptr()), ctypes.c_void_p(w.data_ptr()),
+                                                      ctypes.c_void_p(bias.data_ptr()), ctypes.c_void_p(res.data_ptr()),
+                                                      ctypes.c_void_p(y_pair.data_ptr()), total, pad, n, hidden, 1,
+                                                      ctypes.c_void_p(ws.data_ptr()), ws.numel() * 4, st))
+    y = torch.full((pad, n), 555.0, dtype=torch.bfloat16, device="cuda")
+    N_.check("rass_attention_out_bf16", L.rass_attention_out_bf16(
+        ctypes.c_void_p(qkv.data_ptr()), ctypes.c_void_p(d_cu.data_ptr()), len(lens), total, hidden, heads,
+        ctypes.c_void_p(w.data_ptr()), ctypes.c_void_p(bias.data_ptr()), ctypes.c_void_p(res.data_ptr()),
+        ctypes.c_void_p(y.data_ptr()), n, st))
+    torch.cuda.synchronize()
+    assert bool((y[total:] == 555.0).all()) and bool((y_pair[total:] == 555.0).all())      # rows past the batch untouched
+    # fp32 reference of the whole op on the same bf16 inputs
+    ref_ctx, _ = _reference(torch, qkv[:total], lens, heads)
+    ref = ref_ctx.bfloat16().float() @ w.float().t() + bias + res[:total].float()
+    return y[:total].float(), y_pair[:total].float(), ref
+
+
+@pytest.mark.parametrize("lens", [[1], [11], [16], [17], [23], [32], [9, 7], [12, 15, 5], [1, 1, 1, 1], [16, 16], [3, 13, 2, 14],
+                                  [1] * 32])
+def test_fused_attention_output_projection_equals_the_pair(gpu, lens):
+    """One launch == attention + few-rows GEMM: the context rows carry attention_kernel's bits, the projection sums its 16
+    head slices in another order than the 4-wave GEMM, so the outputs agree to the last bf16 bit almost everywhere and
+    within one ulp elsewhere; both sit within the bf16 bound of the fp32 reference."""
+    torch = gpu
+    y, y_pair, ref = _fused_case(torch, lens, seed=100 + sum(lens))
+    assert bool(torch.isfinite(y).all())
+    # one bf16 ulp of the output, or — where bias + residual cancel the product — the fp32 rounding of O(1) partial sums
+    ulp = 2.0 ** -7 * torch.maximum(y.abs(), y_pair.abs()) + 4e-6
+    assert bool(((y - y_pair).abs() <= ulp).all()), float(((y - y_pair).abs() / ulp).max())
+    assert float((y == y_pair).float().mean()) >= 0.97
+    tol = 2.0 ** -7 * ref.abs() + 0.03
+    assert bool(((y - ref).abs() <= tol).all()), float(((y - ref).abs() - tol).max())
+
+
+def test_fused_attention_output_projection_peaked_scores(gpu):
+    """|q.k| / 8 up to ~40 (probabilities 2^-100 .. 1), ragged sequences."""
+    torch = gpu
+    y, y_pair, ref = _fused_case(torch, [13, 19], seed=7, scale=2.5)
+    ulp = 2.0 ** -7 * torch.maximum(y.abs(), y_pair.abs()) + 4e-6
+    assert bool(((y - y_pair).abs() <= ulp).all())
+
+
+def test_fused_attention_output_projection_refuses_outside_its_range(gpu, monkeypatch):
+    torch = gpu
+    from rassengine_amd import _native as N_
+    L = N_.lib()
+    z = torch.zeros((64, 3072), dtype=torch.bfloat16, device="cuda")
+    cu = torch.tensor([0, 33], dtype=torch.int32, device="cuda")
+    p = ctypes.c_void_p(z.data_ptr())
+    args = lambda total, hidden, heads, n: (p, ctypes.c_void_p(cu.data_ptr()), 1, total, hidden, heads, p, p, p, p, n, None)
+    assert L.rass_attention_out_bf16(*args(33, 1024, 16, 1024)) == -5
+    assert L.rass_attention_out_bf16(*args(16, 768, 12, 768)) == -5
+    assert L.rass_attention_out_bf16(*args(16, 1024, 16, 1000)) == -5
+    monkeypatch.setenv("RASS_ATTN_FUSE", "0")
+    assert L.rass_attention_out_bf16(*args(16, 1024, 16, 1024)) == -5

@@ -599,11 +599,12 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_bf16_fewrows_kernel(const u16
 
 // The few-rows GEMM whose input is LayerNorm(Yin), recomputed by EVERY workgroup into its LDS X tile (<= 16 rows of
 // K = 1024: 32 KiB of L2 reads, issued behind the weight loads already in flight) instead of a LayerNorm launch in
-// front: a launch costs ~4 us here whatever it does.  Workgroup 0 also stores the normalised rows (x_out: the next
+// front (WAVES = 16, the default: a wave normalises ONE row of 16 and owns a 64-deep slice of K — normalising four rows took a
+// 4-wave workgroup ~1.5 us of vector issue, in every workgroup; RASS_GEMM_LNIN_WAVES=4 keeps that form): a launch costs ~4 us here whatever it does.  Workgroup 0 also stores the normalised rows (x_out: the next
 // residual).  The row arithmetic is layernorm_kernel's (wave per row, lane = 8 columns + 512 s, fp32 two-pass,
 // xor-shuffle sums), so x_out has the bits the separate launch would have written.
-template <int EPI, int ROWS>
-__global__ __launch_bounds__(256) void gemm_bf16_lnin_kernel(const u16* __restrict__ Yin, const float* __restrict__ gamma,
+template <int EPI, int ROWS, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void gemm_bf16_lnin_kernel(const u16* __restrict__ Yin, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float eps,
                                                              u16* __restrict__ x_out, const u16* __restrict__ W,
                                                              const float* __restrict__ bias, u16* __restrict__ Y, int M,
@@ -611,23 +612,25 @@ __global__ __launch_bounds__(256) void gemm_bf16_lnin_kernel(const u16* __restri
     constexpr int K = 1024, kPitch = K + 8;   // + 16 B: the 16 rows of a B fragment fall on different banks
     extern __shared__ __attribute__((aligned(16))) unsigned char lnin_lds[];
     u16 (*xs)[kPitch] = reinterpret_cast<u16 (*)[kPitch]>(lnin_lds);                       // [16 ROWS][kPitch]
-    f32x4 (*part)[ROWS][64] = reinterpret_cast<f32x4 (*)[ROWS][64]>(lnin_lds + (size_t)16 * ROWS * kPitch * 2);  // [4]
+    f32x4 (*part)[ROWS][64] = reinterpret_cast<f32x4 (*)[ROWS][64]>(lnin_lds + (size_t)16 * ROWS * kPitch * 2);  // [WAVES]
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int n0 = blockIdx.x * 16;
     const int g = lane >> 4, i = lane & 15;
-    const int k_lo = wave * (K / 4);
+    constexpr int UW = 32 / WAVES;   // 32-deep MFMA steps of a wave's K slice (K / WAVES)
+    const int k_lo = wave * (K / WAVES);
     const u16* wrow = W + (int64_t)(n0 + i) * K + k_lo + 8 * g;
-    bf16x8 a[8];
+    bf16x8 a[UW];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) a[u] = *reinterpret_cast<const bf16x8*>(wrow + 32 * u);
+    for (int u = 0; u < UW; ++u) a[u] = *reinterpret_cast<const bf16x8*>(wrow + 32 * u);
     const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n0 + 4 * g);   // (wave 0's epilogue: not a round trip at the end)
-    // rows wave, wave + 4, ...: all their loads first
-    constexpr int RPW = 4 * ROWS;   // rows per wave
+    // rows wave, wave + WAVES, ...: all their loads first
+    constexpr int RPW = 16 * ROWS / WAVES;   // rows per wave
+    constexpr int G = RPW < 4 ? RPW : 4;     // rows reduced side by side
     uint4 raw[RPW][2];
 #pragma unroll
     for (int j = 0; j < RPW; ++j) {
-        const int r = wave + 4 * j;
+        const int r = wave + WAVES * j;
         const int rc = r < M ? r : 0;
 #pragma unroll
         for (int st = 0; st < 2; ++st)
@@ -647,10 +650,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_lnin_kernel(const u16* __restri
     // the 12 dependent cross-lane steps of a row (2 sums x 6 butterfly steps) overlap with the other rows' instead of running 48
     // deep, and they are DPP / permlane-swap moves, not ds_bpermute round trips (encoder_kernels.h; round 4: 8.2 -> ~5 us per launch)
 #pragma unroll
-    for (int j0 = 0; j0 < RPW; j0 += 4) {
-        float x[4][2][8], sum[4], mean[4], sq[4], rstd[4];
+    for (int j0 = 0; j0 < RPW; j0 += G) {
+        float x[G][2][8], sum[G], mean[G], sq[G], rstd[G];
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
+        for (int jj = 0; jj < G; ++jj) {
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
                 const uint4 w = raw[j0 + jj][st];
@@ -668,9 +671,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_lnin_kernel(const u16* __restri
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1)
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) sum[jj] += wave_xor_partner_dpp(sum[jj], lane, off);
+            for (int jj = 0; jj < G; ++jj) sum[jj] += wave_xor_partner_dpp(sum[jj], lane, off);
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
+        for (int jj = 0; jj < G; ++jj) {
             mean[jj] = sum[jj] / (float)K;
             sq[jj] = 0.f;
 #pragma unroll
@@ -684,11 +687,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_lnin_kernel(const u16* __restri
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1)
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) sq[jj] += wave_xor_partner_dpp(sq[jj], lane, off);
+            for (int jj = 0; jj < G; ++jj) sq[jj] += wave_xor_partner_dpp(sq[jj], lane, off);
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
+        for (int jj = 0; jj < G; ++jj) {
             rstd[jj] = rsqrtf(sq[jj] / (float)K + eps);
-            const int r = wave + 4 * (j0 + jj);
+            const int r = wave + WAVES * (j0 + jj);
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
                 const int c = lane * 8 + 512 * st;
@@ -706,6 +709,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_lnin_kernel(const u16* __restri
                 pk.y = (unsigned)f32_to_bf16(o[2]) | ((unsigned)f32_to_bf16(o[3]) << 16);
                 pk.z = (unsigned)f32_to_bf16(o[4]) | ((unsigned)f32_to_bf16(o[5]) << 16);
                 pk.w = (unsigned)f32_to_bf16(o[6]) | ((unsigned)f32_to_bf16(o[7]) << 16);
+#ifdef RASS_ELIM_LN   // elimination build (timing only, wrong results): the raw row instead of the normalised one
+                pk = raw[j0 + jj][st];
+#endif
                 if (r >= M) pk = make_uint4(0, 0, 0, 0);   // rows past the batch: finite zeros in the operand tile
                 *reinterpret_cast<uint4*>(&xs[r][c]) = pk;
                 if (blockIdx.x == 0 && r < M) *reinterpret_cast<uint4*>(x_out + (int64_t)r * K + c) = pk;
@@ -717,7 +723,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_lnin_kernel(const u16* __restri
 #pragma unroll
     for (int rb = 0; rb < ROWS; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < UW; ++u) {
 #pragma unroll
         for (int rb = 0; rb < ROWS; ++rb) {
             const bf16x8 b = *reinterpret_cast<const bf16x8*>(&xs[16 * rb + i][k_lo + 32 * u + 8 * g]);
@@ -733,7 +739,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_lnin_kernel(const u16* __restri
     for (int rb = 0; rb < ROWS; ++rb) {
         const int m = 16 * rb + i;
         if (m >= M) continue;
-        f32x4 v = ((part[0][rb][lane] + part[1][rb][lane]) + part[2][rb][lane]) + part[3][rb][lane];
+        f32x4 v = part[0][rb][lane];
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) v += part[w][rb][lane];   // in wave order
         v += bv;
         if (EPI == 2) {
             v.x = gelu_erf(v.x);
@@ -2038,20 +2046,27 @@ bool gemm_bf16_ln_input_ok(int M, int N, int K) {
     return M >= 1 && M <= 32 && K == 1024 && N % 16 == 0 && N >= 1024 && fewrows_enabled();
 }
 
-template <int EPI, int ROWS>
+template <int EPI, int ROWS, int WAVES>
 static hipError_t launch_lnin(const u16* yin, const float* gamma, const float* beta, float eps, u16* x_out, const u16* w,
                               const float* bias, u16* y, int M, int N, hipStream_t stream) {
-    constexpr int lds_bytes = 16 * ROWS * (1024 + 8) * 2 + 4 * ROWS * 64 * 16;
+    constexpr int lds_bytes = 16 * ROWS * (1024 + 8) * 2 + WAVES * ROWS * 64 * 16;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_lnin_kernel<EPI, ROWS>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_lnin_kernel<EPI, ROWS, WAVES>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_bf16_lnin_kernel<EPI, ROWS>), dim3(N / 16), dim3(256), lds_bytes, stream, yin, gamma, beta, eps,
-                       x_out, w, bias, y, M, N);
+    hipLaunchKernelGGL((gemm_bf16_lnin_kernel<EPI, ROWS, WAVES>), dim3(N / 16), dim3(64 * WAVES), lds_bytes, stream, yin, gamma,
+                       beta, eps, x_out, w, bias, y, M, N);
     return hipGetLastError();
+}
+
+template <int EPI, int WAVES>
+static hipError_t launch_lnin_rows(const u16* yin, const float* gamma, const float* beta, float eps, u16* xo, const u16* w,
+                                   const float* bias, u16* y, int M, int N, hipStream_t stream) {
+    return M <= 16 ? launch_lnin<EPI, 1, WAVES>(yin, gamma, beta, eps, xo, w, bias, y, M, N, stream)
+                   : launch_lnin<EPI, 2, WAVES>(yin, gamma, beta, eps, xo, w, bias, y, M, N, stream);
 }
 
 hipError_t launch_gemm_bf16_ln_input(const void* Yin, const float* gamma, const float* beta, float eps, void* x_out,
@@ -2062,11 +2077,12 @@ hipError_t launch_gemm_bf16_ln_input(const void* Yin, const float* gamma, const 
     const u16* w = static_cast<const u16*>(W);
     u16* xo = static_cast<u16*>(x_out);
     u16* y = static_cast<u16*>(Y);
-    if (M <= 16)
-        return epilogue == 0 ? launch_lnin<0, 1>(yin, gamma, beta, eps, xo, w, bias, y, M, N, stream)
-                             : launch_lnin<2, 1>(yin, gamma, beta, eps, xo, w, bias, y, M, N, stream);
-    return epilogue == 0 ? launch_lnin<0, 2>(yin, gamma, beta, eps, xo, w, bias, y, M, N, stream)
-                         : launch_lnin<2, 2>(yin, gamma, beta, eps, xo, w, bias, y, M, N, stream);
+    const char* v = getenv("RASS_GEMM_LNIN_WAVES");   // 4: the 4-wave workgroups of rounds 2-3 (A/B; read per launch)
+    if (v && atoi(v) == 4)
+        return epilogue == 0 ? launch_lnin_rows<0, 4>(yin, gamma, beta, eps, xo, w, bias, y, M, N, stream)
+                             : launch_lnin_rows<2, 4>(yin, gamma, beta, eps, xo, w, bias, y, M, N, stream);
+    return epilogue == 0 ? launch_lnin_rows<0, 16>(yin, gamma, beta, eps, xo, w, bias, y, M, N, stream)
+                         : launch_lnin_rows<2, 16>(yin, gamma, beta, eps, xo, w, bias, y, M, N, stream);
 }
 
 }  // namespace rass

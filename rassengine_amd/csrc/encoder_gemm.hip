@@ -264,6 +264,25 @@ __global__ __launch_bounds__(kGemmThreads, 1) void gemm_bf16_mid_kernel(const u1
         if (which < 4) asm volatile("s_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(dma_voff), "s"(wdesc), "s"(so) : "memory");
         else asm volatile("s_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(dma_voff), "s"(xdesc), "s"(so) : "memory");
     };
+    // the epilogue's operands leave FIRST: a workgroup has one tile, so loads issued after the K loop are a dependent L2 / HBM
+    // round trip at the end of every launch (~1 us of 15).  They are older than every tile piece and loads complete in order,
+    // so the counted vmcnt waits below mean what they meant.
+    f32x4 ebias[4];
+    uint2 eres[4][NJ];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = n0 + wn * 64 + i * 16 + (lane >> 4) * 4;
+        ebias[i] = *reinterpret_cast<const f32x4*>(bias + n);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            eres[i][j] = make_uint2(0, 0);
+            if (EPI == 1) {
+                const int m = m0 + wm * (BM / 2) + j * 16 + (lane & 15);
+                eres[i][j] = *reinterpret_cast<const uint2*>(residual + (int64_t)(m < M ? m : M - 1) * N + n);
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
     // prologue: tiles 0, 1, 2 and the W pieces of tile 3
 #pragma unroll
     for (int t = 0; t < 3; ++t)
@@ -357,10 +376,9 @@ __global__ __launch_bounds__(kGemmThreads, 1) void gemm_bf16_mid_kernel(const u1
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int n = n0 + wn * 64 + i * 16 + (lane >> 4) * 4;
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n);
-            f32x4 v = acc[i][j] + bv;
+            f32x4 v = acc[i][j] + ebias[i];
             if (EPI == 1) {
-                const uint2 r = *reinterpret_cast<const uint2*>(residual + (int64_t)m * N + n);
+                const uint2 r = eres[i][j];
                 v.x += bf16_to_f32((u16)(r.x & 0xffff));
                 v.y += bf16_to_f32((u16)(r.x >> 16));
                 v.z += bf16_to_f32((u16)(r.y & 0xffff));

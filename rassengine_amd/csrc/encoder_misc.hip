@@ -302,6 +302,18 @@ __global__ __launch_bounds__(kRowThreadsE) void splitk_residual_layernorm_kernel
 // branch around a step, so EVERY load of the row — the S slices, bias, residual, gamma, beta: 30 x 16 B per lane at S = 4 — is
 // in flight before the first add (the general form above walks the steps one branch at a time: two dependent round trips for
 // the data and a third for gamma / beta, in a kernel that lasts 4 us).  Same arithmetic in the same order: the same bits.
+// 16 bytes, ISSUED here and not waited for: the compiler places its own loads where its register-pressure heuristics like
+// (for this kernel: ten in flight, then load / wait / add in turn — several dependent round trips), and neither sched_barrier nor
+// source order binds the instruction selector's placement of loads and pure arithmetic.  Inline asm is kept in program order;
+// ld16_wait_all() is the one wait, ld16_pin() makes every later use depend on it.
+__device__ __forceinline__ f32x4 ld16_issue(const void* p) {
+    f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void ld16_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void ld16_pin(f32x4& v) { asm volatile("" : "+v"(v)); }
+
 template <int S, int STEPS>
 __global__ __launch_bounds__(kRowThreadsE) void splitk_residual_layernorm_exact_kernel(
     const float* __restrict__ partial, int rows, int rows_pad, const float* __restrict__ bias, const u16* residual,
@@ -311,30 +323,43 @@ __global__ __launch_bounds__(kRowThreadsE) void splitk_residual_layernorm_exact_
     const int wave = threadIdx.x >> 6;
     const int r = blockIdx.x * 4 + wave;
     if (r >= rows) return;
-    f32x4 p0[STEPS][S], p1[STEPS][S], bb[STEPS][2], g[STEPS][2], b[STEPS][2];
-    uint4 rr[STEPS];
+    f32x4 p0[STEPS][S], p1[STEPS][S], bb[STEPS][2], g[STEPS][2], b[STEPS][2], rrv[STEPS];
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
         const int c = lane * 8 + 512 * s;
 #pragma unroll
         for (int sl = 0; sl < S; ++sl) {
             const float* q = partial + ((int64_t)sl * rows_pad + r) * hidden + c;
-            p0[s][sl] = *reinterpret_cast<const f32x4*>(q);
-            p1[s][sl] = *reinterpret_cast<const f32x4*>(q + 4);
+            p0[s][sl] = ld16_issue(q);
+            p1[s][sl] = ld16_issue(q + 4);
         }
-        rr[s] = *reinterpret_cast<const uint4*>(residual + (int64_t)r * hidden + c);
-        bb[s][0] = *reinterpret_cast<const f32x4*>(bias + c);
-        bb[s][1] = *reinterpret_cast<const f32x4*>(bias + c + 4);
+        rrv[s] = ld16_issue(residual + (int64_t)r * hidden + c);
+        bb[s][0] = ld16_issue(bias + c);
+        bb[s][1] = ld16_issue(bias + c + 4);
     }
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
         const int c = lane * 8 + 512 * s;
-        g[s][0] = *reinterpret_cast<const f32x4*>(gamma + c);
-        g[s][1] = *reinterpret_cast<const f32x4*>(gamma + c + 4);
-        b[s][0] = *reinterpret_cast<const f32x4*>(beta + c);
-        b[s][1] = *reinterpret_cast<const f32x4*>(beta + c + 4);
+        g[s][0] = ld16_issue(gamma + c);
+        g[s][1] = ld16_issue(gamma + c + 4);
+        b[s][0] = ld16_issue(beta + c);
+        b[s][1] = ld16_issue(beta + c + 4);
     }
-    __builtin_amdgcn_sched_barrier(0);
+    ld16_wait_all();   // (at most 2 * (2 S + 7) = 46 loads at S = 8: inside the 6-bit counter)
+    uint4 rr[STEPS];
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+#pragma unroll
+        for (int sl = 0; sl < S; ++sl) {
+            ld16_pin(p0[s][sl]);
+            ld16_pin(p1[s][sl]);
+        }
+        ld16_pin(rrv[s]);
+        ld16_pin(bb[s][0]); ld16_pin(bb[s][1]);
+        ld16_pin(g[s][0]); ld16_pin(g[s][1]);
+        ld16_pin(b[s][0]); ld16_pin(b[s][1]);
+        rr[s] = make_uint4(__float_as_uint(rrv[s].x), __float_as_uint(rrv[s].y), __float_as_uint(rrv[s].z), __float_as_uint(rrv[s].w));
+    }
     float x[STEPS][8];
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
@@ -394,11 +419,18 @@ hipError_t launch_splitk_residual_layernorm(const float* partial, int S, int row
     const int blocks = (rows + 3) / 4;
     const u16* res = static_cast<const u16*>(residual);
     u16* o = static_cast<u16*>(out);
-    if (S == 4 && hidden == 1024 && rows <= 64) {   // the query-time reduction (FFN-down's four K slices)
-        const char* v = getenv("RASS_LN_EXACT");    // =0: the general kernel (A/B; read per launch)
+    if (hidden == 1024 && (S == 2 || S == 4 || S == 8)) {   // BERT-large rows: the query-time reduction (FFN-down's four K slices)
+        const char* v = getenv("RASS_LN_EXACT");            // and the mid-size batches' (8); =0: the general kernel (A/B; per launch)
         if (!(v && v[0] == '0')) {
-            hipLaunchKernelGGL((splitk_residual_layernorm_exact_kernel<4, 2>), dim3(blocks), dim3(kRowThreadsE), 0, stream, partial,
-                               rows, rows_pad, bias, res, gamma, beta, eps, o);
+            if (S == 2)
+                hipLaunchKernelGGL((splitk_residual_layernorm_exact_kernel<2, 2>), dim3(blocks), dim3(kRowThreadsE), 0, stream,
+                                   partial, rows, rows_pad, bias, res, gamma, beta, eps, o);
+            else if (S == 4)
+                hipLaunchKernelGGL((splitk_residual_layernorm_exact_kernel<4, 2>), dim3(blocks), dim3(kRowThreadsE), 0, stream,
+                                   partial, rows, rows_pad, bias, res, gamma, beta, eps, o);
+            else
+                hipLaunchKernelGGL((splitk_residual_layernorm_exact_kernel<8, 2>), dim3(blocks), dim3(kRowThreadsE), 0, stream,
+                                   partial, rows, rows_pad, bias, res, gamma, beta, eps, o);
             return hipGetLastError();
         }
     }

@@ -409,7 +409,7 @@ static bool mid_enabled(int M = 512) {
     const char* v = getenv("RASS_GEMM_MID");   // 0: round 3's paths (two-buffer kernel / split-K pair); 2: every shape (the A/Bs)
     if (v != nullptr && atoi(v) == 0) return false;
     if (v != nullptr && atoi(v) == 2) return true;
-    return M > GBM && M <= 8 * GBM;
+    return M > 96 && M <= 8 * GBM;   // (from 129 rows until the end of round 4; 97 .. 128 rows: 120 tokens 1.44 -> 1.31 ms per forward)
 }
 
 // ------------------------------------------------------------------------------------------
@@ -779,7 +779,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_bf16_lnin_kernel(const u16* _
 // (4 waves: K <= 3072); default 128 (r03: 96 tokens 1.405 -> 1.337 ms per forward, 128 tokens 1.539 -> 1.495)
 static int fewrows_max_rows() {
     const char* v = getenv("RASS_GEMM_FEWROWS_MAX");
-    const int m = v ? atoi(v) : 128;
+    const int m = v ? atoi(v) : 96;   // 128 until the end of round 4: from 97 rows the four-stage kernel (mid_enabled) is faster
     return m < 16 ? 16 : (m > 128 ? 128 : m);
 }
 
@@ -800,7 +800,7 @@ static bool fewrows_enabled() {  // RASS_GEMM_FEWROWS=0: the split-K pair instea
 // pair is faster (measured at 48 and 64 tokens); RASS_GEMM_FEWROWS_RES=<rows> moves the limit (A/B)
 static int fewrows_residual_max_rows() {
     const char* v = getenv("RASS_GEMM_FEWROWS_RES");
-    return v ? atoi(v) : 32;
+    return v ? atoi(v) : 64;   // 32 until the end of round 4 (see the comment at launch_gemm_bf16_residual_layernorm)
 }
 
 template <int EPI, int WAVES>
@@ -2026,14 +2026,17 @@ hipError_t launch_gemm_bf16_residual_layernorm(const void* X, const void* W, con
     if (M == 0) return hipSuccess;
     // a query's few rows: the one-launch GEMM (bias + residual in its epilogue) and the row-wise LayerNorm — two launches
     // like the split-K pair below, but 5 + 5 us where that pair takes 6 + 7.4 (16 slices read back by 16 waves)
-    if (splitk_ws != nullptr && M_pad >= 64 && fewrows_enabled() && M <= fewrows_residual_max_rows() && fewrows_waves(M, N, K) != 0) {
+    // (a K of whole 4096s runs as four K slices of 4-wave workgroups: what must fit is a slice)
+    if (splitk_ws != nullptr && M_pad >= 64 && fewrows_enabled() && M <= fewrows_residual_max_rows() &&
+        fewrows_waves(M, N, K % 4096 == 0 ? K / 4 : K) != 0) {
         // K = 4096 (FFN-down): 64 workgroups of 16 waves took 9.4 us; 4 x 64 workgroups of 4 waves write partial tiles and
         // the fused reduce + residual + LayerNorm kernel (4 slices) follows
-        if (K % 4096 == 0 && K / 4 <= 3072 && N % 8 == 0 && N <= 2048 && (size_t)4 * 64 * N * sizeof(float) <= splitk_ws_bytes) {
+        const int rows_pad = M <= 64 ? 64 : 128;
+        if (K % 4096 == 0 && K / 4 <= 3072 && N % 8 == 0 && N <= 2048 && (size_t)4 * rows_pad * N * sizeof(float) <= splitk_ws_bytes) {
             hipError_t e = launch_fewrows_w<-1, 4>(static_cast<const u16*>(X), static_cast<const u16*>(W), nullptr, nullptr,
-                                                   nullptr, M, N, K, stream, splitk_ws, 64, 4);
+                                                   nullptr, M, N, K, stream, splitk_ws, rows_pad, 4);
             if (e != hipSuccess) return e;
-            return launch_splitk_residual_layernorm(splitk_ws, 4, M, 64, N, bias, residual, gamma, beta, eps, out, stream);
+            return launch_splitk_residual_layernorm(splitk_ws, 4, M, rows_pad, N, bias, residual, gamma, beta, eps, out, stream);
         }
         hipError_t e = launch_gemm_bf16(X, W, bias, residual, y, M, M_pad, N, K, 1, stream, splitk_ws, splitk_ws_bytes);
         if (e != hipSuccess) return e;

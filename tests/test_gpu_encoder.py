@@ -258,6 +258,42 @@ def test_large_encoder_sample_matches_oracle(gpu, tmp_path_factory):
         assert np.all(c >= 0.999), c
 
 
+def test_query_forward_switches(gpu, tmp_path_factory, monkeypatch):
+    """The one-query forward's end-of-round-4 kernels against the ones they replace, same encoder, same inputs (the
+    switches are read per launch): the exact-width reduce + LayerNorm kernel changes no bit (same arithmetic in the same
+    order; DPP / permlane butterflies in both); the attention inside the attention-output GEMM and the 16-wave
+    LayerNorm-inside GEMM reorder fp32 partial sums (16 K slices instead of 4): embeddings agree like any two batchings
+    of the same text do."""
+    from rassengine_amd.encoder import EncoderConfig, HipSentenceEncoder, write_random_model_dir
+    d = str(tmp_path_factory.mktemp("large_model_switches"))
+    cfg = EncoderConfig(pooling="mean")
+    write_random_model_dir(d, cfg, seed=5)
+    rng = np.random.default_rng(17)
+    cases = [[list(rng.integers(0, 30522, size=n)) for n in lens] for lens in ([12], [16], [24], [9, 7], [30], [12, 12, 12, 12])]
+    enc = HipSentenceEncoder.from_dir(d, device=0)
+    try:
+        base = [enc.encode_ids(c) for c in cases]
+        again = [enc.encode_ids(c) for c in cases]
+        monkeypatch.setenv("RASS_LN_EXACT", "0")
+        general_ln = [enc.encode_ids(c) for c in cases]
+        monkeypatch.delenv("RASS_LN_EXACT")
+        monkeypatch.setenv("RASS_ATTN_FUSE", "0")
+        pair = [enc.encode_ids(c) for c in cases]
+        monkeypatch.setenv("RASS_ATTN_FUSE", "2")
+        forced = [enc.encode_ids(c) for c in cases]
+        monkeypatch.delenv("RASS_ATTN_FUSE")
+        monkeypatch.setenv("RASS_GEMM_LNIN_WAVES", "4")
+        lnin4 = [enc.encode_ids(c) for c in cases]
+    finally:
+        enc.close()
+    for b, a, g, p_, f, l4 in zip(base, again, general_ln, pair, forced, lnin4):
+        assert np.all(np.isfinite(b))
+        assert np.array_equal(b, a)                       # deterministic
+        assert np.array_equal(b, g)                       # exact-width LayerNorm kernel: the same bits
+        for other in (p_, f, l4):
+            assert np.all(_cos(b, other) >= 0.9995), _cos(b, other)
+
+
 def test_base_shape_encoder_through_the_persistent_gemm(gpu, tmp_path_factory):
     """BERT-base-class layers (768 x 12 heads x 3072, the bge-base / nomic class) with > 1024 packed
     tokens: every linear goes through the persistent 256 x 256 ring GEMM (N % 256 == 0, M >= 1024),

@@ -173,9 +173,13 @@ def main():
             # the step's 1 024 queries travel in ONE broadcast, the per-shard top-k of its 32 launch groups in ONE
             # all-gather (2 collectives per step instead of 64), then one grouped merge launch
             if rank == 0:
-                for j in range(LPS):
-                    g = (i * LPS + j) % n_batches
-                    step_q[j * B:(j + 1) * B].copy_(pool[g * B:(g + 1) * B])
+                g0 = (i * LPS) % n_batches
+                if g0 + LPS <= n_batches:   # the step's launch groups are consecutive pool batches: one device copy
+                    step_q.copy_(pool[g0 * B:(g0 + LPS) * B])
+                else:                       # (a pool that is not a multiple of the step: group by group, as before)
+                    for j in range(LPS):
+                        g = (i * LPS + j) % n_batches
+                        step_q[j * B:(j + 1) * B].copy_(pool[g * B:(g + 1) * B])
             return search.search_batch(step_q, k, B)
         out = None
         for j in range(LPS):   # one step = LPS launch groups of B queries each

@@ -184,6 +184,32 @@ def attention_bf16(qkv: torch.Tensor, cu_seqlens: torch.Tensor, max_seqlen: int,
     return ctx
 
 
+def attention_out_bf16(qkv: torch.Tensor, cu_seqlens: torch.Tensor, heads: int, w: torch.Tensor, bias: torch.Tensor,
+                       residual: torch.Tensor) -> torch.Tensor:
+    """``rass_attention_out_bf16``: query time — attention and its output projection in ONE launch,
+    ``attention(qkv) @ w.T + bias + residual`` (1..32 tokens over all sequences, hidden 1024, 16 heads; anything else
+    raises: the library answers RASS_ERR_UNSUPPORTED).  qkv bf16 [tokens, 3 * hidden], w bf16 [n, hidden], bias fp32 [n],
+    residual bf16 [tokens, n] -> bf16 [tokens, n]."""
+    _req(qkv, torch.bfloat16, "qkv")
+    _req(cu_seqlens, torch.int32, "cu_seqlens")
+    _req(w, torch.bfloat16, "w")
+    _req(bias, torch.float32, "bias")
+    _req(residual, torch.bfloat16, "residual")
+    tokens, three_h = qkv.shape
+    hidden = three_h // 3
+    n = w.shape[0]
+    if three_h != 3 * hidden or w.shape[1] != hidden or bias.shape[0] != n or tuple(residual.shape) != (tokens, n):
+        raise ValueError("attention_out_bf16: qkv [tokens, 3 hidden], w [n, hidden], bias [n], residual [tokens, n]")
+    nseq = int(cu_seqlens.shape[0]) - 1
+    y = torch.empty((tokens, n), dtype=torch.bfloat16, device=qkv.device)
+    N.check("rass_attention_out_bf16",
+            N.lib().rass_attention_out_bf16(ctypes.c_void_p(qkv.data_ptr()), ctypes.c_void_p(cu_seqlens.data_ptr()), nseq,
+                                            int(tokens), int(hidden), int(heads), ctypes.c_void_p(w.data_ptr()),
+                                            ctypes.c_void_p(bias.data_ptr()), ctypes.c_void_p(residual.data_ptr()),
+                                            ctypes.c_void_p(y.data_ptr()), int(n), ctypes.c_void_p(_stream_ptr())))
+    return y
+
+
 def encode(encoder_handle: int, token_ids: torch.Tensor, cu_seqlens: torch.Tensor, max_seqlen: int, hidden: int
            ) -> torch.Tensor:
     """``rass_encode_device`` on torch's current stream: the whole sentence-encoder forward (embeddings + LayerNorm, 24 x
@@ -255,6 +281,15 @@ def _register_torch_ops() -> None:
     @_attn.register_fake
     def _(qkv, cu_seqlens, max_seqlen, heads):
         return qkv.new_empty((qkv.shape[0], qkv.shape[1] // 3))
+
+    @lib.custom_op("rass::attention_out_bf16", mutates_args=())
+    def _attn_out(qkv: torch.Tensor, cu_seqlens: torch.Tensor, heads: int, w: torch.Tensor, bias: torch.Tensor,
+                  residual: torch.Tensor) -> torch.Tensor:
+        return attention_out_bf16(qkv, cu_seqlens, heads, w, bias, residual)
+
+    @_attn_out.register_fake
+    def _(qkv, cu_seqlens, heads, w, bias, residual):
+        return qkv.new_empty((qkv.shape[0], w.shape[0]))
 
     @lib.custom_op("rass::encode", mutates_args=())
     def _encode(encoder_handle: int, token_ids: torch.Tensor, cu_seqlens: torch.Tensor, max_seqlen: int, hidden: int

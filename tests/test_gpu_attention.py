@@ -195,6 +195,28 @@ def test_fused_attention_output_projection_peaked_scores(gpu):
     assert bool(((y - y_pair).abs() <= ulp).all())
 
 
+def test_fused_attention_output_projection_as_torch_op(gpu):
+    """torch.ops.rass.attention_out_bf16 == the C-ABI call (same launch), and it refuses what the library refuses."""
+    torch = gpu
+    import rassengine_amd.ops  # noqa: F401  (registers torch.ops.rass.*)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    qkv = torch.randn((13, 3072), generator=g, device="cuda").bfloat16()
+    w = (torch.randn((1024, 1024), generator=g, device="cuda") * 0.03).bfloat16()
+    bias = torch.randn((1024,), generator=g, device="cuda")
+    res = torch.randn((13, 1024), generator=g, device="cuda").bfloat16()
+    cu = torch.tensor([0, 13], dtype=torch.int32, device="cuda")
+    y = torch.ops.rass.attention_out_bf16(qkv, cu, 16, w, bias, res)
+    ctx = torch.ops.rass.attention_bf16(qkv, cu, 13, 16)
+    ref = ctx.float() @ w.float().t() + bias + res.float()
+    assert y.shape == (13, 1024) and y.dtype == torch.bfloat16
+    assert bool(((y.float() - ref).abs() <= 2.0 ** -7 * ref.abs() + 0.03).all())
+    with pytest.raises(Exception):
+        torch.ops.rass.attention_out_bf16(torch.zeros((40, 3072), dtype=torch.bfloat16, device="cuda"),
+                                          torch.tensor([0, 40], dtype=torch.int32, device="cuda"), 16, w, bias,
+                                          torch.zeros((40, 1024), dtype=torch.bfloat16, device="cuda"))
+
+
 def test_fused_attention_output_projection_refuses_outside_its_range(gpu, monkeypatch):
     torch = gpu
     from rassengine_amd import _native as N_

@@ -171,7 +171,7 @@ def _fused_case(torch, lens, seed, scale=1.0):
 
 
 @pytest.mark.parametrize("lens", [[1], [11], [16], [17], [23], [32], [9, 7], [12, 15, 5], [1, 1, 1, 1], [16, 16], [3, 13, 2, 14],
-                                  [1] * 32])
+                                  [1] * 32, [5, 0, 7], [0, 16]])
 def test_fused_attention_output_projection_equals_the_pair(gpu, lens):
     """One launch == attention + few-rows GEMM: the context rows carry attention_kernel's bits, the projection sums its 16
     head slices in another order than the 4-wave GEMM, so the outputs agree to the last bf16 bit almost everywhere and

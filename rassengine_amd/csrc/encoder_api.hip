@@ -255,6 +255,7 @@ int forward_fold(rass_encoder* e, const int32_t* d_cu, int nseq, int total, int 
 
 int forward(rass_encoder* e, const int32_t* d_ids, const int32_t* d_cu, int nseq, int total, int max_seqlen,
             float* d_out, hipStream_t st) {
+    rass::rass_env_new_scope();   // the kernels' A/B switches are read once per forward
     const rass_encoder_config& c = e->cfg;
     const int H = c.hidden, I = c.intermediate;
     const int Tp = (total + 255) / 256 * 256;  // whole 256-token GEMM tiles
@@ -530,6 +531,7 @@ int rass_encoder_hidden(const rass_encoder_t* e) { return e ? e->cfg.hidden : ef
 /* Stand-alone launcher of the encoder GEMM (tests, micro-benchmarks). */
 int rass_gemm_bf16(const void* d_x, const void* d_w, const float* d_bias, const void* d_residual, void* d_y, int m,
                    int m_pad, int n, int k, int epilogue, void* stream) {
+    rass::rass_env_new_scope();
     if (!d_x || !d_w || !d_bias || !d_y) return efail(RASS_ERR_INVALID, "NULL argument");
     hipError_t err = rass::launch_gemm_bf16(d_x, d_w, d_bias, d_residual, d_y, m, m_pad, n, k, epilogue,
                                             reinterpret_cast<hipStream_t>(stream));
@@ -541,6 +543,7 @@ int rass_gemm_bf16(const void* d_x, const void* d_w, const float* d_bias, const 
  * uses for query-time embedding (tests). */
 int rass_gemm_bf16_ws(const void* d_x, const void* d_w, const float* d_bias, const void* d_residual, void* d_y, int m,
                       int m_pad, int n, int k, int epilogue, void* d_ws, size_t ws_bytes, void* stream) {
+    rass::rass_env_new_scope();
     if (!d_x || !d_w || !d_bias || !d_y) return efail(RASS_ERR_INVALID, "NULL argument");
     hipError_t err = rass::launch_gemm_bf16(d_x, d_w, d_bias, d_residual, d_y, m, m_pad, n, k, epilogue,
                                             reinterpret_cast<hipStream_t>(stream), static_cast<float*>(d_ws), ws_bytes);
@@ -551,6 +554,7 @@ int rass_gemm_bf16_ws(const void* d_x, const void* d_w, const float* d_bias, con
 /* Stand-alone launcher of the encoder's attention (tests, micro-benchmarks). */
 int rass_attention_bf16(const void* d_qkv, const int32_t* d_cu_seqlens, int nseq, int total_tokens, int max_seqlen,
                         int hidden, int heads, void* d_ctx, void* stream) {
+    rass::rass_env_new_scope();
     if (!d_qkv || !d_cu_seqlens || !d_ctx) return efail(RASS_ERR_INVALID, "NULL argument");
     hipError_t err = rass::launch_attention(d_qkv, d_cu_seqlens, nseq, total_tokens, max_seqlen, hidden, heads, d_ctx,
                                             reinterpret_cast<hipStream_t>(stream));
@@ -562,6 +566,7 @@ int rass_attention_bf16(const void* d_qkv, const int32_t* d_cu_seqlens, int nseq
  * d_residual in one launch; RASS_ERR_UNSUPPORTED outside its range (or with RASS_ATTN_FUSE=0). */
 int rass_attention_out_bf16(const void* d_qkv, const int32_t* d_cu_seqlens, int nseq, int total_tokens, int hidden, int heads,
                             const void* d_w, const float* d_bias, const void* d_residual, void* d_y, int n, void* stream) {
+    rass::rass_env_new_scope();
     if (!d_qkv || !d_cu_seqlens || !d_w || !d_bias || !d_residual || !d_y) return efail(RASS_ERR_INVALID, "NULL argument");
     if (!rass::attn_out_fused_ok(total_tokens, nseq, hidden, heads, n))
         return efail(RASS_ERR_UNSUPPORTED, "fused attention + output GEMM: 1..32 tokens in all, hidden 1024, 16 heads, n % 16 == 0");

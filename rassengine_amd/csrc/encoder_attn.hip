@@ -372,9 +372,9 @@ __global__ __launch_bounds__(1024) void attn_out_fewrows_kernel(const u16* __res
 
 bool attn_out_fused_ok(int M, int nseq, int hidden, int heads, int N) {
     // RASS_ATTN_FUSE=0 / RASS_GEMM_FEWROWS=0 (read per launch: the A/B) keep the attention launch + the few-rows GEMM
-    const char* v = getenv("RASS_ATTN_FUSE");
+    const char* v = rass_env("RASS_ATTN_FUSE");
     if (v && v[0] == '0') return false;
-    const char* f = getenv("RASS_GEMM_FEWROWS");
+    const char* f = rass_env("RASS_GEMM_FEWROWS");
     if (f && f[0] == '0') return false;
     return M >= 1 && M <= 32 && nseq >= 1 && nseq <= M && hidden == 16 * kHeadDim && heads == 16 && N % 16 == 0 && N >= 16;
 }
@@ -383,7 +383,7 @@ bool attn_out_fused_pays(int M, int nseq) {
     // a wave walks the sequences one after the other: measured against the pair (scripts/probe_encoder_attn_fuse.py), one
     // sequence of <= 16 tokens gains 1.5-2.5 us per layer, of 23 tokens 0.2, of 32 it loses 0.5; two sequences in 16 tokens gain
     // 0.4, three or more lose
-    const char* v = getenv("RASS_ATTN_FUSE");
+    const char* v = rass_env("RASS_ATTN_FUSE");
     if (v && v[0] == '2') return true;   // wherever it is valid (tests, A/B)
     return (nseq == 1 && M <= 24) || (nseq == 2 && M <= 16);
 }
@@ -939,7 +939,7 @@ static int attn_cus() {  // one persistent workgroup per CU (the K / V image tak
 }
 
 static const char* attn_variant() {
-    const char* v = getenv("RASS_ATTN_VARIANT");
+    const char* v = rass_env("RASS_ATTN_VARIANT");
     return v ? v : "";
 }
 

@@ -406,7 +406,7 @@ __global__ __launch_bounds__(kGemmThreads, 1) void gemm_bf16_mid_kernel(const u1
 // 32 x 32: 2.228 -> 2.04.  Below 129 rows the split-K pair's workgroups win (8 x 12: 1.333 vs 1.376), from 1 536 rows on the
 // two-buffer kernel's two workgroups per CU (48 x 32: 2.515 vs 2.59).
 static bool mid_enabled(int M = 512) {
-    const char* v = getenv("RASS_GEMM_MID");   // 0: round 3's paths (two-buffer kernel / split-K pair); 2: every shape (the A/Bs)
+    const char* v = rass_env("RASS_GEMM_MID");   // 0: round 3's paths (two-buffer kernel / split-K pair); 2: every shape (the A/Bs)
     if (v != nullptr && atoi(v) == 0) return false;
     if (v != nullptr && atoi(v) == 2) return true;
     return M > 96 && M <= 8 * GBM;   // (from 129 rows until the end of round 4; 97 .. 128 rows: 120 tokens 1.44 -> 1.31 ms per forward)
@@ -778,7 +778,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_bf16_lnin_kernel(const u16* _
 // RASS_GEMM_FEWROWS_MAX=<rows> (A/B; read per launch): the one-launch kernel up to that many rows where its partial tiles fit
 // (4 waves: K <= 3072); default 128 (r03: 96 tokens 1.405 -> 1.337 ms per forward, 128 tokens 1.539 -> 1.495)
 static int fewrows_max_rows() {
-    const char* v = getenv("RASS_GEMM_FEWROWS_MAX");
+    const char* v = rass_env("RASS_GEMM_FEWROWS_MAX");
     const int m = v ? atoi(v) : 96;   // 128 until the end of round 4: from 97 rows the four-stage kernel (mid_enabled) is faster
     return m < 16 ? 16 : (m > 128 ? 128 : m);
 }
@@ -792,14 +792,14 @@ static int fewrows_waves(int M, int N, int K) {
 }
 
 static bool fewrows_enabled() {  // RASS_GEMM_FEWROWS=0: the split-K pair instead (A/B; read per launch)
-    const char* v = getenv("RASS_GEMM_FEWROWS");
+    const char* v = rass_env("RASS_GEMM_FEWROWS");
     return !(v && v[0] == '0');
 }
 
 // the residual GEMMs (N = hidden) take the one-launch kernel only for the fewest rows: from 3 row blocks on the split-K
 // pair is faster (measured at 48 and 64 tokens); RASS_GEMM_FEWROWS_RES=<rows> moves the limit (A/B)
 static int fewrows_residual_max_rows() {
-    const char* v = getenv("RASS_GEMM_FEWROWS_RES");
+    const char* v = rass_env("RASS_GEMM_FEWROWS_RES");
     return v ? atoi(v) : 64;   // 32 until the end of round 4 (see the comment at launch_gemm_bf16_residual_layernorm)
 }
 
@@ -847,7 +847,7 @@ static hipError_t launch_fewrows(const u16* x, const u16* w, const float* bias, 
 // 45 -> 28, 2 048 rows 46 -> 34).
 static int splitk_slices(int M_pad, int N, int K, size_t ws_bytes) {
     const int tiles = (N / GBN) * (M_pad / GBM), steps = K / GBK;
-    if (const char* v = getenv("RASS_GEMM_SPLITK_S")) {   // sweeps (scripts/probe_gemm_mid.py)
+    if (const char* v = rass_env("RASS_GEMM_SPLITK_S")) {   // sweeps (scripts/probe_gemm_mid.py)
         int S = atoi(v);
         if (S < 2 || S > 16 || steps % S != 0 || (size_t)S * M_pad * N * sizeof(float) > ws_bytes) return 0;
         return S;
@@ -1788,7 +1788,7 @@ static hipError_t launch_p4_pol(const u16* X, const u16* W, const float* bias, c
 
 // The persistent GEMM of big shapes is p4 since round 4; RASS_GEMM_VARIANT=p5 brings back the 8-wave kernel (the A/B; same bits).
 static bool p4_enabled(int epi) {
-    const char* v = getenv("RASS_GEMM_VARIANT");   // read per launch: the A/B scripts flip it inside one process
+    const char* v = rass_env("RASS_GEMM_VARIANT");   // read per launch: the A/B scripts flip it inside one process
     if (v != nullptr && strcmp(v, "p5") == 0) return false;
     if (v != nullptr && strcmp(v, "p4") == 0) return true;
     return epi != 5;
@@ -1806,7 +1806,7 @@ static hipError_t launch_p5(const u16* X, const u16* W, const float* bias, const
     }
     const int tiles_total = (N / RBN) * (M_pad / RBM);
     int grid = tiles_total < n_cus ? tiles_total : n_cus;
-    if (const char* v = getenv("RASS_GEMM_GRID")) {   // experiment: fewer persistent workgroups than CUs (per-CU vs chip-wide limits)
+    if (const char* v = rass_env("RASS_GEMM_GRID")) {   // experiment: fewer persistent workgroups than CUs (per-CU vs chip-wide limits)
         const int g = atoi(v);
         if (g >= 1 && g < grid) grid = g;
     }
@@ -1814,7 +1814,7 @@ static hipError_t launch_p5(const u16* X, const u16* W, const float* bias, const
     // overlap that epilogue's dependency stalls with; it stays on p5 unless RASS_GEMM_VARIANT=p4 asks for p4 everywhere)
     if (p4_enabled(EPI) && K >= 512 && (uint64_t)M_pad * K * 2 < (1ull << 32) - (1ull << 24) && (uint64_t)N * K * 2 < (1ull << 32) - (1ull << 24))
         return launch_p4_pol<EPI, 1>(X, W, bias, residual, Y, M, N, K, tiles_total, grid, stream, fold);
-    if (const char* v = getenv("RASS_P5_POLICY"))   // A/B: 0 = plain output stores (read per launch)
+    if (const char* v = rass_env("RASS_P5_POLICY"))   // A/B: 0 = plain output stores (read per launch)
         if (atoi(v) == 0) return launch_p5_pol<EPI, 0>(X, W, bias, residual, Y, M, N, K, tiles_total, grid, stream, fold);
     return launch_p5_pol<EPI, 1>(X, W, bias, residual, Y, M, N, K, tiles_total, grid, stream, fold);
 }
@@ -1825,7 +1825,7 @@ static bool p5_eligible(int M, int M_pad, int N, int K) {
 }
 
 bool gemm_bf16_fold_ok(int M, int M_pad, int hidden, int intermediate) {
-    if (const char* v = getenv("RASS_ENCODER_LN_FOLD"))
+    if (const char* v = rass_env("RASS_ENCODER_LN_FOLD"))
         if (atoi(v) == 0) return false;
     return hidden % 256 == 0 && p5_eligible(M, M_pad, hidden, hidden) && p5_eligible(M, M_pad, 3 * hidden, hidden) &&
            p5_eligible(M, M_pad, intermediate, hidden) && p5_eligible(M, M_pad, hidden, intermediate);
@@ -1918,8 +1918,8 @@ static hipError_t launch_epi(const u16* X, const u16* W, const float* bias, cons
     // keep most of the chip's CUs busy (a persistent kernel runs one tile per CU at a time): a 2 048-token upload has
     // 32 tiles at N = 1024 and ran on 32 of 256 CUs; as 128^2 tiles (split over K where those are few) it fills the
     // chip.  RASS_GEMM_VARIANT=p5 keeps the persistent kernel for every shape it accepts (A/B runs, tests).
-    static const bool forced = getenv("RASS_GEMM_VARIANT") != nullptr &&
-                               (strcmp(getenv("RASS_GEMM_VARIANT"), "p5") == 0 || strcmp(getenv("RASS_GEMM_VARIANT"), "p4") == 0);
+    static const bool forced = rass_env("RASS_GEMM_VARIANT") != nullptr &&
+                               (strcmp(rass_env("RASS_GEMM_VARIANT"), "p5") == 0 || strcmp(rass_env("RASS_GEMM_VARIANT"), "p4") == 0);
     const bool enough_tiles = forced || (int64_t)(N / RBN) * (M_pad / RBM) >= 192;
     if (N % RBN == 0 && M_pad % RBM == 0 && K % 64 == 0 && K >= 128 && M >= 1024 && enough_tiles)
         return launch_p5<EPI>(X, W, bias, residual, Y, M, M_pad, N, K, stream);
@@ -1938,7 +1938,7 @@ static hipError_t launch_epi(const u16* X, const u16* W, const float* bias, cons
             mid_attr_set = true;
         }
         int bm = (N / GBN) * ((M + 63) / 64) <= 256 ? 64 : 128;   // 64-row tiles while they still fit one per CU
-        if (const char* v = getenv("RASS_GEMM_MID_BM")) bm = atoi(v) == 128 ? 128 : 64;
+        if (const char* v = rass_env("RASS_GEMM_MID_BM")) bm = atoi(v) == 128 ? 128 : 64;
         if (bm == 128 || M_pad % 64 != 0) {
             hipLaunchKernelGGL((gemm_bf16_mid_kernel<EPI, 128>), dim3((N / GBN) * ((M + 127) / 128)), dim3(kGemmThreads), kMidLdsBytes,
                                stream, X, W, bias, residual, Y, M, N, K);
@@ -2098,7 +2098,7 @@ hipError_t launch_gemm_bf16_ln_input(const void* Yin, const float* gamma, const 
     const u16* w = static_cast<const u16*>(W);
     u16* xo = static_cast<u16*>(x_out);
     u16* y = static_cast<u16*>(Y);
-    const char* v = getenv("RASS_GEMM_LNIN_WAVES");   // 4: the 4-wave workgroups of rounds 2-3 (A/B; read per launch)
+    const char* v = rass_env("RASS_GEMM_LNIN_WAVES");   // 4: the 4-wave workgroups of rounds 2-3 (A/B; read per launch)
     if (v && atoi(v) == 4)
         return epilogue == 0 ? launch_lnin_rows<0, 4>(yin, gamma, beta, eps, xo, w, bias, y, M, N, stream)
                              : launch_lnin_rows<2, 4>(yin, gamma, beta, eps, xo, w, bias, y, M, N, stream);

@@ -8,6 +8,14 @@
 
 namespace rass {
 
+// The A/B switches of the encoder kernels (RASS_GEMM_*, RASS_ATTN_*, RASS_LN_*) are environment variables read "per launch";
+// a one-query forward is 120 launches of ~5 us each with up to a dozen such reads per launch, and getenv walks the whole
+// environment: the host could not enqueue faster than the GPU ran (round 4: 4.5 us per launch on the host).  rass_env(name)
+// = getenv(name), remembered per thread until rass_env_new_scope() — called at every C-ABI entry of the encoder, so a switch is
+// still read once per call.  `name` must be a string literal (the table is keyed by its address).
+const char* rass_env(const char* name);
+void rass_env_new_scope();
+
 // K5: Y = epilogue(X[M,K] * W[N,K]^T + bias); epilogue 0 bias, 1 bias+residual, 2 bias+GELU(erf).
 // M_pad (multiple of 128) rows of X / Y / residual must be allocated; N % 128 == 0, K % 64 == 0.
 // With a scratch (`splitk_ws`, fp32) a GEMM over few rows (M_pad <= 256) is split over K so that enough workgroups

@@ -411,6 +411,34 @@ __global__ __launch_bounds__(kRowThreadsE) void splitk_residual_layernorm_exact_
     }
 }
 
+namespace {
+struct EnvSlot {
+    const char* name;
+    const char* value;
+    unsigned long scope;
+};
+thread_local EnvSlot t_env[48];
+thread_local int t_env_n = 0;
+thread_local unsigned long t_env_scope = 1;
+}  // namespace
+
+void rass_env_new_scope() { ++t_env_scope; }
+
+const char* rass_env(const char* name) {
+    for (int i = 0; i < t_env_n; ++i) {
+        if (t_env[i].name == name) {
+            if (t_env[i].scope != t_env_scope) {
+                t_env[i].value = getenv(name);
+                t_env[i].scope = t_env_scope;
+            }
+            return t_env[i].value;
+        }
+    }
+    const char* v = getenv(name);
+    if (t_env_n < 48) t_env[t_env_n++] = EnvSlot{name, v, t_env_scope};
+    return v;
+}
+
 hipError_t launch_splitk_residual_layernorm(const float* partial, int S, int rows, int rows_pad, int hidden,
                                             const float* bias, const void* residual, const float* gamma,
                                             const float* beta, float eps, void* out, hipStream_t stream) {
@@ -420,7 +448,7 @@ hipError_t launch_splitk_residual_layernorm(const float* partial, int S, int row
     const u16* res = static_cast<const u16*>(residual);
     u16* o = static_cast<u16*>(out);
     if (hidden == 1024 && (S == 2 || S == 4 || S == 8)) {   // BERT-large rows: the query-time reduction (FFN-down's four K slices)
-        const char* v = getenv("RASS_LN_EXACT");            // and the mid-size batches' (8); =0: the general kernel (A/B; per launch)
+        const char* v = rass_env("RASS_LN_EXACT");            // and the mid-size batches' (8); =0: the general kernel (A/B; per launch)
         if (!(v && v[0] == '0')) {
             if (S == 2)
                 hipLaunchKernelGGL((splitk_residual_layernorm_exact_kernel<2, 2>), dim3(blocks), dim3(kRowThreadsE), 0, stream,
@@ -463,7 +491,7 @@ hipError_t launch_layernorm(const void* in, const float* gamma, const float* bet
     // 3 094 chunks/s plain, 3 115 with the loads, 3 073-3 079 with the stores too (the next GEMM reads these rows 4-16 times)
     int nt_mode = rows >= 4096 ? 1 : 0;
     if (rows >= 4096)
-        if (const char* v = getenv("RASS_LN_NT")) nt_mode = atoi(v) & 3;
+        if (const char* v = rass_env("RASS_LN_NT")) nt_mode = atoi(v) & 3;
     switch (steps) {
         case 1: hipLaunchKernelGGL(layernorm_kernel<1>, dim3(blocks), dim3(kRowThreadsE), 0, stream, x, gamma, beta, eps, rows, hidden, y, nt_mode); break;
         case 2: hipLaunchKernelGGL(layernorm_kernel<2>, dim3(blocks), dim3(kRowThreadsE), 0, stream, x, gamma, beta, eps, rows, hidden, y, nt_mode); break;
